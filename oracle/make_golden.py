@@ -1,0 +1,249 @@
+"""Mint golden vectors for the oracle FROM THE REFERENCE'S OWN CODE.  TEST INFRASTRUCTURE ONLY.
+
+Runs only in the build container (needs ``/root/reference``; the GPU box has no copy):
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
+
+What is executed from the reference (nothing is copied):
+  * ``whisper_medusa/models/medusa_utils.py`` imported by path: ``generate_medusa_buffers``,
+    ``generate_candidates``, ``evaluate_posterior`` (both branches);
+  * ``WhisperMedusaModel.forward()`` (Medusa-Linear) under the import stubs of SURVEY.md
+    Appendix B, driven cache-free (full ``decoder_input_ids`` each call) — mathematically the
+    cached path because of causal masking;
+  * HF's own ``SuppressTokensLogitsProcessor`` / ``SuppressTokensAtBeginLogitsProcessor`` /
+    ``ExponentialDecayLengthPenalty`` as the processor list the reference builds
+    (model.py:1168-1207, :1106-1116).
+Only the ~25 lines of loop glue of model.py:634-793 are restated here (``ref_medusa_loop``).
+Outputs: ``tests/golden/*.npz`` (token ids, accept lengths, a few logits) — weights are NOT
+stored; tests regenerate them from the seed with ``whisper_medusa.synth``.
+"""
+import importlib.util
+import os
+import sys
+import types
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "whisper-medusa_amd"))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+from whisper_medusa.config import MedusaConfig, GenParams, ACCEPT_TYPICAL, ACCEPT_GREEDY  # noqa: E402
+from whisper_medusa import synth  # noqa: E402
+from oracle.whisper_medusa_oracle import Oracle, log_mel  # noqa: E402
+
+
+def load_ref_medusa_utils():
+    spec = importlib.util.spec_from_file_location(
+        "ref_medusa_utils", os.path.join(REF, "whisper_medusa/models/medusa_utils.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _import_reference_package():
+    """Import the reference's ``whisper_medusa`` package under an alias so that it does not
+    collide with our own drop-in package of the same name."""
+    import transformers.generation.utils as gu
+    if not hasattr(gu, "NEED_SETUP_CACHE_CLASSES_MAPPING"):
+        gu.NEED_SETUP_CACHE_CLASSES_MAPPING = {}
+    class _Stub(types.ModuleType):          # any attribute of a missing optional dependency -> inert object
+        def __getattr__(self, item):
+            if item.startswith("__"):
+                raise AttributeError(item)
+            return type(item, (), {"__init__": lambda self, *a, **k: None, "__call__": lambda self, *a, **k: None})
+
+    for name in ("wandb", "jiwer", "jiwer.transforms", "torchaudio", "torchaudio.transforms"):
+        if name not in sys.modules:
+            sys.modules[name] = _Stub(name)
+    ours = {k: v for k, v in sys.modules.items() if k == "whisper_medusa" or k.startswith("whisper_medusa.")}
+    for k in ours:
+        del sys.modules[k]
+    sys.path.insert(0, REF)
+    try:
+        import whisper_medusa.models.model as ref_model            # the reference's model.py
+        import whisper_medusa.utils.config_and_args as ref_cfg
+    finally:
+        sys.path.remove(REF)
+        refmods = {k: v for k, v in sys.modules.items() if k == "whisper_medusa" or k.startswith("whisper_medusa.")}
+        for k in refmods:
+            del sys.modules[k]
+        sys.modules.update(ours)
+    return ref_model, ref_cfg
+
+
+def build_ref_linear(cfg: MedusaConfig, sd):
+    from transformers import WhisperConfig
+    ref_model, ref_cfg = _import_reference_package()
+    hf_cfg = WhisperConfig(
+        d_model=cfg.d_model, encoder_layers=cfg.encoder_layers, decoder_layers=cfg.decoder_layers,
+        encoder_attention_heads=cfg.encoder_attention_heads, decoder_attention_heads=cfg.decoder_attention_heads,
+        encoder_ffn_dim=cfg.encoder_ffn_dim, decoder_ffn_dim=cfg.decoder_ffn_dim, vocab_size=cfg.vocab_size,
+        num_mel_bins=cfg.num_mel_bins, max_source_positions=cfg.max_source_positions,
+        max_target_positions=cfg.max_target_positions, eos_token_id=cfg.eos_token_id,
+        pad_token_id=cfg.pad_token_id, bos_token_id=cfg.eos_token_id,
+        decoder_start_token_id=cfg.decoder_start_token_id)
+    ref_cfg.AutoConfig.from_pretrained = staticmethod(lambda name, **kw: hf_cfg)
+    W2M = ref_model.Whisper2MedusaHeadsConditionalGeneration
+    W2M.from_pretrained = classmethod(lambda cls, name, **kw: cls(hf_cfg))
+    mcfg = ref_cfg.MedusaConfig(
+        medusa_num_heads=cfg.medusa_num_heads, medusa_num_layers=1, medusa_hidden_size=cfg.d_model,
+        whisper_model_name="dummy", medusa_choices=[1] * (cfg.medusa_num_heads + 1),
+        medusa_heads_type="base_head")
+    model = ref_model.WhisperMedusaModel(mcfg).eval()
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all("proj_out" in m or "embed_positions" in m for m in missing), missing
+    return model
+
+
+def hf_processors(gp: GenParams):
+    from transformers.generation.logits_process import (
+        LogitsProcessorList, SuppressTokensLogitsProcessor, SuppressTokensAtBeginLogitsProcessor,
+        ExponentialDecayLengthPenalty)
+    procs = []
+    if gp.exp_decay is not None:                     # HF default list first (model.py:1106-1116)
+        procs.append(ExponentialDecayLengthPenalty(gp.exp_decay, gp.eos_token_id, len(gp.prompt)))
+    if gp.begin_suppress_tokens:                     # model.py:1188-1199 prepends begin-suppress ...
+        procs.append(SuppressTokensAtBeginLogitsProcessor(gp.begin_suppress_tokens, begin_index=len(gp.prompt)))
+    if gp.suppress_tokens:                           # ... in front of suppress (model.py:1177-1186)
+        procs.append(SuppressTokensLogitsProcessor(gp.suppress_tokens))
+    return LogitsProcessorList(procs)
+
+
+@torch.no_grad()
+def ref_medusa_loop(model, mu, enc, gp: GenParams, K: int):
+    """Semi-live end-to-end run: reference forward() + reference candidates/posterior; the glue
+    below restates model.py:634-793 (SURVEY.md §8c 'semi-live oracle')."""
+    procs = hf_processors(gp)
+    buffers = mu.generate_medusa_buffers([1] * (K + 1), device="cpu")
+    ids = torch.tensor([gp.prompt], dtype=torch.long)
+    accepts, first_logits = [], None
+    while True:
+        L = ids.shape[1]
+        out = model(encoder_outputs=(enc[None],), decoder_input_ids=ids, use_cache=False, return_dict=True)
+        logits = out.logits[:, :, -1:, :]                                   # [K+1, 1, 1, V] last row only
+        if first_logits is None:
+            first_logits = logits[:, 0, 0].clone()
+        orig = procs(ids, logits[0].squeeze(0)).unsqueeze(0)                # model.py:653-655
+        med = procs(ids, logits[1:].reshape(K, -1)).reshape(K, 1, 1, -1)    # model.py:656-665
+        cands, tree_cands = mu.generate_candidates(med, orig, [1] * K, buffers["tree_indices"])
+        full = torch.cat([ids, tree_cands], dim=1)                          # cache-free verify pass
+        vout = model(encoder_outputs=(enc[None],), decoder_input_ids=full, use_cache=False,
+                     return_dict=True, disable_medusa=True)
+        tree_logits = vout.logits[0][0, L:][buffers["retrieve_indices"]]    # medusa_utils.py:518-521
+        proc = procs(ids, tree_logits.reshape(K + 1, -1)).reshape(1, K + 1, -1)
+        best, a = mu.evaluate_posterior(proc, cands, gp.temperature, gp.posterior_threshold, gp.posterior_alpha)
+        a = int(a)
+        nxt = cands[None, best, : a + 1]
+        if a == 0:                                                          # medusa_utils.py:636-641
+            nxt = torch.cat([nxt, torch.argmax(proc[None, best, 0], dim=-1).unsqueeze(0)], dim=-1)
+        ids = torch.cat([ids, nxt], dim=-1)
+        accepts.append(a)
+        L = ids.shape[1]
+        if (nxt == gp.eos_token_id).any() or L >= gp.max_length or L + K >= gp.hard_max_length:
+            break
+    ids = ids[0].tolist()
+    if gp.eos_token_id in ids:                                              # post-EOS overwrite, model.py:798-810
+        j = ids.index(gp.eos_token_id)
+        ids = ids[: j + 1] + [gp.eos_token_id] * (len(ids) - j - 1)
+    return ids, accepts, first_logits
+
+
+def golden_medusa_utils(mu):
+    """Known-answer vectors from the reference's medusa_utils."""
+    out = {}
+    b = mu.generate_medusa_buffers([1] * 11, device="cpu")
+    out["buf11_tree_indices"] = b["tree_indices"].numpy()
+    out["buf11_retrieve_indices"] = b["retrieve_indices"].numpy()
+    out["buf11_position_ids"] = b["medusa_position_ids"].numpy()
+    b = mu.generate_medusa_buffers([1, 3, 2], device="cpu")
+    out["buf132_retrieve_indices"] = b["retrieve_indices"].numpy()
+    g = torch.Generator().manual_seed(1234)
+    V, K = 257, 6
+    cases_logits, cases_cand, acc_typ, acc_greedy = [], [], [], []
+    for case in range(24):
+        sharp = [0.5, 2.0, 6.0, 12.0][case % 4]
+        logits = torch.randn(K + 1, V, generator=g) * sharp
+        cand = torch.randint(0, V, (K + 1,), generator=g)
+        n_agree = case % (K + 1)
+        am = torch.argmax(logits[:-1], dim=-1)
+        cand[1: 1 + n_agree] = am[:n_agree]                      # first n_agree candidates are the argmax
+        for temp, store in ((1.0, acc_typ), (0.0, acc_greedy)):
+            best, a = mu.evaluate_posterior(logits[None], cand[None], temp, 0.09, 0.3)
+            assert int(best) == 0
+            store.append(int(a))
+        cases_logits.append(logits.numpy())
+        cases_cand.append(cand.numpy())
+    out["post_logits"] = np.stack(cases_logits).astype(np.float32)
+    out["post_cand"] = np.stack(cases_cand)
+    out["post_accept_typical"] = np.array(acc_typ)
+    out["post_accept_greedy"] = np.array(acc_greedy)
+    # candidates: argmax of base row + top-1 of every head row
+    base = torch.randn(1, 1, V, generator=g)
+    med = torch.randn(K, 1, 1, V, generator=g)
+    b = mu.generate_medusa_buffers([1] * (K + 1), device="cpu")
+    c, tc = mu.generate_candidates(med, base, [1] * K, b["tree_indices"])
+    out["cand_base"], out["cand_med"] = base.numpy(), med.numpy()
+    out["cand_out"], out["cand_tree_out"] = c.numpy(), tc.numpy()
+    return out
+
+
+def gen_params_for(cfg, mode, max_new, suppress_eos=True, exp_decay=(6, 1.3)):
+    prompt = synth.default_prompt(cfg)
+    sup = [cfg.eos_token_id] if suppress_eos else []
+    return GenParams(prompt=prompt, eos_token_id=cfg.eos_token_id, pad_token_id=cfg.pad_token_id,
+                     suppress_tokens=sorted(set(sup + [3, 5])), begin_suppress_tokens=list(cfg.begin_suppress_tokens),
+                     max_length=min(len(prompt) + max_new, cfg.max_target_positions),
+                     hard_max_length=cfg.max_length, exp_decay=exp_decay,
+                     accept_mode=mode, temperature=1.0 if mode == ACCEPT_TYPICAL else 0.0)
+
+
+def golden_model(tag, cfg, seed, mu, max_new):
+    """Reference forward()/loop outputs for one seeded Medusa-Linear checkpoint."""
+    sd = synth.synth_state_dict(cfg, seed=seed)
+    model = build_ref_linear(cfg, sd)
+    orc = Oracle(cfg, sd, sim="fp32")
+    wav = synth.synth_clip(0, n_samples=cfg.n_mel_frames * 160)
+    feats = torch.from_numpy(log_mel(wav, cfg.num_mel_bins, cfg.n_mel_frames * 160))
+    with torch.no_grad():
+        enc = model.whisper_model.model.encoder(feats[None]).last_hidden_state[0]      # HF encoder, reference weights
+    out = {f"{tag}_enc_probe": enc[::max(1, enc.shape[0] // 8), :16].numpy()}
+    K = cfg.medusa_num_heads
+    for mode, mname in ((ACCEPT_TYPICAL, "typical"), (ACCEPT_GREEDY, "greedy")):
+        for eos_free, ename in ((True, "noeos"), (False, "eos")):
+            gp = gen_params_for(cfg, mode, max_new, suppress_eos=eos_free)
+            ids, accepts, first_logits = ref_medusa_loop(model, mu, enc, gp, K)
+            key = f"{tag}_{mname}_{ename}"
+            out[key + "_ids"] = np.array(ids)
+            out[key + "_accepts"] = np.array(accepts)
+            if mode == ACCEPT_TYPICAL and eos_free:
+                out[f"{tag}_first_logits_probe"] = first_logits[:, :64].numpy()
+            # self-check: oracle must reproduce the reference run token for token
+            r = orc.decode(enc, gp)
+            assert r.ids[: len(ids)] == ids and r.accept_lengths == accepts, (key, r.ids, ids, r.accept_lengths, accepts)
+            print(f"  {key}: {len(ids) - len(gp.prompt)} tokens, accepts {accepts}")
+    return out
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    mu = load_ref_medusa_utils()
+    np.savez_compressed(os.path.join(GOLD, "medusa_utils_kat.npz"), **golden_medusa_utils(mu))
+    print("medusa_utils known-answer vectors written")
+    out = {}
+    out.update(golden_model("micro", MedusaConfig.micro(K=4), 11, mu, max_new=40))
+    out.update(golden_model("micro10", MedusaConfig.micro(K=10, d_model=128, layers=2), 12, mu, max_new=40))
+    out.update(golden_model("tiny", MedusaConfig.tiny_en(K=4), 0, mu, max_new=24))
+    np.savez_compressed(os.path.join(GOLD, "reference_linear_runs.npz"), **out)
+    print("reference forward()/loop vectors written")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,366 @@
+"""CPU ORACLE for the Whisper-Medusa hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg
+may import this module; the product (``whisper-medusa_amd/``) never does.
+
+It is a plain-PyTorch (CPU, fp32) restatement of the reference algorithm
+(aiola-lab/whisper-medusa @ 2025-03-04) with the HuggingFace generation glue collapsed,
+following SURVEY.md Appendix A.  Each function cites the reference ``file:line`` it
+follows (paths relative to ``/root/reference/whisper_medusa``) or, where the arithmetic
+lives in the un-vendored dependency ``transformers==4.49.0`` (requirements.txt:7), the
+installed copy ``HF:models/whisper/modeling_whisper.py`` (transformers 5.15; the layer
+math is unchanged between the two).
+
+PINNING.  The reference holds no tests, golden vectors or fixtures for this path
+ and cannot run end-to-end on the installed transformers.  The
+oracle is pinned instead against outputs of the reference's *own code* run in the
+build container by ``oracle/make_golden.py``:
+  * ``medusa_utils.generate_medusa_buffers / generate_candidates / evaluate_posterior``
+    imported live from ``/root/reference`` (both acceptance branches);
+  * the reference's own ``WhisperMedusaModel.forward()`` (Medusa-Linear) under import
+    stubs, driven cache-free, single passes and a full decode loop;
+  * HF 5.15 ``WhisperEncoder`` / ``WhisperDecoderLayer`` / ``WhisperFeatureExtractor`` /
+    logits processors with shared seeded weights (also re-checked live in tests/).
+Medusa-Block ``forward`` of the reference crashes under transformers 5.x
+(model.py:1364-1380), so the Block head path is pinned only through the HF decoder
+layer and the Linear path: parity for Block is "restated, partially pinned".
+
+NUMERICS.  ``sim="fp32"`` is the reference's default dtype.  ``sim="bf16"`` mirrors
+the engine's storage/rounding contract: parameters are
+bf16-representable, every GEMM input is rounded to bf16, the self/cross KV cache and
+the encoder output are stored in bf16, and all accumulation / LayerNorm / softmax /
+residual arithmetic is fp32.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HEAD_DIM = 64
+
+
+def _bf16(x: torch.Tensor) -> torch.Tensor:
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+# --------------------------------------------------------------------------------------
+# F0  log-mel front end  (HF:models/whisper/feature_extraction_whisper.py:95-133, called at
+#     eval_whisper_medusa.py:46-50 / README.md:129)
+# --------------------------------------------------------------------------------------
+def _hz_to_mel_slaney(f):
+    f = np.asarray(f, dtype=np.float64)
+    mel = 3.0 * f / 200.0
+    min_log_hz, min_log_mel, logstep = 1000.0, 15.0, 27.0 / np.log(6.4)
+    return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-10) / min_log_hz) * logstep, mel)
+
+
+def _mel_to_hz_slaney(m):
+    m = np.asarray(m, dtype=np.float64)
+    f = 200.0 * m / 3.0
+    min_log_hz, min_log_mel, logstep = 1000.0, 15.0, np.log(6.4) / 27.0
+    return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f)
+
+
+def mel_filter_bank(n_mels: int = 80, n_fft: int = 400, sr: int = 16000, fmax: float = 8000.0) -> np.ndarray:
+    """Slaney-scale, Slaney-normalised triangular filters, [n_fft//2+1, n_mels] float64
+    (HF ``mel_filter_bank(norm='slaney', mel_scale='slaney')``, feature_extraction_whisper.py:95-103)."""
+    n_freq = 1 + n_fft // 2
+    fft_freqs = np.linspace(0.0, sr // 2, n_freq)
+    mel_pts = np.linspace(_hz_to_mel_slaney(0.0), _hz_to_mel_slaney(fmax), n_mels + 2)
+    hz_pts = _mel_to_hz_slaney(mel_pts)
+    fdiff = np.diff(hz_pts)
+    slopes = hz_pts[None, :] - fft_freqs[:, None]
+    down = -slopes[:, :-2] / fdiff[:-1]
+    up = slopes[:, 2:] / fdiff[1:]
+    fb = np.maximum(0.0, np.minimum(down, up))
+    enorm = 2.0 / (hz_pts[2: n_mels + 2] - hz_pts[:n_mels])
+    return fb * enorm[None, :]
+
+
+def log_mel(wav: np.ndarray, n_mels: int = 80, n_samples: int = 480000) -> np.ndarray:
+    """wav [n] float -> [n_mels, n_samples/160] float32.  Pad/trim to ``n_samples``, reflect-pad
+    STFT (n_fft 400, hop 160, periodic Hann), power, drop the last frame, mel, log10, clamp
+    to max-8, (x+4)/4.  (feature_extraction_whisper.py:105-133)"""
+    n_fft, hop = 400, 160
+    w = np.zeros(n_samples, dtype=np.float64)
+    n = min(len(wav), n_samples)
+    w[:n] = np.asarray(wav[:n], dtype=np.float64)
+    w = np.pad(w, (n_fft // 2, n_fft // 2), mode="reflect")
+    n_frames = 1 + (len(w) - n_fft) // hop
+    idx = np.arange(n_fft)[None, :] + hop * np.arange(n_frames)[:, None]
+    window = 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n_fft) / n_fft)       # periodic Hann
+    spec = np.fft.rfft(w[idx] * window[None, :], axis=1)                      # [frames, 201]
+    power = (spec.real ** 2 + spec.imag ** 2)[:-1]                            # drop last frame
+    mel = power @ mel_filter_bank(n_mels, n_fft)                              # [frames-1, n_mels]
+    logs = np.log10(np.maximum(mel, 1e-10))
+    logs = np.maximum(logs, logs.max() - 8.0)
+    return ((logs + 4.0) / 4.0).T.astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------
+# F7  logits processors  (model.py:1168-1207 build order; HF generation/logits_process.py
+#     :1678-1775 exp-decay, :1851-1866 begin-suppress, :1898-1906 suppress)
+# --------------------------------------------------------------------------------------
+def process_logits(scores: torch.Tensor, cur_len: int, gp) -> torch.Tensor:
+    """Apply the processor list to rows ``scores [R, V]``.  Every row sees the SAME
+    ``cur_len`` = ``input_ids.shape[-1]`` before the update (model.py:653-665,689-694).
+    Order = HF default processors (exp-decay) then the Whisper ones the reference prepends
+    to the user list: begin-suppress, suppress (model.py:1177-1199)."""
+    s = scores.clone()
+    if gp.exp_decay is not None:
+        start = gp.exp_decay[0] + len(gp.prompt)          # regulation_start, logits_process.py:1752
+        if cur_len > start:
+            e = gp.eos_token_id
+            s[:, e] = s[:, e] + s[:, e].abs() * (pow(gp.exp_decay[1], cur_len - start) - 1.0)
+    if gp.begin_suppress_tokens and cur_len == gp.begin_index:
+        s[:, list(gp.begin_suppress_tokens)] = -float("inf")
+    if gp.suppress_tokens:
+        s[:, list(gp.suppress_tokens)] = -float("inf")
+    return s
+
+
+# --------------------------------------------------------------------------------------
+# F11  accept / reject for a chain tree  (medusa_utils.py:526-588 with n_candidates == 1)
+# --------------------------------------------------------------------------------------
+def evaluate_posterior_chain(v: torch.Tensor, cand: torch.Tensor, gp) -> Tuple[int, dict]:
+    """``v [K+1, V]`` processed verify logits, ``cand [K+1]`` candidate tokens.  Returns the
+    accept length ``a`` (number of leading accepted candidates c_1..c_K)."""
+    K = cand.numel() - 1
+    dbg = {}
+    if gp.accept_mode == 0 or gp.temperature == 0:                       # :547-560
+        ok = (cand[1:] == torch.argmax(v[:-1], dim=-1))
+    else:                                                                # :562-577
+        p = torch.softmax(v[:-1] / gp.temperature, dim=-1)
+        p_c = torch.gather(p, -1, cand[1:].unsqueeze(-1)).squeeze(-1)
+        H = -torch.sum(p * torch.log(p + 1e-5), dim=-1)
+        thr = torch.minimum(torch.full_like(H, gp.posterior_threshold), torch.exp(-H) * gp.posterior_alpha)
+        ok = p_c > thr
+        dbg = dict(p_c=p_c, H=H, thr=thr)
+    a = int(torch.cumprod(ok.int(), dim=0).sum().item())
+    return a, dbg
+
+
+@dataclass
+class DecodeResult:
+    ids: List[int]                      # prompt + emitted tokens, post-EOS overwrite applied
+    new_tokens: List[int]               # ids[P:] up to (excluding) the first EOS  -> the parity object
+    accept_lengths: List[int] = field(default_factory=list)
+    n_iters: int = 0
+    trace: List[dict] = field(default_factory=list)
+
+
+class Oracle:
+    """Functional Whisper-Medusa over a plain state dict (reference key layout)."""
+
+    def __init__(self, cfg, sd: Dict[str, torch.Tensor], sim: str = "fp32"):
+        assert sim in ("fp32", "bf16")
+        self.cfg, self.sim = cfg, sim
+        self.sd = {k: v.detach().to(torch.float32).cpu() for k, v in sd.items()}
+        self.H = cfg.d_model // HEAD_DIM
+        if "whisper_model.proj_out.weight" not in self.sd:
+            self.sd["whisper_model.proj_out.weight"] = self.sd["whisper_model.model.decoder.embed_tokens.weight"]
+
+    # ---- small helpers --------------------------------------------------------------
+    def _r(self, x):           # rounding point of the engine contract
+        return _bf16(x) if self.sim == "bf16" else x
+
+    def _lin(self, x, prefix, bias=True):
+        y = self._r(x) @ self.sd[prefix + ".weight"].t()
+        if bias and (prefix + ".bias") in self.sd:
+            y = y + self.sd[prefix + ".bias"]
+        return y
+
+    def _ln(self, x, prefix):
+        return F.layer_norm(x, (x.shape[-1],), self.sd[prefix + ".weight"], self.sd[prefix + ".bias"], 1e-5)
+
+    def _heads(self, x):       # [T, d] -> [H, T, 64]
+        return x.view(x.shape[0], self.H, HEAD_DIM).transpose(0, 1)
+
+    def _attend(self, q, k, v, mask=None, round_p=False):
+        """q [H,T,64] (already scaled), k/v [H,S,64] -> [T, d].  Softmax in fp32
+        (HF:modeling_whisper.py:214-238)."""
+        w = q @ k.transpose(1, 2)
+        if mask is not None:
+            w = w + mask
+        w = torch.softmax(w, dim=-1)
+        if round_p:
+            w = self._r(w)
+        o = w @ v
+        return o.transpose(0, 1).reshape(q.shape[1], -1)
+
+    # ---- F1 encoder (HF:modeling_whisper.py:592-646; layer :360-413) --------------------
+    def encode(self, feats: torch.Tensor) -> torch.Tensor:
+        """feats [n_mels, 2*S] fp32 -> encoder output [S, d]."""
+        sd, p = self.sd, "whisper_model.model.encoder"
+        x = self._r(feats.to(torch.float32))[None]
+        x = F.gelu(F.conv1d(x, sd[p + ".conv1.weight"], sd[p + ".conv1.bias"], padding=1))
+        x = F.gelu(F.conv1d(self._r(x), sd[p + ".conv2.weight"], sd[p + ".conv2.bias"], stride=2, padding=1))
+        h = x[0].t() + sd[p + ".embed_positions.weight"]
+        for i in range(self.cfg.encoder_layers):
+            lp = f"{p}.layers.{i}"
+            xn = self._ln(h, lp + ".self_attn_layer_norm")
+            q = self._r(self._lin(xn, lp + ".self_attn.q_proj") * HEAD_DIM ** -0.5)
+            k = self._r(self._lin(xn, lp + ".self_attn.k_proj", bias=False))
+            v = self._r(self._lin(xn, lp + ".self_attn.v_proj"))
+            a = self._attend(self._heads(q), self._heads(k), self._heads(v), round_p=True)
+            h = h + self._lin(a, lp + ".self_attn.out_proj")
+            xn = self._ln(h, lp + ".final_layer_norm")
+            h = h + self._lin(F.gelu(self._lin(xn, lp + ".fc1")), lp + ".fc2")
+        return self._r(self._ln(h, p + ".layer_norm"))
+
+    # ---- F2 cross-KV projection (HF:modeling_whisper.py:322-335; Block: model.py:1382-1393) -----
+    def _kv_layer_prefixes(self) -> List[str]:
+        ps = [f"whisper_model.model.decoder.layers.{i}" for i in range(self.cfg.decoder_layers)]
+        if self.cfg.is_block:
+            ps.append("medusa_block")                     # cache slot L, model.py:248-256
+        return ps
+
+    def cross_kv(self, enc: torch.Tensor):
+        out = []
+        for lp in self._kv_layer_prefixes():
+            k = self._r(self._lin(enc, lp + ".encoder_attn.k_proj", bias=False))
+            v = self._r(self._lin(enc, lp + ".encoder_attn.v_proj"))
+            out.append((self._heads(k), self._heads(v)))
+        return out
+
+    # ---- F3 decoder layer (HF:modeling_whisper.py:416-505) ------------------------------
+    def _dec_layer(self, lp, h, slot, st, T):
+        kv_len = st["kv_len"]
+        xn = self._ln(h, lp + ".self_attn_layer_norm")
+        q = self._lin(xn, lp + ".self_attn.q_proj") * HEAD_DIM ** -0.5
+        k = self._r(self._lin(xn, lp + ".self_attn.k_proj", bias=False))
+        v = self._r(self._lin(xn, lp + ".self_attn.v_proj"))
+        kc, vc = st["self_kv"][slot]
+        kc = torch.cat([kc[:, :kv_len], self._heads(k)], dim=1)      # contiguous cache: rows kv_len.. overwritten
+        vc = torch.cat([vc[:, :kv_len], self._heads(v)], dim=1)
+        st["self_kv"][slot] = (kc, vc)
+        mask = torch.full((T, kv_len + T), 0.0)
+        mask[:, kv_len:] = torch.triu(torch.full((T, T), -float("inf")), diagonal=1)
+        a = self._attend(self._heads(q), kc, vc, mask)
+        h = h + self._lin(a, lp + ".self_attn.out_proj")
+        xn = self._ln(h, lp + ".encoder_attn_layer_norm")
+        q = self._lin(xn, lp + ".encoder_attn.q_proj") * HEAD_DIM ** -0.5
+        kx, vx = st["cross_kv"][slot]
+        a = self._attend(self._heads(q), kx, vx)
+        h = h + self._lin(a, lp + ".encoder_attn.out_proj")
+        xn = self._ln(h, lp + ".final_layer_norm")
+        h = h + self._lin(F.gelu(self._lin(xn, lp + ".fc1")), lp + ".fc2")
+        return h
+
+    def new_state(self, enc: torch.Tensor) -> dict:
+        empty = torch.zeros(self.H, 0, HEAD_DIM)
+        return dict(cross_kv=self.cross_kv(enc), kv_len=0,
+                    self_kv=[(empty, empty) for _ in range(self.cfg.n_kv_layers)])
+
+    def _res_head(self, k, x):
+        """MedusaResBlock: x + SiLU(W x + b)  (model.py:180-210)."""
+        return x + F.silu(self._lin(x, f"medusa_heads.{k}.0.linear"))
+
+    def _vocab(self, y):
+        return self._r(y) @ self.sd["whisper_model.proj_out.weight"].t()       # tied, no bias (model.py:1277)
+
+    def decoder_pass(self, st: dict, tokens: List[int], pos0: int, disable_medusa: bool,
+                     last_only: bool = False) -> torch.Tensor:
+        """One forward of WhisperMedusaModel (model.py:1223-1347 / 1349-1417) over ``tokens`` at
+        positions ``pos0..``; appends T rows to every self-KV slot at ``st['kv_len']``.
+        Returns stacked logits [n_heads_out, T, V] (n_heads_out = 1 if disable_medusa else K+1).
+        Does NOT advance ``kv_len`` (the caller applies the F13 keep rule)."""
+        sd, cfg, p = self.sd, self.cfg, "whisper_model.model.decoder"
+        T = len(tokens)
+        ids = torch.tensor(tokens, dtype=torch.long)
+        h = sd[p + ".embed_tokens.weight"][ids] + sd[p + ".embed_positions.weight"][pos0: pos0 + T]
+        for i in range(cfg.decoder_layers):
+            h = self._dec_layer(f"{p}.layers.{i}", h, i, st, T)
+        hf = self._ln(h, p + ".layer_norm")                       # post-final-LN state (model.py:1262)
+        rows = hf[-1:] if last_only else hf
+        K = cfg.medusa_num_heads
+        if not cfg.is_block:                                      # Medusa-Linear, model.py:1274-1284
+            n = 1 if disable_medusa else K + 1
+            return torch.stack([self._vocab(self._res_head(k, rows)) for k in range(n)])
+        out = [self._vocab(rows)]                                 # Medusa-Block base logits, model.py:1287
+        g = self._dec_layer("medusa_block", hf, cfg.decoder_layers, st, T)   # on post-LN state, model.py:1382-1393
+        if not disable_medusa:                                    # model.py:1410-1417
+            g_rows = g[-1:] if last_only else g
+            out += [self._vocab(self._res_head(k, g_rows)) for k in range(K)]
+        return torch.stack(out)
+
+    # ---- the decode loop (model.py:634-810) --------------------------
+    @torch.no_grad()
+    def decode(self, enc: torch.Tensor, gp, trace: bool = False, max_iters: Optional[int] = None) -> DecodeResult:
+        if gp.vanilla:
+            return self._decode_vanilla(enc, gp, max_iters)
+        cfg = self.cfg
+        K, P, eos = cfg.medusa_num_heads, len(gp.prompt), gp.eos_token_id
+        st = self.new_state(enc)
+        ids = list(gp.prompt)
+        res = DecodeResult(ids=[], new_tokens=[])
+        finished = False
+        while not finished:
+            L, kv = len(ids), st["kv_len"]
+            # (a) base pass over ids[kv:L]                                         model.py:639-648
+            z = self.decoder_pass(st, ids[kv:L], kv, disable_medusa=False, last_only=True)[:, 0]   # [K+1, V]
+            st["kv_len"] = L
+            z = process_logits(z, L, gp)                                          # model.py:653-665
+            cand = torch.argmax(z, dim=-1)                                        # medusa_utils.py:446-458 (top-1 chain)
+            # (d) verify pass over the K+1 candidates at positions L..L+K         medusa_utils.py:494-521
+            v = self.decoder_pass(st, cand.tolist(), L, disable_medusa=True)[0]   # [K+1, V]
+            v = process_logits(v, L, gp)                                          # model.py:689-694 (same L for all rows)
+            a, dbg = evaluate_posterior_chain(v, cand, gp)                        # model.py:697-703
+            if a == 0:                                                            # model.py:710-713, medusa_utils.py:636-641
+                emit = [int(cand[0]), int(torch.argmax(v[0]))]
+                st["kv_len"] = L + 1                                              # model.py:388-392 keep [:a+1]
+            else:
+                emit = [int(t) for t in cand[: a + 1]]
+                st["kv_len"] = L + a                                              # keep [:a]
+            ids += emit
+            res.accept_lengths.append(a)
+            res.n_iters += 1
+            if trace:
+                res.trace.append(dict(L=L, cand=cand.clone(), z_top=z.max(dim=-1).values.clone(),
+                                      v=v.clone(), a=a, emit=list(emit), **dbg))
+            L = len(ids)
+            # (j) stop rules                                                      model.py:774-793
+            finished = (eos in emit) or (L >= gp.max_length) or (L + K >= gp.hard_max_length)
+            if max_iters is not None and res.n_iters >= max_iters:
+                break
+        return self._finish(res, ids, P, eos)
+
+    def _decode_vanilla(self, enc, gp, max_iters=None) -> DecodeResult:
+        """Anchor: plain greedy decoding on head 0 / base logits, one token per pass."""
+        P, eos = len(gp.prompt), gp.eos_token_id
+        st = self.new_state(enc)
+        ids = list(gp.prompt)
+        res = DecodeResult(ids=[], new_tokens=[])
+        while True:
+            L, kv = len(ids), st["kv_len"]
+            z = self.decoder_pass(st, ids[kv:L], kv, disable_medusa=True, last_only=True)[0]
+            st["kv_len"] = L
+            tok = int(torch.argmax(process_logits(z, L, gp)[0]))
+            ids.append(tok)
+            res.n_iters += 1
+            if tok == eos or len(ids) >= gp.max_length or (max_iters is not None and res.n_iters >= max_iters):
+                break
+        return self._finish(res, ids, P, eos)
+
+    @staticmethod
+    def _finish(res, ids, P, eos):
+        # post-EOS overwrite (model.py:798-810)
+        if eos in ids:
+            j = ids.index(eos)
+            ids = ids[: j + 1] + [eos] * (len(ids) - j - 1)
+        res.ids = ids
+        gen = ids[P:]
+        res.new_tokens = gen[: gen.index(eos)] if eos in gen else gen
+        return res
+
+    @torch.no_grad()
+    def transcribe(self, wav: np.ndarray, gp, **kw) -> DecodeResult:
+        """log-mel -> encoder -> Medusa decode for one clip (reference README.md:120-139)."""
+        cfg = self.cfg
+        feats = torch.from_numpy(log_mel(wav, cfg.num_mel_bins, cfg.n_mel_frames * 160))
+        return self.decode(self.encode(feats), gp, **kw)
