@@ -1,0 +1,196 @@
+"""bench.py — headline benchmark of the MI355X Whisper-Medusa engine (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+One STEP = one pass of the whole hot path over one batch of synthetic 30 s clips per GPU:
+log-mel -> Whisper-large-v2 encoder + cross-KV projection -> Medusa-Linear-10 decode loop
+(base pass + verify pass + typical acceptance, replayed from a hipGraph) to a fixed budget of
+128 new tokens per stream with EOS suppressed.  Clips are resident in HBM before
+the timed region.  Streams shard data-parallel over ranks (no data-path collective); weights are
+packed on rank 0 and broadcast once over RCCL (outside the timed region).
+
+Prints ONE JSON line on rank 0: whole-job decoded tokens/s (+ RTF, iterations/s, tokens/iteration,
+the vanilla-greedy anchor), a `roofline` object for the decode iteration (algorithmic bytes of
+SURVEY.md §8d / hipEvent-timed iteration) and a `cpu_baseline` object (the oracle on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "whisper-medusa_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def decode_iter_bytes(cfg, B, mean_len):
+    """Algorithmic HBM bytes of one Medusa iteration: weights of the base pass (K+1 heads)
+    + weights of the verify pass (1 head) + per stream 2 x cross-KV + self-KV read in both passes."""
+    d, f, L, V, K = cfg.d_model, cfg.decoder_ffn_dim, cfg.decoder_layers, cfg.vocab_size, cfg.medusa_num_heads
+    layer = 6 * d * d + 2 * d * f            # q,k,v,out, cross-q, cross-out + fc1, fc2 (cross k/v proj not re-read)
+    if cfg.is_block:
+        w_a = (L + 1) * layer + V * d + K * d * d
+        w_v = L * layer + V * d + 3 * d * d  # block runs only its qkv projection in the verify pass
+        nkv = L + 1
+    else:
+        w_a = L * layer + V * d + (K + 1) * d * d
+        w_v = L * layer + V * d + d * d
+        nkv = L
+    X = nkv * 2 * cfg.max_source_positions * d * 2
+    skv = 2 * (nkv * 2 * mean_len * d * 2)
+    return 2.0 * (w_a + w_v) + B * (2.0 * X + skv)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=1, help="streams per GPU (BASELINE configs[1] = 1)")
+    ap.add_argument("--heads", default="linear", choices=["linear", "block"])
+    ap.add_argument("--model", default="large-v2", choices=["large-v2", "tiny.en", "micro"])
+    ap.add_argument("--max-new", type=int, default=128)
+    ap.add_argument("--logit-std", type=float, default=1.5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=6)
+    args = ap.parse_args()
+
+    from whisper_medusa import MedusaConfig, WhisperMedusaModel, ACCEPT_TYPICAL
+    from whisper_medusa import synth, weights, dist as wd
+
+    rank, local, world = wd.init_from_env()
+    assert world == args.gpus or (world == 1 and args.gpus == 1), f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs a HIP device: the engine has no CPU path")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    heads = "medusa_block" if args.heads == "block" else "base_head"
+    if args.model == "large-v2":
+        cfg = MedusaConfig.large_v2(heads, K=10)
+    elif args.model == "tiny.en":
+        cfg = MedusaConfig.tiny_en(heads, K=4)
+    else:
+        cfg = MedusaConfig.micro(heads_type=heads, K=4)
+    B = args.batch
+
+    # ---- weights: rank 0 builds the packed blob, RCCL broadcast over xGMI (one time, untimed) ----
+    blob = offs = sd = None
+    if rank == 0:
+        sd = synth.synth_state_dict(cfg, seed=0, device=str(dev), logit_std=args.logit_std)
+        blob, offs = weights.build_blob(cfg, sd, device=dev)
+    t0 = time.time()
+    blob, offs = wd.broadcast_blob(blob, offs, device=dev)
+    torch.cuda.synchronize()
+    t_bcast = time.time() - t0
+    model = WhisperMedusaModel.from_blob(cfg, blob, offs, max_batch=B)
+    eng = model.engine
+
+    # ---- inputs resident in HBM ----
+    n_samp = cfg.n_mel_frames * 160
+    wav = torch.from_numpy(np.stack([synth.synth_clip(rank * B + j, n_samp) for j in range(B)])).to(dev)
+    gp = synth.bench_gen_params(cfg, max_new_tokens=args.max_new, accept_mode=ACCEPT_TYPICAL)
+
+    def step():
+        feats = eng.logmel(wav)
+        eng.encode(feats)
+        seqs = eng.decode(gp, B)
+        st = eng.stats()
+        return sum(len(s) - len(gp.prompt) for s in seqs), st
+
+    for _ in range(args.warmup):
+        step()
+    wd.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tokens = 0
+    iters = 0
+    ms_dec = ms_enc = ms_mel = 0.0
+    hist = np.zeros(cfg.medusa_num_heads + 1, dtype=np.int64)
+    replays = 0
+    for _ in range(args.steps):
+        n, st = step()
+        tokens += n
+        iters += st["iterations"]
+        ms_dec += st["ms_decode"]; ms_enc += st["ms_encode"]; ms_mel += st["ms_logmel"]
+        hist += np.asarray(st["accept_hist"], dtype=np.int64)
+        replays += st["graph_replays"]
+    torch.cuda.synchronize()
+    wd.barrier()
+    elapsed = wd.max_over_ranks(time.perf_counter() - t0, dev)
+    tokens_all = wd.sum_over_ranks(float(tokens), dev)
+
+    # ---- anchor: vanilla greedy decoding on the same engine / clips / budget (one untimed-region step) ----
+    gpv = synth.bench_gen_params(cfg, max_new_tokens=args.max_new, vanilla=True)
+    eng.decode(gpv, B)                       # warm
+    eng.decode(gpv, B)
+    stv = eng.stats()
+    vanilla_tps = B * args.max_new / (stv["ms_decode"] * 1e-3)
+    vanilla_ms_step = stv["ms_decode"] / max(stv["iterations"], 1)
+
+    if rank != 0:
+        return
+
+    t_iter_ms = ms_dec / max(iters, 1)
+    mean_len = len(gp.prompt) + args.max_new / 2
+    bytes_iter = decode_iter_bytes(cfg, B, mean_len)
+    achieved = bytes_iter / (t_iter_ms * 1e-3) / 1e9
+    gemm_ms, gemm_bytes = eng.profile_layer_gemms(rows=min(32, B * (cfg.medusa_num_heads + 1)), reps=50)
+    audio_s = args.steps * B * world * 30.0 * cfg.max_source_positions / 1500.0
+    tok_per_iter = tokens / max(iters, 1) / B
+    out = {
+        "metric": "decoded_tokens_per_sec", "value": round(tokens_all / elapsed, 2), "unit": "tokens/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"whisper-{args.model} + medusa-{args.heads} K={cfg.medusa_num_heads}, "
+                               f"{B} x 30 s clip(s) per GPU, log-mel+encoder+decode, max_new_tokens={args.max_new}, "
+                               f"typical acceptance (T=1.0), hipGraph decode loop, random-init weights (logit_std={args.logit_std})",
+                   "streams_per_gpu": B, "parallelism": f"dp{world}", "max_new_tokens": args.max_new},
+        "tokens_per_sec_per_gpu": round(tokens_all / elapsed / world, 2),
+        "rtf": round(elapsed / audio_s, 6), "x_realtime": round(audio_s / elapsed, 2),
+        "decode_tokens_per_sec_per_gpu": round(tokens / (ms_dec * 1e-3), 2),
+        "iters_per_sec": round(iters / (ms_dec * 1e-3), 2), "tokens_per_iter": round(tok_per_iter, 3),
+        "accept_hist": hist.tolist(), "graph_replays": int(replays),
+        "ms_logmel_per_step": round(ms_mel / args.steps, 3), "ms_encode_per_step": round(ms_enc / args.steps, 3),
+        "ms_decode_per_step": round(ms_dec / args.steps, 3), "weight_broadcast_s": round(t_bcast, 3),
+        "vanilla_anchor": {"tokens_per_sec_per_gpu": round(vanilla_tps, 2), "ms_per_token_step": round(vanilla_ms_step, 4),
+                           "medusa_over_vanilla": round(tokens / (ms_dec * 1e-3) / vanilla_tps, 3)},
+        "roofline": {"bound": "hbm", "kernel": "decode iteration (base pass + verify pass, one hipGraph launch)",
+                     "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
+                     "traffic": None, "bytes_per_launch": round(bytes_iter), "ms_per_launch": round(t_iter_ms, 4),
+                     "layer_gemms": {"rows": min(32, B * (cfg.medusa_num_heads + 1)), "ms": round(gemm_ms, 5),
+                                     "bytes": round(gemm_bytes), "achieved_gbs": round(gemm_bytes / (gemm_ms * 1e-3) / 1e9, 1)}},
+    }
+
+    # ---- CPU baseline: the oracle (a port of the reference algorithm) on the host cores, bounded sample ----
+    if not args.no_cpu_baseline and world == 1:
+        try:
+            from oracle.whisper_medusa_oracle import Oracle
+            torch.set_num_threads(os.cpu_count() or 1)
+            enc = eng.encoder_output(1)[0]
+            sd_cpu = {k: v.float().cpu() for k, v in sd.items()}
+            orc = Oracle(cfg, sd_cpu, sim="fp32")
+            tc = time.perf_counter()
+            r = orc.decode(enc, gp, max_iters=args.cpu_iters)
+            dt = time.perf_counter() - tc
+            ntok = len(r.ids) - len(gp.prompt)
+            out["cpu_baseline"] = {"value": round(ntok / dt, 3), "unit": "tokens/s", "cores": torch.get_num_threads(),
+                                   "kind": "port",
+                                   "sample": f"oracle (PyTorch CPU fp32 restatement of the reference loop) on clip 0: cross-KV "
+                                             f"projection + {args.cpu_iters} Medusa iterations ({ntok} tokens) from the GPU "
+                                             f"encoder output, {dt:.1f} s"}
+        except Exception as e:  # noqa: BLE001
+            out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
+                                   "sample": f"failed: {e!r}"}
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

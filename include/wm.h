@@ -1,0 +1,142 @@
+/* wm.h — C-ABI of libwm.so, the MI355X (gfx950) Whisper-Medusa inference engine.
+ *
+ * The reference (aiola-lab/whisper-medusa) is pure Python and has no FFI; its boundary for
+ * this path is the Python API `WhisperMedusaModel.from_pretrained()/generate()/forward()`
+ * (whisper_medusa/models/model.py:265-291, :1419-1779, :1223-1347).  The entry points below
+ * are what a native back end for that API binds; every declaration cites the reference
+ * interface it replaces.  The Python drop-in (whisper-medusa_amd/whisper_medusa/api.py)
+ * calls them through ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions: all functions return 0 on success, <0 on error (wm_last_error(ctx) gives the
+ * text; WM_ERR_* below).  Handles are opaque.  Pointers marked DEV are device (HBM)
+ * pointers, HOST are host pointers.  One context = one GPU + one HIP stream; a context is
+ * not thread-safe, distinct contexts are independent.  Nothing here takes a torch type.
+ */
+#ifndef WM_H_
+#define WM_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WM_ABI_VERSION 1
+
+#define WM_OK 0
+#define WM_ERR_ARG (-1)      /* bad argument / unsupported configuration (reference: ValueError, model.py:225-229) */
+#define WM_ERR_HIP (-2)      /* HIP runtime failure */
+#define WM_ERR_STATE (-3)    /* call sequence violated (e.g. decode before encode) */
+#define WM_ERR_NOMEM (-4)
+
+#define WM_HEADS_LINEAR 0    /* medusa_heads_type="base_head"   (model.py:235-246) */
+#define WM_HEADS_BLOCK 1     /* medusa_heads_type="medusa_block" (model.py:248-256) */
+
+#define WM_ACCEPT_GREEDY 0   /* temperature==0 branch, medusa_utils.py:547-560 */
+#define WM_ACCEPT_TYPICAL 1  /* temperature!=0 branch, medusa_utils.py:562-588 (what generate() runs, model.py:1877-1881) */
+
+typedef struct wm_ctx wm_ctx;
+
+/* Mirrors MedusaConfig + the Whisper dims it inherits (utils/config_and_args.py:17-62). */
+typedef struct wm_config {
+    int32_t abi_version;        /* = WM_ABI_VERSION */
+    int32_t d_model;            /* multiple of 64; head_dim is 64 */
+    int32_t enc_layers, dec_layers;
+    int32_t n_heads;            /* d_model / 64 (encoder == decoder) */
+    int32_t ffn_dim;            /* encoder_ffn_dim == decoder_ffn_dim */
+    int32_t vocab;
+    int32_t n_mels;             /* 80 */
+    int32_t n_ctx;              /* max_source_positions (1500): encoder frames per clip */
+    int32_t n_tgt;              /* max_target_positions (448) */
+    int32_t medusa_heads;       /* K = medusa_num_heads, <= 15; chain tree medusa_choices=[1]*(K+1) */
+    int32_t heads_type;         /* WM_HEADS_* */
+    int32_t max_batch;          /* streams the context is sized for */
+} wm_config;
+
+/* Packed parameter blob (layout: whisper_medusa/weights.py).  The blob
+ * stays owned by the caller and must outlive the context.  Replaces the state-dict load of
+ * model.py:273-278. */
+typedef struct wm_weights {
+    const void* blob;           /* DEV */
+    uint64_t blob_bytes;
+    const uint64_t* offsets;    /* HOST: byte offset of every tensor, canonical order */
+    int32_t n_offsets;
+} wm_weights;
+
+/* Per-call generation parameters: what generate() derives from generation_config
+ * (model.py:1168-1207 processors, :1635-1639 lengths, :774-793 stop rules,
+ * medusa_utils.py:14-18 posterior constants). */
+typedef struct wm_gen_params {
+    const int32_t* prompt;          /* HOST, decoder prompt ids (model.py:1519-1537) */
+    int32_t prompt_len;             /* P = begin_index */
+    int32_t eos_token_id, pad_token_id;
+    const int32_t* suppress;        /* HOST, SuppressTokensLogitsProcessor list */
+    int32_t n_suppress;
+    const int32_t* begin_suppress;  /* HOST, SuppressTokensAtBeginLogitsProcessor list */
+    int32_t n_begin_suppress;
+    int32_t max_length;             /* MaxLengthCriteria: stop when L >= max_length */
+    int32_t hard_max_length;        /* model.py:789-793: stop when L + K >= this */
+    int32_t exp_decay_start;        /* ExponentialDecayLengthPenalty start (relative to P); <0 = off */
+    float exp_decay_factor;
+    float posterior_threshold, posterior_alpha;   /* 0.09 / 0.3 */
+    float temperature;              /* divides verify logits in typical mode (1.0 via generate()) */
+    int32_t accept_mode;            /* WM_ACCEPT_* */
+    int32_t vanilla;                /* 1 = plain greedy decoding on the base head (anchor measurement) */
+} wm_gen_params;
+
+typedef struct wm_stats {
+    int64_t iterations;             /* decode iterations launched since wm_decode_begin */
+    int64_t tokens_emitted;         /* sum over streams of tokens appended after the prompt */
+    int64_t accept_hist[16];        /* histogram of accept length a (0..K), all streams */
+    float ms_logmel, ms_encode, ms_decode;   /* hipEvent-timed on the context's stream, last call of each */
+    int32_t graph_replays;          /* decode iterations that ran as hipGraph replays */
+} wm_stats;
+
+/* ---- lifecycle (replaces WhisperMedusaModel.from_pretrained / .to(device), model.py:265-291) ---- */
+int wm_create(const wm_config* cfg, const wm_weights* w, int device, void* hip_stream /* hipStream_t or NULL */,
+              wm_ctx** out);
+void wm_destroy(wm_ctx* ctx);
+const char* wm_last_error(const wm_ctx* ctx);     /* ctx may be NULL: last create error */
+int wm_abi_version(void);
+
+/* ---- F0 log-mel (replaces WhisperProcessor.__call__, eval_whisper_medusa.py:46-50) ----
+ * wav: DEV float32 [B][n_samples] already padded/trimmed to n_samples = 320*n_ctx (480000).
+ * feats: DEV float32 [B][n_mels][2*n_ctx]. */
+int wm_logmel(wm_ctx* ctx, const float* wav, int B, int n_samples, float* feats);
+
+/* ---- F1+F2 encoder and cross-KV projection (replaces the encoder call of
+ * _prepare_encoder_decoder_kwargs_for_generation, model.py:1005-1011, and the cross K/V
+ * projection hidden in the first decoder pass).  feats: DEV float32 [B][n_mels][2*n_ctx]. */
+int wm_encode(wm_ctx* ctx, const float* feats, int B);
+
+/* ---- F3..F14 the Medusa decode loop (replaces _medusa_greedy_search, model.py:404-835) ---- */
+int wm_decode_begin(wm_ctx* ctx, const wm_gen_params* gp, int B);
+/* Runs up to max_iters iterations (each = base pass + verify pass + accept), replayed from a
+ * hipGraph after the first; returns the number of unfinished streams in *n_unfinished. */
+int wm_decode_run(wm_ctx* ctx, int max_iters, int* n_unfinished);
+/* ids (prompt + generated, post-EOS overwrite of model.py:798-810 applied) of one stream. */
+int wm_get_tokens(wm_ctx* ctx, int stream, int32_t* out /* HOST */, int cap, int* n);
+int wm_get_stats(wm_ctx* ctx, wm_stats* out /* HOST */);
+int wm_sync(wm_ctx* ctx);
+
+/* ---- parity taps (test-only views of intermediate state; no reference equivalent except
+ * forward(), model.py:1223-1347) ---- */
+/* encoder output [B][n_ctx][d_model] as float32 to HOST */
+int wm_get_encoder_output(wm_ctx* ctx, int B, float* out /* HOST */);
+/* One decoder pass for stream 0..B-1 over T (<=16) tokens each at positions pos0.., appending
+ * K/V at kv row pos0; logits_out HOST float32 [n_out][B][T][vocab], n_out = 1 if disable_medusa
+ * else K+1 (all T rows, as forward() returns).  Does not touch the decode-loop state. */
+int wm_forward_logits(wm_ctx* ctx, int B, const int32_t* tokens /* HOST [B][T] */, int T, int pos0,
+                      int disable_medusa, float* logits_out);
+/* cross K/V of one kv-layer/stream/head: HOST float32 [n_ctx][64] each */
+int wm_get_cross_kv(wm_ctx* ctx, int kv_layer, int stream, int head, float* k_out, float* v_out);
+/* Times `reps` launches of one decode-path kernel class in its current shape with hipEvents on
+ * the context stream (bench.py roofline leg).  kernel: 0 = weight-streaming GEMM of one decoder
+ * layer pass (all 6 GEMMs), returns avg ms per rep in *ms and the algorithmic bytes in *bytes. */
+int wm_profile_kernel(wm_ctx* ctx, int kernel, int rows, int reps, float* ms, double* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WM_H_ */

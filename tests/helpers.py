@@ -1,0 +1,38 @@
+"""Shared test helpers: seeded checkpoints, clips and the GenParams used by the golden runs."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "whisper-medusa_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from whisper_medusa.config import MedusaConfig, GenParams, ACCEPT_TYPICAL, ACCEPT_GREEDY  # noqa: E402
+from whisper_medusa import synth  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+# (tag, config factory, checkpoint seed, max_new) — must match oracle/make_golden.py:main()
+GOLDEN_MODELS = {
+    "micro": (lambda: MedusaConfig.micro(K=4), 11, 40),
+    "micro10": (lambda: MedusaConfig.micro(K=10, d_model=128, layers=2), 12, 40),
+    "tiny": (lambda: MedusaConfig.tiny_en(K=4), 0, 24),
+}
+
+
+def golden_gen_params(cfg, mode, max_new, suppress_eos=True, exp_decay=(6, 1.3)):
+    """Same recipe as oracle/make_golden.py:gen_params_for."""
+    prompt = synth.default_prompt(cfg)
+    sup = [cfg.eos_token_id] if suppress_eos else []
+    return GenParams(prompt=prompt, eos_token_id=cfg.eos_token_id, pad_token_id=cfg.pad_token_id,
+                     suppress_tokens=sorted(set(sup + [3, 5])), begin_suppress_tokens=list(cfg.begin_suppress_tokens),
+                     max_length=min(len(prompt) + max_new, cfg.max_target_positions),
+                     hard_max_length=cfg.max_length, exp_decay=exp_decay,
+                     accept_mode=mode, temperature=1.0 if mode == ACCEPT_TYPICAL else 0.0)
+
+
+def clip_for(cfg, i=0):
+    return synth.synth_clip(i, n_samples=cfg.n_mel_frames * 160)

@@ -1,0 +1,168 @@
+"""Parity of the HIP engine (through the C-ABI) against the oracle on the same seeded inputs.
+Run on the GPU box:  python -m pytest tests -m gpu -x -q
+
+Tolerances (engine contract = oracle sim="bf16": bf16 GEMM operands / KV cache, fp32 everything else):
+  log-mel           |d| <= 2e-3 on values in [-1, 2]           (fp32 DFT vs float64 FFT)
+  encoder output    max |d| <= 0.12, mean |d| <= 6e-3 on O(1) values (bf16 rounding points can flip)
+  decoder logits    max |d| <= 6e-2, mean |d| <= 4e-3           (given the SAME encoder output)
+  token ids         bit-exact against the oracle run on the engine's encoder output
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import MedusaConfig, synth, golden_gen_params, clip_for, ACCEPT_TYPICAL, ACCEPT_GREEDY
+from oracle.whisper_medusa_oracle import Oracle, log_mel
+from whisper_medusa import WhisperMedusaModel
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = {
+    "micro": (lambda: MedusaConfig.micro(K=4), 11),
+    "micro10": (lambda: MedusaConfig.micro(K=10), 12),
+    "microblock": (lambda: MedusaConfig.micro(K=4, heads_type="medusa_block"), 13),
+    "micro10block": (lambda: MedusaConfig.micro(K=10, heads_type="medusa_block", d_model=256, layers=3), 14),
+    "tiny": (lambda: MedusaConfig.tiny_en(K=4), 0),
+}
+
+
+class Rig:
+    def __init__(self, tag, dev, B=2):
+        mk, seed = SHAPES[tag]
+        self.cfg = mk()
+        self.sd = synth.synth_state_dict(self.cfg, seed=seed)
+        self.orc = Oracle(self.cfg, self.sd, sim="bf16")
+        self.model = WhisperMedusaModel(self.cfg, self.sd, device=dev, max_batch=B)
+        self.eng = self.model.engine
+        self.dev, self.B = dev, B
+        self.wavs = [clip_for(self.cfg, i) for i in range(B)]
+        self.wavs[-1] = self.wavs[-1][: len(self.wavs[-1]) // 3]          # ragged: one short clip
+        n = self.cfg.n_mel_frames * 160
+        self.feats = np.stack([log_mel(w, self.cfg.num_mel_bins, n) for w in self.wavs])
+        self.eng.encode(torch.from_numpy(self.feats).to(dev))
+        self.enc = self.eng.encoder_output(B)
+
+    def encode(self):
+        self.eng.encode(torch.from_numpy(self.feats).to(self.dev))
+
+
+@pytest.fixture(scope="module", params=list(SHAPES))
+def rig(request, gpu):
+    r = Rig(request.param, gpu)
+    yield r
+    r.eng.close()
+
+
+def test_native_library_is_loaded(gpu):
+    import whisper_medusa.engine as e
+    assert e.load_library()._name.endswith("libwm.so")
+    maps = open("/proc/self/maps").read()
+    assert "libwm.so" in maps
+
+
+def test_logmel(rig):
+    got = rig.model.extract_features(rig.wavs).cpu().numpy()
+    assert got.shape == rig.feats.shape and np.isfinite(got).all()
+    assert np.abs(got - rig.feats).max() <= 2e-3
+
+
+def test_encoder_output(rig):
+    ref = torch.stack([rig.orc.encode(torch.from_numpy(rig.feats[b])) for b in range(rig.B)])
+    d = (rig.enc - ref).abs()
+    assert torch.isfinite(rig.enc).all()
+    assert d.max() <= 0.12 and d.mean() <= 6e-3, (float(d.max()), float(d.mean()))
+
+
+def test_cross_kv(rig):
+    ref = rig.orc.cross_kv(rig.enc[1])
+    for kvl in (0, rig.cfg.n_kv_layers - 1):
+        for hd in (0, rig.cfg.n_heads - 1):
+            k, v = rig.eng.cross_kv(kvl, 1, hd)
+            assert (k - ref[kvl][0][hd]).abs().max() <= 0.04 and (v - ref[kvl][1][hd]).abs().max() <= 0.04
+            assert (k - ref[kvl][0][hd]).abs().mean() <= 1e-3
+
+
+def test_forward_logits_all_heads(rig):
+    prompt = synth.default_prompt(rig.cfg) + [11, 12, 13]
+    toks = [prompt, prompt[::-1]]
+    z = rig.eng.forward_logits(toks, 0, False)                         # [K+1, B, T, V] like forward(), model.py:1301
+    assert z.shape == (rig.cfg.medusa_num_heads + 1, 2, len(prompt), rig.cfg.vocab_size)
+    for b in range(2):
+        ref = rig.orc.decoder_pass(rig.orc.new_state(rig.enc[b]), toks[b], 0, disable_medusa=False)
+        d = (z[:, b] - ref).abs()
+        assert d.max() <= 6e-2 and d.mean() <= 4e-3, (float(d.max()), float(d.mean()))
+
+
+def test_forward_verify_pass_uses_cache(rig):
+    prompt = synth.default_prompt(rig.cfg)
+    K = rig.cfg.medusa_num_heads
+    rig.eng.forward_logits([prompt, prompt], 0, True)
+    cands = [list(range(5, 6 + K)), list(range(40, 41 + K))]
+    z = rig.eng.forward_logits(cands, len(prompt), True)               # disable_medusa: 1 head (medusa_utils.py:510-516)
+    assert z.shape[0] == 1
+    for b in range(2):
+        st = rig.orc.new_state(rig.enc[b])
+        rig.orc.decoder_pass(st, prompt, 0, True)
+        st["kv_len"] = len(prompt)
+        ref = rig.orc.decoder_pass(st, cands[b], len(prompt), True)
+        d = (z[0, b] - ref[0]).abs()
+        assert d.max() <= 6e-2 and d.mean() <= 4e-3
+
+
+@pytest.mark.parametrize("mode", [ACCEPT_TYPICAL, ACCEPT_GREEDY])
+@pytest.mark.parametrize("eos_free", [True, False])
+def test_decode_tokens_bit_exact(rig, mode, eos_free):
+    gp = golden_gen_params(rig.cfg, mode, 40, suppress_eos=eos_free)
+    rig.encode()
+    seqs = rig.eng.decode(gp, rig.B)
+    st = rig.eng.stats()
+    hist = np.zeros(rig.cfg.medusa_num_heads + 1, dtype=np.int64)
+    for b in range(rig.B):
+        r = rig.orc.decode(rig.enc[b], gp)
+        assert seqs[b] == r.ids, (b, seqs[b], r.ids, r.accept_lengths)
+        for a in r.accept_lengths:
+            hist[a] += 1
+    assert st["accept_hist"] == hist.tolist()
+    assert st["tokens_emitted"] >= sum(len(s) - len(gp.prompt) for s in seqs)
+
+
+def test_greedy_mode_equals_vanilla(rig):
+    """size-independent property: exact-match verification reproduces plain greedy decoding."""
+    gp = golden_gen_params(rig.cfg, ACCEPT_GREEDY, 36)
+    rig.encode()
+    med = rig.eng.decode(gp, rig.B)
+    gp.vanilla = True
+    van = rig.eng.decode(gp, rig.B)
+    for b in range(rig.B):
+        n = min(len(med[b]), len(van[b]))
+        assert n >= len(gp.prompt) + 30 and med[b][:n] == van[b][:n]
+        ref = rig.orc.decode(rig.enc[b], gp)
+        assert van[b] == ref.ids
+
+
+def test_batch_equals_independent_streams(rig):
+    """B streams decoded together == each stream decoded alone (reference semantics: batch-1 runs)."""
+    gp = golden_gen_params(rig.cfg, ACCEPT_TYPICAL, 30)
+    rig.encode()
+    both = rig.eng.decode(gp, rig.B)
+    for b in range(rig.B):
+        rig.eng.encode(torch.from_numpy(rig.feats[b: b + 1]).to(rig.dev))
+        alone = rig.eng.decode(gp, 1)[0]
+        assert alone == both[b]
+    rig.encode()
+
+
+def test_generate_api_end_to_end(rig):
+    """from wav: log-mel -> encoder -> decode through the drop-in generate() (README.md:101-142 call shape)."""
+    feats = rig.model.extract_features(rig.wavs[:1])
+    out = rig.model.generate(feats, max_new_tokens=24, exponential_decay_length_penalty=(6, 1.3))
+    assert out.dtype == torch.long and out.shape[0] == 1 and out.is_cuda
+    P = len(synth.default_prompt(rig.cfg))
+    assert out[0, :P].tolist() == synth.default_prompt(rig.cfg)
+    gp = rig.model._gen_params(None, None, (6, 1.3), 24, None, None, False, None, None, None, None, None)
+    enc = rig.eng.encoder_output(1)[0]
+    ref = rig.orc.decode(enc, gp)
+    want = ref.ids[: ref.ids.index(gp.eos_token_id) + 1] if gp.eos_token_id in ref.ids[P:] else ref.ids
+    assert out[0].tolist() == want
+    assert rig.model.last_stats["iterations"] == ref.n_iters
+    rig.encode()

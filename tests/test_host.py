@@ -1,0 +1,140 @@
+"""Host-side logic and the C-ABI surface — no GPU compute."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import ROOT, MedusaConfig, GenParams, synth
+from whisper_medusa import weights, frontend
+from whisper_medusa.config import HEADS_BLOCK
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    hdr = open(os.path.join(ROOT, "include", "wm.h")).read()
+    declared = sorted(set(re.findall(r"\b(wm_[a-z_]+)\s*\(", hdr)))
+    assert "wm_create" in declared and "wm_decode_run" in declared and len(declared) >= 14
+    lib = ctypes.CDLL(built_lib)
+    for name in declared:
+        assert hasattr(lib, name), f"libwm.so does not export {name}"
+    assert lib.wm_abi_version() == 1
+    from whisper_medusa import engine
+    assert sorted(engine.EXPORTS) == declared
+    engine.load_library()          # prototypes resolve
+
+
+def test_create_rejects_bad_arguments(built_lib):
+    from whisper_medusa import engine
+    lib = engine.load_library()
+    h = ctypes.c_void_p()
+    cfg = engine.WmConfig(99, 128, 2, 2, 2, 512, 1031, 80, 96, 64, 4, 0, 1)      # wrong ABI version
+    w = engine.WmWeights(None, 0, None, 0)
+    assert lib.wm_create(ctypes.byref(cfg), ctypes.byref(w), 0, None, ctypes.byref(h)) == -1
+    assert b"ABI" in lib.wm_last_error(None)
+    cfg = engine.WmConfig(1, 100, 2, 2, 2, 512, 1031, 80, 96, 64, 4, 0, 1)       # d_model not a multiple of 128
+    assert lib.wm_create(ctypes.byref(cfg), ctypes.byref(w), 0, None, ctypes.byref(h)) == -1
+
+
+def test_engine_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from whisper_medusa.engine import Engine
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        Engine(MedusaConfig.micro(), torch.zeros(16, dtype=torch.uint8), np.zeros(1, dtype=np.uint64))
+    from whisper_medusa import WhisperMedusaModel
+    cfg = MedusaConfig.micro()
+    m = WhisperMedusaModel(cfg, synth.synth_state_dict(cfg))
+    with pytest.raises(RuntimeError):
+        m.generate(torch.zeros(1, 80, cfg.n_mel_frames))
+
+
+def test_pack_unpack_roundtrip_and_fragment_order():
+    w = torch.arange(32 * 64, dtype=torch.float32).view(32, 64)
+    p = weights.pack_matrix(w)
+    assert torch.equal(weights.unpack_matrix(p, 32, 64).float(), w.bfloat16().float())
+    # tile (nt=1, kt=1): lane l holds row 16 + (l & 15), cols 32 + 8*(l >> 4) .. +8
+    tile = p.view(2, 2, 64, 8)[1, 1].float()
+    for lane in (0, 5, 17, 63):
+        want = w[16 + (lane & 15), 32 + 8 * (lane >> 4): 32 + 8 * (lane >> 4) + 8].bfloat16().float()
+        assert torch.equal(tile[lane], want)
+
+
+@pytest.mark.parametrize("heads", ["base_head", HEADS_BLOCK])
+def test_blob_table(heads):
+    cfg = MedusaConfig.micro(K=4, heads_type=heads)
+    sd = synth.synth_state_dict(cfg, seed=1)
+    blob, offs = weights.build_blob(cfg, sd)
+    assert len(offs) == weights.n_table_entries(cfg) == 19 + 12 * 2 + 18 * cfg.n_kv_layers
+    assert all(int(o) % 256 == 0 for o in offs) and int(offs[-1]) < blob.numel()
+    # spot-check: decoder embed_positions (entry 12) is stored verbatim as fp32
+    pos = sd["whisper_model.model.decoder.embed_positions.weight"]
+    got = blob[int(offs[12]): int(offs[12]) + pos.numel() * 4].view(torch.float32).view_as(pos)
+    assert torch.equal(got, pos)
+    # heads (entry 15): packed [n_res*d][d]
+    n_res = 4 + (0 if cfg.is_block else 1)
+    hw = torch.cat([sd[f"medusa_heads.{k}.0.linear.weight"] for k in range(n_res)], 0)
+    got = blob[int(offs[15]): int(offs[15]) + hw.numel() * 2].view(torch.bfloat16)
+    assert torch.equal(weights.unpack_matrix(got, hw.shape[0], hw.shape[1]).float(), hw)
+
+
+def test_frontend_tables_match_hf():
+    from transformers import WhisperFeatureExtractor
+    fe = WhisperFeatureExtractor()
+    np.testing.assert_allclose(frontend.slaney_mel_bank(80), fe.mel_filters, atol=1e-6)
+    from transformers.audio_utils import window_function
+    np.testing.assert_allclose(frontend.hann_window(), window_function(400, "hann"), atol=1e-7)
+
+
+def test_config_roundtrip_and_validation(tmp_path):
+    cfg = MedusaConfig.large_v2()
+    assert cfg.n_kv_layers == 32 and cfg.medusa_choices == [1] * 11 and cfg.n_mel_frames == 3000
+    cfg.save_pretrained(str(tmp_path))
+    cfg2 = MedusaConfig.from_pretrained(str(tmp_path))
+    assert cfg2.to_dict() == cfg.to_dict()
+    with pytest.raises(ValueError, match="is not supported"):          # reference model.py:225-229
+        MedusaConfig(medusa_heads_type="bogus")
+    with pytest.raises(ValueError):
+        MedusaConfig(medusa_num_heads=3, medusa_choices=[1, 3, 2, 1])   # non-chain tree
+    assert MedusaConfig.large_v2(HEADS_BLOCK).n_kv_layers == 33
+
+
+def test_generate_argument_errors_match_reference():
+    from whisper_medusa import WhisperMedusaModel
+    cfg = MedusaConfig.micro()
+    m = WhisperMedusaModel(cfg, {})
+    x = torch.zeros(1, 80, cfg.n_mel_frames)
+    with pytest.raises(NotImplementedError, match="return_timestamps"):
+        m.generate(x, return_timestamps=True)
+    with pytest.raises(NotImplementedError, match="no_speech"):
+        m.generate(x, no_speech_threshold=0.6)
+    with pytest.raises(Exception, match="Beam search"):
+        m.generate(x, num_beams=4)
+    with pytest.raises(NotImplementedError, match="Longform"):
+        m.generate(torch.zeros(1, 80, cfg.n_mel_frames + 10))
+    big = MedusaConfig.large_v2()
+    assert synth.default_prompt(big, "en") == [50258, 50259, 50359, 50363]
+    assert synth.default_prompt(MedusaConfig.tiny_en()) == [50257, 50362]
+    with pytest.raises(ValueError, match="Unsupported language"):
+        synth.default_prompt(big, "xx")
+
+
+def test_skinny_plan_covers_all_whisper_shapes():
+    """The launch plan's invariants (K-slices are whole rounds of U fragments, <= 16 waves per block)."""
+    def plan(N16, K32, lds):
+        U = 8 if (lds and K32 % 8 == 0) else 4
+        q = K32 // U
+        best = 1
+        for s in range(1, min(16, q) + 1):
+            if q % s:
+                continue
+            best = s
+            if N16 * s >= 1024:
+                break
+        return best, (4 if best == 1 else 1), U
+    for d in (128, 384, 512, 768, 1024, 1280):
+        for (N, K) in ((3 * d, d), (d, d), (4 * d, d), (d, 4 * d), (51968, d), (11 * d, d)):
+            for lds in (True, False):
+                ks, rt, U = plan(N // 16, K // 32, lds)
+                assert (K // 32) % (ks * U) == 0 and ks * rt <= 16

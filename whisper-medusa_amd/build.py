@@ -1,0 +1,48 @@
+"""Build libwm.so (the gfx950 HIP engine) in-tree with hipcc.  No cmake / JIT cache: the built
+library lives next to the Python package so it travels with the repo snapshot to the GPU box.
+
+    python whisper-medusa_amd/build.py [--force]
+"""
+import concurrent.futures as cf
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT_DIR = os.path.join(HERE, "whisper_medusa")
+LIB = os.path.join(OUT_DIR, "libwm.so")
+SOURCES = ["wm_engine.hip", "wm_decoder.hip", "wm_encoder.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _newest_src():
+    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "wm.h")]
+    return max(os.path.getmtime(f) for f in files)
+
+
+def _compile(src):
+    obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+    cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    return obj
+
+
+def build(force=False, verbose=True):
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest_src():
+        return LIB
+    with cf.ThreadPoolExecutor(len(SOURCES)) as ex:
+        objs = list(ex.map(_compile, SOURCES))
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    if verbose:
+        print(f"built {LIB} ({os.path.getsize(LIB) / 1e6:.1f} MB)")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,62 @@
+// wm_common.h — shared device helpers for the gfx950 Whisper-Medusa engine.
+//
+// "Packed" layout (used for EVERY bf16 GEMM operand, weights and activations alike):
+// a row-major [R][K] matrix is stored as [R/16][K/32][64 lanes][8 elems]; lane l of a
+// wavefront holds row (l & 15), columns 8*(l >> 4) .. +8 of the 16x32 tile — exactly the
+// A (and, transposed, B) operand fragment of v_mfma_f32_16x16x32_bf16.  One tile = 1 KiB
+// contiguous, so a wave fetches a fragment with one fully coalesced 16-B-per-lane load and
+// an LDS image of it is read back conflict-free with ds_read_b128 (lane-linear).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;                                       // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;         // one MFMA A/B fragment
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;           // one MFMA C/D fragment
+
+#define WM_HEAD_DIM 64
+#define WM_MAX_ROWS_SKINNY 32      // rows (streams x tokens) the weight-streaming GEMM handles per launch
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+__device__ __forceinline__ bf16_t f2bf(float f) {                    // round-to-nearest-even (== torch)
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);   // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+// element index of (row, k) inside a packed [R][K] matrix with K32 = K/32 k-tiles
+__device__ __host__ __forceinline__ size_t packed_index(int row, int k, int K32) {
+    return ((size_t)(row >> 4) * K32 + (k >> 5)) * 512 + (size_t)(((row & 15) + 16 * ((k & 31) >> 3)) * 8 + (k & 7));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ bf16x8_t ld_frag(const bf16_t* p) {       // 16-B aligned
+    return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(p));
+}
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+__device__ __forceinline__ bf16x8_t ld_frag_nt(const bf16_t* p) {    // streamed-once weights: global_load_dwordx4 ... nt
+    return __builtin_bit_cast(bf16x8_t, __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p)));
+}

@@ -1,0 +1,401 @@
+// wm_encoder.hip — log-mel front end (F0), Whisper encoder (F1) and cross-K/V projection (F2).
+// MFMA-bound prefill: every matmul runs on v_mfma_f32_16x16x32_bf16 from packed operands.
+#include "wm_internal.h"
+#include "wm_epilogues.h"
+
+// =============================================================================================
+// Tiled GEMM  out[m][n] = sum_k X[m][k] W[n][k],  X/W packed bf16.  128x128 tile, BK=64, 4 waves (2x2),
+// each wave 64 features x 64 tokens = 4x4 MFMA tiles.  Operands are staged with global_load_lds
+// (16 B/lane, one 1-KiB packed fragment per wave-instruction): the LDS image is fragment-major, so
+// every ds_read_b128 is lane-linear and bank-conflict-free without any swizzle.  2-stage LDS ring.
+// =============================================================================================
+#define GT_BM 128
+#define GT_BN 128
+#define GT_STAGE_BYTES 32768
+
+__device__ __forceinline__ void glds16(const bf16_t* gsrc, char* lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <class Ep>
+__global__ void __launch_bounds__(256)
+k_gemm_tiled(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32, int tiles_m, int tiles_n, Ep ep)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wn = w >> 1, wm = w & 1;
+    // XCD-aware remap: consecutive tiles of one weight panel stay on one XCD's L2
+    int bid = blockIdx.x;
+    const int nwg = tiles_m * tiles_n;
+    if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+    const int tn = bid / tiles_m, tm = bid - tn * tiles_m;
+
+    const bf16_t* xg = X + (size_t)tm * 8 * K32 * 512 + lane * 8;
+    const bf16_t* wg = W + (size_t)tn * 8 * K32 * 512 + lane * 8;
+    const int nkt = K32 >> 1;
+
+    auto stage_load = [&](int stage, int kt2) {
+        char* sb = smem + stage * GT_STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int blk = w * 8 + i;                 // 0..31: 0..15 X fragments, 16..31 W fragments
+            const int t = (blk & 15) >> 1, kk = blk & 1;
+            const bf16_t* src = ((blk < 16) ? xg : wg) + ((size_t)t * K32 + kt2 * 2 + kk) * 512;
+            glds16(src, sb + blk * 1024);
+        }
+    };
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    stage_load(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int kt2 = 0; kt2 < nkt; ++kt2) {
+        if (kt2 + 1 < nkt) stage_load((kt2 + 1) & 1, kt2 + 1);
+        const bf16_t* xs = reinterpret_cast<const bf16_t*>(smem + (kt2 & 1) * GT_STAGE_BYTES);
+        const bf16_t* ws = xs + 16 * 512;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = ld_frag(ws + (((wn * 4 + i) * 2 + kk) * 64 + lane) * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = ld_frag(xs + (((wm * 4 + j) * 2 + kk) * 64 + lane) * 8);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    const int m0 = tm * GT_BM + wm * 64 + (lane & 15), n0 = tn * GT_BN + wn * 64 + 4 * (lane >> 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ep.store4(m0 + j * 16, n0 + i * 16, acc[i][j]);
+}
+
+template <class Ep>
+static inline hipError_t launch_gemm_tiled(hipStream_t st, const bf16_t* X, const bf16_t* W, int Mrows, int N, int K32, const Ep& ep)
+{
+    const int tiles_m = Mrows / GT_BM, tiles_n = N / GT_BN;
+    auto kern = k_gemm_tiled<Ep>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           2 * GT_STAGE_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), 2 * GT_STAGE_BYTES, st, X, W, K32, tiles_m, tiles_n, ep);
+    return hipGetLastError();
+}
+
+// =============================================================================================
+// Encoder self-attention (non-causal, S keys): flash-style, one wave = 16 queries, 32 keys per step.
+//   S^T = K Q^T   (A = K rows, B = Q^T; a lane then owns 8 scores of ONE query -> softmax reduces over
+//                  2 xor-shuffles), P stays in registers and feeds O^T = V^T P^T directly: the MFMA
+//   k-slot <-> key assignment is permuted identically in the V^T fragment and the P fragment, so no
+//   cross-lane movement is needed.  q is pre-scaled; fp32 softmax; P rounded to bf16.
+// =============================================================================================
+__global__ void __launch_bounds__(256)
+k_flash_enc(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kt, const bf16_t* __restrict__ Vt,
+            bf16_t* __restrict__ out, int S, int Spad, int H, int K32out)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int hd = blockIdx.y, b = blockIdx.z;
+    const size_t bh = (size_t)b * H + hd;
+    const int q0 = blockIdx.x * 64 + w * 16;
+    const bf16_t* qp = Q + (bh * Spad + q0 + c) * 64 + g * 8;
+    const bf16x8_t qb0 = ld_frag(qp), qb1 = ld_frag(qp + 32);
+    const bf16_t* kbase = Kt + bh * Spad * 64;
+    const bf16_t* vbase = Vt + bh * 64 * Spad;
+
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4_t o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    for (int kb = 0; kb < S; kb += 32) {
+        const bf16_t* kp = kbase + (size_t)(kb + c) * 64 + g * 8;
+        const bf16x8_t a00 = ld_frag(kp), a01 = ld_frag(kp + 32);
+        const bf16x8_t a10 = ld_frag(kp + 16 * 64), a11 = ld_frag(kp + 16 * 64 + 32);
+        uint2 vlo[4], vhi[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const bf16_t* vp = vbase + (size_t)(dt * 16 + c) * Spad + kb + 4 * g;
+            vlo[dt] = *reinterpret_cast<const uint2*>(vp);
+            vhi[dt] = *reinterpret_cast<const uint2*>(vp + 16);
+        }
+        f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+        s0 = mfma16(a00, qb0, s0); s0 = mfma16(a01, qb1, s0);
+        s1 = mfma16(a10, qb0, s1); s1 = mfma16(a11, qb1, s1);
+        if (kb + 32 > S) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (kb + 4 * g + r >= S) s0[r] = -INFINITY;
+                if (kb + 16 + 4 * g + r >= S) s1[r] = -INFINITY;
+            }
+        }
+        float mx = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __expf(m_run - m_new);
+        float p0[4], p1[4], rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            p0[r] = __expf(s0[r] - m_new); p1[r] = __expf(s1[r] - m_new);
+            rs += p0[r] + p1[r];
+        }
+        rs += __shfl_xor(rs, 16, 64);
+        rs += __shfl_xor(rs, 32, 64);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+        uint4 pw;
+        pw.x = pack_bf2(p0[0], p0[1]); pw.y = pack_bf2(p0[2], p0[3]);
+        pw.z = pack_bf2(p1[0], p1[1]); pw.w = pack_bf2(p1[2], p1[3]);
+        const bf16x8_t pb = __builtin_bit_cast(bf16x8_t, pw);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            o[dt][0] *= alpha; o[dt][1] *= alpha; o[dt][2] *= alpha; o[dt][3] *= alpha;
+            uint4 vw; vw.x = vlo[dt].x; vw.y = vlo[dt].y; vw.z = vhi[dt].x; vw.w = vhi[dt].y;
+            o[dt] = mfma16(__builtin_bit_cast(bf16x8_t, vw), pb, o[dt]);
+        }
+    }
+    const float inv = 1.0f / l_run;
+    const int row = b * Spad + q0 + c;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        uint2 u;
+        u.x = pack_bf2(o[dt][0] * inv, o[dt][1] * inv);
+        u.y = pack_bf2(o[dt][2] * inv, o[dt][3] * inv);
+        *reinterpret_cast<uint2*>(out + packed_index(row, hd * 64 + dt * 16 + 4 * g, K32out)) = u;
+    }
+}
+
+// =============================================================================================
+// LayerNorm over many rows -> packed bf16 (one wave per row)
+// =============================================================================================
+__global__ void __launch_bounds__(256)
+k_enc_ln(const float* __restrict__ src, const float* __restrict__ gamma, const float* __restrict__ beta,
+         bf16_t* __restrict__ out_p, int K32, int d, int M)
+{
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int nv = d >> 2;
+    const float4* sp = reinterpret_cast<const float4*>(src + (size_t)m * d);
+    float4 v[8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int j = lane + 64 * i;
+        v[i] = (j < nv) ? sp[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (lane + 64 * i < nv) {
+            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, e = v[i].w - mean;
+            q += a * a + b * b + c * c + e * e;
+        }
+    const float rstd = rsqrtf(wave_sum(q) / (float)d + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int j = lane + 64 * i;
+        if (j < nv) {
+            const float4 g = reinterpret_cast<const float4*>(gamma)[j];
+            const float4 b = reinterpret_cast<const float4*>(beta)[j];
+            uint2 o;
+            o.x = pack_bf2((v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y);
+            o.y = pack_bf2((v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w);
+            *reinterpret_cast<uint2*>(out_p + packed_index(m, j * 4, K32)) = o;
+        }
+    }
+}
+
+// =============================================================================================
+// conv front end as implicit GEMM: im2col gathers written directly in packed-operand order
+// (HF:modeling_whisper.py:626-627: conv1 k3 p1, conv2 k3 s2 p1).  One thread = one 16-B chunk.
+// =============================================================================================
+__global__ void k_im2col1(const float* __restrict__ feats, bf16_t* __restrict__ A1, int n_mels, int Tm, int Tmpad, int K32, long nchunks)
+{
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nchunks) return;
+    const long tile = q >> 6; const int ln = (int)(q & 63);
+    const int row = (int)(tile / K32) * 16 + (ln & 15), k0 = (int)(tile % K32) * 32 + (ln >> 4) * 8;
+    const int b = row / Tmpad, t = row - b * Tmpad;
+    uint32_t o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float v2[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = k0 + 2 * e + h;
+            const int kw = k / n_mels, c = k - kw * n_mels, tt = t - 1 + kw;
+            v2[h] = (kw < 3 && t < Tm && tt >= 0 && tt < Tm) ? feats[((size_t)b * n_mels + c) * Tm + tt] : 0.f;
+        }
+        o[e] = pack_bf2(v2[0], v2[1]);
+    }
+    *reinterpret_cast<uint4*>(A1 + q * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+__global__ void k_im2col2(const bf16_t* __restrict__ a1, bf16_t* __restrict__ A2, int d, int Tm, int S, int Spad, int K32, long nchunks)
+{
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nchunks) return;
+    const long tile = q >> 6; const int ln = (int)(q & 63);
+    const int row = (int)(tile / K32) * 16 + (ln & 15), k0 = (int)(tile % K32) * 32 + (ln >> 4) * 8;
+    const int b = row / Spad, s = row - b * Spad;
+    const int kw = k0 / d, c = k0 - kw * d, tt = 2 * s - 1 + kw;
+    uint4 o = make_uint4(0u, 0u, 0u, 0u);
+    if (s < S && tt >= 0 && tt < Tm) o = *reinterpret_cast<const uint4*>(a1 + ((size_t)b * Tm + tt) * d + c);
+    *reinterpret_cast<uint4*>(A2 + q * 8) = o;
+}
+
+// =============================================================================================
+// F0 log-mel: reflect-padded 400-point Hann STFT (hop 160) as a direct DFT in fp32, power, Slaney mel,
+// log10, then per-clip max clamp and (x+4)/4   (HF:feature_extraction_whisper.py:105-133)
+// =============================================================================================
+__device__ __forceinline__ int f2ord(float x) { const int i = __float_as_int(x); return i >= 0 ? i : i ^ 0x7fffffff; }
+__device__ __forceinline__ float ord2f(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7fffffff); }
+
+__global__ void __launch_bounds__(256)
+k_logmel_stft(const float* __restrict__ wav, const float* __restrict__ win, const float* __restrict__ tw,
+              const float* __restrict__ melfb, float* __restrict__ feats, int* __restrict__ clipmax,
+              int n_samples, int Tm, int n_mels)
+{
+    __shared__ float xw[4][400];
+    __shared__ float tws[800];
+    __shared__ float pw[4][208];
+    const int b = blockIdx.y, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int f = blockIdx.x * 4 + w;
+    for (int i = threadIdx.x; i < 800; i += 256) tws[i] = tw[i];
+    const float* x = wav + (size_t)b * n_samples;
+    if (f < Tm) {
+        for (int i = lane; i < 400; i += 64) {
+            int n = f * 160 + i - 200;
+            if (n < 0) n = -n;
+            if (n >= n_samples) n = 2 * (n_samples - 1) - n;
+            xw[w][i] = x[n] * win[i];
+        }
+    }
+    __syncthreads();
+    if (f < Tm) {
+        for (int k = lane; k < 201; k += 64) {
+            float re = 0.f, im = 0.f;
+            int idx = 0;
+            for (int i = 0; i < 400; ++i) {
+                const float v = xw[w][i];
+                re += v * tws[2 * idx]; im -= v * tws[2 * idx + 1];
+                idx += k; if (idx >= 400) idx -= 400;
+            }
+            pw[w][k] = re * re + im * im;
+        }
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    if (f < Tm) {
+        for (int m = lane; m < n_mels; m += 64) {
+            float acc = 0.f;
+            for (int k = 0; k < 201; ++k) acc += melfb[k * n_mels + m] * pw[w][k];
+            const float lg = log10f(fmaxf(acc, 1e-10f));
+            feats[((size_t)b * n_mels + m) * Tm + f] = lg;
+            mx = fmaxf(mx, lg);
+        }
+    }
+    mx = wave_max(mx);
+    if (lane == 0 && f < Tm) atomicMax(clipmax + b, f2ord(mx));
+}
+
+__global__ void k_logmel_norm(float* __restrict__ feats, const int* __restrict__ clipmax, long per_clip, long total)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const float mx = ord2f(clipmax[i / per_clip]);
+    feats[i] = (fmaxf(feats[i], mx - 8.0f) + 4.0f) * 0.25f;
+}
+
+// =============================================================================================
+// host side
+// =============================================================================================
+int wm_enc_logmel(wm_ctx* ctx, const float* wav, int B, int n_samples, float* feats)
+{
+    hipStream_t st = ctx->stream;
+    if (B < 1 || B > ctx->maxB || n_samples != 160 * ctx->Tm) { ctx->err = "wm_logmel: bad B or n_samples (must be 320*n_ctx)"; return WM_ERR_ARG; }
+    WM_HIP(hipEventRecord(ctx->ev0, st));
+    WM_HIP(hipMemsetAsync(ctx->clipmax, 0x80, sizeof(int) * B, st));
+    hipLaunchKernelGGL(k_logmel_stft, dim3((ctx->Tm + 3) / 4, B), dim3(256), 0, st, wav, ctx->win, ctx->twiddle, ctx->melfb, feats,
+                       reinterpret_cast<int*>(ctx->clipmax), n_samples, ctx->Tm, ctx->cfg.n_mels);
+    WM_HIP(hipGetLastError());
+    const long per = (long)ctx->cfg.n_mels * ctx->Tm, total = per * B;
+    hipLaunchKernelGGL(k_logmel_norm, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, feats,
+                       reinterpret_cast<const int*>(ctx->clipmax), per, total);
+    WM_HIP(hipGetLastError());
+    WM_HIP(hipEventRecord(ctx->ev1, st));
+    WM_HIP(hipEventSynchronize(ctx->ev1));
+    WM_HIP(hipEventElapsedTime(&ctx->ms_logmel, ctx->ev0, ctx->ev1));
+    return WM_OK;
+}
+
+int wm_enc_encode(wm_ctx* ctx, const float* feats, int B)
+{
+    hipStream_t st = ctx->stream;
+    if (B < 1 || B > ctx->maxB) { ctx->err = "wm_encode: B out of range"; return WM_ERR_ARG; }
+    const int d = ctx->d, H = ctx->H, ffn = ctx->ffn, S = ctx->S, Spad = ctx->Spad, Tm = ctx->Tm, Tmpad = ctx->Tmpad;
+    const int K32 = d / 32, M = B * Spad;
+    WM_HIP(hipEventRecord(ctx->ev0, st));
+    // conv1 + GELU
+    {
+        const int K32c = ctx->K1pad / 32;
+        const long nch = (long)B * Tmpad * ctx->K1pad / 8;
+        hipLaunchKernelGGL(k_im2col1, dim3((unsigned)((nch + 255) / 256)), dim3(256), 0, st, feats, ctx->A1, ctx->cfg.n_mels, Tm, Tmpad, K32c, nch);
+        WM_HIP(hipGetLastError());
+        WM_HIP(launch_gemm_tiled(st, ctx->A1, ctx->conv1_w, B * Tmpad, d, K32c, EpConv1{ctx->a1, ctx->conv1_b, Tm, Tmpad, d}));
+    }
+    // conv2 (stride 2) + GELU + positions
+    {
+        const int K32c = 3 * d / 32;
+        const long nch = (long)M * 3 * d / 8;
+        hipLaunchKernelGGL(k_im2col2, dim3((unsigned)((nch + 255) / 256)), dim3(256), 0, st, ctx->a1, ctx->A2, d, Tm, S, Spad, K32c, nch);
+        WM_HIP(hipGetLastError());
+        WM_HIP(launch_gemm_tiled(st, ctx->A2, ctx->conv2_w, M, d, K32c, EpConv2{ctx->eh, ctx->conv2_b, ctx->enc_pos, S, Spad, d}));
+    }
+    for (int l = 0; l < ctx->cfg.enc_layers; ++l) {
+        const EncLayerW& w = ctx->enc[l];
+        hipLaunchKernelGGL(k_enc_ln, dim3((M + 3) / 4), dim3(256), 0, st, ctx->eh, w.ln1_w, w.ln1_b, ctx->exn, K32, d, M);
+        WM_HIP(hipGetLastError());
+        WM_HIP(launch_gemm_tiled(st, ctx->exn, w.qkv_w, M, 3 * d, K32, EpQKVEnc{ctx->eq, ctx->ek, ctx->evt, w.qkv_b, Spad, H, d}));
+        hipLaunchKernelGGL(k_flash_enc, dim3(Spad / 64, H, B), dim3(256), 0, st, ctx->eq, ctx->ek, ctx->evt, ctx->exn, S, Spad, H, K32);
+        WM_HIP(hipGetLastError());
+        WM_HIP(launch_gemm_tiled(st, ctx->exn, w.out_w, M, d, K32, EpResidual{ctx->eh, w.out_b, d, M}));
+        hipLaunchKernelGGL(k_enc_ln, dim3((M + 3) / 4), dim3(256), 0, st, ctx->eh, w.ln2_w, w.ln2_b, ctx->exn, K32, d, M);
+        WM_HIP(hipGetLastError());
+        WM_HIP(launch_gemm_tiled(st, ctx->exn, w.fc1_w, M, ffn, K32, EpPackedAct<1>{ctx->eff, w.fc1_b, ffn / 32, M}));
+        WM_HIP(launch_gemm_tiled(st, ctx->eff, w.fc2_w, M, d, ffn / 32, EpResidual{ctx->eh, w.fc2_b, d, M}));
+    }
+    hipLaunchKernelGGL(k_enc_ln, dim3((M + 3) / 4), dim3(256), 0, st, ctx->eh, ctx->enc_lnf_w, ctx->enc_lnf_b, ctx->enc_out, K32, d, M);
+    WM_HIP(hipGetLastError());
+    // cross K/V of every decoder layer (+ the Medusa block) in one GEMM
+    WM_HIP(launch_gemm_tiled(st, ctx->enc_out, ctx->ckv_w, M, ctx->nkv * 2 * d, K32,
+                             EpCrossKV{ctx->kx, ctx->vx, ctx->ckv_b, Spad, H, d, B}));
+    ctx->Benc = B;
+    WM_HIP(hipEventRecord(ctx->ev1, st));
+    WM_HIP(hipEventSynchronize(ctx->ev1));
+    WM_HIP(hipEventElapsedTime(&ctx->ms_encode, ctx->ev0, ctx->ev1));
+    return WM_OK;
+}

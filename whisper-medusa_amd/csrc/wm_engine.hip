@@ -1,0 +1,406 @@
+// wm_engine.hip — C-ABI entry points of libwm.so (include/wm.h): context, parameter table,
+// HBM allocation, decode-loop driver with hipGraph replay, parity taps.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include "wm_internal.h"
+
+static thread_local std::string g_create_err;
+
+static inline int rup(int x, int m) { return (x + m - 1) / m * m; }
+
+template <class T>
+static hipError_t dev_alloc(T** p, size_t n, hipStream_t st)
+{
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(n, 1) * sizeof(T));
+    if (e != hipSuccess) return e;
+    return hipMemsetAsync(*p, 0, std::max<size_t>(n, 1) * sizeof(T), st);
+}
+
+extern "C" int wm_abi_version(void) { return WM_ABI_VERSION; }
+
+extern "C" const char* wm_last_error(const wm_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+extern "C" void wm_destroy(wm_ctx* ctx)
+{
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    if (ctx->graph) hipGraphExecDestroy(ctx->graph);
+    void* bufs[] = {ctx->feats_own, ctx->clipmax, ctx->A1, ctx->a1, ctx->A2, ctx->eh, ctx->exn, ctx->eq, ctx->ek, ctx->evt, ctx->eff,
+                    ctx->enc_out, ctx->kx, ctx->vx, ctx->kc, ctx->vc, ctx->h, ctx->hblk, ctx->hf, ctx->qbuf, ctx->xbuf, ctx->fbuf,
+                    ctx->ybuf, ctx->cml, ctx->co, ctx->logits, ctx->amax, ctx->pc, ctx->ent, ctx->ids, ctx->L, ctx->kvlen,
+                    ctx->finished, ctx->cand, ctx->niter, ctx->hist, ctx->supmask, ctx->exppen, ctx->tap_tok};
+    for (void* b : bufs) if (b) hipFree(b);
+    if (ctx->ev0) hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int wm_create(const wm_config* cfg, const wm_weights* w, int device, void* hip_stream, wm_ctx** out)
+{
+    g_create_err.clear();
+    if (!cfg || !w || !out) { g_create_err = "wm_create: null argument"; return WM_ERR_ARG; }
+    if (cfg->abi_version != WM_ABI_VERSION) { g_create_err = "wm_create: ABI version mismatch"; return WM_ERR_ARG; }
+    if (cfg->d_model <= 0 || cfg->d_model % 128 || cfg->n_heads * WM_HEAD_DIM != cfg->d_model || cfg->d_model > 2048) {
+        g_create_err = "wm_create: d_model must be a multiple of 128 (<= 2048) with 64-wide heads"; return WM_ERR_ARG; }
+    if (cfg->ffn_dim % 128 || cfg->medusa_heads < 1 || cfg->medusa_heads > 15 || cfg->max_batch < 1 || cfg->n_mels * 3 > 256 ||
+        (cfg->heads_type != WM_HEADS_LINEAR && cfg->heads_type != WM_HEADS_BLOCK) || cfg->n_tgt < 8 || cfg->n_ctx < 8) {
+        g_create_err = "wm_create: unsupported configuration"; return WM_ERR_ARG; }
+    wm_ctx* ctx = new wm_ctx();
+    ctx->cfg = *cfg; ctx->device = device;
+#define CREATE_HIP(expr)                                                                       \
+    do { hipError_t _e = (expr); if (_e != hipSuccess) {                                       \
+        g_create_err = std::string(#expr) + ": " + hipGetErrorString(_e); wm_destroy(ctx); return WM_ERR_HIP; } } while (0)
+    CREATE_HIP(hipSetDevice(device));
+    if (hip_stream) ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    else { CREATE_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->own_stream = true; }
+    CREATE_HIP(hipEventCreate(&ctx->ev0));
+    CREATE_HIP(hipEventCreate(&ctx->ev1));
+
+    const int d = ctx->d = cfg->d_model;
+    ctx->H = cfg->n_heads; ctx->ffn = cfg->ffn_dim; ctx->V = cfg->vocab; ctx->Vpad = rup(cfg->vocab, 128);
+    ctx->S = cfg->n_ctx; ctx->Spad = rup(cfg->n_ctx, 128); ctx->Tm = 2 * cfg->n_ctx; ctx->Tmpad = rup(ctx->Tm, 128);
+    ctx->Tmax = cfg->n_tgt; ctx->Tal = cfg->n_tgt + 16; ctx->K = cfg->medusa_heads;
+    ctx->block = cfg->heads_type == WM_HEADS_BLOCK;
+    ctx->nkv = cfg->dec_layers + (ctx->block ? 1 : 0);
+    ctx->nres = ctx->K + (ctx->block ? 0 : 1);
+    ctx->maxB = cfg->max_batch;
+    ctx->K1pad = rup(3 * cfg->n_mels, 128);
+    ctx->NS = std::min(12, std::max(1, ctx->S / 8));
+    ctx->Ck = (ctx->S + ctx->NS - 1) / ctx->NS;
+    if (ctx->Ck > 512) { ctx->NS = (ctx->S + 511) / 512; ctx->Ck = (ctx->S + ctx->NS - 1) / ctx->NS; }
+
+    // ---- parameter table ----
+    const int n_expected = 19 + 12 * cfg->enc_layers + 18 * ctx->nkv;
+    if (w->n_offsets != n_expected || !w->blob || !w->offsets) {
+        g_create_err = "wm_create: weight table has " + std::to_string(w->n_offsets) + " entries, expected " + std::to_string(n_expected);
+        wm_destroy(ctx); return WM_ERR_ARG;
+    }
+    const char* base = reinterpret_cast<const char*>(w->blob);
+    for (int i = 0; i < w->n_offsets; ++i)
+        if (w->offsets[i] >= w->blob_bytes || (w->offsets[i] & 15)) { g_create_err = "wm_create: bad weight offset"; wm_destroy(ctx); return WM_ERR_ARG; }
+    int t = 0;
+    auto F = [&]() { return reinterpret_cast<const float*>(base + w->offsets[t++]); };
+    auto Hh = [&]() { return reinterpret_cast<const bf16_t*>(base + w->offsets[t++]); };
+    ctx->win = F(); ctx->twiddle = F(); ctx->melfb = F();
+    ctx->conv1_w = Hh(); ctx->conv1_b = F(); ctx->conv2_w = Hh(); ctx->conv2_b = F();
+    ctx->enc_pos = F(); ctx->enc_lnf_w = F(); ctx->enc_lnf_b = F();
+    ctx->tok_emb = Hh(); ctx->vocab_w = Hh(); ctx->dec_pos = F(); ctx->dec_lnf_w = F(); ctx->dec_lnf_b = F();
+    ctx->heads_w = Hh(); ctx->heads_b = F(); ctx->ckv_w = Hh(); ctx->ckv_b = F();
+    ctx->enc.resize(cfg->enc_layers);
+    for (auto& e : ctx->enc) {
+        e.ln1_w = F(); e.ln1_b = F(); e.qkv_w = Hh(); e.qkv_b = F(); e.out_w = Hh(); e.out_b = F();
+        e.ln2_w = F(); e.ln2_b = F(); e.fc1_w = Hh(); e.fc1_b = F(); e.fc2_w = Hh(); e.fc2_b = F();
+    }
+    ctx->dec.resize(ctx->nkv);
+    for (auto& e : ctx->dec) {
+        e.ln1_w = F(); e.ln1_b = F(); e.qkv_w = Hh(); e.qkv_b = F(); e.out_w = Hh(); e.out_b = F();
+        e.ln2_w = F(); e.ln2_b = F(); e.cq_w = Hh(); e.cq_b = F(); e.cout_w = Hh(); e.cout_b = F();
+        e.ln3_w = F(); e.ln3_b = F(); e.fc1_w = Hh(); e.fc1_b = F(); e.fc2_w = Hh(); e.fc2_b = F();
+    }
+
+    // ---- HBM allocation ----
+    hipStream_t st = ctx->stream;
+    const size_t B = ctx->maxB, Spad = ctx->Spad, H = ctx->H, Tal = ctx->Tal;
+    const size_t Menc = B * Spad;
+    CREATE_HIP(dev_alloc(&ctx->feats_own, B * cfg->n_mels * ctx->Tm, st));
+    CREATE_HIP(dev_alloc(&ctx->clipmax, B, st));
+    CREATE_HIP(dev_alloc(&ctx->A1, B * ctx->Tmpad * ctx->K1pad, st));
+    CREATE_HIP(dev_alloc(&ctx->a1, B * ctx->Tm * d, st));
+    CREATE_HIP(dev_alloc(&ctx->A2, Menc * 3 * d, st));
+    CREATE_HIP(dev_alloc(&ctx->eh, Menc * d, st));
+    CREATE_HIP(dev_alloc(&ctx->exn, Menc * d, st));
+    CREATE_HIP(dev_alloc(&ctx->eq, Menc * d, st));
+    CREATE_HIP(dev_alloc(&ctx->ek, Menc * d, st));
+    CREATE_HIP(dev_alloc(&ctx->evt, Menc * d, st));
+    CREATE_HIP(dev_alloc(&ctx->eff, Menc * ctx->ffn, st));
+    CREATE_HIP(dev_alloc(&ctx->enc_out, Menc * d, st));
+    CREATE_HIP(dev_alloc(&ctx->kx, (size_t)ctx->nkv * Menc * d, st));
+    CREATE_HIP(dev_alloc(&ctx->vx, (size_t)ctx->nkv * Menc * d, st));
+    CREATE_HIP(dev_alloc(&ctx->kc, (size_t)ctx->nkv * B * H * Tal * 64, st));
+    CREATE_HIP(dev_alloc(&ctx->vc, (size_t)ctx->nkv * B * H * Tal * 64, st));
+    const size_t RW = WM_MAX_ROWS_SKINNY;
+    CREATE_HIP(dev_alloc(&ctx->h, RW * d, st));
+    CREATE_HIP(dev_alloc(&ctx->hblk, RW * d, st));
+    CREATE_HIP(dev_alloc(&ctx->hf, RW * d, st));
+    CREATE_HIP(dev_alloc(&ctx->qbuf, RW * d, st));
+    CREATE_HIP(dev_alloc(&ctx->xbuf, RW * d, st));
+    CREATE_HIP(dev_alloc(&ctx->fbuf, RW * ctx->ffn, st));
+    CREATE_HIP(dev_alloc(&ctx->ybuf, RW * d, st));
+    CREATE_HIP(dev_alloc(&ctx->cml, RW * H * ctx->NS * 2, st));
+    CREATE_HIP(dev_alloc(&ctx->co, RW * H * ctx->NS * 64, st));
+    CREATE_HIP(dev_alloc(&ctx->logits, RW * ctx->Vpad, st));
+    CREATE_HIP(dev_alloc(&ctx->amax, B * 16, st));
+    CREATE_HIP(dev_alloc(&ctx->pc, B * 16, st));
+    CREATE_HIP(dev_alloc(&ctx->ent, B * 16, st));
+    const size_t Tids = ctx->Tal;
+    CREATE_HIP(dev_alloc(&ctx->ids, B * Tids, st));
+    CREATE_HIP(dev_alloc(&ctx->L, B, st));
+    CREATE_HIP(dev_alloc(&ctx->kvlen, B, st));
+    CREATE_HIP(dev_alloc(&ctx->finished, B, st));
+    CREATE_HIP(dev_alloc(&ctx->cand, B * 16, st));
+    CREATE_HIP(dev_alloc(&ctx->niter, B, st));
+    CREATE_HIP(dev_alloc(&ctx->hist, 32, st));
+    CREATE_HIP(dev_alloc(&ctx->supmask, (size_t)ctx->Vpad, st));
+    CREATE_HIP(dev_alloc(&ctx->exppen, Tids + 1, st));
+    CREATE_HIP(dev_alloc(&ctx->tap_tok, 16, st));
+    CREATE_HIP(hipStreamSynchronize(st));
+#undef CREATE_HIP
+    *out = ctx;
+    return WM_OK;
+}
+
+extern "C" int wm_sync(wm_ctx* ctx) { WM_HIP(hipSetDevice(ctx->device)); WM_HIP(hipStreamSynchronize(ctx->stream)); return WM_OK; }
+
+extern "C" int wm_logmel(wm_ctx* ctx, const float* wav, int B, int n_samples, float* feats)
+{
+    if (!ctx || !wav || !feats) return WM_ERR_ARG;
+    WM_HIP(hipSetDevice(ctx->device));
+    return wm_enc_logmel(ctx, wav, B, n_samples, feats);
+}
+
+extern "C" int wm_encode(wm_ctx* ctx, const float* feats, int B)
+{
+    if (!ctx || !feats) return WM_ERR_ARG;
+    WM_HIP(hipSetDevice(ctx->device));
+    ctx->began = false;
+    return wm_enc_encode(ctx, feats, B);
+}
+
+extern "C" int wm_decode_begin(wm_ctx* ctx, const wm_gen_params* gp, int B)
+{
+    if (!ctx || !gp) return WM_ERR_ARG;
+    WM_HIP(hipSetDevice(ctx->device));
+    if (ctx->Benc < 1 || B != ctx->Benc) { ctx->err = "wm_decode_begin: call wm_encode with the same B first"; return WM_ERR_STATE; }
+    const int P = gp->prompt_len, K = ctx->K, Tids = ctx->Tal;
+    if (P < 1 || P > 16 || P >= ctx->Tmax - K - 1) {
+        // same condition class as the reference's over-long prompt ValueError (model.py:1526-1529)
+        ctx->err = "wm_decode_begin: prompt length must be in [1,16]"; return WM_ERR_ARG; }
+    if (gp->eos_token_id < 0 || gp->eos_token_id >= ctx->V) { ctx->err = "wm_decode_begin: eos out of range"; return WM_ERR_ARG; }
+    if (!gp->vanilla && gp->accept_mode == WM_ACCEPT_TYPICAL && !(gp->temperature > 0.f)) {
+        ctx->err = "wm_decode_begin: typical acceptance needs temperature > 0"; return WM_ERR_ARG; }
+    hipStream_t st = ctx->stream;
+    GenDev g{};
+    g.P = P; g.eos = gp->eos_token_id; g.pad = gp->pad_token_id;
+    g.max_length = std::min(gp->max_length, ctx->Tmax);
+    g.hard_max_length = std::min(gp->hard_max_length, ctx->Tmax);
+    g.exp_start = gp->exp_decay_start >= 0 ? gp->exp_decay_start + P : -1;
+    g.thr = gp->posterior_threshold; g.alpha = gp->posterior_alpha;
+    g.inv_temp = (gp->accept_mode == WM_ACCEPT_TYPICAL && gp->temperature > 0.f) ? 1.0f / gp->temperature : 1.0f;
+    g.accept_mode = gp->accept_mode; g.vanilla = gp->vanilla; g.K = K; g.V = ctx->V; g.Vpad = ctx->Vpad; g.Tids = Tids;
+    const bool same = ctx->graph && ctx->graph_B == B && std::memcmp(&g, &ctx->gp, sizeof(GenDev)) == 0;
+    if (!same && ctx->graph) { hipGraphExecDestroy(ctx->graph); ctx->graph = nullptr; }
+    ctx->gp = g; ctx->Bdec = B;
+
+    std::vector<int> ids((size_t)B * Tids, gp->pad_token_id), L(B, P), zero(B, 0);
+    for (int b = 0; b < B; ++b) for (int i = 0; i < P; ++i) ids[(size_t)b * Tids + i] = gp->prompt[i];
+    std::vector<unsigned char> mask(ctx->Vpad, 0);
+    for (int i = 0; i < gp->n_suppress; ++i) if (gp->suppress[i] >= 0 && gp->suppress[i] < ctx->V) mask[gp->suppress[i]] |= 1;
+    for (int i = 0; i < gp->n_begin_suppress; ++i)
+        if (gp->begin_suppress[i] >= 0 && gp->begin_suppress[i] < ctx->V) mask[gp->begin_suppress[i]] |= 2;
+    std::vector<float> pen(Tids + 1, 0.f);
+    if (g.exp_start >= 0)
+        for (int t = 0; t <= Tids; ++t)     // (factor^(cur_len - start) - 1) evaluated in double like the Python scalar
+            pen[t] = t > g.exp_start ? (float)(std::pow((double)gp->exp_decay_factor, (double)(t - g.exp_start)) - 1.0) : 0.f;
+    WM_HIP(hipMemcpyAsync(ctx->ids, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    WM_HIP(hipMemcpyAsync(ctx->L, L.data(), B * sizeof(int), hipMemcpyHostToDevice, st));
+    WM_HIP(hipMemcpyAsync(ctx->kvlen, zero.data(), B * sizeof(int), hipMemcpyHostToDevice, st));
+    WM_HIP(hipMemcpyAsync(ctx->finished, zero.data(), B * sizeof(int), hipMemcpyHostToDevice, st));
+    WM_HIP(hipMemcpyAsync(ctx->niter, zero.data(), B * sizeof(int), hipMemcpyHostToDevice, st));
+    WM_HIP(hipMemsetAsync(ctx->hist, 0, 32 * sizeof(long long), st));
+    WM_HIP(hipMemcpyAsync(ctx->supmask, mask.data(), mask.size(), hipMemcpyHostToDevice, st));
+    WM_HIP(hipMemcpyAsync(ctx->exppen, pen.data(), pen.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    WM_HIP(hipStreamSynchronize(st));      // host vectors go out of scope
+    ctx->began = true; ctx->first_done = false; ctx->iters = 0; ctx->ms_decode = 0.f; ctx->graph_replays = 0;
+    return WM_OK;
+}
+
+static int count_unfinished(wm_ctx* ctx, int* n)
+{
+    std::vector<int> f(ctx->Bdec);
+    WM_HIP(hipMemcpyAsync(f.data(), ctx->finished, ctx->Bdec * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    WM_HIP(hipStreamSynchronize(ctx->stream));
+    int c = 0;
+    for (int v : f) c += v ? 0 : 1;
+    *n = c;
+    return WM_OK;
+}
+
+extern "C" int wm_decode_run(wm_ctx* ctx, int max_iters, int* n_unfinished)
+{
+    if (!ctx) return WM_ERR_ARG;
+    WM_HIP(hipSetDevice(ctx->device));
+    if (!ctx->began) { ctx->err = "wm_decode_run: call wm_decode_begin first"; return WM_ERR_STATE; }
+    hipStream_t st = ctx->stream;
+    const bool use_graph = std::getenv("WM_NO_GRAPH") == nullptr;
+    const int poll = 4;
+    int left = 0, done = 0;
+    int rc = count_unfinished(ctx, &left);
+    if (rc) return rc;
+    WM_HIP(hipEventRecord(ctx->ev0, st));
+    while (left > 0 && done < max_iters) {
+        const int burst = std::min(poll, max_iters - done);
+        for (int i = 0; i < burst; ++i) {
+            if (!ctx->first_done) {                       // iteration 1: the base pass consumes the P prompt tokens
+                rc = wm_dec_iteration(ctx, ctx->gp.P);
+                if (rc) return rc;
+                ctx->first_done = true;
+            } else if (use_graph && ctx->graph) {
+                WM_HIP(hipGraphLaunch(ctx->graph, st));
+                ctx->graph_replays++;
+            } else if (use_graph && ctx->iters >= 2) {    // shapes are warm: capture one steady-state iteration
+                hipGraph_t gr = nullptr;
+                hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+                if (e == hipSuccess) {
+                    rc = wm_dec_iteration(ctx, 1);
+                    hipError_t e2 = hipStreamEndCapture(st, &gr);
+                    if (rc == WM_OK && e2 == hipSuccess && gr) {
+                        hipGraphExec_t ex = nullptr;
+                        if (hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0) == hipSuccess) { ctx->graph = ex; ctx->graph_B = ctx->Bdec; }
+                    }
+                    if (gr) hipGraphDestroy(gr);
+                }
+                if (ctx->graph) { WM_HIP(hipGraphLaunch(ctx->graph, st)); ctx->graph_replays++; }
+                else { (void)hipGetLastError(); rc = wm_dec_iteration(ctx, 1); if (rc) return rc; }
+            } else {
+                rc = wm_dec_iteration(ctx, 1);
+                if (rc) return rc;
+            }
+            ctx->iters++; done++;
+        }
+        rc = count_unfinished(ctx, &left);
+        if (rc) return rc;
+    }
+    WM_HIP(hipEventRecord(ctx->ev1, st));
+    WM_HIP(hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    WM_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    ctx->ms_decode += ms;
+    if (n_unfinished) *n_unfinished = left;
+    return WM_OK;
+}
+
+extern "C" int wm_get_tokens(wm_ctx* ctx, int stream, int32_t* out, int cap, int* n)
+{
+    if (!ctx || !out || !n || stream < 0 || stream >= ctx->Bdec) return WM_ERR_ARG;
+    WM_HIP(hipSetDevice(ctx->device));
+    int L = 0;
+    WM_HIP(hipMemcpyAsync(&L, ctx->L + stream, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    WM_HIP(hipStreamSynchronize(ctx->stream));
+    L = std::min(L, ctx->gp.Tids);
+    std::vector<int> ids(L);
+    WM_HIP(hipMemcpyAsync(ids.data(), ctx->ids + (size_t)stream * ctx->gp.Tids, L * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    WM_HIP(hipStreamSynchronize(ctx->stream));
+    bool seen = false;                       // post-EOS overwrite, model.py:798-810
+    for (int i = 0; i < L; ++i) { if (seen) ids[i] = ctx->gp.eos; else if (ids[i] == ctx->gp.eos) seen = true; }
+    const int m = std::min(L, cap);
+    std::memcpy(out, ids.data(), m * sizeof(int));
+    *n = L;
+    return WM_OK;
+}
+
+extern "C" int wm_get_stats(wm_ctx* ctx, wm_stats* out)
+{
+    if (!ctx || !out) return WM_ERR_ARG;
+    WM_HIP(hipSetDevice(ctx->device));
+    long long h[32];
+    WM_HIP(hipMemcpyAsync(h, ctx->hist, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    WM_HIP(hipStreamSynchronize(ctx->stream));
+    std::memset(out, 0, sizeof(*out));
+    out->iterations = ctx->iters;
+    for (int i = 0; i < 16; ++i) out->accept_hist[i] = h[i];
+    out->tokens_emitted = h[16];
+    out->ms_logmel = ctx->ms_logmel; out->ms_encode = ctx->ms_encode; out->ms_decode = ctx->ms_decode;
+    out->graph_replays = ctx->graph_replays;
+    return WM_OK;
+}
+
+// ---- parity taps ---------------------------------------------------------------------------
+static void unpack_rows(const std::vector<bf16_t>& p, int rows, int K, float* out)
+{
+    const int K32 = K / 32;
+    for (int r = 0; r < rows; ++r)
+        for (int k = 0; k < K; ++k) {
+            const uint32_t u = ((uint32_t)p[packed_index(r, k, K32)]) << 16;
+            float f; std::memcpy(&f, &u, 4);
+            out[(size_t)r * K + k] = f;
+        }
+}
+
+extern "C" int wm_get_encoder_output(wm_ctx* ctx, int B, float* out)
+{
+    if (!ctx || !out || B < 1 || B > ctx->Benc) return WM_ERR_ARG;
+    WM_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)B * ctx->Spad * ctx->d;
+    std::vector<bf16_t> p(n);
+    WM_HIP(hipMemcpyAsync(p.data(), ctx->enc_out, n * sizeof(bf16_t), hipMemcpyDeviceToHost, ctx->stream));
+    WM_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<float> full(n);
+    unpack_rows(p, B * ctx->Spad, ctx->d, full.data());
+    for (int b = 0; b < B; ++b)
+        std::memcpy(out + (size_t)b * ctx->S * ctx->d, full.data() + (size_t)b * ctx->Spad * ctx->d, (size_t)ctx->S * ctx->d * sizeof(float));
+    return WM_OK;
+}
+
+extern "C" int wm_get_cross_kv(wm_ctx* ctx, int kv_layer, int stream, int head, float* k_out, float* v_out)
+{
+    if (!ctx || kv_layer < 0 || kv_layer >= ctx->nkv || stream < 0 || stream >= ctx->Benc || head < 0 || head >= ctx->H) return WM_ERR_ARG;
+    WM_HIP(hipSetDevice(ctx->device));
+    const size_t off = (((size_t)kv_layer * ctx->Benc + stream) * ctx->H + head) * ctx->Spad * 64, n = (size_t)ctx->S * 64;
+    std::vector<bf16_t> kb(n), vb(n);
+    WM_HIP(hipMemcpyAsync(kb.data(), ctx->kx + off, n * sizeof(bf16_t), hipMemcpyDeviceToHost, ctx->stream));
+    WM_HIP(hipMemcpyAsync(vb.data(), ctx->vx + off, n * sizeof(bf16_t), hipMemcpyDeviceToHost, ctx->stream));
+    WM_HIP(hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t u = ((uint32_t)kb[i]) << 16; std::memcpy(k_out + i, &u, 4);
+        u = ((uint32_t)vb[i]) << 16; std::memcpy(v_out + i, &u, 4);
+    }
+    return WM_OK;
+}
+
+// forward(): one decoder pass over T tokens per stream at positions pos0.., K/V appended at row pos0.
+// Uses (and overwrites) the decode-loop state: call it before wm_decode_begin, or begin again afterwards.
+extern "C" int wm_forward_logits(wm_ctx* ctx, int B, const int32_t* tokens, int T, int pos0, int disable_medusa, float* logits_out)
+{
+    if (!ctx || !tokens || !logits_out || B < 1 || B > ctx->Benc || T < 1 || T > 16 || pos0 < 0 || pos0 + T > ctx->Tmax) return WM_ERR_ARG;
+    WM_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int Tids = ctx->Tal, K = ctx->K, V = ctx->V, nout = disable_medusa ? 1 : K + 1;
+    GenDev g = ctx->gp;
+    g.K = K; g.V = V; g.Vpad = ctx->Vpad; g.Tids = Tids; g.vanilla = 0;
+    ctx->gp = g; ctx->began = false;
+    if (ctx->graph) { hipGraphExecDestroy(ctx->graph); ctx->graph = nullptr; }
+    std::vector<float> rowbuf((size_t)nout * ctx->Vpad);
+    for (int b = 0; b < B; ++b) {
+        std::vector<int> v(T);
+        for (int i = 0; i < T; ++i) v[i] = tokens[(size_t)b * T + i];
+        const int kv = pos0, L = pos0 + T;
+        WM_HIP(hipMemcpyAsync(ctx->ids + (size_t)b * Tids + pos0, v.data(), T * sizeof(int), hipMemcpyHostToDevice, st));
+        WM_HIP(hipMemcpyAsync(ctx->kvlen + b, &kv, sizeof(int), hipMemcpyHostToDevice, st));
+        WM_HIP(hipMemcpyAsync(ctx->L + b, &L, sizeof(int), hipMemcpyHostToDevice, st));
+        WM_HIP(hipStreamSynchronize(st));
+        int rc = wm_dec_stage_layers(ctx, b, 1, T, 0);
+        if (rc) return rc;
+        rc = wm_dec_stage_final(ctx, b, 1, T, 0, !disable_medusa);
+        if (rc) return rc;
+        for (int r = 0; r < T; ++r) {
+            rc = wm_dec_stage_heads(ctx, 1, 1, r, !disable_medusa);
+            if (rc) return rc;
+            WM_HIP(hipMemcpyAsync(rowbuf.data(), ctx->logits, rowbuf.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+            WM_HIP(hipStreamSynchronize(st));
+            for (int k = 0; k < nout; ++k)      // out layout [n_out][B][T][V]
+                std::memcpy(logits_out + (((size_t)k * B + b) * T + r) * V, rowbuf.data() + (size_t)k * ctx->Vpad, (size_t)V * sizeof(float));
+        }
+    }
+    return WM_OK;
+}
+
+extern "C" int wm_profile_kernel(wm_ctx* ctx, int kernel, int rows, int reps, float* ms, double* bytes)
+{
+    if (!ctx || !ms || !bytes || reps < 1) return WM_ERR_ARG;
+    WM_HIP(hipSetDevice(ctx->device));
+    return wm_dec_profile(ctx, kernel, rows, reps, ms, bytes);
+}

@@ -1,0 +1,142 @@
+// wm_epilogues.h — fused GEMM epilogues shared by the weight-streaming (decode) GEMM and the
+// tiled (encoder / batched) GEMM.  Both kernels compute D[n][m] with the WEIGHT tile as the
+// MFMA A operand, so a lane owns 4 consecutive output features n..n+3 of one token row m:
+// every functor exposes   store4(m, n, v)   with n % 4 == 0.
+#pragma once
+#include "wm_common.h"
+
+struct EpResidual {            // h[m][n] += v + bias[n]      (out_proj / fc2 + residual, HF:modeling_whisper.py:396-413)
+    float* h; const float* bias; int ld; int M;
+    __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const {
+        if (m >= M) return;
+        float4* p = reinterpret_cast<float4*>(h + (size_t)m * ld + n);
+        float4 o = *p; const float4 b = *reinterpret_cast<const float4*>(bias + n);
+        o.x += v[0] + b.x; o.y += v[1] + b.y; o.z += v[2] + b.z; o.w += v[3] + b.w;
+        *p = o;
+    }
+};
+
+struct EpF32 {                 // out[m][n] = (v + bias[n]) * scale   (cross-attn q; vocabulary logits with bias == nullptr)
+    float* out; const float* bias; int ld; int M; float scale;
+    __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const {
+        if (m >= M) return;
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias) b = *reinterpret_cast<const float4*>(bias + n);
+        *reinterpret_cast<float4*>(out + (size_t)m * ld + n) =
+            make_float4((v[0] + b.x) * scale, (v[1] + b.y) * scale, (v[2] + b.z) * scale, (v[3] + b.w) * scale);
+    }
+};
+
+template <int ACT>             // packed bf16 out = act(v + bias)   (fc1 + GELU -> next GEMM's operand)
+struct EpPackedAct {
+    bf16_t* out; const float* bias; int K32out; int M;
+    __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const {
+        if (m >= M) return;
+        const float4 b = *reinterpret_cast<const float4*>(bias + n);
+        float x0 = v[0] + b.x, x1 = v[1] + b.y, x2 = v[2] + b.z, x3 = v[3] + b.w;
+        if (ACT == 1) { x0 = gelu_erf(x0); x1 = gelu_erf(x1); x2 = gelu_erf(x2); x3 = gelu_erf(x3); }
+        uint2 o; o.x = pack_bf2(x0, x1); o.y = pack_bf2(x2, x3);
+        *reinterpret_cast<uint2*>(out + packed_index(m, n, K32out)) = o;
+    }
+};
+
+// Decoder self-attention projections: q (scaled, fp32) to a row buffer, k/v rows (bf16) straight
+// into the contiguous KV cache at position base[stream] + r   (HF:modeling_whisper.py:288-318; the
+// reference's per-iteration cat-compaction, model.py:378-402, becomes "overwrite rows >= kv_len").
+struct EpQKVDec {
+    float* q; bf16_t* kc; bf16_t* vc; const float* bias; const int* base;
+    int Mper, d, H, Tal, M;
+    __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const {
+        if (m >= M) return;
+        const float4 b = *reinterpret_cast<const float4*>(bias + n);
+        const float x0 = v[0] + b.x, x1 = v[1] + b.y, x2 = v[2] + b.z, x3 = v[3] + b.w;
+        if (n < d) {
+            *reinterpret_cast<float4*>(q + (size_t)m * d + n) = make_float4(x0 * 0.125f, x1 * 0.125f, x2 * 0.125f, x3 * 0.125f);
+            return;
+        }
+        const int s = m / Mper, r = m - s * Mper;
+        int pos = base[s] + r; if (pos > Tal - 1) pos = Tal - 1;
+        const int c = (n < 2 * d) ? n - d : n - 2 * d;
+        bf16_t* dst = (n < 2 * d) ? kc : vc;
+        uint2 o; o.x = pack_bf2(x0, x1); o.y = pack_bf2(x2, x3);
+        *reinterpret_cast<uint2*>(dst + (((size_t)s * H + (c >> 6)) * Tal + pos) * 64 + (c & 63)) = o;
+    }
+};
+
+// Medusa residual heads: y = x + SiLU(W x + b) (model.py:180-210) for head k = n / d, written as
+// packed bf16 row  m*row_mul + row_off + k  of the vocabulary-projection operand.
+struct EpHead {
+    bf16_t* y; const float* hf; const float* bias; int d, K32, row_mul, row_off, M, src_mul, src_off;
+    __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const {
+        if (m >= M) return;
+        const int k = n / d, c = n - k * d;
+        const float4 b = *reinterpret_cast<const float4*>(bias + n);
+        const float4 x = *reinterpret_cast<const float4*>(hf + (size_t)(m * src_mul + src_off) * d + c);
+        uint2 o;
+        o.x = pack_bf2(x.x + silu(v[0] + b.x), x.y + silu(v[1] + b.y));
+        o.y = pack_bf2(x.z + silu(v[2] + b.z), x.w + silu(v[3] + b.w));
+        *reinterpret_cast<uint2*>(y + packed_index(m * row_mul + row_off + k, c, K32)) = o;
+    }
+};
+
+// ---- encoder -----------------------------------------------------------------------------
+struct EpConv1 {               // a1[b][t][n] = gelu(conv1) as row-major bf16 (input of the conv2 im2col)
+    bf16_t* a1; const float* bias; int T, Tpad, d;
+    __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const {
+        const int b = m / Tpad, t = m - b * Tpad;
+        if (t >= T) return;
+        const float4 bb = *reinterpret_cast<const float4*>(bias + n);
+        uint2 o;
+        o.x = pack_bf2(gelu_erf(v[0] + bb.x), gelu_erf(v[1] + bb.y));
+        o.y = pack_bf2(gelu_erf(v[2] + bb.z), gelu_erf(v[3] + bb.w));
+        *reinterpret_cast<uint2*>(a1 + ((size_t)b * T + t) * d + n) = o;
+    }
+};
+
+struct EpConv2 {               // h = gelu(conv2) + embed_positions   (HF:modeling_whisper.py:626-632)
+    float* h; const float* bias; const float* pos; int S, Spad, d;
+    __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const {
+        const int s = m % Spad;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s < S) {
+            const float4 bb = *reinterpret_cast<const float4*>(bias + n);
+            const float4 pp = *reinterpret_cast<const float4*>(pos + (size_t)s * d + n);
+            o = make_float4(gelu_erf(v[0] + bb.x) + pp.x, gelu_erf(v[1] + bb.y) + pp.y,
+                            gelu_erf(v[2] + bb.z) + pp.z, gelu_erf(v[3] + bb.w) + pp.w);
+        }
+        *reinterpret_cast<float4*>(h + (size_t)m * d + n) = o;
+    }
+};
+
+struct EpQKVEnc {              // q (x 64^-1/2), k as [b][h][s][64]; v transposed [b][h][64][s] for the PV MFMA operand
+    bf16_t* q; bf16_t* k; bf16_t* vt; const float* bias; int Spad, H, d;
+    __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const {
+        const int b = m / Spad, s = m - b * Spad;
+        const float4 bb = *reinterpret_cast<const float4*>(bias + n);
+        float x0 = v[0] + bb.x, x1 = v[1] + bb.y, x2 = v[2] + bb.z, x3 = v[3] + bb.w;
+        if (n < 2 * d) {
+            const bool isq = n < d;
+            const int c = isq ? n : n - d;
+            if (isq) { x0 *= 0.125f; x1 *= 0.125f; x2 *= 0.125f; x3 *= 0.125f; }
+            uint2 o; o.x = pack_bf2(x0, x1); o.y = pack_bf2(x2, x3);
+            *reinterpret_cast<uint2*>((isq ? q : k) + (((size_t)b * H + (c >> 6)) * Spad + s) * 64 + (c & 63)) = o;
+        } else {
+            const int c = n - 2 * d;
+            bf16_t* p = vt + (((size_t)b * H + (c >> 6)) * 64 + (c & 63)) * Spad + s;
+            p[0] = f2bf(x0); p[Spad] = f2bf(x1); p[2 * (size_t)Spad] = f2bf(x2); p[3 * (size_t)Spad] = f2bf(x3);
+        }
+    }
+};
+
+struct EpCrossKV {             // K_x / V_x of every kv-layer: [kvl][b][h][s][64] bf16   (HF:modeling_whisper.py:322-335)
+    bf16_t* kx; bf16_t* vx; const float* bias; int Spad, H, d, B;
+    __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const {
+        const int b = m / Spad, s = m - b * Spad;
+        const int kvl = n / (2 * d), rem = n - kvl * 2 * d;
+        const bool isv = rem >= d;
+        const int c = isv ? rem - d : rem;
+        const float4 bb = *reinterpret_cast<const float4*>(bias + n);
+        uint2 o; o.x = pack_bf2(v[0] + bb.x, v[1] + bb.y); o.y = pack_bf2(v[2] + bb.z, v[3] + bb.w);
+        *reinterpret_cast<uint2*>((isv ? vx : kx) + ((((size_t)kvl * B + b) * H + (c >> 6)) * Spad + s) * 64 + (c & 63)) = o;
+    }
+};

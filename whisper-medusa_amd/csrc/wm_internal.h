@@ -1,0 +1,110 @@
+// wm_internal.h — engine context shared by the three translation units of libwm.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include "../../include/wm.h"
+#include "wm_common.h"
+
+#define WM_HIP(expr)                                                                        \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            ctx->err = std::string(#expr) + ": " + hipGetErrorString(_e);                   \
+            return WM_ERR_HIP;                                                              \
+        }                                                                                   \
+    } while (0)
+
+struct EncLayerW {
+    const float *ln1_w, *ln1_b, *qkv_b, *out_b, *ln2_w, *ln2_b, *fc1_b, *fc2_b;
+    const bf16_t *qkv_w, *out_w, *fc1_w, *fc2_w;
+};
+struct DecLayerW {
+    const float *ln1_w, *ln1_b, *qkv_b, *out_b, *ln2_w, *ln2_b, *cq_b, *cout_b, *ln3_w, *ln3_b, *fc1_b, *fc2_b;
+    const bf16_t *qkv_w, *out_w, *cq_w, *cout_w, *fc1_w, *fc2_w;
+};
+
+// scalars every decode kernel may need (passed by value)
+struct GenDev {
+    int P, eos, pad, max_length, hard_max_length, exp_start /* absolute: start + P, or -1 */;
+    float thr, alpha, inv_temp;
+    int accept_mode, vanilla, K, V, Vpad, Tids;
+};
+
+struct wm_ctx {
+    wm_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    // derived sizes
+    int d = 0, H = 0, ffn = 0, V = 0, Vpad = 0, S = 0, Spad = 0, Tm = 0 /* mel frames 2S */, Tmpad = 0;
+    int Tmax = 0 /* n_tgt */, Tal = 0 /* cache rows allocated */, K = 0, nkv = 0, nres = 0, maxB = 0;
+    bool block = false;
+    int NS = 12;        // cross-attention key splits
+    int Ck = 0;         // keys per split
+
+    // ---- parameters (pointers into the caller's blob) ----
+    const float *win = nullptr, *twiddle = nullptr, *melfb = nullptr;
+    const bf16_t *conv1_w = nullptr, *conv2_w = nullptr;
+    const float *conv1_b = nullptr, *conv2_b = nullptr, *enc_pos = nullptr, *enc_lnf_w = nullptr, *enc_lnf_b = nullptr;
+    const bf16_t *tok_emb = nullptr, *vocab_w = nullptr, *heads_w = nullptr, *ckv_w = nullptr;
+    const float *dec_pos = nullptr, *dec_lnf_w = nullptr, *dec_lnf_b = nullptr, *heads_b = nullptr, *ckv_b = nullptr;
+    std::vector<EncLayerW> enc;
+    std::vector<DecLayerW> dec;       // nkv entries (last = medusa_block for Block)
+
+    // ---- encoder scratch (sized for maxB clips) ----
+    float* feats_own = nullptr;       // [B][n_mels][Tm]
+    float* clipmax = nullptr;         // [B] ordered-int encoded
+    bf16_t* A1 = nullptr;             // packed [B*Tmpad][K1pad]
+    bf16_t* a1 = nullptr;             // [B][Tm][d] bf16
+    bf16_t* A2 = nullptr;             // packed [B*Spad][3d]
+    float* eh = nullptr;              // [B*Spad][d] fp32 residual
+    bf16_t* exn = nullptr;            // packed [B*Spad][d]
+    bf16_t *eq = nullptr, *ek = nullptr, *evt = nullptr;   // [B][H][Spad][64] / vt [B][H][64][Spad]
+    bf16_t* eff = nullptr;            // packed [B*Spad][ffn]
+    bf16_t* enc_out = nullptr;        // packed [B*Spad][d]
+    int K1pad = 0;
+
+    // ---- caches ----
+    bf16_t *kx = nullptr, *vx = nullptr;   // cross K/V [nkv][Benc][H][Spad][64]
+    bf16_t *kc = nullptr, *vc = nullptr;   // self K/V  [nkv][maxB][H][Tal][64]
+    int Benc = 0;                          // batch of the last wm_encode
+
+    // ---- decode row scratch (<= WM_MAX_ROWS_SKINNY rows per chunk) ----
+    float *h = nullptr, *hblk = nullptr, *hf = nullptr, *qbuf = nullptr;
+    bf16_t *xbuf = nullptr, *fbuf = nullptr, *ybuf = nullptr;
+    float *cml = nullptr, *co = nullptr;   // cross-attention partials
+    float* logits = nullptr;               // [32][Vpad]
+    int* amax = nullptr; float *pc = nullptr, *ent = nullptr;   // select outputs, [maxB*16]
+
+    // ---- decode state ----
+    int *ids = nullptr, *L = nullptr, *kvlen = nullptr, *finished = nullptr, *cand = nullptr, *niter = nullptr;
+    long long* hist = nullptr;             // [16] accept histogram + [16]=tokens emitted
+    unsigned char* supmask = nullptr;      // [Vpad] bit0 suppress, bit1 begin-suppress
+    float* exppen = nullptr;               // [Tids+1] (factor^(t-start) - 1) as float
+    int* tap_tok = nullptr;
+    GenDev gp{};
+    int Bdec = 0;
+    bool began = false, first_done = false;
+    long long iters = 0;
+
+    hipGraphExec_t graph = nullptr;
+    int graph_B = 0;
+    int graph_replays = 0;
+
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float ms_logmel = 0.f, ms_encode = 0.f, ms_decode = 0.f;
+};
+
+// implemented in wm_encoder.hip
+int wm_enc_logmel(wm_ctx* ctx, const float* wav, int B, int n_samples, float* feats);
+int wm_enc_encode(wm_ctx* ctx, const float* feats, int B);
+// implemented in wm_decoder.hip
+int wm_dec_stage_layers(wm_ctx* ctx, int b0, int nb, int Mper, int mode /*0 base, 1 verify*/);
+int wm_dec_stage_final(wm_ctx* ctx, int b0, int nb, int Mper, int mode, int medusa);
+int wm_dec_stage_heads(wm_ctx* ctx, int nsel, int sel_mul, int sel_off, int medusa);
+int wm_dec_pass(wm_ctx* ctx, int b0, int nb, int Mper, int mode, int medusa, int all_rows);
+int wm_dec_iteration(wm_ctx* ctx, int Mper_base);   // one full iteration over all streams (chunked)
+int wm_dec_profile(wm_ctx* ctx, int kernel, int rows, int reps, float* ms, double* bytes);

@@ -1,0 +1,242 @@
+"""Drop-in ``WhisperMedusaModel`` backed by the HIP engine.
+
+Mirrors the reference's public API for the inference path (whisper_medusa/models/model.py):
+``from_pretrained`` (:265-291), ``generate`` (:1419-1779, same keyword names, same error behaviour for
+the unsupported features), ``forward`` (:1223-1347, logits ``[K+1, B, T, V]``), ``to``/``eval``.
+The canonical caller is eval_whisper_medusa.py:28-69 / README.md:101-142:
+
+    model = WhisperMedusaModel.from_pretrained(path); model = model.to("cuda")
+    ids = model.generate(input_features, language="en")        # LongTensor [1, T]
+    text = processor.decode(ids[0], skip_special_tokens=True)
+
+Differences, all supersets: batch > 1 is accepted (semantics = B independent batch-1 runs, SURVEY.md §0
+fact 2); ``extract_features(wav)`` computes the log-mel on the GPU (the reference leaves it to
+``WhisperProcessor``); ``vanilla=True`` runs plain greedy decoding for the anchor measurement.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from .config import MedusaConfig, GenParams, ACCEPT_TYPICAL, ACCEPT_GREEDY
+from .engine import Engine
+from . import weights as _weights
+from . import synth as _synth
+
+
+@dataclass
+class MedusaForwardOutput:
+    logits: torch.Tensor                 # [K+1 (or 1), B, T, V]  (model.py:1301)
+
+
+class WhisperMedusaModel:
+    def __init__(self, config: MedusaConfig, state_dict: Dict[str, torch.Tensor], device: Union[str, torch.device, None] = None,
+                 max_batch: int = 1):
+        self.config = config
+        self.generation_config = config          # posterior_threshold / alpha / token ids live on the config here
+        self._sd = state_dict
+        self._max_batch = max_batch
+        self._engine: Optional[Engine] = None
+        self._blob = None
+        self.device = torch.device("cpu")
+        if device is not None:
+            self.to(device)
+
+    # ---- construction ---------------------------------------------------------------------
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, *args, device=None, max_batch: int = 1, **kwargs):
+        """Load ``config.json`` + ``model.safetensors`` from a local checkpoint directory
+        (reference model.py:265-291; there is no hub access in this environment)."""
+        config = MedusaConfig.from_pretrained(pretrained_model_name_or_path)
+        sd = _weights.load_state_dict_from_dir(pretrained_model_name_or_path)
+        return cls(config, sd, device=device, max_batch=max_batch)
+
+    @classmethod
+    def from_blob(cls, config: MedusaConfig, blob: torch.Tensor, offsets: np.ndarray, max_batch: int = 1):
+        """Build directly from a packed parameter blob already resident on a GPU (the path the
+        8-GPU data-parallel launcher uses after the RCCL broadcast, ``dist.py``)."""
+        self = cls(config, {}, device=None, max_batch=max_batch)
+        self._blob, self._offsets = blob, offsets
+        self.device = blob.device
+        self._engine = Engine(config, blob, offsets, max_batch=max_batch, device=blob.device)
+        return self
+
+    def to(self, device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            if self._engine is None:
+                self.device = device
+                return self
+            raise RuntimeError("the Whisper-Medusa engine runs on a HIP device only")
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        if self._engine is not None and self.device == device:
+            return self
+        with torch.cuda.device(device):
+            self._blob, self._offsets = _weights.build_blob(self.config, self._sd, device=device)
+            self._engine = Engine(self.config, self._blob, self._offsets, max_batch=self._max_batch, device=device)
+        self.device = device
+        return self
+
+    def cuda(self, device=None):
+        return self.to("cuda" if device is None else device)
+
+    def eval(self):
+        return self
+
+    def set_max_batch(self, max_batch: int):
+        if max_batch != self._max_batch:
+            self._max_batch = max_batch
+            if self._engine is not None:
+                self._engine.close()
+                self._engine = Engine(self.config, self._blob, self._offsets, max_batch=max_batch, device=self.device)
+        return self
+
+    @property
+    def engine(self) -> Engine:
+        if self._engine is None:
+            raise RuntimeError("model is not on a HIP device: call model.to('cuda') first (there is no CPU path)")
+        return self._engine
+
+    def get_medusa_choice(self):
+        return self.config.medusa_choices
+
+    # ---- F0 ---------------------------------------------------------------------------------
+    def extract_features(self, wav: Union[np.ndarray, torch.Tensor, Sequence[np.ndarray]]) -> torch.Tensor:
+        """16 kHz mono waveform(s) -> log-mel ``input_features`` [B, 80, 3000] on the GPU; pads / trims
+        to 30 s like ``WhisperFeatureExtractor`` (eval_whisper_medusa.py:46-50)."""
+        n = 160 * self.config.n_mel_frames
+        if isinstance(wav, (list, tuple)):
+            clips = [np.asarray(w, dtype=np.float32) for w in wav]
+        else:
+            a = wav.detach().cpu().numpy() if isinstance(wav, torch.Tensor) else np.asarray(wav)
+            clips = [a.astype(np.float32)] if a.ndim == 1 else [r.astype(np.float32) for r in a]
+        buf = np.zeros((len(clips), n), dtype=np.float32)
+        for i, c in enumerate(clips):
+            m = min(len(c), n)
+            buf[i, :m] = c[:m]
+        return self.engine.logmel(torch.from_numpy(buf).to(self.device))
+
+    # ---- generate ---------------------------------------------------------------------------
+    def _gen_params(self, language, task, exponential_decay_length_penalty, max_new_tokens, max_length,
+                    temperature, vanilla, posterior_threshold, posterior_alpha, suppress_tokens,
+                    begin_suppress_tokens, prompt_ids) -> GenParams:
+        cfg = self.config
+        prompt = _synth.default_prompt(cfg, language or "en", task or "transcribe")        # G1, model.py:1519-1537
+        if prompt_ids is not None:
+            raise NotImplementedError("prompt_ids conditioning is not supported")
+        P = len(prompt)
+        if max_new_tokens is not None:
+            mlen = P + int(max_new_tokens)                                                # G2, model.py:1635-1639
+        elif max_length is not None:
+            mlen = int(max_length)
+        else:
+            mlen = cfg.max_length
+        mlen = min(mlen, cfg.max_target_positions)
+        if temperature is not None and float(temperature) > 0.0:
+            # reference: do_sample path falls through with `result` unbound (model.py:1128-1156)
+            raise NotImplementedError("sampling (temperature > 0) is not supported with medusa")
+        # G4: generate() forces generation_config.temperature = 1.0 when not sampling (model.py:1877-1881),
+        # so the typical-acceptance branch of evaluate_posterior runs.  temperature=0.0 selects exact-match.
+        mode = ACCEPT_GREEDY if (temperature is not None and float(temperature) == 0.0) else ACCEPT_TYPICAL
+        sup = list(cfg.suppress_tokens or []) if suppress_tokens is None else list(suppress_tokens)
+        bsup = list(cfg.begin_suppress_tokens or []) if begin_suppress_tokens is None else list(begin_suppress_tokens)
+        return GenParams(prompt=prompt, eos_token_id=cfg.eos_token_id, pad_token_id=cfg.pad_token_id,
+                         suppress_tokens=sup, begin_suppress_tokens=bsup, max_length=mlen,
+                         hard_max_length=cfg.max_length,
+                         exp_decay=tuple(exponential_decay_length_penalty) if exponential_decay_length_penalty else None,
+                         posterior_threshold=cfg.posterior_threshold if posterior_threshold is None else posterior_threshold,
+                         posterior_alpha=cfg.posterior_alpha if posterior_alpha is None else posterior_alpha,
+                         accept_mode=mode, temperature=1.0 if mode == ACCEPT_TYPICAL else 0.0, vanilla=bool(vanilla))
+
+    @torch.no_grad()
+    def generate(self, input_features: Optional[torch.Tensor] = None, generation_config=None, logits_processor=None,
+                 stopping_criteria=None, prefix_allowed_tokens_fn=None, synced_gpus: bool = False,
+                 return_timestamps: Optional[bool] = None, task: Optional[str] = None, language: Optional[str] = None,
+                 is_multilingual: Optional[bool] = None, prompt_ids: Optional[torch.Tensor] = None,
+                 prompt_condition_type: Optional[str] = None, condition_on_prev_tokens: Optional[bool] = None,
+                 temperature: Optional[Union[float, Tuple[float, ...]]] = None,
+                 compression_ratio_threshold: Optional[float] = None, logprob_threshold: Optional[float] = None,
+                 no_speech_threshold: Optional[float] = None, num_segment_frames: Optional[int] = None,
+                 attention_mask: Optional[torch.Tensor] = None, time_precision: float = 0.02,
+                 time_precision_features: float = 0.01, return_token_timestamps: Optional[bool] = None,
+                 return_segments: bool = False, return_dict_in_generate: Optional[bool] = None,
+                 force_unique_generate_call: Optional[bool] = None, **kwargs):
+        """Same signature as the reference (model.py:1419-1449).  Returns ``LongTensor [B, T]`` holding the
+        prompt + generated ids, right-padded with ``pad_token_id`` (model.py:1747-1762)."""
+        if return_timestamps:
+            raise NotImplementedError("return_timestamps is not supported with medusa for now")   # model.py:1171-1175
+        if no_speech_threshold is not None:
+            raise NotImplementedError("no_speech_detection is not supported with medusa for now")  # model.py:1201-1205
+        if kwargs.get("num_beams", 1) not in (None, 1):
+            raise Exception("Beam search is not supported with medusa for now")                     # model.py:1153-1156
+        if logits_processor or stopping_criteria or prefix_allowed_tokens_fn:
+            raise NotImplementedError("custom logits processors / stopping criteria are not supported by the HIP engine")
+        if input_features is None:
+            raise ValueError("input_features is required")
+        if input_features.dim() != 3:
+            raise ValueError("input_features must be [B, n_mels, frames]")
+        if input_features.shape[-1] > self.config.n_mel_frames:
+            raise NotImplementedError("Longform generation is not supported yet")                  # model.py:1213-1214
+        B = input_features.shape[0]
+        if B > self._max_batch:
+            self.set_max_batch(B)
+        gp = self._gen_params(language, task, kwargs.get("exponential_decay_length_penalty"),
+                              kwargs.get("max_new_tokens"), kwargs.get("max_length"),
+                              temperature if not isinstance(temperature, (tuple, list)) else temperature[0],
+                              kwargs.get("vanilla", False), kwargs.get("posterior_threshold"),
+                              kwargs.get("posterior_alpha"), kwargs.get("suppress_tokens"),
+                              kwargs.get("begin_suppress_tokens"), prompt_ids)
+        feats = input_features.to(self.device, torch.float32).contiguous()
+        eng = self.engine
+        eng.encode(feats)                                                   # F1 + F2
+        seqs = eng.decode(gp, B)                                            # F3..F14
+        self.last_stats = eng.stats()
+        return self._pad(seqs, gp)
+
+    def _pad(self, seqs: List[List[int]], gp: GenParams) -> torch.Tensor:
+        """G3: strip trailing pad/eos beyond the first EOS, right-pad to a tensor (model.py:1929-1973,1747-1762)."""
+        out = []
+        for s in seqs:
+            if gp.eos_token_id in s[len(gp.prompt):]:
+                j = s.index(gp.eos_token_id, len(gp.prompt))
+                s = s[: j + 1]
+            out.append(s)
+        T = max(len(s) for s in out)
+        t = torch.full((len(out), T), gp.pad_token_id, dtype=torch.long)
+        for i, s in enumerate(out):
+            t[i, : len(s)] = torch.tensor(s, dtype=torch.long)
+        return t.to(self.device)
+
+    def generate_from_wav(self, wav, **kw) -> torch.Tensor:
+        """log-mel on the GPU, then ``generate`` — the whole hot path of SURVEY.md §8a in one call."""
+        return self.generate(self.extract_features(wav), **kw)
+
+    # ---- forward ----------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, input_features: Optional[torch.Tensor] = None, attention_mask=None,
+                decoder_input_ids: Optional[torch.Tensor] = None, decoder_position_ids=None,
+                disable_medusa: bool = False, **kwargs) -> MedusaForwardOutput:
+        """Cache-free forward of the decoder over ``decoder_input_ids`` [B, T<=16] (model.py:1223-1347).
+        If ``input_features`` is given the encoder runs first; otherwise the last encoded batch is reused."""
+        if decoder_input_ids is None:
+            raise ValueError("decoder_input_ids is required")
+        if kwargs.get("labels") is not None:
+            raise NotImplementedError("training (labels / loss) is out of scope for the inference engine")
+        if input_features is not None:
+            self.engine.encode(input_features.to(self.device, torch.float32).contiguous())
+        pos0 = 0
+        if decoder_position_ids is not None:
+            pos0 = int(torch.as_tensor(decoder_position_ids).flatten()[0])
+        toks = decoder_input_ids.tolist()
+        return MedusaForwardOutput(logits=self.engine.forward_logits(toks, pos0, disable_medusa))
+
+    __call__ = forward
+
+
+def get_model(path, device=None):
+    """reference model.py:2079-2097."""
+    return WhisperMedusaModel.from_pretrained(path, device=device)

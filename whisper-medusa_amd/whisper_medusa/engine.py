@@ -1,0 +1,220 @@
+"""ctypes binding of libwm.so (include/wm.h).  PyTorch is used only to own device memory and
+the HIP stream; every call below crosses the C-ABI with plain pointers and sizes.
+
+There is NO fallback: if the HIP library is missing or there is no GPU, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .config import MedusaConfig, GenParams, HEADS_BLOCK
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwm.so")
+WM_ABI_VERSION = 1
+
+
+class WmConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "abi_version", "d_model", "enc_layers", "dec_layers", "n_heads", "ffn_dim", "vocab", "n_mels",
+        "n_ctx", "n_tgt", "medusa_heads", "heads_type", "max_batch")]
+
+
+class WmWeights(C.Structure):
+    _fields_ = [("blob", C.c_void_p), ("blob_bytes", C.c_uint64), ("offsets", C.POINTER(C.c_uint64)),
+                ("n_offsets", C.c_int32)]
+
+
+class WmGenParams(C.Structure):
+    _fields_ = [("prompt", C.POINTER(C.c_int32)), ("prompt_len", C.c_int32),
+                ("eos_token_id", C.c_int32), ("pad_token_id", C.c_int32),
+                ("suppress", C.POINTER(C.c_int32)), ("n_suppress", C.c_int32),
+                ("begin_suppress", C.POINTER(C.c_int32)), ("n_begin_suppress", C.c_int32),
+                ("max_length", C.c_int32), ("hard_max_length", C.c_int32),
+                ("exp_decay_start", C.c_int32), ("exp_decay_factor", C.c_float),
+                ("posterior_threshold", C.c_float), ("posterior_alpha", C.c_float),
+                ("temperature", C.c_float), ("accept_mode", C.c_int32), ("vanilla", C.c_int32)]
+
+
+class WmStats(C.Structure):
+    _fields_ = [("iterations", C.c_int64), ("tokens_emitted", C.c_int64), ("accept_hist", C.c_int64 * 16),
+                ("ms_logmel", C.c_float), ("ms_encode", C.c_float), ("ms_decode", C.c_float),
+                ("graph_replays", C.c_int32)]
+
+
+EXPORTS = ["wm_create", "wm_destroy", "wm_last_error", "wm_abi_version", "wm_logmel", "wm_encode",
+           "wm_decode_begin", "wm_decode_run", "wm_get_tokens", "wm_get_stats", "wm_sync",
+           "wm_get_encoder_output", "wm_forward_logits", "wm_get_cross_kv", "wm_profile_kernel"]
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    """dlopen libwm.so and declare the prototypes.  Raises if the library has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(f"{p} not found: build the HIP engine first (python whisper-medusa_amd/build.py). "
+                           "There is no CPU fallback.")
+    lib = C.CDLL(p)
+    vp, i32, f32p, i32p = C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32)
+    lib.wm_create.argtypes = [C.POINTER(WmConfig), C.POINTER(WmWeights), i32, vp, C.POINTER(vp)]
+    lib.wm_destroy.argtypes = [vp]; lib.wm_destroy.restype = None
+    lib.wm_last_error.argtypes = [vp]; lib.wm_last_error.restype = C.c_char_p
+    lib.wm_abi_version.argtypes = []
+    lib.wm_logmel.argtypes = [vp, vp, i32, i32, vp]
+    lib.wm_encode.argtypes = [vp, vp, i32]
+    lib.wm_decode_begin.argtypes = [vp, C.POINTER(WmGenParams), i32]
+    lib.wm_decode_run.argtypes = [vp, i32, i32p]
+    lib.wm_get_tokens.argtypes = [vp, i32, i32p, i32, i32p]
+    lib.wm_get_stats.argtypes = [vp, C.POINTER(WmStats)]
+    lib.wm_sync.argtypes = [vp]
+    lib.wm_get_encoder_output.argtypes = [vp, i32, f32p]
+    lib.wm_forward_logits.argtypes = [vp, i32, i32p, i32, i32, i32, f32p]
+    lib.wm_get_cross_kv.argtypes = [vp, i32, i32, i32, f32p, f32p]
+    lib.wm_profile_kernel.argtypes = [vp, i32, i32, i32, f32p, C.POINTER(C.c_double)]
+    for name in EXPORTS:
+        if name not in ("wm_destroy", "wm_last_error"):
+            getattr(lib, name).restype = i32
+    if lib.wm_abi_version() != WM_ABI_VERSION:
+        raise RuntimeError("libwm.so ABI version mismatch")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _i32arr(v: Sequence[int]):
+    a = (C.c_int32 * max(len(v), 1))(*[int(x) for x in v])
+    return a
+
+
+class Engine:
+    """One context = one GPU.  ``blob`` is the packed parameter tensor (uint8, on that GPU)."""
+
+    def __init__(self, cfg: MedusaConfig, blob: torch.Tensor, offsets: np.ndarray, max_batch: int = 1,
+                 device: Optional[torch.device] = None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible: the Whisper-Medusa engine has no CPU path")
+        self.lib = load_library()
+        self.cfg = cfg
+        self.device = torch.device(device if device is not None else blob.device)
+        if self.device.type != "cuda" or blob.device != self.device:
+            raise RuntimeError("parameter blob must live on the engine's GPU")
+        self.blob = blob                      # keep alive: the engine borrows it
+        self.max_batch = int(max_batch)
+        self._offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        c = WmConfig(WM_ABI_VERSION, cfg.d_model, cfg.encoder_layers, cfg.decoder_layers, cfg.n_heads,
+                     cfg.decoder_ffn_dim, cfg.vocab_size, cfg.num_mel_bins, cfg.max_source_positions,
+                     cfg.max_target_positions, cfg.medusa_num_heads,
+                     1 if cfg.medusa_heads_type == HEADS_BLOCK else 0, self.max_batch)
+        w = WmWeights(C.c_void_p(blob.data_ptr()), blob.numel(),
+                      self._offsets.ctypes.data_as(C.POINTER(C.c_uint64)), len(self._offsets))
+        self.stream = torch.cuda.current_stream(self.device)
+        h = C.c_void_p()
+        rc = self.lib.wm_create(C.byref(c), C.byref(w), self.device.index or 0, C.c_void_p(self.stream.cuda_stream), C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"wm_create failed ({rc}): {self.lib.wm_last_error(None).decode()}")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.wm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            msg = self.lib.wm_last_error(self.h).decode()
+            if rc == -1:
+                raise ValueError(f"{what}: {msg}")
+            raise RuntimeError(f"{what} failed ({rc}): {msg}")
+
+    # ---- F0 -------------------------------------------------------------------------------
+    def logmel(self, wav: torch.Tensor) -> torch.Tensor:
+        """wav [B, 160*2*n_ctx] float32 on the GPU -> features [B, n_mels, 2*n_ctx]."""
+        assert wav.is_cuda and wav.dtype == torch.float32 and wav.is_contiguous()
+        B, n = wav.shape
+        feats = torch.empty(B, self.cfg.num_mel_bins, self.cfg.n_mel_frames, dtype=torch.float32, device=wav.device)
+        self._check(self.lib.wm_logmel(self.h, C.c_void_p(wav.data_ptr()), B, n, C.c_void_p(feats.data_ptr())), "wm_logmel")
+        return feats
+
+    # ---- F1/F2 ------------------------------------------------------------------------------
+    def encode(self, feats: torch.Tensor) -> None:
+        assert feats.is_cuda and feats.dtype == torch.float32 and feats.is_contiguous()
+        B = feats.shape[0]
+        if tuple(feats.shape[1:]) != (self.cfg.num_mel_bins, self.cfg.n_mel_frames):
+            raise ValueError(f"Whisper expects the mel input features to be of length {self.cfg.n_mel_frames}, "
+                             f"but found {feats.shape[-1]}")
+        self._check(self.lib.wm_encode(self.h, C.c_void_p(feats.data_ptr()), B), "wm_encode")
+        self._B = B
+
+    # ---- F3..F14 ------------------------------------------------------------------------------
+    def decode(self, gp: GenParams, B: int, max_iters: int = 1 << 30) -> List[List[int]]:
+        prompt, sup, bsup = _i32arr(gp.prompt), _i32arr(gp.suppress_tokens), _i32arr(gp.begin_suppress_tokens)
+        g = WmGenParams(prompt, len(gp.prompt), gp.eos_token_id, gp.pad_token_id, sup, len(gp.suppress_tokens),
+                        bsup, len(gp.begin_suppress_tokens), gp.max_length, gp.hard_max_length,
+                        gp.exp_decay[0] if gp.exp_decay is not None else -1,
+                        float(gp.exp_decay[1]) if gp.exp_decay is not None else 1.0,
+                        gp.posterior_threshold, gp.posterior_alpha, gp.temperature if gp.temperature else 0.0,
+                        gp.accept_mode, 1 if gp.vanilla else 0)
+        self._check(self.lib.wm_decode_begin(self.h, C.byref(g), B), "wm_decode_begin")
+        left = C.c_int32(0)
+        self._check(self.lib.wm_decode_run(self.h, max_iters, C.byref(left)), "wm_decode_run")
+        return [self.tokens(b) for b in range(B)]
+
+    def tokens(self, stream: int) -> List[int]:
+        cap = self.cfg.max_target_positions + 16
+        buf = (C.c_int32 * cap)()
+        n = C.c_int32(0)
+        self._check(self.lib.wm_get_tokens(self.h, stream, buf, cap, C.byref(n)), "wm_get_tokens")
+        return list(buf[: min(n.value, cap)])
+
+    def stats(self) -> dict:
+        s = WmStats()
+        self._check(self.lib.wm_get_stats(self.h, C.byref(s)), "wm_get_stats")
+        return dict(iterations=s.iterations, tokens_emitted=s.tokens_emitted,
+                    accept_hist=list(s.accept_hist)[: self.cfg.medusa_num_heads + 1],
+                    ms_logmel=s.ms_logmel, ms_encode=s.ms_encode, ms_decode=s.ms_decode,
+                    graph_replays=s.graph_replays)
+
+    def sync(self):
+        self._check(self.lib.wm_sync(self.h), "wm_sync")
+
+    # ---- taps -------------------------------------------------------------------------------
+    def encoder_output(self, B: int) -> torch.Tensor:
+        out = np.empty((B, self.cfg.max_source_positions, self.cfg.d_model), dtype=np.float32)
+        self._check(self.lib.wm_get_encoder_output(self.h, B, out.ctypes.data_as(C.POINTER(C.c_float))), "wm_get_encoder_output")
+        return torch.from_numpy(out)
+
+    def cross_kv(self, kv_layer: int, stream: int, head: int):
+        S = self.cfg.max_source_positions
+        k = np.empty((S, 64), dtype=np.float32); v = np.empty((S, 64), dtype=np.float32)
+        self._check(self.lib.wm_get_cross_kv(self.h, kv_layer, stream, head, k.ctypes.data_as(C.POINTER(C.c_float)),
+                                             v.ctypes.data_as(C.POINTER(C.c_float))), "wm_get_cross_kv")
+        return torch.from_numpy(k), torch.from_numpy(v)
+
+    def forward_logits(self, tokens: Sequence[Sequence[int]], pos0: int, disable_medusa: bool) -> torch.Tensor:
+        B, T = len(tokens), len(tokens[0])
+        flat = _i32arr([t for row in tokens for t in row])
+        n_out = 1 if disable_medusa else self.cfg.medusa_num_heads + 1
+        out = np.empty((n_out, B, T, self.cfg.vocab_size), dtype=np.float32)
+        self._check(self.lib.wm_forward_logits(self.h, B, flat, T, pos0, 1 if disable_medusa else 0,
+                                               out.ctypes.data_as(C.POINTER(C.c_float))), "wm_forward_logits")
+        return torch.from_numpy(out)
+
+    def profile_layer_gemms(self, rows: int, reps: int = 50):
+        ms, nbytes = C.c_float(0), C.c_double(0)
+        self._check(self.lib.wm_profile_kernel(self.h, 0, rows, reps, C.byref(ms), C.byref(nbytes)), "wm_profile_kernel")
+        return ms.value, nbytes.value
