@@ -99,7 +99,7 @@ def log_mel(wav: np.ndarray, n_mels: int = 80, n_samples: int = 480000) -> np.nd
     mel = power @ mel_filter_bank(n_mels, n_fft)                              # [frames-1, n_mels]
     logs = np.log10(np.maximum(mel, 1e-10))
     logs = np.maximum(logs, logs.max() - 8.0)
-    return ((logs + 4.0) / 4.0).T.astype(np.float32)
+    return np.ascontiguousarray(((logs + 4.0) / 4.0).T, dtype=np.float32)
 
 
 # --------------------------------------------------------------------------------------

@@ -144,7 +144,7 @@ class Engine:
     # ---- F0 -------------------------------------------------------------------------------
     def logmel(self, wav: torch.Tensor) -> torch.Tensor:
         """wav [B, 160*2*n_ctx] float32 on the GPU -> features [B, n_mels, 2*n_ctx]."""
-        assert wav.is_cuda and wav.dtype == torch.float32 and wav.is_contiguous()
+        wav = wav.to(self.device, torch.float32).contiguous()
         B, n = wav.shape
         feats = torch.empty(B, self.cfg.num_mel_bins, self.cfg.n_mel_frames, dtype=torch.float32, device=wav.device)
         self._check(self.lib.wm_logmel(self.h, C.c_void_p(wav.data_ptr()), B, n, C.c_void_p(feats.data_ptr())), "wm_logmel")
@@ -152,7 +152,7 @@ class Engine:
 
     # ---- F1/F2 ------------------------------------------------------------------------------
     def encode(self, feats: torch.Tensor) -> None:
-        assert feats.is_cuda and feats.dtype == torch.float32 and feats.is_contiguous()
+        feats = feats.to(self.device, torch.float32).contiguous()
         B = feats.shape[0]
         if tuple(feats.shape[1:]) != (self.cfg.num_mel_bins, self.cfg.n_mel_frames):
             raise ValueError(f"Whisper expects the mel input features to be of length {self.cfg.n_mel_frames}, "
