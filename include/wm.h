@@ -86,7 +86,8 @@ typedef struct wm_gen_params {
 } wm_gen_params;
 
 typedef struct wm_stats {
-    int64_t iterations;             /* decode iterations launched since wm_decode_begin */
+    int64_t iterations;             /* decode iterations the slowest stream needed since wm_decode_begin */
+    int64_t iterations_launched;    /* iterations enqueued (polling granularity; extra ones are device-side no-ops) */
     int64_t tokens_emitted;         /* sum over streams of tokens appended after the prompt */
     int64_t accept_hist[16];        /* histogram of accept length a (0..K), all streams */
     float ms_logmel, ms_encode, ms_decode;   /* hipEvent-timed on the context's stream, last call of each */
@@ -126,7 +127,8 @@ int wm_sync(wm_ctx* ctx);
 int wm_get_encoder_output(wm_ctx* ctx, int B, float* out /* HOST */);
 /* One decoder pass for stream 0..B-1 over T (<=16) tokens each at positions pos0.., appending
  * K/V at kv row pos0; logits_out HOST float32 [n_out][B][T][vocab], n_out = 1 if disable_medusa
- * else K+1 (all T rows, as forward() returns).  Does not touch the decode-loop state. */
+ * else K+1 (all T rows, as forward() returns).  Uses (and overwrites) the decode-loop state: call it
+ * before wm_decode_begin, or begin again afterwards. */
 int wm_forward_logits(wm_ctx* ctx, int B, const int32_t* tokens /* HOST [B][T] */, int T, int pos0,
                       int disable_medusa, float* logits_out);
 /* cross K/V of one kv-layer/stream/head: HOST float32 [n_ctx][64] each */

@@ -27,8 +27,10 @@ layer and the Linear path: parity for Block is "restated, partially pinned".
 
 NUMERICS.  ``sim="fp32"`` is the reference's default dtype.  ``sim="bf16"`` mirrors
 the engine's storage/rounding contract: parameters are
-bf16-representable, every GEMM input is rounded to bf16, the self/cross KV cache and
-the encoder output are stored in bf16, and all accumulation / LayerNorm / softmax /
+bf16-representable; in the ENCODER every GEMM input is rounded to bf16 (MFMA prefill);
+in the DECODER GEMM/attention operands are carried as a bf16 hi/lo pair (x = hi + lo,
+~17 mantissa bits, ``_rd``) so they are effectively unrounded; the self/cross KV cache
+and the encoder output are stored in bf16; all accumulation / LayerNorm / softmax /
 residual arithmetic is fp32.
 """
 from __future__ import annotations
@@ -166,11 +168,17 @@ class Oracle:
             self.sd["whisper_model.proj_out.weight"] = self.sd["whisper_model.model.decoder.embed_tokens.weight"]
 
     # ---- small helpers --------------------------------------------------------------
-    def _r(self, x):           # rounding point of the engine contract
+    def _r(self, x):           # rounding point of the engine contract (encoder operands, KV / encoder-output storage)
         return _bf16(x) if self.sim == "bf16" else x
 
-    def _lin(self, x, prefix, bias=True):
-        y = self._r(x) @ self.sd[prefix + ".weight"].t()
+    def _rd(self, x):          # decoder operands: bf16 hi + bf16 lo
+        if self.sim != "bf16":
+            return x
+        hi = _bf16(x)
+        return hi + _bf16(x - hi)
+
+    def _lin(self, x, prefix, bias=True, dec=False):
+        y = (self._rd(x) if dec else self._r(x)) @ self.sd[prefix + ".weight"].t()
         if bias and (prefix + ".bias") in self.sd:
             y = y + self.sd[prefix + ".bias"]
         return y
@@ -181,7 +189,7 @@ class Oracle:
     def _heads(self, x):       # [T, d] -> [H, T, 64]
         return x.view(x.shape[0], self.H, HEAD_DIM).transpose(0, 1)
 
-    def _attend(self, q, k, v, mask=None, round_p=False):
+    def _attend(self, q, k, v, mask=None, round_p=False, dec=False):
         """q [H,T,64] (already scaled), k/v [H,S,64] -> [T, d].  Softmax in fp32
         (HF:modeling_whisper.py:214-238)."""
         w = q @ k.transpose(1, 2)
@@ -190,6 +198,8 @@ class Oracle:
         w = torch.softmax(w, dim=-1)
         if round_p:
             w = self._r(w)
+        if dec:
+            w = self._rd(w)
         o = w @ v
         return o.transpose(0, 1).reshape(q.shape[1], -1)
 
@@ -232,24 +242,24 @@ class Oracle:
     def _dec_layer(self, lp, h, slot, st, T):
         kv_len = st["kv_len"]
         xn = self._ln(h, lp + ".self_attn_layer_norm")
-        q = self._lin(xn, lp + ".self_attn.q_proj") * HEAD_DIM ** -0.5
-        k = self._r(self._lin(xn, lp + ".self_attn.k_proj", bias=False))
-        v = self._r(self._lin(xn, lp + ".self_attn.v_proj"))
+        q = self._rd(self._lin(xn, lp + ".self_attn.q_proj", dec=True) * HEAD_DIM ** -0.5)
+        k = self._r(self._lin(xn, lp + ".self_attn.k_proj", bias=False, dec=True))
+        v = self._r(self._lin(xn, lp + ".self_attn.v_proj", dec=True))
         kc, vc = st["self_kv"][slot]
         kc = torch.cat([kc[:, :kv_len], self._heads(k)], dim=1)      # contiguous cache: rows kv_len.. overwritten
         vc = torch.cat([vc[:, :kv_len], self._heads(v)], dim=1)
         st["self_kv"][slot] = (kc, vc)
         mask = torch.full((T, kv_len + T), 0.0)
         mask[:, kv_len:] = torch.triu(torch.full((T, T), -float("inf")), diagonal=1)
-        a = self._attend(self._heads(q), kc, vc, mask)
-        h = h + self._lin(a, lp + ".self_attn.out_proj")
+        a = self._attend(self._heads(q), kc, vc, mask, dec=True)
+        h = h + self._lin(a, lp + ".self_attn.out_proj", dec=True)
         xn = self._ln(h, lp + ".encoder_attn_layer_norm")
-        q = self._lin(xn, lp + ".encoder_attn.q_proj") * HEAD_DIM ** -0.5
+        q = self._rd(self._lin(xn, lp + ".encoder_attn.q_proj", dec=True) * HEAD_DIM ** -0.5)
         kx, vx = st["cross_kv"][slot]
-        a = self._attend(self._heads(q), kx, vx)
-        h = h + self._lin(a, lp + ".encoder_attn.out_proj")
+        a = self._attend(self._heads(q), kx, vx, dec=True)
+        h = h + self._lin(a, lp + ".encoder_attn.out_proj", dec=True)
         xn = self._ln(h, lp + ".final_layer_norm")
-        h = h + self._lin(F.gelu(self._lin(xn, lp + ".fc1")), lp + ".fc2")
+        h = h + self._lin(F.gelu(self._lin(xn, lp + ".fc1", dec=True)), lp + ".fc2", dec=True)
         return h
 
     def new_state(self, enc: torch.Tensor) -> dict:
@@ -259,10 +269,10 @@ class Oracle:
 
     def _res_head(self, k, x):
         """MedusaResBlock: x + SiLU(W x + b)  (model.py:180-210)."""
-        return x + F.silu(self._lin(x, f"medusa_heads.{k}.0.linear"))
+        return x + F.silu(self._lin(x, f"medusa_heads.{k}.0.linear", dec=True))
 
     def _vocab(self, y):
-        return self._r(y) @ self.sd["whisper_model.proj_out.weight"].t()       # tied, no bias (model.py:1277)
+        return self._rd(y) @ self.sd["whisper_model.proj_out.weight"].t()      # tied, no bias (model.py:1277)
 
     def decoder_pass(self, st: dict, tokens: List[int], pos0: int, disable_medusa: bool,
                      last_only: bool = False) -> torch.Tensor:

@@ -44,7 +44,13 @@ print(torch.cuda.get_device_name(0), flush=True)
 
 for tag, cfg, seed in (("micro", MedusaConfig.micro(K=4), 11), ("micro10", MedusaConfig.micro(K=10), 12),
                        ("microblock", MedusaConfig.micro(K=4, heads_type="medusa_block"), 13),
-                       ("tiny", MedusaConfig.tiny_en(K=4), 0)):
+                       ("tiny", MedusaConfig.tiny_en(K=4), 0),
+                       ("wide", MedusaConfig(d_model=1280, encoder_layers=2, decoder_layers=2, encoder_attention_heads=20,
+                                             decoder_attention_heads=20, encoder_ffn_dim=5120, decoder_ffn_dim=5120, vocab_size=4099,
+                                             medusa_num_heads=10, medusa_hidden_size=1280, medusa_choices=[1] * 11,
+                                             eos_token_id=4096, pad_token_id=4096, decoder_start_token_id=4097,
+                                             is_multilingual=False, lang_to_id={}, task_to_id={}, no_timestamps_token_id=4098,
+                                             begin_suppress_tokens=[7, 4096]), 5)):
     sd = synth.synth_state_dict(cfg, seed=seed)
     orc = Oracle(cfg, sd, sim="bf16")
     wavs = [clip_for(cfg, 0), clip_for(cfg, 1)[: cfg.n_mel_frames * 160 // 3]]

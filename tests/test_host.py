@@ -121,20 +121,24 @@ def test_generate_argument_errors_match_reference():
 
 
 def test_skinny_plan_covers_all_whisper_shapes():
-    """The launch plan's invariants (K-slices are whole rounds of U fragments, <= 16 waves per block)."""
+    """The launch plan's invariants (K-slices are whole rounds of U fragments, <= 10 waves per block);
+    mirrors skinny_plan() in csrc/wm_skinny_gemm.h."""
     def plan(N16, K32, lds):
-        U = 8 if (lds and K32 % 8 == 0) else 4
+        U = 8 if K32 % 8 == 0 else 4
         q = K32 // U
         best = 1
-        for s in range(1, min(16, q) + 1):
+        for s in range(1, min(10, q) + 1):
             if q % s:
                 continue
             best = s
             if N16 * s >= 1024:
                 break
-        return best, (4 if best == 1 else 1), U
+        rt = 4 if best == 1 else 1
+        if lds and 1 < best <= 5 and N16 > 256:
+            rt = 2
+        return best, rt, U
     for d in (128, 384, 512, 768, 1024, 1280):
         for (N, K) in ((3 * d, d), (d, d), (4 * d, d), (d, 4 * d), (51968, d), (11 * d, d)):
             for lds in (True, False):
                 ks, rt, U = plan(N // 16, K // 32, lds)
-                assert (K // 32) % (ks * U) == 0 and ks * rt <= 16
+                assert (K // 32) % (ks * U) == 0 and ks * rt <= 10

@@ -15,7 +15,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;         // one MFMA
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;           // one MFMA C/D fragment
 
 #define WM_HEAD_DIM 64
-#define WM_MAX_ROWS_SKINNY 32      // rows (streams x tokens) the weight-streaming GEMM handles per launch
+#define WM_MAX_ROWS_SKINNY 16      // token rows (streams x tokens) the weight-streaming GEMM handles per launch
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
@@ -59,4 +59,14 @@ __device__ __forceinline__ bf16x8_t ld_frag(const bf16_t* p) {       // 16-B ali
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 __device__ __forceinline__ bf16x8_t ld_frag_nt(const bf16_t* p) {    // streamed-once weights: global_load_dwordx4 ... nt
     return __builtin_bit_cast(bf16x8_t, __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p)));
+}
+
+// store 4 consecutive values as a bf16 hi/lo pair (x = hi + lo keeps ~17 mantissa bits)
+__device__ __forceinline__ void st_hilo4(bf16_t* hi, bf16_t* lo, float4 y)
+{
+    const bf16_t h0 = f2bf(y.x), h1 = f2bf(y.y), h2 = f2bf(y.z), h3 = f2bf(y.w);
+    uint2 a; a.x = (uint32_t)h0 | ((uint32_t)h1 << 16); a.y = (uint32_t)h2 | ((uint32_t)h3 << 16);
+    *reinterpret_cast<uint2*>(hi) = a;
+    uint2 b; b.x = pack_bf2(y.x - bf2f(h0), y.y - bf2f(h1)); b.y = pack_bf2(y.z - bf2f(h2), y.w - bf2f(h3));
+    *reinterpret_cast<uint2*>(lo) = b;
 }

@@ -31,11 +31,11 @@ __global__ void k_embed(float* __restrict__ h, const bf16_t* __restrict__ tok_em
 
 // ---------------------------------------------------------------------------------------------
 // rows_norm: one wave per row. out row m <- LayerNorm (or identity) of src row m*src_mul+src_off.
-// Optional outputs: fp32 rows (two copies) and packed-bf16 rows at m*p_mul + p_off.
+// Optional outputs: fp32 rows (two copies) and packed bf16 hi/lo rows at m*p_mul + p_off.
 // ---------------------------------------------------------------------------------------------
 __global__ void k_rows_norm(const float* __restrict__ src, int src_mul, int src_off, const float* __restrict__ gamma,
                             const float* __restrict__ beta, int do_norm, float* __restrict__ out_a, float* __restrict__ out_b,
-                            bf16_t* __restrict__ out_p, int K32, int p_mul, int p_off, int d, int M)
+                            bf16_t* __restrict__ out_p, size_t p_plane, int K32, int p_mul, int p_off, int d, int M)
 {
     const int lane = threadIdx.x & 63;
     const int m = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -76,139 +76,203 @@ __global__ void k_rows_norm(const float* __restrict__ src, int src_mul, int src_
             if (out_a) reinterpret_cast<float4*>(out_a + (size_t)m * d)[j] = y;
             if (out_b) reinterpret_cast<float4*>(out_b + (size_t)m * d)[j] = y;
             if (out_p) {
-                uint2 o; o.x = pack_bf2(y.x, y.y); o.y = pack_bf2(y.z, y.w);
-                *reinterpret_cast<uint2*>(out_p + packed_index(m * p_mul + p_off, j * 4, K32)) = o;
+                const size_t o = packed_index(m * p_mul + p_off, j * 4, K32);
+                st_hilo4(out_p + o, out_p + p_plane + o, y);
             }
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Decode attention for M (<=16) query rows of one (stream, head).
-//  CROSS = false: causal self-attention over the contiguous KV cache (keys 0 .. base+r), output
-//                 written as packed bf16 rows (operand of out_proj).
-//  CROSS = true : keys [split*Ck, ...) of the encoder cross K/V; writes un-normalised partials
-//                 (max, sum, o[64]) that the out_proj loader combines (LdCombine).
-// fp32 scores / softmax, bf16 K/V (HF:modeling_whisper.py:214-238, 288-340).
+// Decode attention on the matrix cores for M (<=16) query rows of one (stream, head).
+//   S^T = K Q^T  : A = 16 keys x 32 dims of the bf16 K cache (row-major rows = 128-B lines),
+//                  B = Q^T as a bf16 hi/lo pair (q keeps ~17 bits) -> a lane owns 8 scores of ONE query,
+//   O^T = V^T P^T: A = V^T (the V cache is stored transposed [64][rows]), B = P hi/lo straight from the
+//                  score registers (the MFMA k-slot <-> key permutation is shared by both operands).
+// fp32 online softmax; 4 waves split the keys and merge through LDS in a fixed order.
+//  CROSS = false: causal over the contiguous self-KV cache (query r sees keys <= base + r); wave w takes the
+//                 32-key steps w, w+4, ...; writes normalised output as packed hi/lo rows (out_proj operand).
+//  CROSS = true : grid.x = key split; the block owns keys [256*split, +256), wave w 64 of them; it publishes
+//                 its un-normalised partial (max, sum, o[64]) with an agent-scope release and takes a ticket;
+//                 the LAST block of a (stream, head) acquires, merges the NS partials in split order
+//                 (deterministic) and writes the packed hi/lo rows — no separate combine launch.
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split_hilo8(const float* x, bf16x8_t& hi, bf16x8_t& lo)
+{
+    uint4 h, l;
+    uint32_t* hp = reinterpret_cast<uint32_t*>(&h); uint32_t* lp = reinterpret_cast<uint32_t*>(&l);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bf16_t a = f2bf(x[2 * i]), b = f2bf(x[2 * i + 1]);
+        hp[i] = (uint32_t)a | ((uint32_t)b << 16);
+        lp[i] = pack_bf2(x[2 * i] - bf2f(a), x[2 * i + 1] - bf2f(b));
+    }
+    hi = __builtin_bit_cast(bf16x8_t, h); lo = __builtin_bit_cast(bf16x8_t, l);
+}
+
 template <bool CROSS>
 __global__ void __launch_bounds__(256)
-k_attn_decode(const float* __restrict__ q, const bf16_t* __restrict__ kmat, const bf16_t* __restrict__ vmat,
-              const int* __restrict__ base, bf16_t* __restrict__ xout, float* __restrict__ ml, float* __restrict__ po,
-              int Mper, int H, int rows_alloc /* Tal or Spad */, int S, int Ck, int NS, int K32)
+k_attn_mfma(const float* __restrict__ q, const bf16_t* __restrict__ kmat, const bf16_t* __restrict__ vtmat,
+            const int* __restrict__ base, bf16_t* __restrict__ xout, size_t xplane, float* __restrict__ ml, float* __restrict__ po,
+            int* __restrict__ ticket, const int* __restrict__ done, int Mper, int H, int rows_alloc, int S, int NS, int K32)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int hd = blockIdx.y, s = blockIdx.z, split = blockIdx.x;
-    const int tid = threadIdx.x, d = H * 64;
-    const int ldp = CROSS ? Ck : rows_alloc;                // ps row stride
-    float* qs = reinterpret_cast<float*>(smem);             // [16][64]
-    float* ps = qs + 16 * 64;                               // [16][ldp]
-    float* red = ps + 16 * ldp;                             // [4][16][64]
+    if (done && *done) return;
+    __shared__ float s_m[4][16], s_l[4][16];
+    __shared__ int s_last;
+    __shared__ __attribute__((aligned(16))) float s_o[4][16][68];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+    const int hd = blockIdx.y, s = blockIdx.z, split = blockIdx.x, d = H * 64;
 
-    int k0, k1;
-    if (CROSS) { k0 = split * Ck; k1 = min(S, k0 + Ck); }
-    else { k0 = 0; k1 = min(base[s] + Mper, rows_alloc); }
-    const int nk = max(k1 - k0, 0);
-    const int b0 = CROSS ? 0 : base[s];
-    const bf16_t* kp = kmat + ((size_t)s * H + hd) * rows_alloc * 64;
-    const bf16_t* vp = vmat + ((size_t)s * H + hd) * rows_alloc * 64;
-
-    for (int e = tid; e < Mper * 64; e += 256) qs[e] = q[(size_t)(s * Mper + (e >> 6)) * d + hd * 64 + (e & 63)];
-    __syncthreads();
-
-    // ---- scores ----
-    for (int j = tid; j < nk; j += 256) {
-        const uint4* kr = reinterpret_cast<const uint4*>(kp + (size_t)(k0 + j) * 64);
-        float kf[64];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const uint4 u = kr[i];
-            kf[8 * i + 0] = bf2f((bf16_t)(u.x & 0xffff)); kf[8 * i + 1] = bf2f((bf16_t)(u.x >> 16));
-            kf[8 * i + 2] = bf2f((bf16_t)(u.y & 0xffff)); kf[8 * i + 3] = bf2f((bf16_t)(u.y >> 16));
-            kf[8 * i + 4] = bf2f((bf16_t)(u.z & 0xffff)); kf[8 * i + 5] = bf2f((bf16_t)(u.z >> 16));
-            kf[8 * i + 6] = bf2f((bf16_t)(u.w & 0xffff)); kf[8 * i + 7] = bf2f((bf16_t)(u.w >> 16));
-        }
-        for (int r = 0; r < Mper; ++r) {
-            const float4* qr = reinterpret_cast<const float4*>(qs + r * 64);
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float4 qq = qr[i];
-                a0 += qq.x * kf[4 * i]; a1 += qq.y * kf[4 * i + 1]; a2 += qq.z * kf[4 * i + 2]; a3 += qq.w * kf[4 * i + 3];
-            }
-            float sc = (a0 + a1) + (a2 + a3);
-            if (!CROSS && (k0 + j) > b0 + r) sc = -INFINITY;      // causal: row r sees keys <= base + r
-            ps[r * ldp + j] = sc;
-        }
-    }
-    __syncthreads();
-
-    // ---- softmax statistics: wave w owns rows w, w+4, ... ----
+    bf16x8_t qhi[2], qlo[2];
     {
-        const int lane = tid & 63, w = tid >> 6;
-        for (int r = w; r < Mper; r += 4) {
-            float mx = -INFINITY;
-            for (int j = lane; j < nk; j += 64) mx = fmaxf(mx, ps[r * ldp + j]);
-            mx = wave_max(mx);
-            float sum = 0.f;
-            for (int j = lane; j < nk; j += 64) {
-                const float e = (mx == -INFINITY) ? 0.f : __expf(ps[r * ldp + j] - mx);
-                ps[r * ldp + j] = e; sum += e;
-            }
-            sum = wave_sum(sum);
-            if (CROSS) {
-                if (lane == 0) {
-                    float* o = ml + (((size_t)(s * Mper + r) * H + hd) * NS + split) * 2;
-                    o[0] = mx; o[1] = sum;
-                }
+        float qv[8];
+#pragma unroll
+        for (int ds = 0; ds < 2; ++ds) {
+            if (c < Mper) {
+                const float4* qp = reinterpret_cast<const float4*>(q + (size_t)(s * Mper + c) * d + hd * 64 + ds * 32 + g * 8);
+                const float4 u0 = qp[0], u1 = qp[1];
+                qv[0] = u0.x; qv[1] = u0.y; qv[2] = u0.z; qv[3] = u0.w; qv[4] = u1.x; qv[5] = u1.y; qv[6] = u1.z; qv[7] = u1.w;
             } else {
-                const float inv = 1.0f / sum;
-                for (int j = lane; j < nk; j += 64) ps[r * ldp + j] *= inv;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) qv[i] = 0.f;
             }
+            split_hilo8(qv, qhi[ds], qlo[ds]);
         }
     }
-    __syncthreads();
+    const int b0 = CROSS ? 0 : base[s];
+    const int limit = CROSS ? S : min(b0 + c + 1, rows_alloc);            // keys < limit are visible to query c
+    int kb, kend, kstep;
+    if (CROSS) { kb = split * 256 + w * 64; kend = min(S, kb + 64); kstep = 32; }
+    else { kb = 32 * w; kend = min(b0 + Mper, rows_alloc); kstep = 128; }
+    const bf16_t* kp = kmat + ((size_t)s * H + hd) * rows_alloc * 64;
+    const bf16_t* vp = vtmat + ((size_t)s * H + hd) * 64 * rows_alloc;
 
-    // ---- P.V: thread = (dd, key-group g); fixed-order reduction over the 4 groups ----
-    {
-        const int dd = tid & 63, g = tid >> 6;
-        float acc[16];
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4_t o[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        for (int j = g; j < nk; j += 4) {
-            const float vv = bf2f(vp[(size_t)(k0 + j) * 64 + dd]);
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    for (; kb < kend; kb += kstep) {
+        const bf16_t* kr = kp + (size_t)(kb + c) * 64 + g * 8;
+        const bf16x8_t a00 = ld_frag(kr), a01 = ld_frag(kr + 32);
+        const bf16x8_t a10 = ld_frag(kr + 16 * 64), a11 = ld_frag(kr + 16 * 64 + 32);
+        uint2 vlo[4], vhi[4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (r < Mper) acc[r] += ps[r * ldp + j] * vv;
+        for (int dt = 0; dt < 4; ++dt) {
+            const bf16_t* vr = vp + (size_t)(dt * 16 + c) * rows_alloc + kb + 4 * g;
+            vlo[dt] = *reinterpret_cast<const uint2*>(vr);
+            vhi[dt] = *reinterpret_cast<const uint2*>(vr + 16);
         }
+        f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+        s0 = mfma16(a00, qhi[0], s0); s0 = mfma16(a01, qhi[1], s0); s0 = mfma16(a00, qlo[0], s0); s0 = mfma16(a01, qlo[1], s0);
+        s1 = mfma16(a10, qhi[0], s1); s1 = mfma16(a11, qhi[1], s1); s1 = mfma16(a10, qlo[0], s1); s1 = mfma16(a11, qlo[1], s1);
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (r < Mper) red[(g * 16 + r) * 64 + dd] = acc[r];
+        for (int r = 0; r < 4; ++r) {
+            if (kb + 4 * g + r >= limit) s0[r] = -INFINITY;
+            if (kb + 16 + 4 * g + r >= limit) s1[r] = -INFINITY;
+        }
+        float mx = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = (m_new == -INFINITY) ? 1.f : __expf(m_run - m_new);
+        float p[8], rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            p[r] = (m_new == -INFINITY) ? 0.f : __expf(s0[r] - m_new);
+            p[4 + r] = (m_new == -INFINITY) ? 0.f : __expf(s1[r] - m_new);
+            rs += p[r] + p[4 + r];
+        }
+        rs += __shfl_xor(rs, 16, 64);
+        rs += __shfl_xor(rs, 32, 64);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+        bf16x8_t phi, plo;
+        split_hilo8(p, phi, plo);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            o[dt][0] *= alpha; o[dt][1] *= alpha; o[dt][2] *= alpha; o[dt][3] *= alpha;
+            uint4 vw; vw.x = vlo[dt].x; vw.y = vlo[dt].y; vw.z = vhi[dt].x; vw.w = vhi[dt].y;
+            const bf16x8_t va = __builtin_bit_cast(bf16x8_t, vw);
+            o[dt] = mfma16(va, phi, o[dt]);
+            o[dt] = mfma16(va, plo, o[dt]);
+        }
+    }
+    if (g == 0) { s_m[w][c] = m_run; s_l[w][c] = l_run; }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+        *reinterpret_cast<float4*>(&s_o[w][c][dt * 16 + 4 * g]) = make_float4(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
+    __syncthreads();
+    const int qr = threadIdx.x >> 4, ch = (threadIdx.x & 15) * 4;
+    const int row = s * Mper + qr;
+    float M = -INFINITY, L = 0.f; float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (qr < Mper) {
+        M = fmaxf(fmaxf(s_m[0][qr], s_m[1][qr]), fmaxf(s_m[2][qr], s_m[3][qr]));
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) {
+            const float e = (s_m[ww][qr] == -INFINITY) ? 0.f : __expf(s_m[ww][qr] - M);
+            L += s_l[ww][qr] * e;
+            const float4 ov = *reinterpret_cast<const float4*>(&s_o[ww][qr][ch]);
+            acc.x += ov.x * e; acc.y += ov.y * e; acc.z += ov.z * e; acc.w += ov.w * e;
+        }
+    }
+    if (!CROSS) {
+        if (qr < Mper) {
+            const float inv = 1.0f / L;
+            const size_t oi = packed_index(row, hd * 64 + ch, K32);
+            st_hilo4(xout + oi, xout + xplane + oi, make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv));
+        }
+        return;
+    }
+    // ---- publish this block's partial; the last block of the (stream, head) merges all NS partials ----
+    if (qr < Mper) {
+        if (ch == 0) { float* mo = ml + (((size_t)row * H + hd) * NS + split) * 2; mo[0] = M; mo[1] = L; }
+        *reinterpret_cast<float4*>(po + (((size_t)row * H + hd) * NS + split) * 64 + ch) = acc;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int t = __hip_atomic_fetch_add(ticket + s * H + hd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (t == NS - 1);
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(ticket + s * H + hd, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch / replay
+        }
+        s_last = last;
     }
     __syncthreads();
-    for (int e = tid; e < Mper * 16; e += 256) {
-        const int r = e >> 4, c = (e & 15) * 4;
-        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 p = *reinterpret_cast<const float4*>(red + (g * 16 + r) * 64 + c);
-            o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+    if (!s_last || qr >= Mper) return;
+    {
+        const float* mlp = ml + ((size_t)row * H + hd) * NS * 2;
+        const float* op = po + ((size_t)row * H + hd) * NS * 64 + ch;
+        float Mx = -INFINITY;
+        for (int sp = 0; sp < NS; ++sp) Mx = fmaxf(Mx, mlp[2 * sp]);
+        float Lt = 0.f; float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int sp = 0; sp < NS; ++sp) {
+            const float e = (mlp[2 * sp] == -INFINITY) ? 0.f : __expf(mlp[2 * sp] - Mx);
+            Lt += mlp[2 * sp + 1] * e;
+            const float4 ov = *reinterpret_cast<const float4*>(op + (size_t)sp * 64);
+            o4.x += ov.x * e; o4.y += ov.y * e; o4.z += ov.z * e; o4.w += ov.w * e;
         }
-        const int row = s * Mper + r;
-        if (CROSS) {
-            *reinterpret_cast<float4*>(po + (((size_t)row * H + hd) * NS + split) * 64 + c) = o;
-        } else {
-            uint2 u; u.x = pack_bf2(o.x, o.y); u.y = pack_bf2(o.z, o.w);
-            *reinterpret_cast<uint2*>(xout + packed_index(row, hd * 64 + c, K32)) = u;
-        }
+        const float inv = 1.0f / Lt;
+        const size_t oi = packed_index(row, hd * 64 + ch, K32);
+        st_hilo4(xout + oi, xout + xplane + oi, make_float4(o4.x * inv, o4.y * inv, o4.z * inv, o4.w * inv));
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// select: logits processors (F7) + argmax (F9) + typical-acceptance statistics (F11) for one row.
+// select: logits processors (F7) + argmax (F9) + typical-acceptance statistics (F11), split over
+// SEL_SP blocks per logits row.
 //   row -> stream s = row / rps, slot i = row % rps;  cur_len = L[s] (same for every row, model.py:689-694)
-//   mode 0: argmax only.  mode 1: also p(candidate_{i+1}) and entropy of softmax(x / T).
+//   k_select1: per-slice (max, first argmax, sum exp(x - max_slice))        -> part1[row][sp][3]
+//   k_select2: global max / Z / argmax from the slices, then the slice's share of
+//              -sum p log(p + 1e-5) (medusa_utils.py:566-568)               -> part2[row][sp]; slice 0 also
+//              writes argmax and p(candidate_{i+1}).
 // ---------------------------------------------------------------------------------------------
+#define SEL_SP 16
+
 __device__ __forceinline__ float proc_logit(float x, int n, int cur_len, const GenDev& gp, const unsigned char* mask,
                                             const float* exppen)
 {
@@ -218,19 +282,18 @@ __device__ __forceinline__ float proc_logit(float x, int n, int cur_len, const G
     return x;
 }
 
-__global__ void __launch_bounds__(512)
-k_select(const float* __restrict__ logits, GenDev gp, const unsigned char* __restrict__ mask, const float* __restrict__ exppen,
-         const int* __restrict__ L, const int* __restrict__ cand, int rps, int mode, int out_row0,
-         int* __restrict__ amax, float* __restrict__ pc, float* __restrict__ ent)
+__global__ void __launch_bounds__(256)
+k_select1(const float* __restrict__ logits, GenDev gp, const unsigned char* __restrict__ mask, const float* __restrict__ exppen,
+          const int* __restrict__ L, int rps, float* __restrict__ part1)
 {
-    __shared__ float sv[8]; __shared__ int si[8]; __shared__ float sb[2];
-    const int row = blockIdx.x, s = row / rps, i = row - s * rps;
+    __shared__ float sv[4]; __shared__ int si[4]; __shared__ float sz[4];
+    const int row = blockIdx.y, sp = blockIdx.x, s = row / rps;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int cur_len = L[s];
     const float* x = logits + (size_t)row * gp.Vpad;
-    // pass 1: max / first argmax
+    const int per = (gp.V + SEL_SP - 1) / SEL_SP, n0 = sp * per, n1 = min(gp.V, n0 + per);
     float mx = -INFINITY; int mi = 0x7fffffff;
-    for (int n = tid; n < gp.V; n += 512) {
+    for (int n = n0 + tid; n < n1; n += 256) {
         const float v = proc_logit(x[n], n, cur_len, gp, mask, exppen);
         if (v > mx || (v == mx && n < mi)) { mx = v; mi = n; }
     }
@@ -243,44 +306,84 @@ k_select(const float* __restrict__ logits, GenDev gp, const unsigned char* __res
     __syncthreads();
     mx = sv[0]; mi = si[0];
 #pragma unroll
-    for (int k = 1; k < 8; ++k) if (sv[k] > mx || (sv[k] == mx && si[k] < mi)) { mx = sv[k]; mi = si[k]; }
-    const int orow = out_row0 + row;
-    if (tid == 0) amax[orow] = mi;
-    if (mode == 0 || i + 1 >= rps) return;
-    // pass 2: Z = sum exp((x - max)/T)
+    for (int k = 1; k < 4; ++k) if (sv[k] > mx || (sv[k] == mx && si[k] < mi)) { mx = sv[k]; mi = si[k]; }
     float z = 0.f;
-    for (int n = tid; n < gp.V; n += 512) {
-        const float v = proc_logit(x[n], n, cur_len, gp, mask, exppen);
-        z += (v == -INFINITY) ? 0.f : expf((v - mx) * gp.inv_temp);
-    }
+    if (mx != -INFINITY)
+        for (int n = n0 + tid; n < n1; n += 256) {
+            const float v = proc_logit(x[n], n, cur_len, gp, mask, exppen);
+            z += (v == -INFINITY) ? 0.f : expf((v - mx) * gp.inv_temp);
+        }
     z = wave_sum(z);
-    __syncthreads();
-    if (lane == 0) sv[w] = z;
-    __syncthreads();
-    z = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) z += sv[k];
-    // pass 3: H = -sum p log(p + 1e-5)      (medusa_utils.py:566-568)
-    float hsum = 0.f;
-    const float invz = 1.0f / z;
-    for (int n = tid; n < gp.V; n += 512) {
-        const float v = proc_logit(x[n], n, cur_len, gp, mask, exppen);
-        const float p = (v == -INFINITY) ? 0.f : expf((v - mx) * gp.inv_temp) * invz;
-        hsum += p * logf(p + 1e-5f);
-    }
-    hsum = wave_sum(hsum);
-    __syncthreads();
-    if (lane == 0) sv[w] = hsum;
+    if (lane == 0) sz[w] = z;
     __syncthreads();
     if (tid == 0) {
-        float hh = 0.f;
-        for (int k = 0; k < 8; ++k) hh += sv[k];
-        const int c = cand[s * 16 + i + 1];
-        const float vc = proc_logit(x[c], c, cur_len, gp, mask, exppen);
-        pc[orow] = (vc == -INFINITY) ? 0.f : expf((vc - mx) * gp.inv_temp) * invz;
-        ent[orow] = -hh;
+        float* o = part1 + ((size_t)row * SEL_SP + sp) * 4;
+        o[0] = mx; o[1] = __int_as_float(mi); o[2] = (sz[0] + sz[1]) + (sz[2] + sz[3]);
     }
-    (void)sb;
+}
+
+__global__ void __launch_bounds__(256)
+k_select2(const float* __restrict__ logits, GenDev gp, const unsigned char* __restrict__ mask, const float* __restrict__ exppen,
+          const int* __restrict__ L, const int* __restrict__ cand, int rps, int out_row0, const float* __restrict__ part1,
+          float* __restrict__ part2, int* __restrict__ amax, float* __restrict__ pc)
+{
+    __shared__ float sh[4];
+    const int row = blockIdx.y, sp = blockIdx.x, s = row / rps, i = row - s * rps;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int cur_len = L[s];
+    const float* x = logits + (size_t)row * gp.Vpad;
+    const float* p1 = part1 + (size_t)row * SEL_SP * 4;
+    float mx = -INFINITY; int mi = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < SEL_SP; ++k) {
+        const float v = p1[4 * k]; const int idx = __float_as_int(p1[4 * k + 1]);
+        if (v > mx || (v == mx && idx < mi)) { mx = v; mi = idx; }
+    }
+    float z = 0.f;
+#pragma unroll
+    for (int k = 0; k < SEL_SP; ++k) {
+        const float v = p1[4 * k];
+        z += (v == -INFINITY) ? 0.f : p1[4 * k + 2] * expf((v - mx) * gp.inv_temp);
+    }
+    const float invz = 1.0f / z;
+    const int per = (gp.V + SEL_SP - 1) / SEL_SP, n0 = sp * per, n1 = min(gp.V, n0 + per);
+    float hs = 0.f;
+    for (int n = n0 + tid; n < n1; n += 256) {
+        const float v = proc_logit(x[n], n, cur_len, gp, mask, exppen);
+        const float p = (v == -INFINITY) ? 0.f : expf((v - mx) * gp.inv_temp) * invz;
+        hs += p * logf(p + 1e-5f);
+    }
+    hs = wave_sum(hs);
+    if (lane == 0) sh[w] = hs;
+    __syncthreads();
+    if (tid == 0) {
+        const int orow = out_row0 + row;
+        part2[(size_t)orow * SEL_SP + sp] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+        if (sp == 0) {
+            amax[orow] = mi;
+            float pcv = 0.f;
+            if (i + 1 < rps) {
+                const int c = cand[s * 16 + i + 1];
+                const float vc = proc_logit(x[c], c, cur_len, gp, mask, exppen);
+                pcv = (vc == -INFINITY) ? 0.f : expf((vc - mx) * gp.inv_temp) * invz;
+            }
+            pc[orow] = pcv;
+        }
+    }
+}
+
+// argmax of each row from the slice partials (base pass candidates / vanilla token)
+__global__ void k_select_argmax(const float* __restrict__ part1, int nrows, int out_row0, int* __restrict__ amax)
+{
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= nrows) return;
+    const float* p1 = part1 + (size_t)row * SEL_SP * 4;
+    float mx = -INFINITY; int mi = 0x7fffffff;
+    for (int k = 0; k < SEL_SP; ++k) {
+        const float v = p1[4 * k]; const int idx = __float_as_int(p1[4 * k + 1]);
+        if (v > mx || (v == mx && idx < mi)) { mx = v; mi = idx; }
+    }
+    amax[out_row0 + row] = mi;
 }
 
 // candidates of the base pass: cand[s][i] = argmax of head i   (medusa_utils.py:446-458, top-1 chain)
@@ -297,8 +400,8 @@ __global__ void k_set_cand(const int* __restrict__ amax, int* __restrict__ cand,
 // the stop rules (model.py:774-793).
 // ---------------------------------------------------------------------------------------------
 __global__ void k_accept(GenDev gp, const int* __restrict__ cand, const int* __restrict__ amax, const float* __restrict__ pc,
-                         const float* __restrict__ ent, int* __restrict__ ids, int* __restrict__ L, int* __restrict__ kvlen,
-                         int* __restrict__ finished, int* __restrict__ niter, long long* __restrict__ hist)
+                         const float* __restrict__ part2, int* __restrict__ ids, int* __restrict__ L, int* __restrict__ kvlen,
+                         int* __restrict__ finished, int* __restrict__ niter, long long* __restrict__ hist, int* __restrict__ done, int B)
 {
     const int s = blockIdx.x, lane = threadIdx.x;
     if (finished[s]) return;
@@ -307,7 +410,11 @@ __global__ void k_accept(GenDev gp, const int* __restrict__ cand, const int* __r
     if (lane < K) {
         if (gp.accept_mode == WM_ACCEPT_GREEDY) ok = (cand[s * 16 + lane + 1] == amax[s * rps + lane]);
         else {
-            const float thr = fminf(gp.thr, gp.alpha * expf(-ent[s * rps + lane]));
+            const float* hp = part2 + (size_t)(s * rps + lane) * SEL_SP;
+            float hsum = 0.f;
+#pragma unroll
+            for (int k = 0; k < SEL_SP; ++k) hsum += hp[k];
+            const float thr = fminf(gp.thr, gp.alpha * expf(hsum));            // H = -hsum
             ok = pc[s * rps + lane] > thr;
         }
     }
@@ -330,13 +437,16 @@ __global__ void k_accept(GenDev gp, const int* __restrict__ cand, const int* __r
         niter[s] += 1;
         atomicAdd(reinterpret_cast<unsigned long long*>(hist + a), 1ull);
         atomicAdd(reinterpret_cast<unsigned long long*>(hist + 16), (unsigned long long)n_emit);
-        if (hit_eos || Ln >= gp.max_length || Ln + K >= gp.hard_max_length) finished[s] = 1;
+        if (hit_eos || Ln >= gp.max_length || Ln + K >= gp.hard_max_length) {
+            finished[s] = 1;
+            if (atomicAdd(done + 1, 1) == B - 1) done[0] = 1;           // done[1] counts finished streams
+        }
     }
 }
 
 __global__ void k_accept_vanilla1(GenDev gp, int B, const int* __restrict__ amax, int* __restrict__ ids, int* __restrict__ L,
                                   int* __restrict__ kvlen, int* __restrict__ finished, int* __restrict__ niter,
-                                  long long* __restrict__ hist)
+                                  long long* __restrict__ hist, int* __restrict__ done)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= B || finished[s]) return;
@@ -344,55 +454,47 @@ __global__ void k_accept_vanilla1(GenDev gp, int B, const int* __restrict__ amax
     if (Lcur < gp.Tids) ids[(size_t)s * gp.Tids + Lcur] = tok;
     L[s] = Lcur + 1; kvlen[s] = Lcur; niter[s] += 1;
     atomicAdd(reinterpret_cast<unsigned long long*>(hist + 16), 1ull);
-    if (tok == gp.eos || Lcur + 1 >= gp.max_length) finished[s] = 1;
+    if (tok == gp.eos || Lcur + 1 >= gp.max_length) {
+        finished[s] = 1;
+        if (atomicAdd(done + 1, 1) == B - 1) done[0] = 1;
+    }
 }
 
 // =============================================================================================
 // host side
 // =============================================================================================
-static inline int r16(int x) { return (x + 15) & ~15; }
-
 static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0, int nb, int Mper, const int* base, bool kv_only)
 {
     hipStream_t st = ctx->stream;
-    const int d = ctx->d, H = ctx->H, K32 = d / 32, R = nb * Mper;
+    const int d = ctx->d, H = ctx->H, K32 = d / 32, R = nb * Mper, F32 = ctx->ffn / 32;
+    const size_t xpl = (size_t)16 * d, fpl = (size_t)16 * ctx->ffn;
     bf16_t* kc = ctx->kc + ((size_t)slot * ctx->maxB + b0) * H * ctx->Tal * 64;
     bf16_t* vc = ctx->vc + ((size_t)slot * ctx->maxB + b0) * H * ctx->Tal * 64;
     const bf16_t* kx = ctx->kx + ((size_t)slot * ctx->Benc + b0) * H * ctx->Spad * 64;
     const bf16_t* vx = ctx->vx + ((size_t)slot * ctx->Benc + b0) * H * ctx->Spad * 64;
-    // 1. LN1 + QKV, k/v rows straight into the cache
-    WM_HIP(launch_skinny(st, w.qkv_w, 3 * d / 16, K32, R,
-                         LdNorm{h, w.ln1_w, w.ln1_b, nullptr, d, K32, R, 1, 0, 1},
-                         EpQKVDec{ctx->qbuf, kc, vc, w.qkv_b, base, Mper, d, H, ctx->Tal, R}));
+    // 1. LN1 + QKV; k rows / transposed v rows straight into the cache
+    WM_HIP(launch_skinny_norm(st, w.qkv_w, 3 * d / 16, K32, h, w.ln1_w, w.ln1_b, d, R, 1, 0, 1,
+                              EpQKVDec{ctx->qbuf, kc, vc, w.qkv_b, base, Mper, d, H, ctx->Tal, R}));
     if (kv_only) return WM_OK;
     // 2. causal self-attention over the contiguous cache
-    {
-        const size_t lds = (size_t)(16 * 64 + 16 * ctx->Tal + 4 * 16 * 64) * sizeof(float);
-        hipLaunchKernelGGL(k_attn_decode<false>, dim3(1, H, nb), dim3(256), lds, st, ctx->qbuf, kc, vc, base, ctx->xbuf,
-                           nullptr, nullptr, Mper, H, ctx->Tal, 0, 0, 1, K32);
-        WM_HIP(hipGetLastError());
-    }
+    hipLaunchKernelGGL(k_attn_mfma<false>, dim3(1, H, nb), dim3(256), 0, st, ctx->qbuf, kc, vc, base, ctx->xbuf, xpl,
+                       nullptr, nullptr, nullptr, g_skinny_done, Mper, H, ctx->Tal, 0, 1, K32);
+    WM_HIP(hipGetLastError());
     // 3. out_proj + residual
-    WM_HIP(launch_skinny(st, w.out_w, d / 16, K32, R, LdPacked{ctx->xbuf, K32}, EpResidual{h, w.out_b, d, R}));
+    WM_HIP(launch_skinny(st, w.out_w, d / 16, K32, LdPacked{ctx->xbuf, K32, xpl}, EpResidual{h, w.out_b, d, R}));
     // 4. LN2 + cross-attention q
-    WM_HIP(launch_skinny(st, w.cq_w, d / 16, K32, R, LdNorm{h, w.ln2_w, w.ln2_b, nullptr, d, K32, R, 1, 0, 1},
-                         EpF32{ctx->qbuf, w.cq_b, d, R, 0.125f}));
-    // 5. cross-attention over the encoder K/V, split over keys
-    {
-        const size_t lds = (size_t)(16 * 64 + 16 * ctx->Ck + 4 * 16 * 64) * sizeof(float);
-        hipLaunchKernelGGL(k_attn_decode<true>, dim3(ctx->NS, H, nb), dim3(256), lds, st, ctx->qbuf, kx, vx, base, nullptr,
-                           ctx->cml, ctx->co, Mper, H, ctx->Spad, ctx->S, ctx->Ck, ctx->NS, K32);
-        WM_HIP(hipGetLastError());
-    }
-    // 6. combine splits + out_proj + residual
-    WM_HIP(launch_skinny(st, w.cout_w, d / 16, K32, R, LdCombine{ctx->cml, ctx->co, H, ctx->NS, K32, R},
-                         EpResidual{h, w.cout_b, d, R}));
+    WM_HIP(launch_skinny_norm(st, w.cq_w, d / 16, K32, h, w.ln2_w, w.ln2_b, d, R, 1, 0, 1, EpF32{ctx->qbuf, w.cq_b, d, R, 0.125f}));
+    // 5. cross-attention over the encoder K/V, 256 keys per block
+    hipLaunchKernelGGL(k_attn_mfma<true>, dim3(ctx->NS, H, nb), dim3(256), 0, st, ctx->qbuf, kx, vx, base, ctx->xbuf, xpl,
+                       ctx->cml, ctx->co, ctx->ticket, g_skinny_done, Mper, H, ctx->Spad, ctx->S, ctx->NS, K32);
+    WM_HIP(hipGetLastError());
+    // 6. out_proj + residual
+    WM_HIP(launch_skinny(st, w.cout_w, d / 16, K32, LdPacked{ctx->xbuf, K32, xpl}, EpResidual{h, w.cout_b, d, R}));
     // 7. LN3 + fc1 + GELU
-    WM_HIP(launch_skinny(st, w.fc1_w, ctx->ffn / 16, K32, R, LdNorm{h, w.ln3_w, w.ln3_b, nullptr, d, K32, R, 1, 0, 1},
-                         EpPackedAct<1>{ctx->fbuf, w.fc1_b, ctx->ffn / 32, R}));
+    WM_HIP(launch_skinny_norm(st, w.fc1_w, ctx->ffn / 16, K32, h, w.ln3_w, w.ln3_b, d, R, 1, 0, 1,
+                              EpPackedAct<1>{ctx->fbuf, ctx->fbuf + fpl, w.fc1_b, F32, R}));
     // 8. fc2 + residual
-    WM_HIP(launch_skinny(st, w.fc2_w, d / 16, ctx->ffn / 32, R, LdPacked{ctx->fbuf, ctx->ffn / 32},
-                         EpResidual{h, w.fc2_b, d, R}));
+    WM_HIP(launch_skinny(st, w.fc2_w, d / 16, F32, LdPacked{ctx->fbuf, F32, fpl}, EpResidual{h, w.fc2_b, d, R}));
     return WM_OK;
 }
 
@@ -402,9 +504,10 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
 int wm_dec_stage_layers(wm_ctx* ctx, int b0, int nb, int Mper, int mode)
 {
     hipStream_t st = ctx->stream;
+    g_skinny_done = ctx->use_done ? ctx->done : nullptr;
     const int d = ctx->d, R = nb * Mper;
     const int* base = (mode == 0 ? ctx->kvlen : ctx->L) + b0;
-    if (R > WM_MAX_ROWS_SKINNY || Mper > 16) { ctx->err = "decode chunk exceeds 32 rows / 16 tokens per stream"; return WM_ERR_ARG; }
+    if (R > WM_MAX_ROWS_SKINNY) { ctx->err = "decode chunk exceeds 16 token rows"; return WM_ERR_ARG; }
     if (mode == 0)
         hipLaunchKernelGGL(k_embed, dim3(R), dim3(256), 0, st, ctx->h, ctx->tok_emb, ctx->dec_pos, base,
                            ctx->ids + (size_t)b0 * ctx->gp.Tids, ctx->gp.Tids, 1, Mper, d, ctx->V, ctx->Tmax);
@@ -428,7 +531,7 @@ int wm_dec_stage_final(wm_ctx* ctx, int b0, int nb, int Mper, int mode, int medu
     const int d = ctx->d, K32 = d / 32, R = nb * Mper;
     const int* base = (mode == 0 ? ctx->kvlen : ctx->L) + b0;
     hipLaunchKernelGGL(k_rows_norm, dim3((R + 3) / 4), dim3(256), 0, st, ctx->h, 1, 0, ctx->dec_lnf_w, ctx->dec_lnf_b, 1,
-                       ctx->hf, ctx->block ? ctx->hblk : nullptr, nullptr, K32, 1, 0, d, R);
+                       ctx->hf, ctx->block ? ctx->hblk : nullptr, nullptr, (size_t)0, K32, 1, 0, d, R);
     WM_HIP(hipGetLastError());
     if (ctx->block && !ctx->gp.vanilla) {
         int rc = dec_layer(ctx, ctx->dec[ctx->nkv - 1], ctx->nkv - 1, ctx->hblk, b0, nb, Mper, base, !medusa);
@@ -444,24 +547,23 @@ int wm_dec_stage_heads(wm_ctx* ctx, int nsel, int sel_mul, int sel_off, int medu
     hipStream_t st = ctx->stream;
     const int d = ctx->d, K32 = d / 32, K = ctx->K;
     const int nout = medusa ? K + 1 : 1;
-    if (nsel * nout > WM_MAX_ROWS_SKINNY) { ctx->err = "head stage exceeds 32 logit rows"; return WM_ERR_ARG; }
+    const size_t ypl = (size_t)16 * d;
+    if (nsel * nout > WM_MAX_ROWS_SKINNY) { ctx->err = "head stage exceeds 16 logit rows"; return WM_ERR_ARG; }
     if (!ctx->block) {
         // Medusa-Linear: every head (incl. base head 0) = x + SiLU(W_k x + b_k), then proj_out (model.py:1274-1284)
-        WM_HIP(launch_skinny(st, ctx->heads_w, nout * d / 16, K32, nsel,
-                             LdNorm{ctx->hf, nullptr, nullptr, nullptr, d, K32, nsel, sel_mul, sel_off, 0},
-                             EpHead{ctx->ybuf, ctx->hf, ctx->heads_b, d, K32, nout, 0, nsel, sel_mul, sel_off}));
+        WM_HIP(launch_skinny_norm(st, ctx->heads_w, nout * d / 16, K32, ctx->hf, nullptr, nullptr, d, nsel, sel_mul, sel_off, 0,
+                                  EpHead{ctx->ybuf, ctx->ybuf + ypl, ctx->hf, ctx->heads_b, d, K32, nout, 0, nsel, sel_mul, sel_off}));
     } else {
         // Medusa-Block: base logits = proj_out(hf) (model.py:1287); K heads on the block output (model.py:1414-1417)
         hipLaunchKernelGGL(k_rows_norm, dim3((nsel + 3) / 4), dim3(256), 0, st, ctx->hf, sel_mul, sel_off, nullptr, nullptr, 0,
-                           nullptr, nullptr, ctx->ybuf, K32, nout, 0, d, nsel);
+                           nullptr, nullptr, ctx->ybuf, ypl, K32, nout, 0, d, nsel);
         WM_HIP(hipGetLastError());
         if (medusa)
-            WM_HIP(launch_skinny(st, ctx->heads_w, K * d / 16, K32, nsel,
-                                 LdNorm{ctx->hblk, nullptr, nullptr, nullptr, d, K32, nsel, sel_mul, sel_off, 0},
-                                 EpHead{ctx->ybuf, ctx->hblk, ctx->heads_b, d, K32, nout, 1, nsel, sel_mul, sel_off}));
+            WM_HIP(launch_skinny_norm(st, ctx->heads_w, K * d / 16, K32, ctx->hblk, nullptr, nullptr, d, nsel, sel_mul, sel_off, 0,
+                                      EpHead{ctx->ybuf, ctx->ybuf + ypl, ctx->hblk, ctx->heads_b, d, K32, nout, 1, nsel, sel_mul, sel_off}));
     }
     // shared vocabulary projection (tied proj_out, model.py:1277)
-    WM_HIP(launch_skinny(st, ctx->vocab_w, ctx->Vpad / 16, K32, nsel * nout, LdPacked{ctx->ybuf, K32},
+    WM_HIP(launch_skinny(st, ctx->vocab_w, ctx->Vpad / 16, K32, LdPacked{ctx->ybuf, K32, ypl},
                          EpF32{ctx->logits, nullptr, ctx->Vpad, nsel * nout, 1.0f}));
     return WM_OK;
 }
@@ -476,7 +578,7 @@ int wm_dec_pass(wm_ctx* ctx, int b0, int nb, int Mper, int mode, int medusa, int
     return wm_dec_stage_heads(ctx, nb, Mper, Mper - 1, medusa);
 }
 
-// One full Medusa iteration (or one vanilla step) over all Bdec streams, chunked to <= 32 rows.
+// One full Medusa iteration (or one vanilla step) over all Bdec streams, chunked to <= 16 token rows.
 int wm_dec_iteration(wm_ctx* ctx, int Mper_base)
 {
     hipStream_t st = ctx->stream;
@@ -488,12 +590,14 @@ int wm_dec_iteration(wm_ctx* ctx, int Mper_base)
             const int nb = min(chunk, B - b0);
             int rc = wm_dec_pass(ctx, b0, nb, Mper_base, 0, 0, 0);
             if (rc) return rc;
-            hipLaunchKernelGGL(k_select, dim3(nb), dim3(512), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen, ctx->L + b0,
-                               ctx->cand + b0 * 16, 1, 0, b0, ctx->amax, ctx->pc, ctx->ent);
+            hipLaunchKernelGGL(k_select1, dim3(SEL_SP, nb), dim3(256), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen,
+                               ctx->L + b0, 1, ctx->part1);
+            WM_HIP(hipGetLastError());
+            hipLaunchKernelGGL(k_select_argmax, dim3(1), dim3(64), 0, st, ctx->part1, nb, b0, ctx->amax);
             WM_HIP(hipGetLastError());
         }
         hipLaunchKernelGGL(k_accept_vanilla1, dim3((B + 63) / 64), dim3(64), 0, st, gp, B, ctx->amax, ctx->ids, ctx->L,
-                           ctx->kvlen, ctx->finished, ctx->niter, ctx->hist);
+                           ctx->kvlen, ctx->finished, ctx->niter, ctx->hist, ctx->done);
         WM_HIP(hipGetLastError());
         return WM_OK;
     }
@@ -503,11 +607,12 @@ int wm_dec_iteration(wm_ctx* ctx, int Mper_base)
         const int nb = min(chunk, B - b0);
         int rc = wm_dec_pass(ctx, b0, nb, Mper_base, 0, 1, 0);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_select, dim3(nb * rps), dim3(512), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen, ctx->L + b0,
-                           ctx->cand + b0 * 16, rps, 0, b0 * rps, ctx->amax, ctx->pc, ctx->ent);
+        hipLaunchKernelGGL(k_select1, dim3(SEL_SP, nb * rps), dim3(256), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen,
+                           ctx->L + b0, rps, ctx->part1);
         WM_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_set_cand, dim3((nb * rps + 63) / 64), dim3(64), 0, st, ctx->amax + b0 * rps, ctx->cand + b0 * 16,
-                           rps, nb * rps);
+        hipLaunchKernelGGL(k_select_argmax, dim3(1), dim3(64), 0, st, ctx->part1, nb * rps, b0 * rps, ctx->amax);
+        WM_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_set_cand, dim3(1), dim3(64), 0, st, ctx->amax + b0 * rps, ctx->cand + b0 * 16, rps, nb * rps);
         WM_HIP(hipGetLastError());
     }
     // (d) verify pass over the candidates at positions L..L+K, then posterior statistics
@@ -515,14 +620,19 @@ int wm_dec_iteration(wm_ctx* ctx, int Mper_base)
         const int nb = min(chunk, B - b0);
         int rc = wm_dec_pass(ctx, b0, nb, rps, 1, 0, 1);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_select, dim3(nb * rps), dim3(512), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen, ctx->L + b0,
-                           ctx->cand + b0 * 16, rps, gp.accept_mode == WM_ACCEPT_TYPICAL ? 1 : 0, b0 * rps, ctx->amax, ctx->pc,
-                           ctx->ent);
+        hipLaunchKernelGGL(k_select1, dim3(SEL_SP, nb * rps), dim3(256), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen,
+                           ctx->L + b0, rps, ctx->part1);
+        WM_HIP(hipGetLastError());
+        if (gp.accept_mode == WM_ACCEPT_TYPICAL)
+            hipLaunchKernelGGL(k_select2, dim3(SEL_SP, nb * rps), dim3(256), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen,
+                               ctx->L + b0, ctx->cand + b0 * 16, rps, b0 * rps, ctx->part1, ctx->part2, ctx->amax, ctx->pc);
+        else
+            hipLaunchKernelGGL(k_select_argmax, dim3(1), dim3(64), 0, st, ctx->part1, nb * rps, b0 * rps, ctx->amax);
         WM_HIP(hipGetLastError());
     }
     // (f)-(j) accept / emit / compact / stop
-    hipLaunchKernelGGL(k_accept, dim3(B), dim3(64), 0, st, gp, ctx->cand, ctx->amax, ctx->pc, ctx->ent, ctx->ids, ctx->L,
-                       ctx->kvlen, ctx->finished, ctx->niter, ctx->hist);
+    hipLaunchKernelGGL(k_accept, dim3(B), dim3(64), 0, st, gp, ctx->cand, ctx->amax, ctx->pc, ctx->part2, ctx->ids, ctx->L,
+                       ctx->kvlen, ctx->finished, ctx->niter, ctx->hist, ctx->done, B);
     WM_HIP(hipGetLastError());
     return WM_OK;
 }
@@ -531,22 +641,22 @@ int wm_dec_iteration(wm_ctx* ctx, int Mper_base)
 int wm_dec_profile(wm_ctx* ctx, int kernel, int rows, int reps, float* ms, double* bytes)
 {
     if (kernel != 0 || rows < 1 || rows > WM_MAX_ROWS_SKINNY) { ctx->err = "wm_profile_kernel: bad arguments"; return WM_ERR_ARG; }
+    g_skinny_done = nullptr;
     hipStream_t st = ctx->stream;
-    const int d = ctx->d, K32 = d / 32, R = rows, H = ctx->H;
+    const int d = ctx->d, K32 = d / 32, R = rows, H = ctx->H, F32 = ctx->ffn / 32;
+    const size_t xpl = (size_t)16 * d, fpl = (size_t)16 * ctx->ffn;
     const DecLayerW& w = ctx->dec[0];
     WM_HIP(hipMemsetAsync(ctx->h, 0, (size_t)WM_MAX_ROWS_SKINNY * d * sizeof(float), st));
     WM_HIP(hipMemsetAsync(ctx->kvlen, 0, sizeof(int) * ctx->maxB, st));
     auto body = [&]() -> int {
-        WM_HIP(launch_skinny(st, w.qkv_w, 3 * d / 16, K32, R, LdNorm{ctx->h, w.ln1_w, w.ln1_b, nullptr, d, K32, R, 1, 0, 1},
-                             EpQKVDec{ctx->qbuf, ctx->kc, ctx->vc, w.qkv_b, ctx->kvlen, R, d, H, ctx->Tal, R}));
-        WM_HIP(launch_skinny(st, w.out_w, d / 16, K32, R, LdPacked{ctx->xbuf, K32}, EpResidual{ctx->h, w.out_b, d, R}));
-        WM_HIP(launch_skinny(st, w.cq_w, d / 16, K32, R, LdNorm{ctx->h, w.ln2_w, w.ln2_b, nullptr, d, K32, R, 1, 0, 1},
-                             EpF32{ctx->qbuf, w.cq_b, d, R, 0.125f}));
-        WM_HIP(launch_skinny(st, w.cout_w, d / 16, K32, R, LdPacked{ctx->xbuf, K32}, EpResidual{ctx->h, w.cout_b, d, R}));
-        WM_HIP(launch_skinny(st, w.fc1_w, ctx->ffn / 16, K32, R, LdNorm{ctx->h, w.ln3_w, w.ln3_b, nullptr, d, K32, R, 1, 0, 1},
-                             EpPackedAct<1>{ctx->fbuf, w.fc1_b, ctx->ffn / 32, R}));
-        WM_HIP(launch_skinny(st, w.fc2_w, d / 16, ctx->ffn / 32, R, LdPacked{ctx->fbuf, ctx->ffn / 32},
-                             EpResidual{ctx->h, w.fc2_b, d, R}));
+        WM_HIP(launch_skinny_norm(st, w.qkv_w, 3 * d / 16, K32, ctx->h, w.ln1_w, w.ln1_b, d, R, 1, 0, 1,
+                                  EpQKVDec{ctx->qbuf, ctx->kc, ctx->vc, w.qkv_b, ctx->kvlen, R, d, H, ctx->Tal, R}));
+        WM_HIP(launch_skinny(st, w.out_w, d / 16, K32, LdPacked{ctx->xbuf, K32, xpl}, EpResidual{ctx->h, w.out_b, d, R}));
+        WM_HIP(launch_skinny_norm(st, w.cq_w, d / 16, K32, ctx->h, w.ln2_w, w.ln2_b, d, R, 1, 0, 1, EpF32{ctx->qbuf, w.cq_b, d, R, 0.125f}));
+        WM_HIP(launch_skinny(st, w.cout_w, d / 16, K32, LdPacked{ctx->xbuf, K32, xpl}, EpResidual{ctx->h, w.cout_b, d, R}));
+        WM_HIP(launch_skinny_norm(st, w.fc1_w, ctx->ffn / 16, K32, ctx->h, w.ln3_w, w.ln3_b, d, R, 1, 0, 1,
+                                  EpPackedAct<1>{ctx->fbuf, ctx->fbuf + fpl, w.fc1_b, F32, R}));
+        WM_HIP(launch_skinny(st, w.fc2_w, d / 16, F32, LdPacked{ctx->fbuf, F32, fpl}, EpResidual{ctx->h, w.fc2_b, d, R}));
         return WM_OK;
     };
     int rc = body();

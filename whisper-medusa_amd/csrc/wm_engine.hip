@@ -30,8 +30,8 @@ extern "C" void wm_destroy(wm_ctx* ctx)
     if (ctx->graph) hipGraphExecDestroy(ctx->graph);
     void* bufs[] = {ctx->feats_own, ctx->clipmax, ctx->A1, ctx->a1, ctx->A2, ctx->eh, ctx->exn, ctx->eq, ctx->ek, ctx->evt, ctx->eff,
                     ctx->enc_out, ctx->kx, ctx->vx, ctx->kc, ctx->vc, ctx->h, ctx->hblk, ctx->hf, ctx->qbuf, ctx->xbuf, ctx->fbuf,
-                    ctx->ybuf, ctx->cml, ctx->co, ctx->logits, ctx->amax, ctx->pc, ctx->ent, ctx->ids, ctx->L, ctx->kvlen,
-                    ctx->finished, ctx->cand, ctx->niter, ctx->hist, ctx->supmask, ctx->exppen, ctx->tap_tok};
+                    ctx->ybuf, ctx->cml, ctx->co, ctx->ticket, ctx->logits, ctx->amax, ctx->pc, ctx->part1, ctx->part2, ctx->ids, ctx->L, ctx->kvlen,
+                    ctx->finished, ctx->cand, ctx->niter, ctx->hist, ctx->supmask, ctx->exppen, ctx->tap_tok, ctx->done};
     for (void* b : bufs) if (b) hipFree(b);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
@@ -63,15 +63,14 @@ extern "C" int wm_create(const wm_config* cfg, const wm_weights* w, int device, 
     const int d = ctx->d = cfg->d_model;
     ctx->H = cfg->n_heads; ctx->ffn = cfg->ffn_dim; ctx->V = cfg->vocab; ctx->Vpad = rup(cfg->vocab, 128);
     ctx->S = cfg->n_ctx; ctx->Spad = rup(cfg->n_ctx, 128); ctx->Tm = 2 * cfg->n_ctx; ctx->Tmpad = rup(ctx->Tm, 128);
-    ctx->Tmax = cfg->n_tgt; ctx->Tal = cfg->n_tgt + 16; ctx->K = cfg->medusa_heads;
+    ctx->Tmax = cfg->n_tgt; ctx->Tal = rup(cfg->n_tgt + 16, 32); ctx->K = cfg->medusa_heads;
     ctx->block = cfg->heads_type == WM_HEADS_BLOCK;
     ctx->nkv = cfg->dec_layers + (ctx->block ? 1 : 0);
     ctx->nres = ctx->K + (ctx->block ? 0 : 1);
     ctx->maxB = cfg->max_batch;
     ctx->K1pad = rup(3 * cfg->n_mels, 128);
-    ctx->NS = std::min(12, std::max(1, ctx->S / 8));
-    ctx->Ck = (ctx->S + ctx->NS - 1) / ctx->NS;
-    if (ctx->Ck > 512) { ctx->NS = (ctx->S + 511) / 512; ctx->Ck = (ctx->S + ctx->NS - 1) / ctx->NS; }
+    ctx->NS = (ctx->Spad + 255) / 256;
+    if (ctx->NS > 16 || ctx->H > 32) { g_create_err = "wm_create: n_ctx > 4096 or more than 32 heads unsupported"; wm_destroy(ctx); return WM_ERR_ARG; }
 
     // ---- parameter table ----
     const int n_expected = 19 + 12 * cfg->enc_layers + 18 * ctx->nkv;
@@ -127,15 +126,17 @@ extern "C" int wm_create(const wm_config* cfg, const wm_weights* w, int device, 
     CREATE_HIP(dev_alloc(&ctx->hblk, RW * d, st));
     CREATE_HIP(dev_alloc(&ctx->hf, RW * d, st));
     CREATE_HIP(dev_alloc(&ctx->qbuf, RW * d, st));
-    CREATE_HIP(dev_alloc(&ctx->xbuf, RW * d, st));
-    CREATE_HIP(dev_alloc(&ctx->fbuf, RW * ctx->ffn, st));
-    CREATE_HIP(dev_alloc(&ctx->ybuf, RW * d, st));
+    CREATE_HIP(dev_alloc(&ctx->xbuf, 2 * RW * d, st));          // hi + lo planes
+    CREATE_HIP(dev_alloc(&ctx->fbuf, 2 * RW * ctx->ffn, st));
+    CREATE_HIP(dev_alloc(&ctx->ybuf, 2 * RW * d, st));
     CREATE_HIP(dev_alloc(&ctx->cml, RW * H * ctx->NS * 2, st));
     CREATE_HIP(dev_alloc(&ctx->co, RW * H * ctx->NS * 64, st));
+    CREATE_HIP(dev_alloc(&ctx->ticket, RW * H, st));
     CREATE_HIP(dev_alloc(&ctx->logits, RW * ctx->Vpad, st));
     CREATE_HIP(dev_alloc(&ctx->amax, B * 16, st));
     CREATE_HIP(dev_alloc(&ctx->pc, B * 16, st));
-    CREATE_HIP(dev_alloc(&ctx->ent, B * 16, st));
+    CREATE_HIP(dev_alloc(&ctx->part1, RW * 16 * 4, st));
+    CREATE_HIP(dev_alloc(&ctx->part2, B * 16 * 16, st));
     const size_t Tids = ctx->Tal;
     CREATE_HIP(dev_alloc(&ctx->ids, B * Tids, st));
     CREATE_HIP(dev_alloc(&ctx->L, B, st));
@@ -147,6 +148,7 @@ extern "C" int wm_create(const wm_config* cfg, const wm_weights* w, int device, 
     CREATE_HIP(dev_alloc(&ctx->supmask, (size_t)ctx->Vpad, st));
     CREATE_HIP(dev_alloc(&ctx->exppen, Tids + 1, st));
     CREATE_HIP(dev_alloc(&ctx->tap_tok, 16, st));
+    CREATE_HIP(dev_alloc(&ctx->done, 4, st));
     CREATE_HIP(hipStreamSynchronize(st));
 #undef CREATE_HIP
     *out = ctx;
@@ -211,6 +213,8 @@ extern "C" int wm_decode_begin(wm_ctx* ctx, const wm_gen_params* gp, int B)
     WM_HIP(hipMemcpyAsync(ctx->finished, zero.data(), B * sizeof(int), hipMemcpyHostToDevice, st));
     WM_HIP(hipMemcpyAsync(ctx->niter, zero.data(), B * sizeof(int), hipMemcpyHostToDevice, st));
     WM_HIP(hipMemsetAsync(ctx->hist, 0, 32 * sizeof(long long), st));
+    WM_HIP(hipMemsetAsync(ctx->done, 0, 4 * sizeof(int), st));
+    ctx->use_done = true;
     WM_HIP(hipMemcpyAsync(ctx->supmask, mask.data(), mask.size(), hipMemcpyHostToDevice, st));
     WM_HIP(hipMemcpyAsync(ctx->exppen, pen.data(), pen.size() * sizeof(float), hipMemcpyHostToDevice, st));
     WM_HIP(hipStreamSynchronize(st));      // host vectors go out of scope
@@ -307,10 +311,13 @@ extern "C" int wm_get_stats(wm_ctx* ctx, wm_stats* out)
     if (!ctx || !out) return WM_ERR_ARG;
     WM_HIP(hipSetDevice(ctx->device));
     long long h[32];
+    std::vector<int> ni(std::max(ctx->Bdec, 1), 0);
     WM_HIP(hipMemcpyAsync(h, ctx->hist, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->Bdec > 0) WM_HIP(hipMemcpyAsync(ni.data(), ctx->niter, ctx->Bdec * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     WM_HIP(hipStreamSynchronize(ctx->stream));
     std::memset(out, 0, sizeof(*out));
-    out->iterations = ctx->iters;
+    out->iterations = *std::max_element(ni.begin(), ni.end());
+    out->iterations_launched = ctx->iters;
     for (int i = 0; i < 16; ++i) out->accept_hist[i] = h[i];
     out->tokens_emitted = h[16];
     out->ms_logmel = ctx->ms_logmel; out->ms_encode = ctx->ms_encode; out->ms_decode = ctx->ms_decode;
@@ -350,14 +357,14 @@ extern "C" int wm_get_cross_kv(wm_ctx* ctx, int kv_layer, int stream, int head, 
     if (!ctx || kv_layer < 0 || kv_layer >= ctx->nkv || stream < 0 || stream >= ctx->Benc || head < 0 || head >= ctx->H) return WM_ERR_ARG;
     WM_HIP(hipSetDevice(ctx->device));
     const size_t off = (((size_t)kv_layer * ctx->Benc + stream) * ctx->H + head) * ctx->Spad * 64, n = (size_t)ctx->S * 64;
-    std::vector<bf16_t> kb(n), vb(n);
+    const size_t nv = (size_t)ctx->Spad * 64;
+    std::vector<bf16_t> kb(n), vb(nv);
     WM_HIP(hipMemcpyAsync(kb.data(), ctx->kx + off, n * sizeof(bf16_t), hipMemcpyDeviceToHost, ctx->stream));
-    WM_HIP(hipMemcpyAsync(vb.data(), ctx->vx + off, n * sizeof(bf16_t), hipMemcpyDeviceToHost, ctx->stream));
+    WM_HIP(hipMemcpyAsync(vb.data(), ctx->vx + off, nv * sizeof(bf16_t), hipMemcpyDeviceToHost, ctx->stream));
     WM_HIP(hipStreamSynchronize(ctx->stream));
-    for (size_t i = 0; i < n; ++i) {
-        uint32_t u = ((uint32_t)kb[i]) << 16; std::memcpy(k_out + i, &u, 4);
-        u = ((uint32_t)vb[i]) << 16; std::memcpy(v_out + i, &u, 4);
-    }
+    for (size_t i = 0; i < n; ++i) { const uint32_t u = ((uint32_t)kb[i]) << 16; std::memcpy(k_out + i, &u, 4); }
+    for (int s = 0; s < ctx->S; ++s)            // V is stored transposed [64][Spad]
+        for (int dd = 0; dd < 64; ++dd) { const uint32_t u = ((uint32_t)vb[(size_t)dd * ctx->Spad + s]) << 16; std::memcpy(v_out + (size_t)s * 64 + dd, &u, 4); }
     return WM_OK;
 }
 
@@ -371,7 +378,7 @@ extern "C" int wm_forward_logits(wm_ctx* ctx, int B, const int32_t* tokens, int 
     const int Tids = ctx->Tal, K = ctx->K, V = ctx->V, nout = disable_medusa ? 1 : K + 1;
     GenDev g = ctx->gp;
     g.K = K; g.V = V; g.Vpad = ctx->Vpad; g.Tids = Tids; g.vanilla = 0;
-    ctx->gp = g; ctx->began = false;
+    ctx->gp = g; ctx->began = false; ctx->use_done = false;
     if (ctx->graph) { hipGraphExecDestroy(ctx->graph); ctx->graph = nullptr; }
     std::vector<float> rowbuf((size_t)nout * ctx->Vpad);
     for (int b = 0; b < B; ++b) {

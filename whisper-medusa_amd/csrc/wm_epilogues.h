@@ -28,22 +28,24 @@ struct EpF32 {                 // out[m][n] = (v + bias[n]) * scale   (cross-att
 };
 
 template <int ACT>             // packed bf16 out = act(v + bias)   (fc1 + GELU -> next GEMM's operand)
-struct EpPackedAct {
-    bf16_t* out; const float* bias; int K32out; int M;
+struct EpPackedAct {           // out_lo != nullptr: decoder path, value kept as a bf16 hi/lo pair
+    bf16_t* out; bf16_t* out_lo; const float* bias; int K32out; int M;
     __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const {
         if (m >= M) return;
         const float4 b = *reinterpret_cast<const float4*>(bias + n);
         float x0 = v[0] + b.x, x1 = v[1] + b.y, x2 = v[2] + b.z, x3 = v[3] + b.w;
         if (ACT == 1) { x0 = gelu_erf(x0); x1 = gelu_erf(x1); x2 = gelu_erf(x2); x3 = gelu_erf(x3); }
-        uint2 o; o.x = pack_bf2(x0, x1); o.y = pack_bf2(x2, x3);
-        *reinterpret_cast<uint2*>(out + packed_index(m, n, K32out)) = o;
+        const size_t o = packed_index(m, n, K32out);
+        if (out_lo) { st_hilo4(out + o, out_lo + o, make_float4(x0, x1, x2, x3)); return; }
+        uint2 u; u.x = pack_bf2(x0, x1); u.y = pack_bf2(x2, x3);
+        *reinterpret_cast<uint2*>(out + o) = u;
     }
 };
 
 // Decoder self-attention projections: q (scaled, fp32) to a row buffer, k/v rows (bf16) straight
 // into the contiguous KV cache at position base[stream] + r   (HF:modeling_whisper.py:288-318; the
 // reference's per-iteration cat-compaction, model.py:378-402, becomes "overwrite rows >= kv_len").
-struct EpQKVDec {
+struct EpQKVDec {              // K cache [s][h][pos][64]; V cache transposed [s][h][64][pos] (MFMA A operand of P.V)
     float* q; bf16_t* kc; bf16_t* vc; const float* bias; const int* base;
     int Mper, d, H, Tal, M;
     __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const {
@@ -56,26 +58,30 @@ struct EpQKVDec {
         }
         const int s = m / Mper, r = m - s * Mper;
         int pos = base[s] + r; if (pos > Tal - 1) pos = Tal - 1;
-        const int c = (n < 2 * d) ? n - d : n - 2 * d;
-        bf16_t* dst = (n < 2 * d) ? kc : vc;
-        uint2 o; o.x = pack_bf2(x0, x1); o.y = pack_bf2(x2, x3);
-        *reinterpret_cast<uint2*>(dst + (((size_t)s * H + (c >> 6)) * Tal + pos) * 64 + (c & 63)) = o;
+        if (n < 2 * d) {
+            const int c = n - d;
+            uint2 o; o.x = pack_bf2(x0, x1); o.y = pack_bf2(x2, x3);
+            *reinterpret_cast<uint2*>(kc + (((size_t)s * H + (c >> 6)) * Tal + pos) * 64 + (c & 63)) = o;
+        } else {
+            const int c = n - 2 * d;
+            bf16_t* p = vc + (((size_t)s * H + (c >> 6)) * 64 + (c & 63)) * Tal + pos;
+            p[0] = f2bf(x0); p[Tal] = f2bf(x1); p[2 * (size_t)Tal] = f2bf(x2); p[3 * (size_t)Tal] = f2bf(x3);
+        }
     }
 };
 
 // Medusa residual heads: y = x + SiLU(W x + b) (model.py:180-210) for head k = n / d, written as
 // packed bf16 row  m*row_mul + row_off + k  of the vocabulary-projection operand.
 struct EpHead {
-    bf16_t* y; const float* hf; const float* bias; int d, K32, row_mul, row_off, M, src_mul, src_off;
+    bf16_t* y; bf16_t* y_lo; const float* hf; const float* bias; int d, K32, row_mul, row_off, M, src_mul, src_off;
     __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const {
         if (m >= M) return;
         const int k = n / d, c = n - k * d;
         const float4 b = *reinterpret_cast<const float4*>(bias + n);
         const float4 x = *reinterpret_cast<const float4*>(hf + (size_t)(m * src_mul + src_off) * d + c);
-        uint2 o;
-        o.x = pack_bf2(x.x + silu(v[0] + b.x), x.y + silu(v[1] + b.y));
-        o.y = pack_bf2(x.z + silu(v[2] + b.z), x.w + silu(v[3] + b.w));
-        *reinterpret_cast<uint2*>(y + packed_index(m * row_mul + row_off + k, c, K32)) = o;
+        const size_t o = packed_index(m * row_mul + row_off + k, c, K32);
+        st_hilo4(y + o, y_lo + o, make_float4(x.x + silu(v[0] + b.x), x.y + silu(v[1] + b.y),
+                                               x.z + silu(v[2] + b.z), x.w + silu(v[3] + b.w)));
     }
 };
 
@@ -128,7 +134,7 @@ struct EpQKVEnc {              // q (x 64^-1/2), k as [b][h][s][64]; v transpose
     }
 };
 
-struct EpCrossKV {             // K_x / V_x of every kv-layer: [kvl][b][h][s][64] bf16   (HF:modeling_whisper.py:322-335)
+struct EpCrossKV {             // K_x [kvl][b][h][s][64], V_x transposed [kvl][b][h][64][s] bf16   (HF:modeling_whisper.py:322-335)
     bf16_t* kx; bf16_t* vx; const float* bias; int Spad, H, d, B;
     __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const {
         const int b = m / Spad, s = m - b * Spad;
@@ -136,7 +142,13 @@ struct EpCrossKV {             // K_x / V_x of every kv-layer: [kvl][b][h][s][64
         const bool isv = rem >= d;
         const int c = isv ? rem - d : rem;
         const float4 bb = *reinterpret_cast<const float4*>(bias + n);
-        uint2 o; o.x = pack_bf2(v[0] + bb.x, v[1] + bb.y); o.y = pack_bf2(v[2] + bb.z, v[3] + bb.w);
-        *reinterpret_cast<uint2*>((isv ? vx : kx) + ((((size_t)kvl * B + b) * H + (c >> 6)) * Spad + s) * 64 + (c & 63)) = o;
+        const size_t slab = (((size_t)kvl * B + b) * H + (c >> 6)) * Spad * 64;
+        if (!isv) {
+            uint2 o; o.x = pack_bf2(v[0] + bb.x, v[1] + bb.y); o.y = pack_bf2(v[2] + bb.z, v[3] + bb.w);
+            *reinterpret_cast<uint2*>(kx + slab + (size_t)s * 64 + (c & 63)) = o;
+        } else {
+            bf16_t* p = vx + slab + (size_t)(c & 63) * Spad + s;
+            p[0] = f2bf(v[0] + bb.x); p[Spad] = f2bf(v[1] + bb.y); p[2 * (size_t)Spad] = f2bf(v[2] + bb.z); p[3 * (size_t)Spad] = f2bf(v[3] + bb.w);
+        }
     }
 };

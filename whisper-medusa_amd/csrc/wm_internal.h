@@ -42,8 +42,7 @@ struct wm_ctx {
     int d = 0, H = 0, ffn = 0, V = 0, Vpad = 0, S = 0, Spad = 0, Tm = 0 /* mel frames 2S */, Tmpad = 0;
     int Tmax = 0 /* n_tgt */, Tal = 0 /* cache rows allocated */, K = 0, nkv = 0, nres = 0, maxB = 0;
     bool block = false;
-    int NS = 12;        // cross-attention key splits
-    int Ck = 0;         // keys per split
+    int NS = 1;         // cross-attention key splits (256 keys per block)
 
     // ---- parameters (pointers into the caller's blob) ----
     const float *win = nullptr, *twiddle = nullptr, *melfb = nullptr;
@@ -76,8 +75,10 @@ struct wm_ctx {
     float *h = nullptr, *hblk = nullptr, *hf = nullptr, *qbuf = nullptr;
     bf16_t *xbuf = nullptr, *fbuf = nullptr, *ybuf = nullptr;
     float *cml = nullptr, *co = nullptr;   // cross-attention partials
+    int* ticket = nullptr;                 // [16 streams][H] arrival tickets of the cross-attention key splits
     float* logits = nullptr;               // [32][Vpad]
-    int* amax = nullptr; float *pc = nullptr, *ent = nullptr;   // select outputs, [maxB*16]
+    int* amax = nullptr; float *pc = nullptr;                   // select outputs, [maxB*16]
+    float *part1 = nullptr, *part2 = nullptr;                   // select slice partials [16][SEL_SP][4] / [maxB*16][SEL_SP]
 
     // ---- decode state ----
     int *ids = nullptr, *L = nullptr, *kvlen = nullptr, *finished = nullptr, *cand = nullptr, *niter = nullptr;
@@ -85,6 +86,8 @@ struct wm_ctx {
     unsigned char* supmask = nullptr;      // [Vpad] bit0 suppress, bit1 begin-suppress
     float* exppen = nullptr;               // [Tids+1] (factor^(t-start) - 1) as float
     int* tap_tok = nullptr;
+    int* done = nullptr;                   // [0] = all streams finished, [1] = number of finished streams
+    bool use_done = false;
     GenDev gp{};
     int Bdec = 0;
     bool began = false, first_done = false;

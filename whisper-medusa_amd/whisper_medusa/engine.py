@@ -42,7 +42,8 @@ class WmGenParams(C.Structure):
 
 
 class WmStats(C.Structure):
-    _fields_ = [("iterations", C.c_int64), ("tokens_emitted", C.c_int64), ("accept_hist", C.c_int64 * 16),
+    _fields_ = [("iterations", C.c_int64), ("iterations_launched", C.c_int64), ("tokens_emitted", C.c_int64),
+                ("accept_hist", C.c_int64 * 16),
                 ("ms_logmel", C.c_float), ("ms_encode", C.c_float), ("ms_decode", C.c_float),
                 ("graph_replays", C.c_int32)]
 
@@ -184,7 +185,7 @@ class Engine:
     def stats(self) -> dict:
         s = WmStats()
         self._check(self.lib.wm_get_stats(self.h, C.byref(s)), "wm_get_stats")
-        return dict(iterations=s.iterations, tokens_emitted=s.tokens_emitted,
+        return dict(iterations=s.iterations, iterations_launched=s.iterations_launched, tokens_emitted=s.tokens_emitted,
                     accept_hist=list(s.accept_hist)[: self.cfg.medusa_num_heads + 1],
                     ms_logmel=s.ms_logmel, ms_encode=s.ms_encode, ms_decode=s.ms_decode,
                     graph_replays=s.graph_replays)
