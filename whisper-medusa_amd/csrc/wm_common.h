@@ -19,15 +19,15 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;           // one MFMA
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-__device__ __forceinline__ bf16_t f2bf(float f) {                    // round-to-nearest-even (== torch)
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);   // NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+
+// round-to-nearest-even (== torch) on the gfx950 converter: one v_cvt_pk_bf16_f32 per pair
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
 // element index of (row, k) inside a packed [R][K] matrix with K32 = K/32 k-tiles
@@ -64,9 +64,10 @@ __device__ __forceinline__ bf16x8_t ld_frag_nt(const bf16_t* p) {    // streamed
 // store 4 consecutive values as a bf16 hi/lo pair (x = hi + lo keeps ~17 mantissa bits)
 __device__ __forceinline__ void st_hilo4(bf16_t* hi, bf16_t* lo, float4 y)
 {
-    const bf16_t h0 = f2bf(y.x), h1 = f2bf(y.y), h2 = f2bf(y.z), h3 = f2bf(y.w);
-    uint2 a; a.x = (uint32_t)h0 | ((uint32_t)h1 << 16); a.y = (uint32_t)h2 | ((uint32_t)h3 << 16);
+    uint2 a; a.x = pack_bf2(y.x, y.y); a.y = pack_bf2(y.z, y.w);
     *reinterpret_cast<uint2*>(hi) = a;
-    uint2 b; b.x = pack_bf2(y.x - bf2f(h0), y.y - bf2f(h1)); b.y = pack_bf2(y.z - bf2f(h2), y.w - bf2f(h3));
+    uint2 b;
+    b.x = pack_bf2(y.x - __uint_as_float(a.x << 16), y.y - __uint_as_float(a.x & 0xffff0000u));
+    b.y = pack_bf2(y.z - __uint_as_float(a.y << 16), y.w - __uint_as_float(a.y & 0xffff0000u));
     *reinterpret_cast<uint2*>(lo) = b;
 }

@@ -100,13 +100,11 @@ __global__ void k_rows_norm(const float* __restrict__ src, int src_mul, int src_
 __device__ __forceinline__ void split_hilo8(const float* x, bf16x8_t& hi, bf16x8_t& lo)
 {
     uint4 h, l;
-    uint32_t* hp = reinterpret_cast<uint32_t*>(&h); uint32_t* lp = reinterpret_cast<uint32_t*>(&l);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const bf16_t a = f2bf(x[2 * i]), b = f2bf(x[2 * i + 1]);
-        hp[i] = (uint32_t)a | ((uint32_t)b << 16);
-        lp[i] = pack_bf2(x[2 * i] - bf2f(a), x[2 * i + 1] - bf2f(b));
-    }
+    h.x = pack_bf2(x[0], x[1]); h.y = pack_bf2(x[2], x[3]); h.z = pack_bf2(x[4], x[5]); h.w = pack_bf2(x[6], x[7]);
+    l.x = pack_bf2(x[0] - __uint_as_float(h.x << 16), x[1] - __uint_as_float(h.x & 0xffff0000u));
+    l.y = pack_bf2(x[2] - __uint_as_float(h.y << 16), x[3] - __uint_as_float(h.y & 0xffff0000u));
+    l.z = pack_bf2(x[4] - __uint_as_float(h.z << 16), x[5] - __uint_as_float(h.z & 0xffff0000u));
+    l.w = pack_bf2(x[6] - __uint_as_float(h.w << 16), x[7] - __uint_as_float(h.w & 0xffff0000u));
     hi = __builtin_bit_cast(bf16x8_t, h); lo = __builtin_bit_cast(bf16x8_t, l);
 }
 

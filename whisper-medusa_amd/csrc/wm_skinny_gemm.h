@@ -34,13 +34,12 @@ struct LdPacked {
 
 __device__ __forceinline__ void hilo8_to_lds(bf16_t* xh, bf16_t* xl, int q, float4 y0, float4 y1)
 {
-    const bf16_t a0 = f2bf(y0.x), a1 = f2bf(y0.y), a2 = f2bf(y0.z), a3 = f2bf(y0.w);
-    const bf16_t a4 = f2bf(y1.x), a5 = f2bf(y1.y), a6 = f2bf(y1.z), a7 = f2bf(y1.w);
     uint4 h, l;
-    h.x = (uint32_t)a0 | ((uint32_t)a1 << 16); h.y = (uint32_t)a2 | ((uint32_t)a3 << 16);
-    h.z = (uint32_t)a4 | ((uint32_t)a5 << 16); h.w = (uint32_t)a6 | ((uint32_t)a7 << 16);
-    l.x = pack_bf2(y0.x - bf2f(a0), y0.y - bf2f(a1)); l.y = pack_bf2(y0.z - bf2f(a2), y0.w - bf2f(a3));
-    l.z = pack_bf2(y1.x - bf2f(a4), y1.y - bf2f(a5)); l.w = pack_bf2(y1.z - bf2f(a6), y1.w - bf2f(a7));
+    h.x = pack_bf2(y0.x, y0.y); h.y = pack_bf2(y0.z, y0.w); h.z = pack_bf2(y1.x, y1.y); h.w = pack_bf2(y1.z, y1.w);
+    l.x = pack_bf2(y0.x - __uint_as_float(h.x << 16), y0.y - __uint_as_float(h.x & 0xffff0000u));
+    l.y = pack_bf2(y0.z - __uint_as_float(h.y << 16), y0.w - __uint_as_float(h.y & 0xffff0000u));
+    l.z = pack_bf2(y1.x - __uint_as_float(h.z << 16), y1.y - __uint_as_float(h.z & 0xffff0000u));
+    l.w = pack_bf2(y1.z - __uint_as_float(h.w << 16), y1.w - __uint_as_float(h.w & 0xffff0000u));
     reinterpret_cast<uint4*>(xh)[q] = h;          // chunk q = 16 B: lane-linear, bank-conflict-free
     reinterpret_cast<uint4*>(xl)[q] = l;
 }
@@ -59,14 +58,7 @@ struct LdNorm {
     static constexpr int UB = 8;                 // packed chunks per thread per batch
     __host__ __device__ __forceinline__ static size_t lds_bytes(int K32) { return (size_t)2 * K32 * 1024 + 2048 + (size_t)K32 * 256; }
 
-#define WM_LDN_LOAD_BATCH(Q0)                                                                              \
-    _Pragma("unroll") for (int i = 0; i < UB; ++i) {                                                       \
-        const int q_ = (Q0) + i * T, ln_ = q_ & 63, r_ = ln_ & 15, k0_ = (q_ >> 6) * 32 + (ln_ >> 4) * 8;   \
-        if (q_ < nq && r_ < M) {                                                                           \
-            const float4* src_ = reinterpret_cast<const float4*>(h + (size_t)(r_ * row_mul + row_off) * d + k0_); \
-            v0[i] = src_[0]; v1[i] = src_[1];                                                              \
-        } else { v0[i] = make_float4(0.f, 0.f, 0.f, 0.f); v1[i] = v0[i]; }                                 \
-    }
+    // requires K32 * 64 <= UB * blockDim.x (the whole 16 x K tile in one batch; checked by the launcher)
     __device__ __forceinline__ void prepare(char* smem) const {
         bf16_t* xh = reinterpret_cast<bf16_t*>(smem);
         bf16_t* xl = xh + (size_t)K32 * 512;
@@ -74,10 +66,18 @@ struct LdNorm {
         float* gb = reinterpret_cast<float*>(smem + (size_t)2 * K32 * 1024 + 2048);      // gamma[d] then beta[d]
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
         const int nv = d >> 2, nq = K32 * 64, T = blockDim.x;
-        const bool single = nq <= UB * T;        // whole tile in one batch: data stays in registers
         const int r = lane & 15;                 // the row of every chunk this thread touches
+        const int g8 = (lane >> 4) * 8;
+        const float* hrow = h + (size_t)(r * row_mul + row_off) * d + g8;
         float4 v0[UB], v1[UB];
-        WM_LDN_LOAD_BATCH(threadIdx.x)
+#pragma unroll
+        for (int i = 0; i < UB; ++i) {
+            const int q = threadIdx.x + i * T;
+            if (q < nq && r < M) {
+                const float4* src = reinterpret_cast<const float4*>(hrow + (q >> 6) * 32);
+                v0[i] = src[0]; v1[i] = src[1];
+            } else { v0[i] = make_float4(0.f, 0.f, 0.f, 0.f); v1[i] = v0[i]; }
+        }
         float mean = 0.f, rstd = 1.f;
         if (do_norm) {
             for (int c = threadIdx.x; c < nv; c += T) {
@@ -85,14 +85,11 @@ struct LdNorm {
                 reinterpret_cast<float4*>(gb + d)[c] = reinterpret_cast<const float4*>(beta)[c];
             }
             float s = 0.f, q2 = 0.f;
-            for (int q0 = threadIdx.x; q0 < nq; q0 += UB * T) {
-                if (q0 != (int)threadIdx.x) { WM_LDN_LOAD_BATCH(q0) }
 #pragma unroll
-                for (int i = 0; i < UB; ++i) {
-                    s += (v0[i].x + v0[i].y) + (v0[i].z + v0[i].w) + (v1[i].x + v1[i].y) + (v1[i].z + v1[i].w);
-                    q2 += (v0[i].x * v0[i].x + v0[i].y * v0[i].y) + (v0[i].z * v0[i].z + v0[i].w * v0[i].w) +
-                          (v1[i].x * v1[i].x + v1[i].y * v1[i].y) + (v1[i].z * v1[i].z + v1[i].w * v1[i].w);
-                }
+            for (int i = 0; i < UB; ++i) {
+                s += (v0[i].x + v0[i].y) + (v0[i].z + v0[i].w) + (v1[i].x + v1[i].y) + (v1[i].z + v1[i].w);
+                q2 += (v0[i].x * v0[i].x + v0[i].y * v0[i].y) + (v0[i].z * v0[i].z + v0[i].w * v0[i].w) +
+                      (v1[i].x * v1[i].x + v1[i].y * v1[i].y) + (v1[i].z * v1[i].z + v1[i].w * v1[i].w);
             }
             s += __shfl_xor(s, 16, 64); q2 += __shfl_xor(q2, 16, 64);
             s += __shfl_xor(s, 32, 64); q2 += __shfl_xor(q2, 32, 64);
@@ -103,23 +100,21 @@ struct LdNorm {
             mean = ts / (float)d;
             rstd = rsqrtf(fmaxf(tq / (float)d - mean * mean, 0.f) + 1e-5f);
         }
-        for (int q0 = threadIdx.x; q0 < nq; q0 += UB * T) {
-            if (!single) { WM_LDN_LOAD_BATCH(q0) }
+        const bool norm_row = do_norm && r < M;
 #pragma unroll
-            for (int i = 0; i < UB; ++i) {
-                const int q = q0 + i * T, k0 = (q >> 6) * 32 + ((q & 63) >> 4) * 8;
-                if (q >= nq) continue;
-                float4 y0 = v0[i], y1 = v1[i];
-                if (do_norm && r < M) {
-                    const float4 g0 = *reinterpret_cast<const float4*>(gb + k0), g1 = *reinterpret_cast<const float4*>(gb + k0 + 4);
-                    const float4 b0 = *reinterpret_cast<const float4*>(gb + d + k0), b1 = *reinterpret_cast<const float4*>(gb + d + k0 + 4);
-                    y0.x = (y0.x - mean) * rstd * g0.x + b0.x; y0.y = (y0.y - mean) * rstd * g0.y + b0.y;
-                    y0.z = (y0.z - mean) * rstd * g0.z + b0.z; y0.w = (y0.w - mean) * rstd * g0.w + b0.w;
-                    y1.x = (y1.x - mean) * rstd * g1.x + b1.x; y1.y = (y1.y - mean) * rstd * g1.y + b1.y;
-                    y1.z = (y1.z - mean) * rstd * g1.z + b1.z; y1.w = (y1.w - mean) * rstd * g1.w + b1.w;
-                }
-                hilo8_to_lds(xh, xl, q, y0, y1);
+        for (int i = 0; i < UB; ++i) {
+            const int q = threadIdx.x + i * T, k0 = (q >> 6) * 32 + g8;
+            if (q >= nq) continue;
+            float4 y0 = v0[i], y1 = v1[i];
+            if (norm_row) {
+                const float4 g0 = *reinterpret_cast<const float4*>(gb + k0), g1 = *reinterpret_cast<const float4*>(gb + k0 + 4);
+                const float4 b0 = *reinterpret_cast<const float4*>(gb + d + k0), b1 = *reinterpret_cast<const float4*>(gb + d + k0 + 4);
+                y0.x = (y0.x - mean) * rstd * g0.x + b0.x; y0.y = (y0.y - mean) * rstd * g0.y + b0.y;
+                y0.z = (y0.z - mean) * rstd * g0.z + b0.z; y0.w = (y0.w - mean) * rstd * g0.w + b0.w;
+                y1.x = (y1.x - mean) * rstd * g1.x + b1.x; y1.y = (y1.y - mean) * rstd * g1.y + b1.y;
+                y1.z = (y1.z - mean) * rstd * g1.z + b1.z; y1.w = (y1.w - mean) * rstd * g1.w + b1.w;
             }
+            hilo8_to_lds(xh, xl, q, y0, y1);
         }
         __syncthreads();
     }
@@ -240,9 +235,15 @@ static inline hipError_t launch_skinny(hipStream_t st, const bf16_t* W, int N16,
     return launch_skinny_u<4>(st, W, N16, K32, p, ld, ep);
 }
 
-// LayerNorm-fused launch
+// LayerNorm-fused launch.  The fused loader needs the whole 16 x K tile in one batch of the block's threads
+// (true for every Whisper size: K/32 <= 8 x waves per block); otherwise the caller must un-fuse.
+static inline bool skinny_norm_fusable(int N16, int K32) {
+    const SkinnyPlan p = skinny_plan(N16, K32, true);
+    return K32 <= LdNorm::UB * p.ksplit * p.rt;
+}
 template <class Ep>
 static inline hipError_t launch_skinny_norm(hipStream_t st, const bf16_t* W, int N16, int K32, const float* h, const float* gamma,
                                             const float* beta, int d, int M, int row_mul, int row_off, int do_norm, const Ep& ep) {
+    if (!skinny_norm_fusable(N16, K32)) return hipErrorInvalidConfiguration;
     return launch_skinny(st, W, N16, K32, LdNorm{h, gamma, beta, d, K32, M, row_mul, row_off, do_norm}, ep);
 }
