@@ -1,0 +1,26 @@
+"""HBM traffic per decode iteration from a `rocprofv3 --pmc FETCH_SIZE --kernel-trace` run of bench.py.
+FETCH_SIZE is reported in KB; on gfx950 it counts 64 B per 128-B request for wide coalesced streams, i.e.
+HALF of the bytes (MI355X_MICROARCH.md §HBM) -> multiply by 2.  python tests/pmc_summary.py <db> [out.md]"""
+import re
+import sqlite3
+import sys
+
+c = sqlite3.connect(sys.argv[1])
+rows = c.execute("select name, count(*), sum(counter_value), sum(end-start)/1e3 from pmc_events where counter_name='FETCH_SIZE' "
+                 "group by name order by 3 desc").fetchall()
+ours = [(re.sub(r"\(.*", "", n)[:90], k, v, t) for n, k, v, t in rows
+        if re.search(r"k_skinny|k_attn|k_select|k_embed|k_rows_norm|k_accept|k_set_cand", n)]
+n_iter = sum(k for n, k, v, t in ours if n.startswith("k_accept") and "vanilla" not in n)
+n_van = sum(k for n, k, v, t in ours if "k_accept_vanilla" in n)
+lines = [f"Medusa iterations profiled: {n_iter}; vanilla steps: {n_van}", "",
+         "| kernel | calls | FETCH_SIZE sum (MB, raw) | x2-corrected MB | corrected MB / call |", "|---|---|---|---|---|"]
+tot = 0.0
+for n, k, v, t in ours:
+    mb = v / 1024.0
+    tot += mb
+    lines.append(f"| `{n}` | {k} | {mb:.1f} | {2 * mb:.1f} | {2 * mb / k:.3f} |")
+lines += ["", f"decode-path total: raw {tot:.1f} MB, corrected {2 * tot:.1f} MB over {n_iter} Medusa iterations + {n_van} vanilla steps"]
+out = "\n".join(lines)
+print(out)
+if len(sys.argv) > 2:
+    open(sys.argv[2], "w").write(out + "\n")
