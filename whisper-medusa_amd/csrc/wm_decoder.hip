@@ -35,13 +35,18 @@ __global__ void k_embed(float* __restrict__ h, const bf16_t* __restrict__ tok_em
 // ---------------------------------------------------------------------------------------------
 __global__ void k_rows_norm(const float* __restrict__ src, int src_mul, int src_off, const float* __restrict__ gamma,
                             const float* __restrict__ beta, int do_norm, float* __restrict__ out_a, float* __restrict__ out_b,
-                            bf16_t* __restrict__ out_p, size_t p_plane, int K32, int p_mul, int p_off, int d, int M)
+                            bf16_t* __restrict__ out_p, size_t p_plane, int K32, int p_mul, int p_off, int d, int M,
+                            const int* __restrict__ carry, const float* __restrict__ hf_keep)
 {
     const int lane = threadIdx.x & 63;
     const int m = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (m >= M) return;
     const int nv = d >> 2;
     const float4* sp = reinterpret_cast<const float4*>(src + (size_t)(m * src_mul + src_off) * d);
+    if (carry && carry[m]) {          // hidden-state carry: the post-LN row was saved by k_accept; the layers were skipped
+        sp = reinterpret_cast<const float4*>(hf_keep + (size_t)m * d);
+        do_norm = 0;
+    }
     float4 v[8];
     float s = 0.f;
 #pragma unroll
@@ -112,9 +117,10 @@ template <bool CROSS>
 __global__ void __launch_bounds__(256)
 k_attn_mfma(const float* __restrict__ q, const bf16_t* __restrict__ kmat, const bf16_t* __restrict__ vtmat,
             const int* __restrict__ base, bf16_t* __restrict__ xout, size_t xplane, float* __restrict__ ml, float* __restrict__ po,
-            int* __restrict__ ticket, const int* __restrict__ done, int Mper, int H, int rows_alloc, int S, int NS, int K32)
+            int* __restrict__ ticket, const int* __restrict__ done, const int* __restrict__ skip, int Mper, int H, int rows_alloc,
+            int S, int NS, int K32)
 {
-    if (done && *done) return;
+    if ((done && *done) || (skip && *skip)) return;
     __shared__ float s_m[4][16], s_l[4][16];
     __shared__ int s_last;
     __shared__ __attribute__((aligned(16))) float s_o[4][16][68];
@@ -399,7 +405,8 @@ __global__ void k_set_cand(const int* __restrict__ amax, int* __restrict__ cand,
 // ---------------------------------------------------------------------------------------------
 __global__ void k_accept(GenDev gp, const int* __restrict__ cand, const int* __restrict__ amax, const float* __restrict__ pc,
                          const float* __restrict__ part2, int* __restrict__ ids, int* __restrict__ L, int* __restrict__ kvlen,
-                         int* __restrict__ finished, int* __restrict__ niter, long long* __restrict__ hist, int* __restrict__ done, int B)
+                         int* __restrict__ finished, int* __restrict__ niter, long long* __restrict__ hist, int* __restrict__ done, int B,
+                         int* __restrict__ carry, const float* __restrict__ hf, float* __restrict__ hf_keep, int d)
 {
     const int s = blockIdx.x, lane = threadIdx.x;
     if (finished[s]) return;
@@ -428,10 +435,20 @@ __global__ void k_accept(GenDev gp, const int* __restrict__ cand, const int* __r
         if (Lcur + lane < gp.Tids) ids[(size_t)s * gp.Tids + Lcur + lane] = tok;
     }
     const bool hit_eos = __ballot(lane < n_emit && tok == gp.eos) != 0ull;
+    // hidden-state carry (a > 0): row a of the verify pass saw exactly the accepted prefix, so its post-LN state IS
+    // what the next base pass would recompute for token c_a, and its K/V row is already in the cache: keep a+1 rows,
+    // save the row, and let the next (redundant) base pass skip its layers.  Bit-identical tokens, half the passes.
+    const bool do_carry = carry != nullptr && a > 0;
+    if (do_carry) {
+        const float4* srcp = reinterpret_cast<const float4*>(hf + (size_t)(s * rps + a) * d);
+        float4* dstp = reinterpret_cast<float4*>(hf_keep + (size_t)s * d);
+        for (int j = lane; j < (d >> 2); j += 64) dstp[j] = srcp[j];
+    }
     if (lane == 0) {
         const int Ln = Lcur + n_emit;
         L[s] = Ln;
-        kvlen[s] = (a == 0) ? Lcur + 1 : Lcur + a;
+        kvlen[s] = (a == 0) ? Lcur + 1 : (do_carry ? Ln : Lcur + a);
+        if (carry) carry[s] = do_carry ? 1 : 0;
         niter[s] += 1;
         atomicAdd(reinterpret_cast<unsigned long long*>(hist + a), 1ull);
         atomicAdd(reinterpret_cast<unsigned long long*>(hist + 16), (unsigned long long)n_emit);
@@ -476,7 +493,7 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
     if (kv_only) return WM_OK;
     // 2. causal self-attention over the contiguous cache
     hipLaunchKernelGGL(k_attn_mfma<false>, dim3(1, H, nb), dim3(256), 0, st, ctx->qbuf, kc, vc, base, ctx->xbuf, xpl,
-                       nullptr, nullptr, nullptr, g_skinny_done, Mper, H, ctx->Tal, 0, 1, K32);
+                       nullptr, nullptr, nullptr, g_skinny_done, g_skinny_skip, Mper, H, ctx->Tal, 0, 1, K32);
     WM_HIP(hipGetLastError());
     // 3. out_proj + residual
     WM_HIP(launch_skinny(st, w.out_w, d / 16, K32, LdPacked{ctx->xbuf, K32, xpl}, EpResidual{h, w.out_b, d, R}));
@@ -484,7 +501,7 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
     WM_HIP(launch_skinny_norm(st, w.cq_w, d / 16, K32, h, w.ln2_w, w.ln2_b, d, R, 1, 0, 1, EpF32{ctx->qbuf, w.cq_b, d, R, 0.125f}));
     // 5. cross-attention over the encoder K/V, 256 keys per block
     hipLaunchKernelGGL(k_attn_mfma<true>, dim3(ctx->NS, H, nb), dim3(256), 0, st, ctx->qbuf, kx, vx, base, ctx->xbuf, xpl,
-                       ctx->cml, ctx->co, ctx->ticket, g_skinny_done, Mper, H, ctx->Spad, ctx->S, ctx->NS, K32);
+                       ctx->cml, ctx->co, ctx->ticket, g_skinny_done, g_skinny_skip, Mper, H, ctx->Spad, ctx->S, ctx->NS, K32);
     WM_HIP(hipGetLastError());
     // 6. out_proj + residual
     WM_HIP(launch_skinny(st, w.cout_w, d / 16, K32, LdPacked{ctx->xbuf, K32, xpl}, EpResidual{h, w.cout_b, d, R}));
@@ -503,6 +520,8 @@ int wm_dec_stage_layers(wm_ctx* ctx, int b0, int nb, int Mper, int mode)
 {
     hipStream_t st = ctx->stream;
     g_skinny_done = ctx->use_done ? ctx->done : nullptr;
+    g_skinny_skip = (mode == 0 && nb == 1 && Mper == 1 && ctx->use_done && ctx->fuse && !ctx->block && (WM_MAX_ROWS_SKINNY / (ctx->K + 1)) == 1 && !ctx->gp.vanilla)
+                        ? ctx->carry + b0 : nullptr;
     const int d = ctx->d, R = nb * Mper;
     const int* base = (mode == 0 ? ctx->kvlen : ctx->L) + b0;
     if (R > WM_MAX_ROWS_SKINNY) { ctx->err = "decode chunk exceeds 16 token rows"; return WM_ERR_ARG; }
@@ -528,9 +547,13 @@ int wm_dec_stage_final(wm_ctx* ctx, int b0, int nb, int Mper, int mode, int medu
     hipStream_t st = ctx->stream;
     const int d = ctx->d, K32 = d / 32, R = nb * Mper;
     const int* base = (mode == 0 ? ctx->kvlen : ctx->L) + b0;
+    float* hf = ctx->hf + (size_t)b0 * Mper * d;          // rows of this chunk; persists until the stream's next pass
     hipLaunchKernelGGL(k_rows_norm, dim3((R + 3) / 4), dim3(256), 0, st, ctx->h, 1, 0, ctx->dec_lnf_w, ctx->dec_lnf_b, 1,
-                       ctx->hf, ctx->block ? ctx->hblk : nullptr, nullptr, (size_t)0, K32, 1, 0, d, R);
+                       hf, ctx->block ? ctx->hblk : nullptr, nullptr, (size_t)0, K32, 1, 0, d, R,
+                       g_skinny_skip, ctx->hf_keep + (size_t)b0 * d);
     WM_HIP(hipGetLastError());
+    g_skinny_skip = nullptr;                               // heads / vocabulary projection always run
+    ctx->hf_cur = hf;
     if (ctx->block && !ctx->gp.vanilla) {
         int rc = dec_layer(ctx, ctx->dec[ctx->nkv - 1], ctx->nkv - 1, ctx->hblk, b0, nb, Mper, base, !medusa);
         if (rc) return rc;
@@ -549,12 +572,12 @@ int wm_dec_stage_heads(wm_ctx* ctx, int nsel, int sel_mul, int sel_off, int medu
     if (nsel * nout > WM_MAX_ROWS_SKINNY) { ctx->err = "head stage exceeds 16 logit rows"; return WM_ERR_ARG; }
     if (!ctx->block) {
         // Medusa-Linear: every head (incl. base head 0) = x + SiLU(W_k x + b_k), then proj_out (model.py:1274-1284)
-        WM_HIP(launch_skinny_norm(st, ctx->heads_w, nout * d / 16, K32, ctx->hf, nullptr, nullptr, d, nsel, sel_mul, sel_off, 0,
-                                  EpHead{ctx->ybuf, ctx->ybuf + ypl, ctx->hf, ctx->heads_b, d, K32, nout, 0, nsel, sel_mul, sel_off}));
+        WM_HIP(launch_skinny_norm(st, ctx->heads_w, nout * d / 16, K32, ctx->hf_cur, nullptr, nullptr, d, nsel, sel_mul, sel_off, 0,
+                                  EpHead{ctx->ybuf, ctx->ybuf + ypl, ctx->hf_cur, ctx->heads_b, d, K32, nout, 0, nsel, sel_mul, sel_off}));
     } else {
         // Medusa-Block: base logits = proj_out(hf) (model.py:1287); K heads on the block output (model.py:1414-1417)
-        hipLaunchKernelGGL(k_rows_norm, dim3((nsel + 3) / 4), dim3(256), 0, st, ctx->hf, sel_mul, sel_off, nullptr, nullptr, 0,
-                           nullptr, nullptr, ctx->ybuf, ypl, K32, nout, 0, d, nsel);
+        hipLaunchKernelGGL(k_rows_norm, dim3((nsel + 3) / 4), dim3(256), 0, st, ctx->hf_cur, sel_mul, sel_off, nullptr, nullptr, 0,
+                           nullptr, nullptr, ctx->ybuf, ypl, K32, nout, 0, d, nsel, nullptr, nullptr);
         WM_HIP(hipGetLastError());
         if (medusa)
             WM_HIP(launch_skinny_norm(st, ctx->heads_w, K * d / 16, K32, ctx->hblk, nullptr, nullptr, d, nsel, sel_mul, sel_off, 0,
@@ -600,6 +623,7 @@ int wm_dec_iteration(wm_ctx* ctx, int Mper_base)
         return WM_OK;
     }
     const int chunk = max(1, WM_MAX_ROWS_SKINNY / max(Mper_base, rps));
+    const bool fuse = ctx->fuse && !ctx->block && (WM_MAX_ROWS_SKINNY / rps) == 1;     // one stream per chunk: per-stream skip word
     // (a) base pass -> K+1 candidates per stream
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int nb = min(chunk, B - b0);
@@ -630,7 +654,7 @@ int wm_dec_iteration(wm_ctx* ctx, int Mper_base)
     }
     // (f)-(j) accept / emit / compact / stop
     hipLaunchKernelGGL(k_accept, dim3(B), dim3(64), 0, st, gp, ctx->cand, ctx->amax, ctx->pc, ctx->part2, ctx->ids, ctx->L,
-                       ctx->kvlen, ctx->finished, ctx->niter, ctx->hist, ctx->done, B);
+                       ctx->kvlen, ctx->finished, ctx->niter, ctx->hist, ctx->done, B, fuse ? ctx->carry : nullptr, ctx->hf, ctx->hf_keep, ctx->d);
     WM_HIP(hipGetLastError());
     return WM_OK;
 }
@@ -639,7 +663,7 @@ int wm_dec_iteration(wm_ctx* ctx, int Mper_base)
 int wm_dec_profile(wm_ctx* ctx, int kernel, int rows, int reps, float* ms, double* bytes)
 {
     if (kernel != 0 || rows < 1 || rows > WM_MAX_ROWS_SKINNY) { ctx->err = "wm_profile_kernel: bad arguments"; return WM_ERR_ARG; }
-    g_skinny_done = nullptr;
+    g_skinny_done = nullptr; g_skinny_skip = nullptr;
     hipStream_t st = ctx->stream;
     const int d = ctx->d, K32 = d / 32, R = rows, H = ctx->H, F32 = ctx->ffn / 32;
     const size_t xpl = (size_t)16 * d, fpl = (size_t)16 * ctx->ffn;

@@ -31,7 +31,8 @@ extern "C" void wm_destroy(wm_ctx* ctx)
     void* bufs[] = {ctx->feats_own, ctx->clipmax, ctx->A1, ctx->a1, ctx->A2, ctx->eh, ctx->exn, ctx->eq, ctx->ek, ctx->evt, ctx->eff,
                     ctx->enc_out, ctx->kx, ctx->vx, ctx->kc, ctx->vc, ctx->h, ctx->hblk, ctx->hf, ctx->qbuf, ctx->xbuf, ctx->fbuf,
                     ctx->ybuf, ctx->cml, ctx->co, ctx->ticket, ctx->logits, ctx->amax, ctx->pc, ctx->part1, ctx->part2, ctx->ids, ctx->L, ctx->kvlen,
-                    ctx->finished, ctx->cand, ctx->niter, ctx->hist, ctx->supmask, ctx->exppen, ctx->tap_tok, ctx->done};
+                    ctx->finished, ctx->cand, ctx->niter, ctx->hist, ctx->supmask, ctx->exppen, ctx->tap_tok, ctx->done,
+                    ctx->hf_keep, ctx->carry};
     for (void* b : bufs) if (b) hipFree(b);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
@@ -124,7 +125,9 @@ extern "C" int wm_create(const wm_config* cfg, const wm_weights* w, int device, 
     const size_t RW = WM_MAX_ROWS_SKINNY;
     CREATE_HIP(dev_alloc(&ctx->h, RW * d, st));
     CREATE_HIP(dev_alloc(&ctx->hblk, RW * d, st));
-    CREATE_HIP(dev_alloc(&ctx->hf, RW * d, st));
+    CREATE_HIP(dev_alloc(&ctx->hf, B * 16 * d, st));
+    CREATE_HIP(dev_alloc(&ctx->hf_keep, B * d, st));
+    CREATE_HIP(dev_alloc(&ctx->carry, B, st));
     CREATE_HIP(dev_alloc(&ctx->qbuf, RW * d, st));
     CREATE_HIP(dev_alloc(&ctx->xbuf, 2 * RW * d, st));          // hi + lo planes
     CREATE_HIP(dev_alloc(&ctx->fbuf, 2 * RW * ctx->ffn, st));
@@ -193,6 +196,8 @@ extern "C" int wm_decode_begin(wm_ctx* ctx, const wm_gen_params* gp, int B)
     g.thr = gp->posterior_threshold; g.alpha = gp->posterior_alpha;
     g.inv_temp = (gp->accept_mode == WM_ACCEPT_TYPICAL && gp->temperature > 0.f) ? 1.0f / gp->temperature : 1.0f;
     g.accept_mode = gp->accept_mode; g.vanilla = gp->vanilla; g.K = K; g.V = ctx->V; g.Vpad = ctx->Vpad; g.Tids = Tids;
+    ctx->fuse = std::getenv("WM_NO_CARRY") == nullptr;
+    g.fuse = ctx->fuse ? 1 : 0;
     const bool same = ctx->graph && ctx->graph_B == B && std::memcmp(&g, &ctx->gp, sizeof(GenDev)) == 0;
     if (!same && ctx->graph) { hipGraphExecDestroy(ctx->graph); ctx->graph = nullptr; }
     ctx->gp = g; ctx->Bdec = B;
@@ -214,6 +219,7 @@ extern "C" int wm_decode_begin(wm_ctx* ctx, const wm_gen_params* gp, int B)
     WM_HIP(hipMemcpyAsync(ctx->niter, zero.data(), B * sizeof(int), hipMemcpyHostToDevice, st));
     WM_HIP(hipMemsetAsync(ctx->hist, 0, 32 * sizeof(long long), st));
     WM_HIP(hipMemsetAsync(ctx->done, 0, 4 * sizeof(int), st));
+    WM_HIP(hipMemsetAsync(ctx->carry, 0, ctx->maxB * sizeof(int), st));
     ctx->use_done = true;
     WM_HIP(hipMemcpyAsync(ctx->supmask, mask.data(), mask.size(), hipMemcpyHostToDevice, st));
     WM_HIP(hipMemcpyAsync(ctx->exppen, pen.data(), pen.size() * sizeof(float), hipMemcpyHostToDevice, st));

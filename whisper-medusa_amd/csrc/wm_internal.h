@@ -28,7 +28,7 @@ struct DecLayerW {
 struct GenDev {
     int P, eos, pad, max_length, hard_max_length, exp_start /* absolute: start + P, or -1 */;
     float thr, alpha, inv_temp;
-    int accept_mode, vanilla, K, V, Vpad, Tids;
+    int accept_mode, vanilla, K, V, Vpad, Tids, fuse;
 };
 
 struct wm_ctx {
@@ -72,7 +72,10 @@ struct wm_ctx {
     int Benc = 0;                          // batch of the last wm_encode
 
     // ---- decode row scratch (<= WM_MAX_ROWS_SKINNY rows per chunk) ----
-    float *h = nullptr, *hblk = nullptr, *hf = nullptr, *qbuf = nullptr;
+    float *h = nullptr, *hblk = nullptr, *hf = nullptr, *qbuf = nullptr;    // hf: [maxB*16][d] post-final-LN rows
+    float *hf_cur = nullptr, *hf_keep = nullptr;                            // current chunk's rows; carried row per stream
+    int* carry = nullptr;                                                   // [maxB] next base pass is redundant
+    bool fuse = true;
     bf16_t *xbuf = nullptr, *fbuf = nullptr, *ybuf = nullptr;
     float *cml = nullptr, *co = nullptr;   // cross-attention partials
     int* ticket = nullptr;                 // [16 streams][H] arrival tickets of the cross-attention key splits
