@@ -127,6 +127,32 @@ k_attn_mfma(const float* __restrict__ q, const bf16_t* __restrict__ kmat, const 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
     const int hd = blockIdx.y, s = blockIdx.z, split = blockIdx.x, d = H * 64;
 
+    const int b0 = CROSS ? 0 : base[s];
+    const int limit = CROSS ? S : min(b0 + c + 1, rows_alloc);            // keys < limit are visible to query c
+    int kb, kend, kstep;
+    if (CROSS) { kb = split * 256 + w * 64; kend = min(S, kb + 64); kstep = 32; }
+    else { kb = 32 * w; kend = min(b0 + Mper, rows_alloc); kstep = 128; }
+    const bf16_t* kp = kmat + ((size_t)s * H + hd) * rows_alloc * 64;
+    const bf16_t* vp = vtmat + ((size_t)s * H + hd) * 64 * rows_alloc;
+
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4_t o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // fragments of the first step; inside the loop the NEXT step's loads are issued before this step's math
+    bf16x8_t a00, a01, a10, a11;
+    uint2 vlo[4], vhi[4];
+#define WM_ATTN_LOAD(KB, A00, A01, A10, A11, VLO, VHI)                                             \
+    {                                                                                              \
+        const bf16_t* kr_ = kp + (size_t)((KB) + c) * 64 + g * 8;                                  \
+        A00 = ld_frag(kr_); A01 = ld_frag(kr_ + 32); A10 = ld_frag(kr_ + 16 * 64); A11 = ld_frag(kr_ + 16 * 64 + 32); \
+        _Pragma("unroll") for (int dt = 0; dt < 4; ++dt) {                                         \
+            const bf16_t* vr_ = vp + (size_t)(dt * 16 + c) * rows_alloc + (KB) + 4 * g;            \
+            VLO[dt] = *reinterpret_cast<const uint2*>(vr_); VHI[dt] = *reinterpret_cast<const uint2*>(vr_ + 16); \
+        }                                                                                          \
+    }
+    if (kb < kend) WM_ATTN_LOAD(kb, a00, a01, a10, a11, vlo, vhi)     // K/V do not depend on q: issue first
     bf16x8_t qhi[2], qlo[2];
     {
         float qv[8];
@@ -143,30 +169,12 @@ k_attn_mfma(const float* __restrict__ q, const bf16_t* __restrict__ kmat, const 
             split_hilo8(qv, qhi[ds], qlo[ds]);
         }
     }
-    const int b0 = CROSS ? 0 : base[s];
-    const int limit = CROSS ? S : min(b0 + c + 1, rows_alloc);            // keys < limit are visible to query c
-    int kb, kend, kstep;
-    if (CROSS) { kb = split * 256 + w * 64; kend = min(S, kb + 64); kstep = 32; }
-    else { kb = 32 * w; kend = min(b0 + Mper, rows_alloc); kstep = 128; }
-    const bf16_t* kp = kmat + ((size_t)s * H + hd) * rows_alloc * 64;
-    const bf16_t* vp = vtmat + ((size_t)s * H + hd) * 64 * rows_alloc;
-
-    float m_run = -INFINITY, l_run = 0.f;
-    f32x4_t o[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
     for (; kb < kend; kb += kstep) {
-        const bf16_t* kr = kp + (size_t)(kb + c) * 64 + g * 8;
-        const bf16x8_t a00 = ld_frag(kr), a01 = ld_frag(kr + 32);
-        const bf16x8_t a10 = ld_frag(kr + 16 * 64), a11 = ld_frag(kr + 16 * 64 + 32);
-        uint2 vlo[4], vhi[4];
+        bf16x8_t n00 = a00, n01 = a01, n10 = a10, n11 = a11;
+        uint2 nlo[4], nhi[4];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const bf16_t* vr = vp + (size_t)(dt * 16 + c) * rows_alloc + kb + 4 * g;
-            vlo[dt] = *reinterpret_cast<const uint2*>(vr);
-            vhi[dt] = *reinterpret_cast<const uint2*>(vr + 16);
-        }
+        for (int dt = 0; dt < 4; ++dt) { nlo[dt] = vlo[dt]; nhi[dt] = vhi[dt]; }
+        if (kb + kstep < kend) WM_ATTN_LOAD(kb + kstep, n00, n01, n10, n11, nlo, nhi)
         f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
         s0 = mfma16(a00, qhi[0], s0); s0 = mfma16(a01, qhi[1], s0); s0 = mfma16(a00, qlo[0], s0); s0 = mfma16(a01, qlo[1], s0);
         s1 = mfma16(a10, qhi[0], s1); s1 = mfma16(a11, qhi[1], s1); s1 = mfma16(a10, qlo[0], s1); s1 = mfma16(a11, qlo[1], s1);
@@ -201,7 +209,11 @@ k_attn_mfma(const float* __restrict__ q, const bf16_t* __restrict__ kmat, const 
             o[dt] = mfma16(va, phi, o[dt]);
             o[dt] = mfma16(va, plo, o[dt]);
         }
+        a00 = n00; a01 = n01; a10 = n10; a11 = n11;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { vlo[dt] = nlo[dt]; vhi[dt] = nhi[dt]; }
     }
+#undef WM_ATTN_LOAD
     if (g == 0) { s_m[w][c] = m_run; s_l[w][c] = l_run; }
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
@@ -229,35 +241,50 @@ k_attn_mfma(const float* __restrict__ q, const bf16_t* __restrict__ kmat, const 
         return;
     }
     // ---- publish this block's partial; the last block of the (stream, head) merges all NS partials ----
+    // Hand-off in the "8-byte agent-scope atomics on both sides" form (cdna_hip_programming.md G16): payload
+    // stores are relaxed agent-scope atomics (write-through sc1), every storing wave drains vmcnt, one lane takes
+    // a relaxed ticket; the last arriver reads the other partials with relaxed agent-scope atomic loads (L1 bypass).
+    typedef unsigned long long u64;
     if (qr < Mper) {
-        if (ch == 0) { float* mo = ml + (((size_t)row * H + hd) * NS + split) * 2; mo[0] = M; mo[1] = L; }
-        *reinterpret_cast<float4*>(po + (((size_t)row * H + hd) * NS + split) * 64 + ch) = acc;
+        u64* pd = reinterpret_cast<u64*>(po + (((size_t)row * H + hd) * NS + split) * 64 + ch);
+        __hip_atomic_store(pd, ((u64)__float_as_uint(acc.y) << 32) | __float_as_uint(acc.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pd + 1, ((u64)__float_as_uint(acc.w) << 32) | __float_as_uint(acc.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ch == 0)
+            __hip_atomic_store(reinterpret_cast<u64*>(ml + (((size_t)row * H + hd) * NS + split) * 2),
+                               ((u64)__float_as_uint(L) << 32) | __float_as_uint(M), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int t = __hip_atomic_fetch_add(ticket + s * H + hd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = (t == NS - 1);
-        if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __hip_atomic_store(ticket + s * H + hd, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch / replay
-        }
+        if (last) __hip_atomic_store(ticket + s * H + hd, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch / replay
         s_last = last;
     }
     __syncthreads();
     if (!s_last || qr >= Mper) return;
     {
-        const float* mlp = ml + ((size_t)row * H + hd) * NS * 2;
-        const float* op = po + ((size_t)row * H + hd) * NS * 64 + ch;
+        const u64* mlp = reinterpret_cast<const u64*>(ml + ((size_t)row * H + hd) * NS * 2);
+        const u64* op = reinterpret_cast<const u64*>(po + ((size_t)row * H + hd) * NS * 64 + ch);
+        float ms[16], ls[16];
         float Mx = -INFINITY;
-        for (int sp = 0; sp < NS; ++sp) Mx = fmaxf(Mx, mlp[2 * sp]);
+        for (int sp = 0; sp < NS; ++sp) {
+            const u64 v = (sp == split) ? (((u64)__float_as_uint(L) << 32) | __float_as_uint(M))
+                                        : __hip_atomic_load(mlp + sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ms[sp] = __uint_as_float((unsigned)v); ls[sp] = __uint_as_float((unsigned)(v >> 32));
+            Mx = fmaxf(Mx, ms[sp]);
+        }
         float Lt = 0.f; float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int sp = 0; sp < NS; ++sp) {
-            const float e = (mlp[2 * sp] == -INFINITY) ? 0.f : __expf(mlp[2 * sp] - Mx);
-            Lt += mlp[2 * sp + 1] * e;
-            const float4 ov = *reinterpret_cast<const float4*>(op + (size_t)sp * 64);
+            const float e = (ms[sp] == -INFINITY) ? 0.f : __expf(ms[sp] - Mx);
+            Lt += ls[sp] * e;
+            float4 ov = acc;
+            if (sp != split) {
+                const u64 v0 = __hip_atomic_load(op + (size_t)sp * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const u64 v1 = __hip_atomic_load(op + (size_t)sp * 32 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ov = make_float4(__uint_as_float((unsigned)v0), __uint_as_float((unsigned)(v0 >> 32)),
+                                 __uint_as_float((unsigned)v1), __uint_as_float((unsigned)(v1 >> 32)));
+            }
             o4.x += ov.x * e; o4.y += ov.y * e; o4.z += ov.z * e; o4.w += ov.w * e;
         }
         const float inv = 1.0f / Lt;
