@@ -152,7 +152,7 @@ def main():
     mean_len = len(gp.prompt) + args.max_new / 2
     bytes_iter = decode_iter_bytes(cfg, B, mean_len)
     achieved = bytes_iter / (t_iter_ms * 1e-3) / 1e9
-    gemm_ms, gemm_bytes = eng.profile_layer_gemms(rows=min(32, B * (cfg.medusa_num_heads + 1)), reps=50)
+    gemm_ms, gemm_bytes = eng.profile_layer_gemms(rows=min(16, B * (cfg.medusa_num_heads + 1)), reps=50)
     audio_s = args.steps * B * world * 30.0 * cfg.max_source_positions / 1500.0
     tok_per_iter = tokens / max(iters, 1) / B
     out = {

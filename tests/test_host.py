@@ -131,7 +131,7 @@ def test_skinny_plan_covers_all_whisper_shapes():
             if q % s:
                 continue
             best = s
-            if N16 * s >= 1024:
+            if N16 * s >= 1024 and K32 // s <= 16:
                 break
         rt = 4 if best == 1 else 1
         if lds and 1 < best <= 5 and N16 > 256:
@@ -142,3 +142,4 @@ def test_skinny_plan_covers_all_whisper_shapes():
             for lds in (True, False):
                 ks, rt, U = plan(N // 16, K // 32, lds)
                 assert (K // 32) % (ks * U) == 0 and ks * rt <= 10
+                assert (K // 32) // ks in (4, 8, 12, 16)          # the batched kernel keeps a whole K-slice in registers

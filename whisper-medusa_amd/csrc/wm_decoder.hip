@@ -509,34 +509,35 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
 {
     hipStream_t st = ctx->stream;
     const int d = ctx->d, H = ctx->H, K32 = d / 32, R = nb * Mper, F32 = ctx->ffn / 32;
-    const size_t xpl = (size_t)16 * d, fpl = (size_t)16 * ctx->ffn;
+    const size_t xpl = (size_t)ctx->Rcap * d, fpl = (size_t)ctx->Rcap * ctx->ffn;
     bf16_t* kc = ctx->kc + ((size_t)slot * ctx->maxB + b0) * H * ctx->Tal * 64;
     bf16_t* vc = ctx->vc + ((size_t)slot * ctx->maxB + b0) * H * ctx->Tal * 64;
     const bf16_t* kx = ctx->kx + ((size_t)slot * ctx->Benc + b0) * H * ctx->Spad * 64;
     const bf16_t* vx = ctx->vx + ((size_t)slot * ctx->Benc + b0) * H * ctx->Spad * 64;
     // 1. LN1 + QKV; k rows / transposed v rows straight into the cache
     WM_HIP(launch_skinny_norm(st, w.qkv_w, 3 * d / 16, K32, h, w.ln1_w, w.ln1_b, d, R, 1, 0, 1,
-                              EpQKVDec{ctx->qbuf, kc, vc, w.qkv_b, base, Mper, d, H, ctx->Tal, R}));
+                              EpQKVDec{ctx->qbuf, kc, vc, w.qkv_b, base, Mper, d, H, ctx->Tal, R}, ctx->xbuf, xpl));
     if (kv_only) return WM_OK;
     // 2. causal self-attention over the contiguous cache
     hipLaunchKernelGGL(k_attn_mfma<false>, dim3(1, H, nb), dim3(256), 0, st, ctx->qbuf, kc, vc, base, ctx->xbuf, xpl,
                        nullptr, nullptr, nullptr, g_skinny_done, g_skinny_skip, Mper, H, ctx->Tal, 0, 1, K32);
     WM_HIP(hipGetLastError());
     // 3. out_proj + residual
-    WM_HIP(launch_skinny(st, w.out_w, d / 16, K32, LdPacked{ctx->xbuf, K32, xpl}, EpResidual{h, w.out_b, d, R}));
+    WM_HIP(launch_skinny_rows(st, w.out_w, d / 16, K32, R, ctx->xbuf, xpl, EpResidual{h, w.out_b, d, R}));
     // 4. LN2 + cross-attention q
-    WM_HIP(launch_skinny_norm(st, w.cq_w, d / 16, K32, h, w.ln2_w, w.ln2_b, d, R, 1, 0, 1, EpF32{ctx->qbuf, w.cq_b, d, R, 0.125f}));
+    WM_HIP(launch_skinny_norm(st, w.cq_w, d / 16, K32, h, w.ln2_w, w.ln2_b, d, R, 1, 0, 1, EpF32{ctx->qbuf, w.cq_b, d, R, 0.125f},
+                              ctx->xbuf, xpl));
     // 5. cross-attention over the encoder K/V, 256 keys per block
     hipLaunchKernelGGL(k_attn_mfma<true>, dim3(ctx->NS, H, nb), dim3(256), 0, st, ctx->qbuf, kx, vx, base, ctx->xbuf, xpl,
                        ctx->cml, ctx->co, ctx->ticket, g_skinny_done, g_skinny_skip, Mper, H, ctx->Spad, ctx->S, ctx->NS, K32);
     WM_HIP(hipGetLastError());
     // 6. out_proj + residual
-    WM_HIP(launch_skinny(st, w.cout_w, d / 16, K32, LdPacked{ctx->xbuf, K32, xpl}, EpResidual{h, w.cout_b, d, R}));
+    WM_HIP(launch_skinny_rows(st, w.cout_w, d / 16, K32, R, ctx->xbuf, xpl, EpResidual{h, w.cout_b, d, R}));
     // 7. LN3 + fc1 + GELU
     WM_HIP(launch_skinny_norm(st, w.fc1_w, ctx->ffn / 16, K32, h, w.ln3_w, w.ln3_b, d, R, 1, 0, 1,
-                              EpPackedAct<1>{ctx->fbuf, ctx->fbuf + fpl, w.fc1_b, F32, R}));
+                              EpPackedAct<1>{ctx->fbuf, ctx->fbuf + fpl, w.fc1_b, F32, R}, ctx->xbuf, xpl));
     // 8. fc2 + residual
-    WM_HIP(launch_skinny(st, w.fc2_w, d / 16, F32, LdPacked{ctx->fbuf, F32, fpl}, EpResidual{h, w.fc2_b, d, R}));
+    WM_HIP(launch_skinny_rows(st, w.fc2_w, d / 16, F32, R, ctx->fbuf, fpl, EpResidual{h, w.fc2_b, d, R}));
     return WM_OK;
 }
 
@@ -547,11 +548,11 @@ int wm_dec_stage_layers(wm_ctx* ctx, int b0, int nb, int Mper, int mode)
 {
     hipStream_t st = ctx->stream;
     g_skinny_done = ctx->use_done ? ctx->done : nullptr;
-    g_skinny_skip = (mode == 0 && nb == 1 && Mper == 1 && ctx->use_done && ctx->fuse && !ctx->block && (WM_MAX_ROWS_SKINNY / (ctx->K + 1)) == 1 && !ctx->gp.vanilla)
+    g_skinny_skip = (mode == 0 && nb == 1 && ctx->Bdec == 1 && Mper == 1 && ctx->use_done && ctx->fuse && !ctx->block && !ctx->gp.vanilla)
                         ? ctx->carry + b0 : nullptr;
     const int d = ctx->d, R = nb * Mper;
     const int* base = (mode == 0 ? ctx->kvlen : ctx->L) + b0;
-    if (R > WM_MAX_ROWS_SKINNY) { ctx->err = "decode chunk exceeds 16 token rows"; return WM_ERR_ARG; }
+    if (R > ctx->Rcap || Mper > 16) { ctx->err = "decode pass exceeds the row capacity of the context"; return WM_ERR_ARG; }
     if (mode == 0)
         hipLaunchKernelGGL(k_embed, dim3(R), dim3(256), 0, st, ctx->h, ctx->tok_emb, ctx->dec_pos, base,
                            ctx->ids + (size_t)b0 * ctx->gp.Tids, ctx->gp.Tids, 1, Mper, d, ctx->V, ctx->Tmax);
@@ -595,12 +596,13 @@ int wm_dec_stage_heads(wm_ctx* ctx, int nsel, int sel_mul, int sel_off, int medu
     hipStream_t st = ctx->stream;
     const int d = ctx->d, K32 = d / 32, K = ctx->K;
     const int nout = medusa ? K + 1 : 1;
-    const size_t ypl = (size_t)16 * d;
-    if (nsel * nout > WM_MAX_ROWS_SKINNY) { ctx->err = "head stage exceeds 16 logit rows"; return WM_ERR_ARG; }
+    const size_t ypl = (size_t)ctx->Rcap * d;
+    if (nsel * nout > ctx->Rcap) { ctx->err = "head stage exceeds the row capacity of the context"; return WM_ERR_ARG; }
     if (!ctx->block) {
         // Medusa-Linear: every head (incl. base head 0) = x + SiLU(W_k x + b_k), then proj_out (model.py:1274-1284)
         WM_HIP(launch_skinny_norm(st, ctx->heads_w, nout * d / 16, K32, ctx->hf_cur, nullptr, nullptr, d, nsel, sel_mul, sel_off, 0,
-                                  EpHead{ctx->ybuf, ctx->ybuf + ypl, ctx->hf_cur, ctx->heads_b, d, K32, nout, 0, nsel, sel_mul, sel_off}));
+                                  EpHead{ctx->ybuf, ctx->ybuf + ypl, ctx->hf_cur, ctx->heads_b, d, K32, nout, 0, nsel, sel_mul, sel_off},
+                                  ctx->xbuf, ypl));
     } else {
         // Medusa-Block: base logits = proj_out(hf) (model.py:1287); K heads on the block output (model.py:1414-1417)
         hipLaunchKernelGGL(k_rows_norm, dim3((nsel + 3) / 4), dim3(256), 0, st, ctx->hf_cur, sel_mul, sel_off, nullptr, nullptr, 0,
@@ -608,11 +610,12 @@ int wm_dec_stage_heads(wm_ctx* ctx, int nsel, int sel_mul, int sel_off, int medu
         WM_HIP(hipGetLastError());
         if (medusa)
             WM_HIP(launch_skinny_norm(st, ctx->heads_w, K * d / 16, K32, ctx->hblk, nullptr, nullptr, d, nsel, sel_mul, sel_off, 0,
-                                      EpHead{ctx->ybuf, ctx->ybuf + ypl, ctx->hblk, ctx->heads_b, d, K32, nout, 1, nsel, sel_mul, sel_off}));
+                                      EpHead{ctx->ybuf, ctx->ybuf + ypl, ctx->hblk, ctx->heads_b, d, K32, nout, 1, nsel, sel_mul, sel_off},
+                                      ctx->xbuf, ypl));
     }
     // shared vocabulary projection (tied proj_out, model.py:1277)
-    WM_HIP(launch_skinny(st, ctx->vocab_w, ctx->Vpad / 16, K32, LdPacked{ctx->ybuf, K32, ypl},
-                         EpF32{ctx->logits, nullptr, ctx->Vpad, nsel * nout, 1.0f}));
+    WM_HIP(launch_skinny_rows(st, ctx->vocab_w, ctx->Vpad / 16, K32, nsel * nout, ctx->ybuf, ypl,
+                              EpF32{ctx->logits, nullptr, ctx->Vpad, nsel * nout, 1.0f}));
     return WM_OK;
 }
 
@@ -633,7 +636,7 @@ int wm_dec_iteration(wm_ctx* ctx, int Mper_base)
     const int B = ctx->Bdec, K = ctx->K, rps = K + 1;
     const GenDev gp = ctx->gp;
     if (gp.vanilla) {
-        const int chunk = max(1, WM_MAX_ROWS_SKINNY / Mper_base);
+        const int chunk = B;
         for (int b0 = 0; b0 < B; b0 += chunk) {
             const int nb = min(chunk, B - b0);
             int rc = wm_dec_pass(ctx, b0, nb, Mper_base, 0, 0, 0);
@@ -641,7 +644,7 @@ int wm_dec_iteration(wm_ctx* ctx, int Mper_base)
             hipLaunchKernelGGL(k_select1, dim3(SEL_SP, nb), dim3(256), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen,
                                ctx->L + b0, 1, ctx->part1);
             WM_HIP(hipGetLastError());
-            hipLaunchKernelGGL(k_select_argmax, dim3(1), dim3(64), 0, st, ctx->part1, nb, b0, ctx->amax);
+            hipLaunchKernelGGL(k_select_argmax, dim3((nb + 63) / 64), dim3(64), 0, st, ctx->part1, nb, b0, ctx->amax);
             WM_HIP(hipGetLastError());
         }
         hipLaunchKernelGGL(k_accept_vanilla1, dim3((B + 63) / 64), dim3(64), 0, st, gp, B, ctx->amax, ctx->ids, ctx->L,
@@ -649,8 +652,8 @@ int wm_dec_iteration(wm_ctx* ctx, int Mper_base)
         WM_HIP(hipGetLastError());
         return WM_OK;
     }
-    const int chunk = max(1, WM_MAX_ROWS_SKINNY / max(Mper_base, rps));
-    const bool fuse = ctx->fuse && !ctx->block && (WM_MAX_ROWS_SKINNY / rps) == 1;     // one stream per chunk: per-stream skip word
+    const int chunk = B;                                                   // all streams in one pass (batched kernels)
+    const bool fuse = ctx->fuse && !ctx->block && B == 1;                  // per-stream skip word needs a single stream per pass
     // (a) base pass -> K+1 candidates per stream
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int nb = min(chunk, B - b0);
@@ -659,9 +662,9 @@ int wm_dec_iteration(wm_ctx* ctx, int Mper_base)
         hipLaunchKernelGGL(k_select1, dim3(SEL_SP, nb * rps), dim3(256), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen,
                            ctx->L + b0, rps, ctx->part1);
         WM_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_select_argmax, dim3(1), dim3(64), 0, st, ctx->part1, nb * rps, b0 * rps, ctx->amax);
+        hipLaunchKernelGGL(k_select_argmax, dim3((nb * rps + 63) / 64), dim3(64), 0, st, ctx->part1, nb * rps, b0 * rps, ctx->amax);
         WM_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_set_cand, dim3(1), dim3(64), 0, st, ctx->amax + b0 * rps, ctx->cand + b0 * 16, rps, nb * rps);
+        hipLaunchKernelGGL(k_set_cand, dim3((nb * rps + 63) / 64), dim3(64), 0, st, ctx->amax + b0 * rps, ctx->cand + b0 * 16, rps, nb * rps);
         WM_HIP(hipGetLastError());
     }
     // (d) verify pass over the candidates at positions L..L+K, then posterior statistics
@@ -676,7 +679,7 @@ int wm_dec_iteration(wm_ctx* ctx, int Mper_base)
             hipLaunchKernelGGL(k_select2, dim3(SEL_SP, nb * rps), dim3(256), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen,
                                ctx->L + b0, ctx->cand + b0 * 16, rps, b0 * rps, ctx->part1, ctx->part2, ctx->amax, ctx->pc);
         else
-            hipLaunchKernelGGL(k_select_argmax, dim3(1), dim3(64), 0, st, ctx->part1, nb * rps, b0 * rps, ctx->amax);
+            hipLaunchKernelGGL(k_select_argmax, dim3((nb * rps + 63) / 64), dim3(64), 0, st, ctx->part1, nb * rps, b0 * rps, ctx->amax);
         WM_HIP(hipGetLastError());
     }
     // (f)-(j) accept / emit / compact / stop
@@ -689,23 +692,24 @@ int wm_dec_iteration(wm_ctx* ctx, int Mper_base)
 // Times the six weight-streaming GEMMs of one decoder layer for `rows` token rows (bench.py roofline leg).
 int wm_dec_profile(wm_ctx* ctx, int kernel, int rows, int reps, float* ms, double* bytes)
 {
-    if (kernel != 0 || rows < 1 || rows > WM_MAX_ROWS_SKINNY) { ctx->err = "wm_profile_kernel: bad arguments"; return WM_ERR_ARG; }
+    if (kernel != 0 || rows < 1 || rows > 16) { ctx->err = "wm_profile_kernel: bad arguments"; return WM_ERR_ARG; }
     g_skinny_done = nullptr; g_skinny_skip = nullptr;
     hipStream_t st = ctx->stream;
     const int d = ctx->d, K32 = d / 32, R = rows, H = ctx->H, F32 = ctx->ffn / 32;
-    const size_t xpl = (size_t)16 * d, fpl = (size_t)16 * ctx->ffn;
+    const size_t xpl = (size_t)ctx->Rcap * d, fpl = (size_t)ctx->Rcap * ctx->ffn;
     const DecLayerW& w = ctx->dec[0];
-    WM_HIP(hipMemsetAsync(ctx->h, 0, (size_t)WM_MAX_ROWS_SKINNY * d * sizeof(float), st));
+    WM_HIP(hipMemsetAsync(ctx->h, 0, (size_t)16 * d * sizeof(float), st));
     WM_HIP(hipMemsetAsync(ctx->kvlen, 0, sizeof(int) * ctx->maxB, st));
     auto body = [&]() -> int {
         WM_HIP(launch_skinny_norm(st, w.qkv_w, 3 * d / 16, K32, ctx->h, w.ln1_w, w.ln1_b, d, R, 1, 0, 1,
-                                  EpQKVDec{ctx->qbuf, ctx->kc, ctx->vc, w.qkv_b, ctx->kvlen, R, d, H, ctx->Tal, R}));
-        WM_HIP(launch_skinny(st, w.out_w, d / 16, K32, LdPacked{ctx->xbuf, K32, xpl}, EpResidual{ctx->h, w.out_b, d, R}));
-        WM_HIP(launch_skinny_norm(st, w.cq_w, d / 16, K32, ctx->h, w.ln2_w, w.ln2_b, d, R, 1, 0, 1, EpF32{ctx->qbuf, w.cq_b, d, R, 0.125f}));
-        WM_HIP(launch_skinny(st, w.cout_w, d / 16, K32, LdPacked{ctx->xbuf, K32, xpl}, EpResidual{ctx->h, w.cout_b, d, R}));
+                                  EpQKVDec{ctx->qbuf, ctx->kc, ctx->vc, w.qkv_b, ctx->kvlen, R, d, H, ctx->Tal, R}, ctx->xbuf, xpl));
+        WM_HIP(launch_skinny_rows(st, w.out_w, d / 16, K32, R, ctx->xbuf, xpl, EpResidual{ctx->h, w.out_b, d, R}));
+        WM_HIP(launch_skinny_norm(st, w.cq_w, d / 16, K32, ctx->h, w.ln2_w, w.ln2_b, d, R, 1, 0, 1, EpF32{ctx->qbuf, w.cq_b, d, R, 0.125f},
+                                  ctx->xbuf, xpl));
+        WM_HIP(launch_skinny_rows(st, w.cout_w, d / 16, K32, R, ctx->xbuf, xpl, EpResidual{ctx->h, w.cout_b, d, R}));
         WM_HIP(launch_skinny_norm(st, w.fc1_w, ctx->ffn / 16, K32, ctx->h, w.ln3_w, w.ln3_b, d, R, 1, 0, 1,
-                                  EpPackedAct<1>{ctx->fbuf, ctx->fbuf + fpl, w.fc1_b, F32, R}));
-        WM_HIP(launch_skinny(st, w.fc2_w, d / 16, F32, LdPacked{ctx->fbuf, F32, fpl}, EpResidual{ctx->h, w.fc2_b, d, R}));
+                                  EpPackedAct<1>{ctx->fbuf, ctx->fbuf + fpl, w.fc1_b, F32, R}, ctx->xbuf, xpl));
+        WM_HIP(launch_skinny_rows(st, w.fc2_w, d / 16, F32, R, ctx->fbuf, fpl, EpResidual{ctx->h, w.fc2_b, d, R}));
         return WM_OK;
     };
     int rc = body();

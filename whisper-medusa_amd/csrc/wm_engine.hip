@@ -122,10 +122,11 @@ extern "C" int wm_create(const wm_config* cfg, const wm_weights* w, int device, 
     CREATE_HIP(dev_alloc(&ctx->vx, (size_t)ctx->nkv * Menc * d, st));
     CREATE_HIP(dev_alloc(&ctx->kc, (size_t)ctx->nkv * B * H * Tal * 64, st));
     CREATE_HIP(dev_alloc(&ctx->vc, (size_t)ctx->nkv * B * H * Tal * 64, st));
-    const size_t RW = WM_MAX_ROWS_SKINNY;
+    ctx->Rcap = 16 * ctx->maxB;
+    const size_t RW = ctx->Rcap;
     CREATE_HIP(dev_alloc(&ctx->h, RW * d, st));
     CREATE_HIP(dev_alloc(&ctx->hblk, RW * d, st));
-    CREATE_HIP(dev_alloc(&ctx->hf, B * 16 * d, st));
+    CREATE_HIP(dev_alloc(&ctx->hf, RW * d, st));
     CREATE_HIP(dev_alloc(&ctx->hf_keep, B * d, st));
     CREATE_HIP(dev_alloc(&ctx->carry, B, st));
     CREATE_HIP(dev_alloc(&ctx->qbuf, RW * d, st));
@@ -134,7 +135,7 @@ extern "C" int wm_create(const wm_config* cfg, const wm_weights* w, int device, 
     CREATE_HIP(dev_alloc(&ctx->ybuf, 2 * RW * d, st));
     CREATE_HIP(dev_alloc(&ctx->cml, RW * H * ctx->NS * 2, st));
     CREATE_HIP(dev_alloc(&ctx->co, RW * H * ctx->NS * 64, st));
-    CREATE_HIP(dev_alloc(&ctx->ticket, RW * H, st));
+    CREATE_HIP(dev_alloc(&ctx->ticket, B * 32, st));
     CREATE_HIP(dev_alloc(&ctx->logits, RW * ctx->Vpad, st));
     CREATE_HIP(dev_alloc(&ctx->amax, B * 16, st));
     CREATE_HIP(dev_alloc(&ctx->pc, B * 16, st));

@@ -43,6 +43,7 @@ struct wm_ctx {
     int Tmax = 0 /* n_tgt */, Tal = 0 /* cache rows allocated */, K = 0, nkv = 0, nres = 0, maxB = 0;
     bool block = false;
     int NS = 1;         // cross-attention key splits (256 keys per block)
+    int Rcap = 16;      // token-row capacity of the decode scratch (16 rows per stream)
 
     // ---- parameters (pointers into the caller's blob) ----
     const float *win = nullptr, *twiddle = nullptr, *melfb = nullptr;

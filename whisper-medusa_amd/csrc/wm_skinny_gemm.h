@@ -56,24 +56,30 @@ struct LdNorm {
     int d, K32, M, row_mul, row_off, do_norm;
     static constexpr bool kLds = true;
     static constexpr int UB = 8;                 // packed chunks per thread per batch
-    __host__ __device__ __forceinline__ static size_t lds_bytes(int K32) { return (size_t)2 * K32 * 1024 + 2048 + (size_t)K32 * 256; }
+    __host__ __device__ __forceinline__ static size_t scratch_bytes(int K32) { return 2048 + (size_t)K32 * 256; }
+    __host__ __device__ __forceinline__ static size_t lds_bytes(int K32) { return (size_t)2 * K32 * 1024 + scratch_bytes(K32); }
 
     // requires K32 * 64 <= UB * blockDim.x (the whole 16 x K tile in one batch; checked by the launcher)
     __device__ __forceinline__ void prepare(char* smem) const {
         bf16_t* xh = reinterpret_cast<bf16_t*>(smem);
-        bf16_t* xl = xh + (size_t)K32 * 512;
-        float2* part = reinterpret_cast<float2*>(smem + (size_t)2 * K32 * 1024);          // [waves <= 16][16 rows]
-        float* gb = reinterpret_cast<float*>(smem + (size_t)2 * K32 * 1024 + 2048);      // gamma[d] then beta[d]
+        prepare_to(xh, xh + (size_t)K32 * 512, smem + (size_t)2 * K32 * 1024, 0);
+    }
+    // rows row0 .. row0+15 of the GEMM -> fragments at xh / xl (LDS for the fused GEMM, global memory for the
+    // batched path: the arithmetic and its order are the same, so both give bit-identical operands)
+    __device__ __forceinline__ void prepare_to(bf16_t* xh, bf16_t* xl, char* scratch, int row0) const {
+        float2* part = reinterpret_cast<float2*>(scratch);                              // [waves <= 16][16 rows]
+        float* gb = reinterpret_cast<float*>(scratch + 2048);                           // gamma[d] then beta[d]
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
         const int nv = d >> 2, nq = K32 * 64, T = blockDim.x;
         const int r = lane & 15;                 // the row of every chunk this thread touches
         const int g8 = (lane >> 4) * 8;
-        const float* hrow = h + (size_t)(r * row_mul + row_off) * d + g8;
+        const bool rvalid = row0 + r < M;
+        const float* hrow = h + (size_t)((row0 + r) * row_mul + row_off) * d + g8;
         float4 v0[UB], v1[UB];
 #pragma unroll
         for (int i = 0; i < UB; ++i) {
             const int q = threadIdx.x + i * T;
-            if (q < nq && r < M) {
+            if (q < nq && rvalid) {
                 const float4* src = reinterpret_cast<const float4*>(hrow + (q >> 6) * 32);
                 v0[i] = src[0]; v1[i] = src[1];
             } else { v0[i] = make_float4(0.f, 0.f, 0.f, 0.f); v1[i] = v0[i]; }
@@ -100,7 +106,7 @@ struct LdNorm {
             mean = ts / (float)d;
             rstd = rsqrtf(fmaxf(tq / (float)d - mean * mean, 0.f) + 1e-5f);
         }
-        const bool norm_row = do_norm && r < M;
+        const bool norm_row = do_norm && rvalid;
 #pragma unroll
         for (int i = 0; i < UB; ++i) {
             const int q = threadIdx.x + i * T, k0 = (q >> 6) * 32 + g8;
@@ -194,11 +200,79 @@ k_skinny_gemm(const bf16_t* __restrict__ W, int N16, int K32, int ksplit, int rt
     }
 }
 
+// ---- batched path (token rows R > 16) ----------------------------------------------------------
+// LayerNorm of all row tiles to global packed hi/lo planes: the SAME code as the fused loader, run with the
+// same block size, so the operand bits equal those of a 16-row launch.
+__global__ void __launch_bounds__(640)
+k_ln_tiles(LdNorm ld, bf16_t* __restrict__ xg, size_t plane, const int* __restrict__ done)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (done && *done) return;
+    const size_t off = (size_t)blockIdx.x * ld.K32 * 512;
+    ld.prepare_to(xg + off, xg + plane + off, smem, blockIdx.x * 16);
+}
+
+// Weight-stationary variant for many token rows: a wave keeps its NKR weight fragments (its whole K-slice) in
+// registers and walks the MT 16-row token tiles, reading their packed hi/lo fragments from L2.  Per output the
+// accumulation order (k ascending, hi then lo; then K-slices in order) is exactly the 16-row kernel's.
+template <int NKR, class Ep>
+__global__ void __launch_bounds__(640)
+k_skinny_gemm_mt(const bf16_t* __restrict__ W, int N16, int K32, int ksplit, int rt_per_wg, const int* __restrict__ done,
+                 const bf16_t* __restrict__ X, size_t plane, int MT, Ep ep)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (done && *done) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ks = wave % ksplit, rtl = wave / ksplit;
+    const int rt = blockIdx.x * rt_per_wg + rtl;
+    float4* red = reinterpret_cast<float4*>(smem);
+    const int kt0 = ks * NKR;
+    const bool active = rt < N16;
+    const bf16_t* wp = W + ((size_t)(active ? rt : 0) * K32 + kt0) * 512 + lane * 8;
+    bf16x8_t a[NKR];
+#pragma unroll
+    for (int u = 0; u < NKR; ++u) a[u] = ld_frag_nt(wp + (size_t)u * 512);
+    constexpr int G = (NKR % 8 == 0) ? 8 : 4;
+    for (int mt = 0; mt < MT; ++mt) {
+        const bf16_t* xp = X + ((size_t)(mt * K32 + kt0) * 64 + lane) * 8;
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kg = 0; kg < NKR; kg += G) {
+            bf16x8_t xh[G], xl[G];
+#pragma unroll
+            for (int u = 0; u < G; ++u) { xh[u] = ld_frag(xp + (size_t)(kg + u) * 512); xl[u] = ld_frag(xp + plane + (size_t)(kg + u) * 512); }
+#pragma unroll
+            for (int u = 0; u < G; ++u) { acc = mfma16(a[kg + u], xh[u], acc); acc = mfma16(a[kg + u], xl[u], acc); }
+        }
+        if (ksplit > 1) {
+            red[(rtl * ksplit + ks) * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            __syncthreads();
+            for (int e = threadIdx.x; e < rt_per_wg * 64; e += blockDim.x) {
+                const int rtl2 = e >> 6, l2 = e & 63;
+                f32x4_t sacc = {0.f, 0.f, 0.f, 0.f};
+                for (int k2 = 0; k2 < ksplit; ++k2) {
+                    const float4 p = red[(rtl2 * ksplit + k2) * 64 + l2];
+                    sacc[0] += p.x; sacc[1] += p.y; sacc[2] += p.z; sacc[3] += p.w;
+                }
+                const int rt2 = blockIdx.x * rt_per_wg + rtl2;
+                if (rt2 < N16) ep.store4(mt * 16 + (l2 & 15), rt2 * 16 + 4 * (l2 >> 4), sacc);
+            }
+            __syncthreads();
+        } else if (active) {
+            ep.store4(mt * 16 + (lane & 15), rt * 16 + 4 * (lane >> 4), acc);
+        }
+    }
+}
+
 // ---- host-side launch plan -------------------------------------------------------------------
 static const int* g_skinny_done = nullptr;     // device flags checked by every launch of this translation unit
 static const int* g_skinny_skip = nullptr;
 struct SkinnyPlan { int ksplit, rt, U; };
 
+// K-slices of at most 16 fragments (so the batched kernel can hold a slice in registers) and, if possible,
+// >= 1024 waves.  The plan depends only on (N16, K32, loader kind): 16-row and batched launches of one GEMM
+// share it, which is what makes their results bit-identical.
 static inline SkinnyPlan skinny_plan(int N16, int K32, bool lds_loader) {
     SkinnyPlan p; p.U = (K32 % 8 == 0) ? 8 : 4;
     const int q = K32 / p.U;                // candidate ksplit must divide q
@@ -206,7 +280,7 @@ static inline SkinnyPlan skinny_plan(int N16, int K32, bool lds_loader) {
     for (int s = 1; s <= 10 && s <= q; ++s) {      // <= 10 waves per block (launch bound 640 threads)
         if (q % s) continue;
         best = s;
-        if ((long)N16 * s >= 1024) break;   // enough waves to cover 256 CUs x 4 SIMDs
+        if ((long)N16 * s >= 1024 && K32 / s <= 16) break;
     }
     p.ksplit = best;
     p.rt = (best == 1) ? 4 : 1;
@@ -231,23 +305,54 @@ static inline hipError_t launch_skinny_u(hipStream_t st, const bf16_t* W, int N1
     return hipGetLastError();
 }
 
-// out = X (M <= 16 rows) times W^T (N = 16*N16 features, K = 32*K32)
 template <class Ld, class Ep>
-static inline hipError_t launch_skinny(hipStream_t st, const bf16_t* W, int N16, int K32, const Ld& ld, const Ep& ep) {
-    const SkinnyPlan p = skinny_plan(N16, K32, Ld::kLds);
+static inline hipError_t launch_skinny(hipStream_t st, const bf16_t* W, int N16, int K32, const SkinnyPlan& p, const Ld& ld, const Ep& ep) {
     if (p.U == 8) return launch_skinny_u<8>(st, W, N16, K32, p, ld, ep);
     return launch_skinny_u<4>(st, W, N16, K32, p, ld, ep);
 }
 
-// LayerNorm-fused launch.  The fused loader needs the whole 16 x K tile in one batch of the block's threads
-// (true for every Whisper size: K/32 <= 8 x waves per block); otherwise the caller must un-fuse.
+template <class Ep>
+static inline hipError_t launch_skinny_mt(hipStream_t st, const bf16_t* W, int N16, int K32, const SkinnyPlan& p,
+                                          const bf16_t* X, size_t plane, int MT, const Ep& ep) {
+    const int grid = (N16 + p.rt - 1) / p.rt, threads = 64 * p.ksplit * p.rt, nk = K32 / p.ksplit;
+    const size_t lds = p.ksplit > 1 ? (size_t)p.rt * p.ksplit * 1024 : 0;
+    if (nk == 16) hipLaunchKernelGGL((k_skinny_gemm_mt<16, Ep>), dim3(grid), dim3(threads), lds, st, W, N16, K32, p.ksplit, p.rt, g_skinny_done, X, plane, MT, ep);
+    else if (nk == 12) hipLaunchKernelGGL((k_skinny_gemm_mt<12, Ep>), dim3(grid), dim3(threads), lds, st, W, N16, K32, p.ksplit, p.rt, g_skinny_done, X, plane, MT, ep);
+    else if (nk == 8) hipLaunchKernelGGL((k_skinny_gemm_mt<8, Ep>), dim3(grid), dim3(threads), lds, st, W, N16, K32, p.ksplit, p.rt, g_skinny_done, X, plane, MT, ep);
+    else if (nk == 4) hipLaunchKernelGGL((k_skinny_gemm_mt<4, Ep>), dim3(grid), dim3(threads), lds, st, W, N16, K32, p.ksplit, p.rt, g_skinny_done, X, plane, MT, ep);
+    else return hipErrorInvalidConfiguration;
+    return hipGetLastError();
+}
+
+// out = X (R token rows, packed hi/lo planes in global memory) times W^T (N = 16*N16 features, K = 32*K32)
+template <class Ep>
+static inline hipError_t launch_skinny_rows(hipStream_t st, const bf16_t* W, int N16, int K32, int R, const bf16_t* X, size_t plane,
+                                            const Ep& ep) {
+    const SkinnyPlan p = skinny_plan(N16, K32, false);
+    if (R <= 16) return launch_skinny(st, W, N16, K32, p, LdPacked{X, K32, plane}, ep);
+    return launch_skinny_mt(st, W, N16, K32, p, X, plane, (R + 15) / 16, ep);
+}
+
 static inline bool skinny_norm_fusable(int N16, int K32) {
     const SkinnyPlan p = skinny_plan(N16, K32, true);
     return K32 <= LdNorm::UB * p.ksplit * p.rt;
 }
+
+// LayerNorm-fused GEMM over R token rows.  R <= 16: one fused launch.  R > 16: the same LayerNorm code writes
+// the packed hi/lo operand to `xscr` (global), then the weight-stationary batched kernel runs.  The fused loader
+// needs the whole 16 x K tile in one batch of the block's threads (true for every Whisper size).
 template <class Ep>
 static inline hipError_t launch_skinny_norm(hipStream_t st, const bf16_t* W, int N16, int K32, const float* h, const float* gamma,
-                                            const float* beta, int d, int M, int row_mul, int row_off, int do_norm, const Ep& ep) {
+                                            const float* beta, int d, int R, int row_mul, int row_off, int do_norm, const Ep& ep,
+                                            bf16_t* xscr, size_t plane) {
     if (!skinny_norm_fusable(N16, K32)) return hipErrorInvalidConfiguration;
-    return launch_skinny(st, W, N16, K32, LdNorm{h, gamma, beta, d, K32, M, row_mul, row_off, do_norm}, ep);
+    const SkinnyPlan p = skinny_plan(N16, K32, true);
+    const LdNorm ld{h, gamma, beta, d, K32, R, row_mul, row_off, do_norm};
+    if (R <= 16) return launch_skinny(st, W, N16, K32, p, ld, ep);
+    const int MT = (R + 15) / 16;
+    hipLaunchKernelGGL(k_ln_tiles, dim3(MT), dim3(64 * p.ksplit * p.rt), LdNorm::scratch_bytes(K32), st, ld, xscr, plane, g_skinny_done);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    SkinnyPlan q = p; q.rt = (p.ksplit == 1) ? 4 : 1;
+    return launch_skinny_mt(st, W, N16, K32, q, xscr, plane, MT, ep);
 }
