@@ -5,18 +5,24 @@
 #pragma once
 #include "wm_common.h"
 
-struct EpResidual {            // h[m][n] += v + bias[n]      (out_proj / fc2 + residual, HF:modeling_whisper.py:396-413)
+struct EpResidual {            // h[m][n] = (h[m][n] + bias[n]) + v      (out_proj / fc2 + residual, HF:modeling_whisper.py:396-413)
     float* h; const float* bias; int ld; int M;
-    __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const {
-        if (m >= M) return;
-        float4* p = reinterpret_cast<float4*>(h + (size_t)m * ld + n);
-        float4 o = *p; const float4 b = *reinterpret_cast<const float4*>(bias + n);
-        o.x += v[0] + b.x; o.y += v[1] + b.y; o.z += v[2] + b.z; o.w += v[3] + b.w;
-        *p = o;
+    static constexpr bool kPre = true;           // the (h + bias) operand can be fetched while the weights stream
+    __device__ __forceinline__ float4 pre4(int m, int n) const {
+        if (m >= M) return make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 o = *reinterpret_cast<const float4*>(h + (size_t)m * ld + n);
+        const float4 b = *reinterpret_cast<const float4*>(bias + n);
+        return make_float4(o.x + b.x, o.y + b.y, o.z + b.z, o.w + b.w);
     }
+    __device__ __forceinline__ void store4p(int m, int n, f32x4_t v, float4 pre) const {
+        if (m >= M) return;
+        *reinterpret_cast<float4*>(h + (size_t)m * ld + n) = make_float4(pre.x + v[0], pre.y + v[1], pre.z + v[2], pre.w + v[3]);
+    }
+    __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const { store4p(m, n, v, pre4(m, n)); }
 };
 
 struct EpF32 {                 // out[m][n] = (v + bias[n]) * scale   (cross-attn q; vocabulary logits with bias == nullptr)
+    static constexpr bool kPre = false;
     float* out; const float* bias; int ld; int M; float scale;
     __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const {
         if (m >= M) return;
@@ -29,6 +35,7 @@ struct EpF32 {                 // out[m][n] = (v + bias[n]) * scale   (cross-att
 
 template <int ACT>             // packed bf16 out = act(v + bias)   (fc1 + GELU -> next GEMM's operand)
 struct EpPackedAct {           // out_lo != nullptr: decoder path, value kept as a bf16 hi/lo pair
+    static constexpr bool kPre = false;
     bf16_t* out; bf16_t* out_lo; const float* bias; int K32out; int M;
     __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const {
         if (m >= M) return;
@@ -46,6 +53,7 @@ struct EpPackedAct {           // out_lo != nullptr: decoder path, value kept as
 // into the contiguous KV cache at position base[stream] + r   (HF:modeling_whisper.py:288-318; the
 // reference's per-iteration cat-compaction, model.py:378-402, becomes "overwrite rows >= kv_len").
 struct EpQKVDec {              // K cache [s][h][pos][64]; V cache transposed [s][h][64][pos] (MFMA A operand of P.V)
+    static constexpr bool kPre = false;
     float* q; bf16_t* kc; bf16_t* vc; const float* bias; const int* base;
     int Mper, d, H, Tal, M;
     __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const {
@@ -73,6 +81,7 @@ struct EpQKVDec {              // K cache [s][h][pos][64]; V cache transposed [s
 // Medusa residual heads: y = x + SiLU(W x + b) (model.py:180-210) for head k = n / d, written as
 // packed bf16 row  m*row_mul + row_off + k  of the vocabulary-projection operand.
 struct EpHead {
+    static constexpr bool kPre = false;
     bf16_t* y; bf16_t* y_lo; const float* hf; const float* bias; int d, K32, row_mul, row_off, M, src_mul, src_off;
     __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const {
         if (m >= M) return;
@@ -87,6 +96,7 @@ struct EpHead {
 
 // ---- encoder -----------------------------------------------------------------------------
 struct EpConv1 {               // a1[b][t][n] = gelu(conv1) as row-major bf16 (input of the conv2 im2col)
+    static constexpr bool kPre = false;
     bf16_t* a1; const float* bias; int T, Tpad, d;
     __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const {
         const int b = m / Tpad, t = m - b * Tpad;
@@ -100,6 +110,7 @@ struct EpConv1 {               // a1[b][t][n] = gelu(conv1) as row-major bf16 (i
 };
 
 struct EpConv2 {               // h = gelu(conv2) + embed_positions   (HF:modeling_whisper.py:626-632)
+    static constexpr bool kPre = false;
     float* h; const float* bias; const float* pos; int S, Spad, d;
     __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const {
         const int s = m % Spad;
@@ -115,6 +126,7 @@ struct EpConv2 {               // h = gelu(conv2) + embed_positions   (HF:modeli
 };
 
 struct EpQKVEnc {              // q (x 64^-1/2), k as [b][h][s][64]; v transposed [b][h][64][s] for the PV MFMA operand
+    static constexpr bool kPre = false;
     bf16_t* q; bf16_t* k; bf16_t* vt; const float* bias; int Spad, H, d;
     __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const {
         const int b = m / Spad, s = m - b * Spad;
@@ -135,6 +147,7 @@ struct EpQKVEnc {              // q (x 64^-1/2), k as [b][h][s][64]; v transpose
 };
 
 struct EpCrossKV {             // K_x [kvl][b][h][s][64], V_x transposed [kvl][b][h][64][s] bf16   (HF:modeling_whisper.py:322-335)
+    static constexpr bool kPre = false;
     bf16_t* kx; bf16_t* vx; const float* bias; int Spad, H, d, B;
     __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const {
         const int b = m / Spad, s = m - b * Spad;

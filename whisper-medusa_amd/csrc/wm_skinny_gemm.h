@@ -152,6 +152,19 @@ k_skinny_gemm(const bf16_t* __restrict__ W, int N16, int K32, int ksplit, int rt
 #pragma unroll
     for (int u = 0; u < U; ++u) a[u] = ld_frag_nt(wp + (size_t)u * 512);
 
+    // epilogue operand (residual + bias) of the element this thread will finish: fetched under the weight stream
+    float4 pre = make_float4(0.f, 0.f, 0.f, 0.f);
+    int em = 0, en = 0; bool edo = false;
+    if constexpr (Ep::kPre) {
+        if (ksplit > 1) {
+            if (threadIdx.x < rt_per_wg * 64) {
+                const int rt2 = blockIdx.x * rt_per_wg + (threadIdx.x >> 6);
+                em = lane & 15; en = rt2 * 16 + 4 * (lane >> 4); edo = rt2 < N16;
+            }
+        } else { em = lane & 15; en = rt * 16 + 4 * (lane >> 4); edo = active; }
+        if (edo) pre = ep.pre4(em, en);
+    }
+
     ld.prepare(smem);
 
     if (!Ld::kLds) {
@@ -185,18 +198,22 @@ k_skinny_gemm(const bf16_t* __restrict__ W, int N16, int K32, int ksplit, int rt
     if (ksplit > 1) {
         red[(rtl * ksplit + ks) * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
         __syncthreads();
-        for (int e = threadIdx.x; e < rt_per_wg * 64; e += blockDim.x) {
-            const int rtl2 = e >> 6, l2 = e & 63;
+        if (threadIdx.x < rt_per_wg * 64) {              // blockDim >= 64 * rt_per_wg: one output quad per thread
+            const int rtl2 = threadIdx.x >> 6, l2 = lane;
             f32x4_t s = {0.f, 0.f, 0.f, 0.f};
             for (int k2 = 0; k2 < ksplit; ++k2) {
                 const float4 p = red[(rtl2 * ksplit + k2) * 64 + l2];
                 s[0] += p.x; s[1] += p.y; s[2] += p.z; s[3] += p.w;
             }
             const int rt2 = blockIdx.x * rt_per_wg + rtl2;
-            if (rt2 < N16) ep.store4(l2 & 15, rt2 * 16 + 4 * (l2 >> 4), s);
+            if (rt2 < N16) {
+                if constexpr (Ep::kPre) ep.store4p(l2 & 15, rt2 * 16 + 4 * (l2 >> 4), s, pre);
+                else ep.store4(l2 & 15, rt2 * 16 + 4 * (l2 >> 4), s);
+            }
         }
     } else if (active) {
-        ep.store4(lane & 15, rt * 16 + 4 * (lane >> 4), acc);
+        if constexpr (Ep::kPre) ep.store4p(lane & 15, rt * 16 + 4 * (lane >> 4), acc, pre);
+        else ep.store4(lane & 15, rt * 16 + 4 * (lane >> 4), acc);
     }
 }
 
