@@ -190,3 +190,54 @@ def test_generate_api_end_to_end(rig):
     assert out[0].tolist() == want
     assert rig.model.last_stats["iterations"] == ref.n_iters
     rig.encode()
+
+
+def test_runs_to_the_hard_length_limit(gpu):
+    """No EOS, no max_new_tokens: decoding stops by the reference's `L + K >= max_length` rule (model.py:789-793)
+    with the KV cache and position table used up to their last rows."""
+    cfg = MedusaConfig.micro(K=4, n_tgt=64)
+    sd = synth.synth_state_dict(cfg, seed=31)
+    model = WhisperMedusaModel(cfg, sd, device=gpu)
+    orc = Oracle(cfg, sd, sim="bf16")
+    feats = model.extract_features(clip_for(cfg, 2))
+    gp = golden_gen_params(cfg, ACCEPT_TYPICAL, 10 ** 6)              # max_length clamps to n_tgt
+    assert gp.max_length == 64 and gp.hard_max_length == 64
+    model.engine.encode(feats)
+    got = model.engine.decode(gp, 1)[0]
+    ref = orc.decode(model.engine.encoder_output(1)[0], gp)
+    assert got == ref.ids and 64 - 4 - 1 <= len(got) <= 64
+    model.engine.close()
+
+
+def test_silence_and_clipping_inputs(gpu):
+    """Edge inputs of the front end: digital silence (every mel bin hits the 1e-10 floor) and a full-scale square wave."""
+    cfg = MedusaConfig.micro(K=4)
+    sd = synth.synth_state_dict(cfg, seed=32)
+    model = WhisperMedusaModel(cfg, sd, device=gpu, max_batch=2)
+    n = cfg.n_mel_frames * 160
+    wavs = [np.zeros(n, dtype=np.float32), np.sign(np.sin(np.arange(n) * 0.05)).astype(np.float32)]
+    got = model.extract_features(wavs).cpu().numpy()
+    ref = np.stack([log_mel(w, 80, n) for w in wavs])
+    assert np.abs(got - ref).max() <= 2e-3
+    assert np.allclose(got[0], got[0].flat[0])                          # silence: constant feature map
+    out = model.generate(torch.from_numpy(ref).to(gpu), max_new_tokens=12)
+    assert out.shape[0] == 2 and out.shape[1] >= len(synth.default_prompt(cfg)) + 12
+    model.engine.close()
+
+
+def test_from_pretrained_checkpoint_directory(gpu, tmp_path):
+    """config.json + model.safetensors on disk -> from_pretrained -> generate (reference call shape, README.md:101-142)."""
+    from safetensors.torch import save_file
+    cfg = MedusaConfig.micro(K=4, heads_type="medusa_block")
+    sd = synth.synth_state_dict(cfg, seed=33)
+    cfg.save_pretrained(str(tmp_path))
+    save_file({k: v.contiguous().clone() for k, v in sd.items() if k != "whisper_model.proj_out.weight"}, str(tmp_path / "model.safetensors"))
+    model = WhisperMedusaModel.from_pretrained(str(tmp_path)).to(gpu)
+    assert model.config.is_block and model.config.medusa_num_heads == 4
+    feats = model.extract_features(clip_for(cfg, 0))
+    out = model.generate(feats, max_new_tokens=16)
+    ref_model = WhisperMedusaModel(cfg, sd, device=gpu)
+    assert torch.equal(out, ref_model.generate(feats, max_new_tokens=16))
+    fw = model(input_features=feats, decoder_input_ids=torch.tensor([synth.default_prompt(cfg)]))
+    assert fw.logits.shape == (5, 1, 2, cfg.vocab_size)                  # [K+1, B, T, V] like the reference forward()
+    model.engine.close(); ref_model.engine.close()

@@ -143,3 +143,17 @@ def test_skinny_plan_covers_all_whisper_shapes():
                 ks, rt, U = plan(N // 16, K // 32, lds)
                 assert (K // 32) % (ks * U) == 0 and ks * rt <= 10
                 assert (K // 32) // ks in (4, 8, 12, 16)          # the batched kernel keeps a whole K-slice in registers
+
+
+def test_checkpoint_directory_roundtrip_cpu(tmp_path):
+    """save config.json + model.safetensors, read them back with the loader from_pretrained uses, pack identically."""
+    from safetensors.torch import save_file
+    cfg = MedusaConfig.micro(K=4)
+    sd = synth.synth_state_dict(cfg, seed=2)
+    cfg.save_pretrained(str(tmp_path))
+    save_file({k: v.contiguous().clone() for k, v in sd.items() if k != "whisper_model.proj_out.weight"}, str(tmp_path / "model.safetensors"))
+    cfg2 = MedusaConfig.from_pretrained(str(tmp_path))
+    sd2 = weights.load_state_dict_from_dir(str(tmp_path))
+    b1, o1 = weights.build_blob(cfg, sd)
+    b2, o2 = weights.build_blob(cfg2, sd2)           # tied proj_out falls back to embed_tokens
+    assert torch.equal(b1, b2) and o1.tolist() == o2.tolist()
