@@ -433,7 +433,8 @@ __global__ void k_set_cand(const int* __restrict__ amax, int* __restrict__ cand,
 __global__ void k_accept(GenDev gp, const int* __restrict__ cand, const int* __restrict__ amax, const float* __restrict__ pc,
                          const float* __restrict__ part2, int* __restrict__ ids, int* __restrict__ L, int* __restrict__ kvlen,
                          int* __restrict__ finished, int* __restrict__ niter, long long* __restrict__ hist, int* __restrict__ done, int B,
-                         int* __restrict__ carry, const float* __restrict__ hf, float* __restrict__ hf_keep, int d)
+                         int* __restrict__ carry, const float* __restrict__ hf, float* __restrict__ hf_keep, int d,
+                         int* __restrict__ hostflags)
 {
     const int s = blockIdx.x, lane = threadIdx.x;
     if (finished[s]) return;
@@ -479,10 +480,12 @@ __global__ void k_accept(GenDev gp, const int* __restrict__ cand, const int* __r
         niter[s] += 1;
         atomicAdd(reinterpret_cast<unsigned long long*>(hist + a), 1ull);
         atomicAdd(reinterpret_cast<unsigned long long*>(hist + 16), (unsigned long long)n_emit);
-        if (hit_eos || Ln >= gp.max_length || Ln + K >= gp.hard_max_length) {
+        const bool fin = hit_eos || Ln >= gp.max_length || Ln + K >= gp.hard_max_length;
+        if (fin) {
             finished[s] = 1;
             if (atomicAdd(done + 1, 1) == B - 1) done[0] = 1;           // done[1] counts finished streams
         }
+        if (hostflags) { hostflags[0] = do_carry ? 1 : 0; hostflags[1] = fin ? 1 : 0; }   // host-mapped (single-stream runs)
     }
 }
 
@@ -548,8 +551,7 @@ int wm_dec_stage_layers(wm_ctx* ctx, int b0, int nb, int Mper, int mode)
 {
     hipStream_t st = ctx->stream;
     g_skinny_done = ctx->use_done ? ctx->done : nullptr;
-    g_skinny_skip = (mode == 0 && nb == 1 && ctx->Bdec == 1 && Mper == 1 && ctx->use_done && ctx->fuse && !ctx->block && !ctx->gp.vanilla)
-                        ? ctx->carry + b0 : nullptr;
+    g_skinny_skip = nullptr;
     const int d = ctx->d, R = nb * Mper;
     const int* base = (mode == 0 ? ctx->kvlen : ctx->L) + b0;
     if (R > ctx->Rcap || Mper > 16) { ctx->err = "decode pass exceeds the row capacity of the context"; return WM_ERR_ARG; }
@@ -652,39 +654,52 @@ int wm_dec_iteration(wm_ctx* ctx, int Mper_base)
         WM_HIP(hipGetLastError());
         return WM_OK;
     }
-    const int chunk = B;                                                   // all streams in one pass (batched kernels)
-    const bool fuse = ctx->fuse && !ctx->block && B == 1;                  // per-stream skip word needs a single stream per pass
-    // (a) base pass -> K+1 candidates per stream
-    for (int b0 = 0; b0 < B; b0 += chunk) {
-        const int nb = min(chunk, B - b0);
-        int rc = wm_dec_pass(ctx, b0, nb, Mper_base, 0, 1, 0);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_select1, dim3(SEL_SP, nb * rps), dim3(256), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen,
-                           ctx->L + b0, rps, ctx->part1);
-        WM_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_select_argmax, dim3((nb * rps + 63) / 64), dim3(64), 0, st, ctx->part1, nb * rps, b0 * rps, ctx->amax);
-        WM_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_set_cand, dim3((nb * rps + 63) / 64), dim3(64), 0, st, ctx->amax + b0 * rps, ctx->cand + b0 * 16, rps, nb * rps);
-        WM_HIP(hipGetLastError());
-    }
+    int rc = wm_dec_iter_base(ctx, Mper_base);
+    if (rc) return rc;
+    return wm_dec_iter_rest(ctx, Mper_base);
+}
+
+// (a1) base pass layers + final LayerNorm -> hf rows (skipped by the host when the hidden state was carried)
+int wm_dec_iter_base(wm_ctx* ctx, int Mper_base)
+{
+    int rc = wm_dec_stage_layers(ctx, 0, ctx->Bdec, Mper_base, 0);
+    if (rc) return rc;
+    return wm_dec_stage_final(ctx, 0, ctx->Bdec, Mper_base, 0, 1);
+}
+
+// (a2) heads + candidates, (d) verify pass + posterior statistics, (f)-(j) accept
+int wm_dec_iter_rest(wm_ctx* ctx, int Mper_base)
+{
+    hipStream_t st = ctx->stream;
+    const int B = ctx->Bdec, K = ctx->K, rps = K + 1, nb = B;
+    const GenDev gp = ctx->gp;
+    const bool carry = ctx->host_carry;
+    ctx->hf_cur = ctx->hf;
+    g_skinny_done = ctx->use_done ? ctx->done : nullptr; g_skinny_skip = nullptr;
+    int rc = wm_dec_stage_heads(ctx, nb, Mper_base, Mper_base - 1, 1);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_select1, dim3(SEL_SP, nb * rps), dim3(256), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen, ctx->L, rps, ctx->part1);
+    WM_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_select_argmax, dim3((nb * rps + 63) / 64), dim3(64), 0, st, ctx->part1, nb * rps, 0, ctx->amax);
+    WM_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_set_cand, dim3((nb * rps + 63) / 64), dim3(64), 0, st, ctx->amax, ctx->cand, rps, nb * rps);
+    WM_HIP(hipGetLastError());
     // (d) verify pass over the candidates at positions L..L+K, then posterior statistics
-    for (int b0 = 0; b0 < B; b0 += chunk) {
-        const int nb = min(chunk, B - b0);
-        int rc = wm_dec_pass(ctx, b0, nb, rps, 1, 0, 1);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_select1, dim3(SEL_SP, nb * rps), dim3(256), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen,
-                           ctx->L + b0, rps, ctx->part1);
-        WM_HIP(hipGetLastError());
-        if (gp.accept_mode == WM_ACCEPT_TYPICAL)
-            hipLaunchKernelGGL(k_select2, dim3(SEL_SP, nb * rps), dim3(256), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen,
-                               ctx->L + b0, ctx->cand + b0 * 16, rps, b0 * rps, ctx->part1, ctx->part2, ctx->amax, ctx->pc);
-        else
-            hipLaunchKernelGGL(k_select_argmax, dim3((nb * rps + 63) / 64), dim3(64), 0, st, ctx->part1, nb * rps, b0 * rps, ctx->amax);
-        WM_HIP(hipGetLastError());
-    }
-    // (f)-(j) accept / emit / compact / stop
+    rc = wm_dec_pass(ctx, 0, nb, rps, 1, 0, 1);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_select1, dim3(SEL_SP, nb * rps), dim3(256), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen, ctx->L, rps, ctx->part1);
+    WM_HIP(hipGetLastError());
+    if (gp.accept_mode == WM_ACCEPT_TYPICAL)
+        hipLaunchKernelGGL(k_select2, dim3(SEL_SP, nb * rps), dim3(256), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen, ctx->L,
+                           ctx->cand, rps, 0, ctx->part1, ctx->part2, ctx->amax, ctx->pc);
+    else
+        hipLaunchKernelGGL(k_select_argmax, dim3((nb * rps + 63) / 64), dim3(64), 0, st, ctx->part1, nb * rps, 0, ctx->amax);
+    WM_HIP(hipGetLastError());
+    // (f)-(j) accept / emit / compact / stop.  With host_carry the carried post-LN row goes straight to hf row 0
+    // (where the skipped base pass would have put it) and the carry / finished flags to host-mapped memory.
     hipLaunchKernelGGL(k_accept, dim3(B), dim3(64), 0, st, gp, ctx->cand, ctx->amax, ctx->pc, ctx->part2, ctx->ids, ctx->L,
-                       ctx->kvlen, ctx->finished, ctx->niter, ctx->hist, ctx->done, B, fuse ? ctx->carry : nullptr, ctx->hf, ctx->hf_keep, ctx->d);
+                       ctx->kvlen, ctx->finished, ctx->niter, ctx->hist, ctx->done, B, carry ? ctx->carry : nullptr, ctx->hf,
+                       ctx->hf, ctx->d, carry ? ctx->hostflags_dev : nullptr);
     WM_HIP(hipGetLastError());
     return WM_OK;
 }

@@ -28,6 +28,8 @@ extern "C" void wm_destroy(wm_ctx* ctx)
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     if (ctx->graph) hipGraphExecDestroy(ctx->graph);
+    if (ctx->graph_base) hipGraphExecDestroy(ctx->graph_base);
+    if (ctx->hostflags) hipHostFree(ctx->hostflags);
     void* bufs[] = {ctx->feats_own, ctx->clipmax, ctx->A1, ctx->a1, ctx->A2, ctx->eh, ctx->exn, ctx->eq, ctx->ek, ctx->evt, ctx->eff,
                     ctx->enc_out, ctx->kx, ctx->vx, ctx->kc, ctx->vc, ctx->h, ctx->hblk, ctx->hf, ctx->qbuf, ctx->xbuf, ctx->fbuf,
                     ctx->ybuf, ctx->cml, ctx->co, ctx->ticket, ctx->logits, ctx->amax, ctx->pc, ctx->part1, ctx->part2, ctx->ids, ctx->L, ctx->kvlen,
@@ -153,6 +155,9 @@ extern "C" int wm_create(const wm_config* cfg, const wm_weights* w, int device, 
     CREATE_HIP(dev_alloc(&ctx->exppen, Tids + 1, st));
     CREATE_HIP(dev_alloc(&ctx->tap_tok, 16, st));
     CREATE_HIP(dev_alloc(&ctx->done, 4, st));
+    CREATE_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->hostflags), 64, hipHostMallocMapped));
+    CREATE_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->hostflags_dev), ctx->hostflags, 0));
+    ctx->hostflags[0] = ctx->hostflags[1] = 0;
     CREATE_HIP(hipStreamSynchronize(st));
 #undef CREATE_HIP
     *out = ctx;
@@ -198,9 +203,11 @@ extern "C" int wm_decode_begin(wm_ctx* ctx, const wm_gen_params* gp, int B)
     g.inv_temp = (gp->accept_mode == WM_ACCEPT_TYPICAL && gp->temperature > 0.f) ? 1.0f / gp->temperature : 1.0f;
     g.accept_mode = gp->accept_mode; g.vanilla = gp->vanilla; g.K = K; g.V = ctx->V; g.Vpad = ctx->Vpad; g.Tids = Tids;
     ctx->fuse = std::getenv("WM_NO_CARRY") == nullptr;
-    g.fuse = ctx->fuse ? 1 : 0;
+    ctx->host_carry = ctx->fuse && !ctx->block && B == 1 && !gp->vanilla;
+    g.fuse = ctx->host_carry ? 1 : 0;
     const bool same = ctx->graph && ctx->graph_B == B && std::memcmp(&g, &ctx->gp, sizeof(GenDev)) == 0;
     if (!same && ctx->graph) { hipGraphExecDestroy(ctx->graph); ctx->graph = nullptr; }
+    if (!same && ctx->graph_base) { hipGraphExecDestroy(ctx->graph_base); ctx->graph_base = nullptr; }
     ctx->gp = g; ctx->Bdec = B;
 
     std::vector<int> ids((size_t)B * Tids, gp->pad_token_id), L(B, P), zero(B, 0);
@@ -225,6 +232,7 @@ extern "C" int wm_decode_begin(wm_ctx* ctx, const wm_gen_params* gp, int B)
     WM_HIP(hipMemcpyAsync(ctx->supmask, mask.data(), mask.size(), hipMemcpyHostToDevice, st));
     WM_HIP(hipMemcpyAsync(ctx->exppen, pen.data(), pen.size() * sizeof(float), hipMemcpyHostToDevice, st));
     WM_HIP(hipStreamSynchronize(st));      // host vectors go out of scope
+    ctx->hostflags[0] = 0; ctx->hostflags[1] = 0;
     ctx->began = true; ctx->first_done = false; ctx->iters = 0; ctx->ms_decode = 0.f; ctx->graph_replays = 0;
     return WM_OK;
 }
@@ -240,6 +248,23 @@ static int count_unfinished(wm_ctx* ctx, int* n)
     return WM_OK;
 }
 
+static int capture_graph(wm_ctx* ctx, hipGraphExec_t* out, int (*body)(wm_ctx*, int))
+{
+    hipStream_t st = ctx->stream;
+    hipGraph_t gr = nullptr;
+    *out = nullptr;
+    if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return WM_OK; }
+    const int rc = body(ctx, 1);
+    const hipError_t e2 = hipStreamEndCapture(st, &gr);
+    if (rc == WM_OK && e2 == hipSuccess && gr) {
+        hipGraphExec_t ex = nullptr;
+        if (hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0) == hipSuccess) *out = ex;
+    }
+    if (gr) hipGraphDestroy(gr);
+    (void)hipGetLastError();
+    return WM_OK;
+}
+
 extern "C" int wm_decode_run(wm_ctx* ctx, int max_iters, int* n_unfinished)
 {
     if (!ctx) return WM_ERR_ARG;
@@ -247,43 +272,57 @@ extern "C" int wm_decode_run(wm_ctx* ctx, int max_iters, int* n_unfinished)
     if (!ctx->began) { ctx->err = "wm_decode_run: call wm_decode_begin first"; return WM_ERR_STATE; }
     hipStream_t st = ctx->stream;
     const bool use_graph = std::getenv("WM_NO_GRAPH") == nullptr;
-    const int poll = 4;
     int left = 0, done = 0;
     int rc = count_unfinished(ctx, &left);
     if (rc) return rc;
     WM_HIP(hipEventRecord(ctx->ev0, st));
-    while (left > 0 && done < max_iters) {
-        const int burst = std::min(poll, max_iters - done);
-        for (int i = 0; i < burst; ++i) {
-            if (!ctx->first_done) {                       // iteration 1: the base pass consumes the P prompt tokens
-                rc = wm_dec_iteration(ctx, ctx->gp.P);
+    if (ctx->host_carry) {
+        // Single stream: the host reads {carry, finished} (host-mapped, written by k_accept) after every iteration and
+        // launches the base-pass graph only when the hidden state was NOT carried over from the verify pass.
+        while (left > 0 && done < max_iters) {
+            if (!ctx->first_done) {
+                rc = wm_dec_iteration(ctx, ctx->gp.P);            // iteration 1: the base pass consumes the P prompt tokens
                 if (rc) return rc;
                 ctx->first_done = true;
-            } else if (use_graph && ctx->graph) {
-                WM_HIP(hipGraphLaunch(ctx->graph, st));
-                ctx->graph_replays++;
-            } else if (use_graph && ctx->iters >= 2) {    // shapes are warm: capture one steady-state iteration
-                hipGraph_t gr = nullptr;
-                hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
-                if (e == hipSuccess) {
-                    rc = wm_dec_iteration(ctx, 1);
-                    hipError_t e2 = hipStreamEndCapture(st, &gr);
-                    if (rc == WM_OK && e2 == hipSuccess && gr) {
-                        hipGraphExec_t ex = nullptr;
-                        if (hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0) == hipSuccess) { ctx->graph = ex; ctx->graph_B = ctx->Bdec; }
-                    }
-                    if (gr) hipGraphDestroy(gr);
-                }
-                if (ctx->graph) { WM_HIP(hipGraphLaunch(ctx->graph, st)); ctx->graph_replays++; }
-                else { (void)hipGetLastError(); rc = wm_dec_iteration(ctx, 1); if (rc) return rc; }
             } else {
-                rc = wm_dec_iteration(ctx, 1);
-                if (rc) return rc;
+                const bool need_base = ctx->hostflags[0] == 0;
+                const bool warm = ctx->iters >= 2;
+                if (need_base) {
+                    if (use_graph && warm && !ctx->graph_base) { rc = capture_graph(ctx, &ctx->graph_base, wm_dec_iter_base); if (rc) return rc; }
+                    if (use_graph && ctx->graph_base) WM_HIP(hipGraphLaunch(ctx->graph_base, st));
+                    else { rc = wm_dec_iter_base(ctx, 1); if (rc) return rc; }
+                }
+                if (use_graph && warm && !ctx->graph) { rc = capture_graph(ctx, &ctx->graph, wm_dec_iter_rest); if (rc) return rc; ctx->graph_B = ctx->Bdec; }
+                if (use_graph && ctx->graph) { WM_HIP(hipGraphLaunch(ctx->graph, st)); ctx->graph_replays++; }
+                else { rc = wm_dec_iter_rest(ctx, 1); if (rc) return rc; }
             }
+            WM_HIP(hipStreamSynchronize(st));
             ctx->iters++; done++;
+            left = ctx->hostflags[1] ? 0 : 1;
         }
-        rc = count_unfinished(ctx, &left);
-        if (rc) return rc;
+    } else {
+        const int poll = 4;
+        while (left > 0 && done < max_iters) {
+            const int burst = std::min(poll, max_iters - done);
+            for (int i = 0; i < burst; ++i) {
+                if (!ctx->first_done) {                       // iteration 1: the base pass consumes the P prompt tokens
+                    rc = wm_dec_iteration(ctx, ctx->gp.P);
+                    if (rc) return rc;
+                    ctx->first_done = true;
+                } else {
+                    if (use_graph && ctx->iters >= 2 && !ctx->graph) {   // shapes are warm: capture one steady-state iteration
+                        rc = capture_graph(ctx, &ctx->graph, wm_dec_iteration);
+                        if (rc) return rc;
+                        ctx->graph_B = ctx->Bdec;
+                    }
+                    if (use_graph && ctx->graph) { WM_HIP(hipGraphLaunch(ctx->graph, st)); ctx->graph_replays++; }
+                    else { rc = wm_dec_iteration(ctx, 1); if (rc) return rc; }
+                }
+                ctx->iters++; done++;
+            }
+            rc = count_unfinished(ctx, &left);
+            if (rc) return rc;
+        }
     }
     WM_HIP(hipEventRecord(ctx->ev1, st));
     WM_HIP(hipEventSynchronize(ctx->ev1));
@@ -385,8 +424,9 @@ extern "C" int wm_forward_logits(wm_ctx* ctx, int B, const int32_t* tokens, int 
     const int Tids = ctx->Tal, K = ctx->K, V = ctx->V, nout = disable_medusa ? 1 : K + 1;
     GenDev g = ctx->gp;
     g.K = K; g.V = V; g.Vpad = ctx->Vpad; g.Tids = Tids; g.vanilla = 0;
-    ctx->gp = g; ctx->began = false; ctx->use_done = false;
+    ctx->gp = g; ctx->began = false; ctx->use_done = false; ctx->host_carry = false;
     if (ctx->graph) { hipGraphExecDestroy(ctx->graph); ctx->graph = nullptr; }
+    if (ctx->graph_base) { hipGraphExecDestroy(ctx->graph_base); ctx->graph_base = nullptr; }
     std::vector<float> rowbuf((size_t)nout * ctx->Vpad);
     for (int b = 0; b < B; ++b) {
         std::vector<int> v(T);

@@ -77,6 +77,9 @@ struct wm_ctx {
     float *hf_cur = nullptr, *hf_keep = nullptr;                            // current chunk's rows; carried row per stream
     int* carry = nullptr;                                                   // [maxB] next base pass is redundant
     bool fuse = true;
+    bool host_carry = false;                                                // single-stream runs: the host skips the base pass
+    int *hostflags = nullptr, *hostflags_dev = nullptr;                     // host-mapped {carry, finished}
+    hipGraphExec_t graph_base = nullptr;
     bf16_t *xbuf = nullptr, *fbuf = nullptr, *ybuf = nullptr;
     float *cml = nullptr, *co = nullptr;   // cross-attention partials
     int* ticket = nullptr;                 // [16 streams][H] arrival tickets of the cross-attention key splits
@@ -113,5 +116,7 @@ int wm_dec_stage_layers(wm_ctx* ctx, int b0, int nb, int Mper, int mode /*0 base
 int wm_dec_stage_final(wm_ctx* ctx, int b0, int nb, int Mper, int mode, int medusa);
 int wm_dec_stage_heads(wm_ctx* ctx, int nsel, int sel_mul, int sel_off, int medusa);
 int wm_dec_pass(wm_ctx* ctx, int b0, int nb, int Mper, int mode, int medusa, int all_rows);
-int wm_dec_iteration(wm_ctx* ctx, int Mper_base);   // one full iteration over all streams (chunked)
+int wm_dec_iteration(wm_ctx* ctx, int Mper_base);   // one full iteration over all streams
+int wm_dec_iter_base(wm_ctx* ctx, int Mper_base);   // base pass layers + final LN
+int wm_dec_iter_rest(wm_ctx* ctx, int Mper_base);   // heads, candidates, verify pass, accept
 int wm_dec_profile(wm_ctx* ctx, int kernel, int rows, int reps, float* ms, double* bytes);
