@@ -47,6 +47,15 @@ def decode_iter_bytes(cfg, B, mean_len):
     return 2.0 * (w_a + w_v) + B * (2.0 * X + skv)
 
 
+def prefill_flops(cfg):
+    """Algorithmic FLOPs of the encoder + cross-KV projection for one 30 s clip."""
+    d, f, S, L = cfg.d_model, cfg.encoder_ffn_dim, cfg.max_source_positions, cfg.encoder_layers
+    per_layer = 4 * 2 * S * d * d + 2 * 2 * S * S * d + 2 * 2 * S * d * f
+    conv = 2 * (2 * S) * d * 3 * cfg.num_mel_bins + 2 * S * d * 3 * d
+    cross = cfg.n_kv_layers * 2 * 2 * S * d * d
+    return L * per_layer + conv + cross
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -176,6 +185,10 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "decode iteration (base pass + verify pass, one hipGraph launch)",
                      "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
                      "traffic": traffic, "bytes_per_launch": round(bytes_iter), "ms_per_launch": round(t_iter_ms, 4),
+                     "prefill": {"bound": "mfma", "tflops_per_clip": round(prefill_flops(cfg) / 1e12, 3),
+                                 "achieved": round(prefill_flops(cfg) * B / (ms_enc / args.steps * 1e-3) / 1e12, 1),
+                                 "peak": 2500.0, "unit": "TFLOP/s",
+                                 "frac": round(prefill_flops(cfg) * B / (ms_enc / args.steps * 1e-3) / 2.5e15, 4)},
                      "layer_gemms": {"rows": min(32, B * (cfg.medusa_num_heads + 1)), "ms": round(gemm_ms, 5),
                                      "bytes": round(gemm_bytes), "achieved_gbs": round(gemm_bytes / (gemm_ms * 1e-3) / 1e9, 1)}},
     }

@@ -9,9 +9,7 @@
 // (16 B/lane, one 1-KiB packed fragment per wave-instruction): the LDS image is fragment-major, so
 // every ds_read_b128 is lane-linear and bank-conflict-free without any swizzle.  2-stage LDS ring.
 // =============================================================================================
-#define GT_BM 128
 #define GT_BN 128
-#define GT_STAGE_BYTES 32768
 
 __device__ __forceinline__ void glds16(const bf16_t* gsrc, char* lds_wave_base)
 {
@@ -19,11 +17,15 @@ __device__ __forceinline__ void glds16(const bf16_t* gsrc, char* lds_wave_base)
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <class Ep>
+template <int BM, class Ep>      // BM = token rows per tile: 128 (default) or 64 (doubles the block count of the N=d GEMMs)
 __global__ void __launch_bounds__(256)
 k_gemm_tiled(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32, int tiles_m, int tiles_n, Ep ep)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int XB = BM / 16 * 2;            // X fragments per stage (m-tiles x 2 k-tiles)
+    constexpr int NB = XB + 16;                // + 16 W fragments (8 n-tiles x 2 k-tiles)
+    constexpr int STAGE = NB * 1024;
+    constexpr int MJ = BM / 32;                // token tiles per wave
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wn = w >> 1, wm = w & 1;
@@ -33,26 +35,28 @@ k_gemm_tiled(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32
     if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
     const int tn = bid / tiles_m, tm = bid - tn * tiles_m;
 
-    const bf16_t* xg = X + (size_t)tm * 8 * K32 * 512 + lane * 8;
+    const bf16_t* xg = X + (size_t)tm * (BM / 16) * K32 * 512 + lane * 8;
     const bf16_t* wg = W + (size_t)tn * 8 * K32 * 512 + lane * 8;
     const int nkt = K32 >> 1;
 
     auto stage_load = [&](int stage, int kt2) {
-        char* sb = smem + stage * GT_STAGE_BYTES;
+        char* sb = smem + stage * STAGE;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int blk = w * 8 + i;                 // 0..31: 0..15 X fragments, 16..31 W fragments
-            const int t = (blk & 15) >> 1, kk = blk & 1;
-            const bf16_t* src = ((blk < 16) ? xg : wg) + ((size_t)t * K32 + kt2 * 2 + kk) * 512;
+        for (int i = 0; i < NB / 4; ++i) {
+            const int blk = w * (NB / 4) + i;          // 0..XB-1 X fragments, then 16 W fragments
+            const bool isx = blk < XB;
+            const int bb = isx ? blk : blk - XB;
+            const int t = bb >> 1, kk = bb & 1;
+            const bf16_t* src = (isx ? xg : wg) + ((size_t)t * K32 + kt2 * 2 + kk) * 512;
             glds16(src, sb + blk * 1024);
         }
     };
 
-    f32x4_t acc[4][4];
+    f32x4_t acc[4][MJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     stage_load(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -60,45 +64,46 @@ k_gemm_tiled(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32
 
     for (int kt2 = 0; kt2 < nkt; ++kt2) {
         if (kt2 + 1 < nkt) stage_load((kt2 + 1) & 1, kt2 + 1);
-        const bf16_t* xs = reinterpret_cast<const bf16_t*>(smem + (kt2 & 1) * GT_STAGE_BYTES);
-        const bf16_t* ws = xs + 16 * 512;
+        const bf16_t* xs = reinterpret_cast<const bf16_t*>(smem + (kt2 & 1) * STAGE);
+        const bf16_t* ws = xs + XB * 512;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8_t a[4], b[4];
+            bf16x8_t a[4], b[MJ];
 #pragma unroll
             for (int i = 0; i < 4; ++i) a[i] = ld_frag(ws + (((wn * 4 + i) * 2 + kk) * 64 + lane) * 8);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = ld_frag(xs + (((wm * 4 + j) * 2 + kk) * 64 + lane) * 8);
+            for (int j = 0; j < MJ; ++j) b[j] = ld_frag(xs + (((wm * MJ + j) * 2 + kk) * 64 + lane) * 8);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+                for (int j = 0; j < MJ; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
-    const int m0 = tm * GT_BM + wm * 64 + (lane & 15), n0 = tn * GT_BN + wn * 64 + 4 * (lane >> 4);
+    const int m0 = tm * BM + wm * (BM / 2) + (lane & 15), n0 = tn * GT_BN + wn * 64 + 4 * (lane >> 4);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ep.store4(m0 + j * 16, n0 + i * 16, acc[i][j]);
+        for (int j = 0; j < MJ; ++j) ep.store4(m0 + j * 16, n0 + i * 16, acc[i][j]);
+}
+
+template <int BM, class Ep>
+static inline hipError_t launch_gemm_tiled_bm(hipStream_t st, const bf16_t* X, const bf16_t* W, int Mrows, int N, int K32, const Ep& ep)
+{
+    const int tiles_m = Mrows / BM, tiles_n = N / GT_BN;
+    constexpr int lds = 2 * (BM / 16 * 2 + 16) * 1024;
+    hipLaunchKernelGGL((k_gemm_tiled<BM, Ep>), dim3(tiles_m * tiles_n), dim3(256), lds, st, X, W, K32, tiles_m, tiles_n, ep);
+    return hipGetLastError();
 }
 
 template <class Ep>
 static inline hipError_t launch_gemm_tiled(hipStream_t st, const bf16_t* X, const bf16_t* W, int Mrows, int N, int K32, const Ep& ep)
 {
-    const int tiles_m = Mrows / GT_BM, tiles_n = N / GT_BN;
-    auto kern = k_gemm_tiled<Ep>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           2 * GT_STAGE_BYTES);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), 2 * GT_STAGE_BYTES, st, X, W, K32, tiles_m, tiles_n, ep);
-    return hipGetLastError();
+    // fewer than ~one block per CU with 128-row tiles: halve the tile to fill the chip
+    if ((Mrows / 128) * (N / GT_BN) < 200) return launch_gemm_tiled_bm<64>(st, X, W, Mrows, N, K32, ep);
+    return launch_gemm_tiled_bm<128>(st, X, W, Mrows, N, K32, ep);
 }
 
 // =============================================================================================
@@ -108,6 +113,7 @@ static inline hipError_t launch_gemm_tiled(hipStream_t st, const bf16_t* X, cons
 //   k-slot <-> key assignment is permuted identically in the V^T fragment and the P fragment, so no
 //   cross-lane movement is needed.  q is pre-scaled; fp32 softmax; P rounded to bf16.
 // =============================================================================================
+template <int QT>                 // QT x 16 queries per wave: every K / V^T fragment is reused by QT query tiles
 __global__ void __launch_bounds__(256)
 k_flash_enc(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kt, const bf16_t* __restrict__ Vt,
             bf16_t* __restrict__ out, int S, int Spad, int H, int K32out)
@@ -116,72 +122,87 @@ k_flash_enc(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kt, const b
     const int g = lane >> 4, c = lane & 15;
     const int hd = blockIdx.y, b = blockIdx.z;
     const size_t bh = (size_t)b * H + hd;
-    const int q0 = blockIdx.x * 64 + w * 16;
-    const bf16_t* qp = Q + (bh * Spad + q0 + c) * 64 + g * 8;
-    const bf16x8_t qb0 = ld_frag(qp), qb1 = ld_frag(qp + 32);
+    const int q0 = (blockIdx.x * 4 + w) * 16 * QT;
+    bf16x8_t qb[QT][2];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const bf16_t* qp = Q + (bh * Spad + q0 + t * 16 + c) * 64 + g * 8;
+        qb[t][0] = ld_frag(qp); qb[t][1] = ld_frag(qp + 32);
+    }
     const bf16_t* kbase = Kt + bh * Spad * 64;
     const bf16_t* vbase = Vt + bh * 64 * Spad;
 
-    float m_run = -INFINITY, l_run = 0.f;
-    f32x4_t o[4];
+    float m_run[QT], l_run[QT];
+    f32x4_t o[QT][4];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < QT; ++t) {
+        m_run[t] = -INFINITY; l_run[t] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[t][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
 
     for (int kb = 0; kb < S; kb += 32) {
         const bf16_t* kp = kbase + (size_t)(kb + c) * 64 + g * 8;
         const bf16x8_t a00 = ld_frag(kp), a01 = ld_frag(kp + 32);
         const bf16x8_t a10 = ld_frag(kp + 16 * 64), a11 = ld_frag(kp + 16 * 64 + 32);
-        uint2 vlo[4], vhi[4];
+        bf16x8_t va[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             const bf16_t* vp = vbase + (size_t)(dt * 16 + c) * Spad + kb + 4 * g;
-            vlo[dt] = *reinterpret_cast<const uint2*>(vp);
-            vhi[dt] = *reinterpret_cast<const uint2*>(vp + 16);
+            const uint2 lo = *reinterpret_cast<const uint2*>(vp), hi = *reinterpret_cast<const uint2*>(vp + 16);
+            uint4 vw; vw.x = lo.x; vw.y = lo.y; vw.z = hi.x; vw.w = hi.y;
+            va[dt] = __builtin_bit_cast(bf16x8_t, vw);
         }
-        f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-        s0 = mfma16(a00, qb0, s0); s0 = mfma16(a01, qb1, s0);
-        s1 = mfma16(a10, qb0, s1); s1 = mfma16(a11, qb1, s1);
-        if (kb + 32 > S) {
+        const bool tail = kb + 32 > S;
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+            s0 = mfma16(a00, qb[t][0], s0); s0 = mfma16(a01, qb[t][1], s0);
+            s1 = mfma16(a10, qb[t][0], s1); s1 = mfma16(a11, qb[t][1], s1);
+            if (tail) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (kb + 4 * g + r >= S) s0[r] = -INFINITY;
+                    if (kb + 16 + 4 * g + r >= S) s1[r] = -INFINITY;
+                }
+            }
+            float mx = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[t], mx);
+            const float alpha = __expf(m_run[t] - m_new);
+            float p0[4], p1[4], rs = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (kb + 4 * g + r >= S) s0[r] = -INFINITY;
-                if (kb + 16 + 4 * g + r >= S) s1[r] = -INFINITY;
+                p0[r] = __expf(s0[r] - m_new); p1[r] = __expf(s1[r] - m_new);
+                rs += p0[r] + p1[r];
+            }
+            rs += __shfl_xor(rs, 16, 64);
+            rs += __shfl_xor(rs, 32, 64);
+            l_run[t] = l_run[t] * alpha + rs;
+            m_run[t] = m_new;
+            uint4 pw;
+            pw.x = pack_bf2(p0[0], p0[1]); pw.y = pack_bf2(p0[2], p0[3]);
+            pw.z = pack_bf2(p1[0], p1[1]); pw.w = pack_bf2(p1[2], p1[3]);
+            const bf16x8_t pb = __builtin_bit_cast(bf16x8_t, pw);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                o[t][dt][0] *= alpha; o[t][dt][1] *= alpha; o[t][dt][2] *= alpha; o[t][dt][3] *= alpha;
+                o[t][dt] = mfma16(va[dt], pb, o[t][dt]);
             }
         }
-        float mx = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __expf(m_run - m_new);
-        float p0[4], p1[4], rs = 0.f;
+    }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            p0[r] = __expf(s0[r] - m_new); p1[r] = __expf(s1[r] - m_new);
-            rs += p0[r] + p1[r];
-        }
-        rs += __shfl_xor(rs, 16, 64);
-        rs += __shfl_xor(rs, 32, 64);
-        l_run = l_run * alpha + rs;
-        m_run = m_new;
-        uint4 pw;
-        pw.x = pack_bf2(p0[0], p0[1]); pw.y = pack_bf2(p0[2], p0[3]);
-        pw.z = pack_bf2(p1[0], p1[1]); pw.w = pack_bf2(p1[2], p1[3]);
-        const bf16x8_t pb = __builtin_bit_cast(bf16x8_t, pw);
+    for (int t = 0; t < QT; ++t) {
+        const float inv = 1.0f / l_run[t];
+        const int row = b * Spad + q0 + t * 16 + c;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-            o[dt][0] *= alpha; o[dt][1] *= alpha; o[dt][2] *= alpha; o[dt][3] *= alpha;
-            uint4 vw; vw.x = vlo[dt].x; vw.y = vlo[dt].y; vw.z = vhi[dt].x; vw.w = vhi[dt].y;
-            o[dt] = mfma16(__builtin_bit_cast(bf16x8_t, vw), pb, o[dt]);
+            uint2 u;
+            u.x = pack_bf2(o[t][dt][0] * inv, o[t][dt][1] * inv);
+            u.y = pack_bf2(o[t][dt][2] * inv, o[t][dt][3] * inv);
+            *reinterpret_cast<uint2*>(out + packed_index(row, hd * 64 + dt * 16 + 4 * g, K32out)) = u;
         }
-    }
-    const float inv = 1.0f / l_run;
-    const int row = b * Spad + q0 + c;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-        uint2 u;
-        u.x = pack_bf2(o[dt][0] * inv, o[dt][1] * inv);
-        u.y = pack_bf2(o[dt][2] * inv, o[dt][3] * inv);
-        *reinterpret_cast<uint2*>(out + packed_index(row, hd * 64 + dt * 16 + 4 * g, K32out)) = u;
     }
 }
 
@@ -380,7 +401,10 @@ int wm_enc_encode(wm_ctx* ctx, const float* feats, int B)
         hipLaunchKernelGGL(k_enc_ln, dim3((M + 3) / 4), dim3(256), 0, st, ctx->eh, w.ln1_w, w.ln1_b, ctx->exn, K32, d, M);
         WM_HIP(hipGetLastError());
         WM_HIP(launch_gemm_tiled(st, ctx->exn, w.qkv_w, M, 3 * d, K32, EpQKVEnc{ctx->eq, ctx->ek, ctx->evt, w.qkv_b, Spad, H, d}));
-        hipLaunchKernelGGL(k_flash_enc, dim3(Spad / 64, H, B), dim3(256), 0, st, ctx->eq, ctx->ek, ctx->evt, ctx->exn, S, Spad, H, K32);
+        if (B * (Spad / 128) * H >= 256 && Spad % 256 == 0)
+            hipLaunchKernelGGL(k_flash_enc<4>, dim3(Spad / 256, H, B), dim3(256), 0, st, ctx->eq, ctx->ek, ctx->evt, ctx->exn, S, Spad, H, K32);
+        else
+            hipLaunchKernelGGL(k_flash_enc<2>, dim3(Spad / 128, H, B), dim3(256), 0, st, ctx->eq, ctx->ek, ctx->evt, ctx->exn, S, Spad, H, K32);
         WM_HIP(hipGetLastError());
         WM_HIP(launch_gemm_tiled(st, ctx->exn, w.out_w, M, d, K32, EpResidual{ctx->eh, w.out_b, d, M}));
         hipLaunchKernelGGL(k_enc_ln, dim3((M + 3) / 4), dim3(256), 0, st, ctx->eh, w.ln2_w, w.ln2_b, ctx->exn, K32, d, M);
