@@ -19,6 +19,7 @@
 //   LdNorm    — fp32 residual rows -> LayerNorm (or identity) -> hi/lo fragments in LDS, fused
 // Results leave through a fused EPILOGUE functor (wm_epilogues.h).
 #pragma once
+#include <cstdlib>
 #include "wm_common.h"
 #include "wm_epilogues.h"
 
@@ -290,20 +291,28 @@ struct SkinnyPlan { int ksplit, rt, U; };
 // K-slices of at most 16 fragments (so the batched kernel can hold a slice in registers) and, if possible,
 // >= 1024 waves.  The plan depends only on (N16, K32, loader kind): 16-row and batched launches of one GEMM
 // share it, which is what makes their results bit-identical.
+static inline int skinny_env(const char* name, int dflt) {
+    const char* v = std::getenv(name);
+    return v ? std::atoi(v) : dflt;
+}
 static inline SkinnyPlan skinny_plan(int N16, int K32, bool lds_loader) {
+    static const int cap = skinny_env("WM_PLAN_WAVE_CAP", 10);          // tuning knobs (bench sweeps); defaults are the shipped plan
+    static const int target = skinny_env("WM_PLAN_TARGET_WAVES", 1024);
+    static const int nkmax = skinny_env("WM_PLAN_NK_MAX", 16);
+    static const int rt2 = skinny_env("WM_PLAN_RT2", 1);
     SkinnyPlan p; p.U = (K32 % 8 == 0) ? 8 : 4;
     const int q = K32 / p.U;                // candidate ksplit must divide q
     int best = 1;
-    for (int s = 1; s <= 10 && s <= q; ++s) {      // <= 10 waves per block (launch bound 640 threads)
+    for (int s = 1; s <= cap && s <= q; ++s) {      // <= 10 waves per block (launch bound 640 threads)
         if (q % s) continue;
         best = s;
-        if ((long)N16 * s >= 1024 && K32 / s <= 16) break;
+        if ((long)N16 * s >= target && K32 / s <= nkmax) break;
     }
     p.ksplit = best;
     p.rt = (best == 1) ? 4 : 1;
     // LDS loaders hold the whole 16 x K operand (one block per CU): when there are more row tiles than CUs,
     // let two tiles share one block (and one LayerNorm) instead of running a second round of blocks
-    if (lds_loader && best > 1 && best <= 5 && N16 > 256) p.rt = 2;
+    if (rt2 && lds_loader && best > 1 && best <= 5 && N16 > 256) p.rt = 2;
     return p;
 }
 
