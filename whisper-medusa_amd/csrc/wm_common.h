@@ -35,6 +35,15 @@ __device__ __host__ __forceinline__ size_t packed_index(int row, int k, int K32)
     return ((size_t)(row >> 4) * K32 + (k >> 5)) * 512 + (size_t)(((row & 15) + 16 * ((k & 31) >> 3)) * 8 + (k & 7));
 }
 
+// V operand of the decode attention (self V cache and cross V): per (stream, head) the [rows][64] matrix is stored
+// as MFMA A fragments of V^T, [rows/32][4 dim tiles][64 lanes][8]: lane (c = dim & 15, g) of fragment (t, dt) holds
+// V[32t + 4g .. +3][16dt + c] and V[32t + 16 + 4g .. +3][16dt + c] — the k-slot <-> key permutation of the P
+// operand the score MFMAs leave in registers.  A wave fetches a 32-key step of V as four contiguous 1 KiB loads.
+__device__ __host__ __forceinline__ size_t vfrag_index(int key, int dim) {
+    const int r = key & 31, rr = r & 15;
+    return ((size_t)((key >> 5) * 4 + (dim >> 4)) * 64 + (dim & 15) + 16 * (rr >> 2)) * 8 + (r >> 4) * 4 + (rr & 3);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

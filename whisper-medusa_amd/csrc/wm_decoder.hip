@@ -4,6 +4,8 @@
 // tokens per stream) + accept.  All lengths live on the device (L, kvlen, finished), every kernel has a
 // static shape, so the whole iteration is captured once as a hipGraph and replayed (wm_engine.hip).
 #include "wm_internal.h"
+#include <algorithm>
+#include <cstdlib>
 #include "wm_skinny_gemm.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -113,46 +115,95 @@ __device__ __forceinline__ void split_hilo8(const float* x, bf16x8_t& hi, bf16x8
     hi = __builtin_bit_cast(bf16x8_t, h); lo = __builtin_bit_cast(bf16x8_t, l);
 }
 
+#define WM_XATTN_SPB_MAX 6          // key splits one block may walk (LDS copy of its partials)
+
+struct KVStep { bf16x8_t k00, k01, k10, k11, v[4]; };        // one 32-key step: K rows as A fragments, V^T fragments
+struct AttnAcc { float m_run, l_run; f32x4_t o[4]; };
+
+// 8 fully coalesced 16-B-per-lane loads: K rows are 128-B lines, the V^T fragments of a step are 4 contiguous KiB
+__device__ __forceinline__ void kv_load(KVStep& t, const bf16_t* kp, const bf16_t* vp, int kb, int c, int g, int lane)
+{
+    const bf16_t* kr = kp + (size_t)(kb + c) * 64 + g * 8;
+    t.k00 = ld_frag(kr); t.k01 = ld_frag(kr + 32); t.k10 = ld_frag(kr + 16 * 64); t.k11 = ld_frag(kr + 16 * 64 + 32);
+    const bf16_t* vr = vp + ((size_t)(kb >> 5) * 256 + lane) * 8;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) t.v[dt] = ld_frag(vr + dt * 512);
+}
+
+// scores of 32 keys x 16 queries, online softmax, O^T += V^T P^T
+__device__ __forceinline__ void attn_step(AttnAcc& st, const KVStep& t, const bf16x8_t (&qhi)[2], const bf16x8_t (&qlo)[2],
+                                          int kb, int g, int limit)
+{
+    f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+    s0 = mfma16(t.k00, qhi[0], s0); s0 = mfma16(t.k01, qhi[1], s0); s0 = mfma16(t.k00, qlo[0], s0); s0 = mfma16(t.k01, qlo[1], s0);
+    s1 = mfma16(t.k10, qhi[0], s1); s1 = mfma16(t.k11, qhi[1], s1); s1 = mfma16(t.k10, qlo[0], s1); s1 = mfma16(t.k11, qlo[1], s1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (kb + 4 * g + r >= limit) s0[r] = -INFINITY;
+        if (kb + 16 + 4 * g + r >= limit) s1[r] = -INFINITY;
+    }
+    float mx = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(st.m_run, mx);
+    const float alpha = (m_new == -INFINITY) ? 1.f : __expf(st.m_run - m_new);
+    float p[8], rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        p[r] = (m_new == -INFINITY) ? 0.f : __expf(s0[r] - m_new);
+        p[4 + r] = (m_new == -INFINITY) ? 0.f : __expf(s1[r] - m_new);
+        rs += p[r] + p[4 + r];
+    }
+    rs += __shfl_xor(rs, 16, 64);
+    rs += __shfl_xor(rs, 32, 64);
+    st.l_run = st.l_run * alpha + rs;
+    st.m_run = m_new;
+    bf16x8_t phi, plo;
+    split_hilo8(p, phi, plo);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        st.o[dt][0] *= alpha; st.o[dt][1] *= alpha; st.o[dt][2] *= alpha; st.o[dt][3] *= alpha;
+        st.o[dt] = mfma16(t.v[dt], phi, st.o[dt]);
+        st.o[dt] = mfma16(t.v[dt], plo, st.o[dt]);
+    }
+}
+
 template <bool CROSS>
 __global__ void __launch_bounds__(256)
 k_attn_mfma(const float* __restrict__ q, const bf16_t* __restrict__ kmat, const bf16_t* __restrict__ vtmat,
             const int* __restrict__ base, bf16_t* __restrict__ xout, size_t xplane, float* __restrict__ ml, float* __restrict__ po,
-            int* __restrict__ ticket, const int* __restrict__ done, const int* __restrict__ skip, int Mper, int H, int rows_alloc,
-            int S, int NS, int K32)
+            int* __restrict__ ticket, const int* __restrict__ done, const int* __restrict__ skip, const int* __restrict__ sskip,
+            int Mper, int H, int rows_alloc, int S, int NS, int K32)
 {
     if ((done && *done) || (skip && *skip)) return;
+    // per-stream skip: the stream carried its hidden state, this base-pass row is not used (its K/V reads are saved)
+    if (sskip && sskip[blockIdx.z]) return;
     __shared__ float s_m[4][16], s_l[4][16];
     __shared__ int s_last;
     __shared__ __attribute__((aligned(16))) float s_o[4][16][68];
+    __shared__ __attribute__((aligned(16))) float s_part[CROSS ? WM_XATTN_SPB_MAX : 1][16][68];   // [..][64] = max, [..][65] = sum
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
-    const int hd = blockIdx.y, s = blockIdx.z, split = blockIdx.x, d = H * 64;
+    const int hd = blockIdx.y, s = blockIdx.z, d = H * 64;
+    // CROSS: the block walks key splits [sp0, sp1); with gridDim.x == NS that is one split per block (single stream:
+    // all CUs busy), with fewer blocks per (stream, head) each walks several (large batches: fewer partial hand-offs).
+    // The arithmetic per split and the merge order over splits do not depend on the grouping: bit-identical outputs.
+    const int spb = CROSS ? (NS + gridDim.x - 1) / gridDim.x : 1;
+    const int sp0 = CROSS ? blockIdx.x * spb : 0, sp1 = CROSS ? min(NS, sp0 + spb) : 1;
 
     const int b0 = CROSS ? 0 : base[s];
     const int limit = CROSS ? S : min(b0 + c + 1, rows_alloc);            // keys < limit are visible to query c
-    int kb, kend, kstep;
-    if (CROSS) { kb = split * 256 + w * 64; kend = min(S, kb + 64); kstep = 32; }
-    else { kb = 32 * w; kend = min(b0 + Mper, rows_alloc); kstep = 128; }
     const bf16_t* kp = kmat + ((size_t)s * H + hd) * rows_alloc * 64;
     const bf16_t* vp = vtmat + ((size_t)s * H + hd) * 64 * rows_alloc;
 
-    float m_run = -INFINITY, l_run = 0.f;
-    f32x4_t o[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    // fragments of the first step; inside the loop the NEXT step's loads are issued before this step's math
-    bf16x8_t a00, a01, a10, a11;
-    uint2 vlo[4], vhi[4];
-#define WM_ATTN_LOAD(KB, A00, A01, A10, A11, VLO, VHI)                                             \
-    {                                                                                              \
-        const bf16_t* kr_ = kp + (size_t)((KB) + c) * 64 + g * 8;                                  \
-        A00 = ld_frag(kr_); A01 = ld_frag(kr_ + 32); A10 = ld_frag(kr_ + 16 * 64); A11 = ld_frag(kr_ + 16 * 64 + 32); \
-        _Pragma("unroll") for (int dt = 0; dt < 4; ++dt) {                                         \
-            const bf16_t* vr_ = vp + (size_t)(dt * 16 + c) * rows_alloc + (KB) + 4 * g;            \
-            VLO[dt] = *reinterpret_cast<const uint2*>(vr_); VHI[dt] = *reinterpret_cast<const uint2*>(vr_ + 16); \
-        }                                                                                          \
-    }
-    if (kb < kend) WM_ATTN_LOAD(kb, a00, a01, a10, a11, vlo, vhi)     // K/V do not depend on q: issue first
+    // K/V do not depend on q: the first loads go out before anything else.  Self: wave w walks the 32-key steps
+    // w, w+4, ... with the next step in flight.  Cross: a wave owns 64 keys (two steps) of every split and keeps the
+    // whole NEXT split (16 KiB per wave) in flight while it works on this one — bytes in flight, not occupancy, is what
+    // the cross-K/V stream needs.
+    KVStep c0 = {}, c1 = {};
+    int kb = CROSS ? sp0 * 256 + w * 64 : 32 * w;
+    int kend = CROSS ? min(S, kb + 64) : min(b0 + Mper, rows_alloc);
+    if (kb < kend) kv_load(c0, kp, vp, kb, c, g, lane);
+    if (CROSS && kb + 32 < kend) kv_load(c1, kp, vp, kb + 32, c, g, lane);
     bf16x8_t qhi[2], qlo[2];
     {
         float qv[8];
@@ -169,68 +220,67 @@ k_attn_mfma(const float* __restrict__ q, const bf16_t* __restrict__ kmat, const 
             split_hilo8(qv, qhi[ds], qlo[ds]);
         }
     }
-    for (; kb < kend; kb += kstep) {
-        bf16x8_t n00 = a00, n01 = a01, n10 = a10, n11 = a11;
-        uint2 nlo[4], nhi[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) { nlo[dt] = vlo[dt]; nhi[dt] = vhi[dt]; }
-        if (kb + kstep < kend) WM_ATTN_LOAD(kb + kstep, n00, n01, n10, n11, nlo, nhi)
-        f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-        s0 = mfma16(a00, qhi[0], s0); s0 = mfma16(a01, qhi[1], s0); s0 = mfma16(a00, qlo[0], s0); s0 = mfma16(a01, qlo[1], s0);
-        s1 = mfma16(a10, qhi[0], s1); s1 = mfma16(a11, qhi[1], s1); s1 = mfma16(a10, qlo[0], s1); s1 = mfma16(a11, qlo[1], s1);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (kb + 4 * g + r >= limit) s0[r] = -INFINITY;
-            if (kb + 16 + 4 * g + r >= limit) s1[r] = -INFINITY;
-        }
-        float mx = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = (m_new == -INFINITY) ? 1.f : __expf(m_run - m_new);
-        float p[8], rs = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            p[r] = (m_new == -INFINITY) ? 0.f : __expf(s0[r] - m_new);
-            p[4 + r] = (m_new == -INFINITY) ? 0.f : __expf(s1[r] - m_new);
-            rs += p[r] + p[4 + r];
-        }
-        rs += __shfl_xor(rs, 16, 64);
-        rs += __shfl_xor(rs, 32, 64);
-        l_run = l_run * alpha + rs;
-        m_run = m_new;
-        bf16x8_t phi, plo;
-        split_hilo8(p, phi, plo);
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            o[dt][0] *= alpha; o[dt][1] *= alpha; o[dt][2] *= alpha; o[dt][3] *= alpha;
-            uint4 vw; vw.x = vlo[dt].x; vw.y = vlo[dt].y; vw.z = vhi[dt].x; vw.w = vhi[dt].y;
-            const bf16x8_t va = __builtin_bit_cast(bf16x8_t, vw);
-            o[dt] = mfma16(va, phi, o[dt]);
-            o[dt] = mfma16(va, plo, o[dt]);
-        }
-        a00 = n00; a01 = n01; a10 = n10; a11 = n11;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) { vlo[dt] = nlo[dt]; vhi[dt] = nhi[dt]; }
-    }
-#undef WM_ATTN_LOAD
-    if (g == 0) { s_m[w][c] = m_run; s_l[w][c] = l_run; }
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-        *reinterpret_cast<float4*>(&s_o[w][c][dt * 16 + 4 * g]) = make_float4(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
-    __syncthreads();
     const int qr = threadIdx.x >> 4, ch = (threadIdx.x & 15) * 4;
     const int row = s * Mper + qr;
+    typedef unsigned long long u64;
     float M = -INFINITY, L = 0.f; float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (qr < Mper) {
-        M = fmaxf(fmaxf(s_m[0][qr], s_m[1][qr]), fmaxf(s_m[2][qr], s_m[3][qr]));
+
+    for (int sp = sp0; sp < sp1; ++sp) {
+        AttnAcc st;
+        st.m_run = -INFINITY; st.l_run = 0.f;
 #pragma unroll
-        for (int ww = 0; ww < 4; ++ww) {
-            const float e = (s_m[ww][qr] == -INFINITY) ? 0.f : __expf(s_m[ww][qr] - M);
-            L += s_l[ww][qr] * e;
-            const float4 ov = *reinterpret_cast<const float4*>(&s_o[ww][qr][ch]);
-            acc.x += ov.x * e; acc.y += ov.y * e; acc.z += ov.z * e; acc.w += ov.w * e;
+        for (int dt = 0; dt < 4; ++dt) st.o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (CROSS) {
+            KVStep n0 = c0, n1 = c1;
+            const int nkb = (sp + 1) * 256 + w * 64, nkend = min(S, nkb + 64);
+            if (sp + 1 < sp1 && nkb < nkend) kv_load(n0, kp, vp, nkb, c, g, lane);
+            if (sp + 1 < sp1 && nkb + 32 < nkend) kv_load(n1, kp, vp, nkb + 32, c, g, lane);
+            if (kb < kend) attn_step(st, c0, qhi, qlo, kb, g, limit);
+            if (kb + 32 < kend) attn_step(st, c1, qhi, qlo, kb + 32, g, limit);
+            c0 = n0; c1 = n1; kb = nkb; kend = nkend;
+        } else {
+            for (; kb < kend; kb += 128) {
+                KVStep n0 = c0;
+                if (kb + 128 < kend) kv_load(n0, kp, vp, kb + 128, c, g, lane);
+                attn_step(st, c0, qhi, qlo, kb, g, limit);
+                c0 = n0;
+            }
         }
+        const float m_run = st.m_run, l_run = st.l_run;
+        const f32x4_t (&o)[4] = st.o;
+        // merge the 4 waves' partials of this split (fixed order)
+        if (g == 0) { s_m[w][c] = m_run; s_l[w][c] = l_run; }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+            *reinterpret_cast<float4*>(&s_o[w][c][dt * 16 + 4 * g]) = make_float4(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
+        __syncthreads();
+        M = -INFINITY; L = 0.f; acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (qr < Mper) {
+            M = fmaxf(fmaxf(s_m[0][qr], s_m[1][qr]), fmaxf(s_m[2][qr], s_m[3][qr]));
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) {
+                const float e = (s_m[ww][qr] == -INFINITY) ? 0.f : __expf(s_m[ww][qr] - M);
+                L += s_l[ww][qr] * e;
+                const float4 ov = *reinterpret_cast<const float4*>(&s_o[ww][qr][ch]);
+                acc.x += ov.x * e; acc.y += ov.y * e; acc.z += ov.z * e; acc.w += ov.w * e;
+            }
+        }
+        if (!CROSS) break;
+        if (qr < Mper) {
+            // keep the partial for this block's own merge (LDS) and, when other blocks share the (stream, head),
+            // publish it: relaxed agent-scope atomics (write-through sc1), see the hand-off note below
+            *reinterpret_cast<float4*>(&s_part[sp - sp0][qr][ch]) = acc;
+            if (ch == 0) { s_part[sp - sp0][qr][64] = M; s_part[sp - sp0][qr][65] = L; }
+            if (gridDim.x > 1) {
+                u64* pd = reinterpret_cast<u64*>(po + (((size_t)row * H + hd) * NS + sp) * 64 + ch);
+                __hip_atomic_store(pd, ((u64)__float_as_uint(acc.y) << 32) | __float_as_uint(acc.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(pd + 1, ((u64)__float_as_uint(acc.w) << 32) | __float_as_uint(acc.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (ch == 0)
+                    __hip_atomic_store(reinterpret_cast<u64*>(ml + (((size_t)row * H + hd) * NS + sp) * 2),
+                                       ((u64)__float_as_uint(L) << 32) | __float_as_uint(M), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (sp + 1 < sp1) __syncthreads();                 // s_o / s_m / s_l are rewritten by the next split
     }
     if (!CROSS) {
         if (qr < Mper) {
@@ -240,46 +290,43 @@ k_attn_mfma(const float* __restrict__ q, const bf16_t* __restrict__ kmat, const 
         }
         return;
     }
-    // ---- publish this block's partial; the last block of the (stream, head) merges all NS partials ----
+    // ---- the last block of the (stream, head) merges all NS partials ----
     // Hand-off in the "8-byte agent-scope atomics on both sides" form (cdna_hip_programming.md G16): payload
     // stores are relaxed agent-scope atomics (write-through sc1), every storing wave drains vmcnt, one lane takes
     // a relaxed ticket; the last arriver reads the other partials with relaxed agent-scope atomic loads (L1 bypass).
-    typedef unsigned long long u64;
-    if (qr < Mper) {
-        u64* pd = reinterpret_cast<u64*>(po + (((size_t)row * H + hd) * NS + split) * 64 + ch);
-        __hip_atomic_store(pd, ((u64)__float_as_uint(acc.y) << 32) | __float_as_uint(acc.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(pd + 1, ((u64)__float_as_uint(acc.w) << 32) | __float_as_uint(acc.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (ch == 0)
-            __hip_atomic_store(reinterpret_cast<u64*>(ml + (((size_t)row * H + hd) * NS + split) * 2),
-                               ((u64)__float_as_uint(L) << 32) | __float_as_uint(M), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int t = __hip_atomic_fetch_add(ticket + s * H + hd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = (t == NS - 1);
-        if (last) __hip_atomic_store(ticket + s * H + hd, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch / replay
-        s_last = last;
-    }
-    __syncthreads();
-    if (!s_last || qr >= Mper) return;
+    if (gridDim.x > 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int t = __hip_atomic_fetch_add(ticket + s * H + hd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = (t == (int)gridDim.x - 1);
+            if (last) __hip_atomic_store(ticket + s * H + hd, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch / replay
+            s_last = last;
+        }
+        __syncthreads();
+        if (!s_last) return;
+    } else __syncthreads();
+    if (qr >= Mper) return;
     {
         const u64* mlp = reinterpret_cast<const u64*>(ml + ((size_t)row * H + hd) * NS * 2);
         const u64* op = reinterpret_cast<const u64*>(po + ((size_t)row * H + hd) * NS * 64 + ch);
         float ms[16], ls[16];
         float Mx = -INFINITY;
         for (int sp = 0; sp < NS; ++sp) {
-            const u64 v = (sp == split) ? (((u64)__float_as_uint(L) << 32) | __float_as_uint(M))
-                                        : __hip_atomic_load(mlp + sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ms[sp] = __uint_as_float((unsigned)v); ls[sp] = __uint_as_float((unsigned)(v >> 32));
+            if (sp >= sp0 && sp < sp1) { ms[sp] = s_part[sp - sp0][qr][64]; ls[sp] = s_part[sp - sp0][qr][65]; }
+            else {
+                const u64 v = __hip_atomic_load(mlp + sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ms[sp] = __uint_as_float((unsigned)v); ls[sp] = __uint_as_float((unsigned)(v >> 32));
+            }
             Mx = fmaxf(Mx, ms[sp]);
         }
         float Lt = 0.f; float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int sp = 0; sp < NS; ++sp) {
             const float e = (ms[sp] == -INFINITY) ? 0.f : __expf(ms[sp] - Mx);
             Lt += ls[sp] * e;
-            float4 ov = acc;
-            if (sp != split) {
+            float4 ov;
+            if (sp >= sp0 && sp < sp1) ov = *reinterpret_cast<const float4*>(&s_part[sp - sp0][qr][ch]);
+            else {
                 const u64 v0 = __hip_atomic_load(op + (size_t)sp * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const u64 v1 = __hip_atomic_load(op + (size_t)sp * 32 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ov = make_float4(__uint_as_float((unsigned)v0), __uint_as_float((unsigned)(v0 >> 32)),
@@ -505,10 +552,22 @@ __global__ void k_accept_vanilla1(GenDev gp, int B, const int* __restrict__ amax
     }
 }
 
+// blocks per (stream, head) of the cross-attention: one per 256-key split while that is what fills the chip
+// (single stream), fewer — each walking several splits — once streams x heads alone do.  Results do not depend on it.
+static inline int xattn_blocks_per_head(int NS, int heads_total)
+{
+    static const int target = [] { const char* v = std::getenv("WM_XATTN_TARGET_BLOCKS"); return v ? std::atoi(v) : 768; }();
+    int gx = (target + heads_total - 1) / heads_total;
+    gx = std::max(1, std::min(gx, NS));
+    int spb = std::min((NS + gx - 1) / gx, WM_XATTN_SPB_MAX);
+    return (NS + spb - 1) / spb;
+}
+
 // =============================================================================================
 // host side
 // =============================================================================================
-static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0, int nb, int Mper, const int* base, bool kv_only)
+static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0, int nb, int Mper, const int* base, bool kv_only,
+                     const int* sskip = nullptr)
 {
     hipStream_t st = ctx->stream;
     const int d = ctx->d, H = ctx->H, K32 = d / 32, R = nb * Mper, F32 = ctx->ffn / 32;
@@ -523,7 +582,7 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
     if (kv_only) return WM_OK;
     // 2. causal self-attention over the contiguous cache
     hipLaunchKernelGGL(k_attn_mfma<false>, dim3(1, H, nb), dim3(256), 0, st, ctx->qbuf, kc, vc, base, ctx->xbuf, xpl,
-                       nullptr, nullptr, nullptr, g_skinny_done, g_skinny_skip, Mper, H, ctx->Tal, 0, 1, K32);
+                       nullptr, nullptr, nullptr, g_skinny_done, g_skinny_skip, sskip, Mper, H, ctx->Tal, 0, 1, K32);
     WM_HIP(hipGetLastError());
     // 3. out_proj + residual
     WM_HIP(launch_skinny_rows(st, w.out_w, d / 16, K32, R, ctx->xbuf, xpl, EpResidual{h, w.out_b, d, R}));
@@ -531,8 +590,8 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
     WM_HIP(launch_skinny_norm(st, w.cq_w, d / 16, K32, h, w.ln2_w, w.ln2_b, d, R, 1, 0, 1, EpF32{ctx->qbuf, w.cq_b, d, R, 0.125f},
                               ctx->xbuf, xpl));
     // 5. cross-attention over the encoder K/V, 256 keys per block
-    hipLaunchKernelGGL(k_attn_mfma<true>, dim3(ctx->NS, H, nb), dim3(256), 0, st, ctx->qbuf, kx, vx, base, ctx->xbuf, xpl,
-                       ctx->cml, ctx->co, ctx->ticket, g_skinny_done, g_skinny_skip, Mper, H, ctx->Spad, ctx->S, ctx->NS, K32);
+    hipLaunchKernelGGL(k_attn_mfma<true>, dim3(xattn_blocks_per_head(ctx->NS, H * nb), H, nb), dim3(256), 0, st, ctx->qbuf, kx, vx, base, ctx->xbuf, xpl,
+                       ctx->cml, ctx->co, ctx->ticket, g_skinny_done, g_skinny_skip, sskip, Mper, H, ctx->Spad, ctx->S, ctx->NS, K32);
     WM_HIP(hipGetLastError());
     // 6. out_proj + residual
     WM_HIP(launch_skinny_rows(st, w.cout_w, d / 16, K32, R, ctx->xbuf, xpl, EpResidual{h, w.cout_b, d, R}));
@@ -562,8 +621,12 @@ int wm_dec_stage_layers(wm_ctx* ctx, int b0, int nb, int Mper, int mode)
         hipLaunchKernelGGL(k_embed, dim3(R), dim3(256), 0, st, ctx->h, ctx->tok_emb, ctx->dec_pos, base,
                            ctx->cand + (size_t)b0 * 16, 16, 0, Mper, d, ctx->V, ctx->Tmax);
     WM_HIP(hipGetLastError());
+    // batched hidden-state carry: a stream whose previous verify pass accepted a > 0 candidates already has the state
+    // of its base token (k_accept saved it, k_rows_norm below picks it up); its rows still ride through the GEMMs
+    // (the weights are streamed once for everybody) but its attention blocks exit, saving their K/V reads
+    const int* sskip = (mode == 0 && Mper == 1 && ctx->dev_carry) ? ctx->carry + b0 : nullptr;
     for (int l = 0; l < ctx->cfg.dec_layers; ++l) {
-        int rc = dec_layer(ctx, ctx->dec[l], l, ctx->h, b0, nb, Mper, base, false);
+        int rc = dec_layer(ctx, ctx->dec[l], l, ctx->h, b0, nb, Mper, base, false, sskip);
         if (rc) return rc;
     }
     return WM_OK;
@@ -580,7 +643,7 @@ int wm_dec_stage_final(wm_ctx* ctx, int b0, int nb, int Mper, int mode, int medu
     float* hf = ctx->hf + (size_t)b0 * Mper * d;          // rows of this chunk; persists until the stream's next pass
     hipLaunchKernelGGL(k_rows_norm, dim3((R + 3) / 4), dim3(256), 0, st, ctx->h, 1, 0, ctx->dec_lnf_w, ctx->dec_lnf_b, 1,
                        hf, ctx->block ? ctx->hblk : nullptr, nullptr, (size_t)0, K32, 1, 0, d, R,
-                       g_skinny_skip, ctx->hf_keep + (size_t)b0 * d);
+                       (mode == 0 && Mper == 1 && ctx->dev_carry) ? ctx->carry + b0 : g_skinny_skip, ctx->hf_keep + (size_t)b0 * d);
     WM_HIP(hipGetLastError());
     g_skinny_skip = nullptr;                               // heads / vocabulary projection always run
     ctx->hf_cur = hf;
@@ -696,10 +759,11 @@ int wm_dec_iter_rest(wm_ctx* ctx, int Mper_base)
         hipLaunchKernelGGL(k_select_argmax, dim3((nb * rps + 63) / 64), dim3(64), 0, st, ctx->part1, nb * rps, 0, ctx->amax);
     WM_HIP(hipGetLastError());
     // (f)-(j) accept / emit / compact / stop.  With host_carry the carried post-LN row goes straight to hf row 0
-    // (where the skipped base pass would have put it) and the carry / finished flags to host-mapped memory.
+    // (where the skipped base pass would have put it) and the carry / finished flags to host-mapped memory; with
+    // dev_carry (several streams) it goes to hf_keep[stream] and the next base pass's final LayerNorm selects it.
     hipLaunchKernelGGL(k_accept, dim3(B), dim3(64), 0, st, gp, ctx->cand, ctx->amax, ctx->pc, ctx->part2, ctx->ids, ctx->L,
-                       ctx->kvlen, ctx->finished, ctx->niter, ctx->hist, ctx->done, B, carry ? ctx->carry : nullptr, ctx->hf,
-                       ctx->hf, ctx->d, carry ? ctx->hostflags_dev : nullptr);
+                       ctx->kvlen, ctx->finished, ctx->niter, ctx->hist, ctx->done, B, (carry || ctx->dev_carry) ? ctx->carry : nullptr, ctx->hf,
+                       carry ? ctx->hf : ctx->hf_keep, ctx->d, carry ? ctx->hostflags_dev : nullptr);
     WM_HIP(hipGetLastError());
     return WM_OK;
 }

@@ -204,7 +204,8 @@ extern "C" int wm_decode_begin(wm_ctx* ctx, const wm_gen_params* gp, int B)
     g.accept_mode = gp->accept_mode; g.vanilla = gp->vanilla; g.K = K; g.V = ctx->V; g.Vpad = ctx->Vpad; g.Tids = Tids;
     ctx->fuse = std::getenv("WM_NO_CARRY") == nullptr;
     ctx->host_carry = ctx->fuse && !ctx->block && B == 1 && !gp->vanilla;
-    g.fuse = ctx->host_carry ? 1 : 0;
+    ctx->dev_carry = ctx->fuse && !ctx->block && B > 1 && !gp->vanilla;
+    g.fuse = ctx->host_carry ? 1 : (ctx->dev_carry ? 2 : 0);
     const bool same = ctx->graph && ctx->graph_B == B && std::memcmp(&g, &ctx->gp, sizeof(GenDev)) == 0;
     if (!same && ctx->graph) { hipGraphExecDestroy(ctx->graph); ctx->graph = nullptr; }
     if (!same && ctx->graph_base) { hipGraphExecDestroy(ctx->graph_base); ctx->graph_base = nullptr; }
@@ -409,8 +410,8 @@ extern "C" int wm_get_cross_kv(wm_ctx* ctx, int kv_layer, int stream, int head, 
     WM_HIP(hipMemcpyAsync(vb.data(), ctx->vx + off, nv * sizeof(bf16_t), hipMemcpyDeviceToHost, ctx->stream));
     WM_HIP(hipStreamSynchronize(ctx->stream));
     for (size_t i = 0; i < n; ++i) { const uint32_t u = ((uint32_t)kb[i]) << 16; std::memcpy(k_out + i, &u, 4); }
-    for (int s = 0; s < ctx->S; ++s)            // V is stored transposed [64][Spad]
-        for (int dd = 0; dd < 64; ++dd) { const uint32_t u = ((uint32_t)vb[(size_t)dd * ctx->Spad + s]) << 16; std::memcpy(v_out + (size_t)s * 64 + dd, &u, 4); }
+    for (int s = 0; s < ctx->S; ++s)            // V is stored as V^T MFMA fragments
+        for (int dd = 0; dd < 64; ++dd) { const uint32_t u = ((uint32_t)vb[vfrag_index(s, dd)]) << 16; std::memcpy(v_out + (size_t)s * 64 + dd, &u, 4); }
     return WM_OK;
 }
 
@@ -424,7 +425,7 @@ extern "C" int wm_forward_logits(wm_ctx* ctx, int B, const int32_t* tokens, int 
     const int Tids = ctx->Tal, K = ctx->K, V = ctx->V, nout = disable_medusa ? 1 : K + 1;
     GenDev g = ctx->gp;
     g.K = K; g.V = V; g.Vpad = ctx->Vpad; g.Tids = Tids; g.vanilla = 0;
-    ctx->gp = g; ctx->began = false; ctx->use_done = false; ctx->host_carry = false;
+    ctx->gp = g; ctx->began = false; ctx->use_done = false; ctx->host_carry = false; ctx->dev_carry = false;
     if (ctx->graph) { hipGraphExecDestroy(ctx->graph); ctx->graph = nullptr; }
     if (ctx->graph_base) { hipGraphExecDestroy(ctx->graph_base); ctx->graph_base = nullptr; }
     std::vector<float> rowbuf((size_t)nout * ctx->Vpad);

@@ -52,7 +52,7 @@ struct EpPackedAct {           // out_lo != nullptr: decoder path, value kept as
 // Decoder self-attention projections: q (scaled, fp32) to a row buffer, k/v rows (bf16) straight
 // into the contiguous KV cache at position base[stream] + r   (HF:modeling_whisper.py:288-318; the
 // reference's per-iteration cat-compaction, model.py:378-402, becomes "overwrite rows >= kv_len").
-struct EpQKVDec {              // K cache [s][h][pos][64]; V cache transposed [s][h][64][pos] (MFMA A operand of P.V)
+struct EpQKVDec {              // K cache [s][h][pos][64]; V cache [s][h] as V^T MFMA fragments (vfrag_index)
     static constexpr bool kPre = false;
     float* q; bf16_t* kc; bf16_t* vc; const float* bias; const int* base;
     int Mper, d, H, Tal, M;
@@ -72,8 +72,8 @@ struct EpQKVDec {              // K cache [s][h][pos][64]; V cache transposed [s
             *reinterpret_cast<uint2*>(kc + (((size_t)s * H + (c >> 6)) * Tal + pos) * 64 + (c & 63)) = o;
         } else {
             const int c = n - 2 * d;
-            bf16_t* p = vc + (((size_t)s * H + (c >> 6)) * 64 + (c & 63)) * Tal + pos;
-            p[0] = f2bf(x0); p[Tal] = f2bf(x1); p[2 * (size_t)Tal] = f2bf(x2); p[3 * (size_t)Tal] = f2bf(x3);
+            bf16_t* p = vc + ((size_t)s * H + (c >> 6)) * 64 * Tal + vfrag_index(pos, c & 63);     // dims c..c+3: lanes 8 elements apart
+            p[0] = f2bf(x0); p[8] = f2bf(x1); p[16] = f2bf(x2); p[24] = f2bf(x3);
         }
     }
 };
@@ -146,7 +146,7 @@ struct EpQKVEnc {              // q (x 64^-1/2), k as [b][h][s][64]; v transpose
     }
 };
 
-struct EpCrossKV {             // K_x [kvl][b][h][s][64], V_x transposed [kvl][b][h][64][s] bf16   (HF:modeling_whisper.py:322-335)
+struct EpCrossKV {             // K_x [kvl][b][h][s][64], V_x [kvl][b][h] as V^T MFMA fragments (vfrag_index)   (HF:modeling_whisper.py:322-335)
     static constexpr bool kPre = false;
     bf16_t* kx; bf16_t* vx; const float* bias; int Spad, H, d, B;
     __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const {
@@ -160,8 +160,8 @@ struct EpCrossKV {             // K_x [kvl][b][h][s][64], V_x transposed [kvl][b
             uint2 o; o.x = pack_bf2(v[0] + bb.x, v[1] + bb.y); o.y = pack_bf2(v[2] + bb.z, v[3] + bb.w);
             *reinterpret_cast<uint2*>(kx + slab + (size_t)s * 64 + (c & 63)) = o;
         } else {
-            bf16_t* p = vx + slab + (size_t)(c & 63) * Spad + s;
-            p[0] = f2bf(v[0] + bb.x); p[Spad] = f2bf(v[1] + bb.y); p[2 * (size_t)Spad] = f2bf(v[2] + bb.z); p[3 * (size_t)Spad] = f2bf(v[3] + bb.w);
+            bf16_t* p = vx + slab + vfrag_index(s, c & 63);
+            p[0] = f2bf(v[0] + bb.x); p[8] = f2bf(v[1] + bb.y); p[16] = f2bf(v[2] + bb.z); p[24] = f2bf(v[3] + bb.w);
         }
     }
 };

@@ -78,6 +78,7 @@ struct wm_ctx {
     int* carry = nullptr;                                                   // [maxB] next base pass is redundant
     bool fuse = true;
     bool host_carry = false;                                                // single-stream runs: the host skips the base pass
+    bool dev_carry = false;                                                 // several streams: per-stream carry flags on the device
     int *hostflags = nullptr, *hostflags_dev = nullptr;                     // host-mapped {carry, finished}
     hipGraphExec_t graph_base = nullptr;
     bf16_t *xbuf = nullptr, *fbuf = nullptr, *ybuf = nullptr;

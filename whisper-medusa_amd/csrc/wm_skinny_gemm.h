@@ -283,6 +283,76 @@ k_skinny_gemm_mt(const bf16_t* __restrict__ W, int N16, int K32, int ksplit, int
     }
 }
 
+// Many token tiles (verify pass of a large batch): a wave owns RT weight row tiles x TT token tiles x ONE K-slice,
+// so every weight fragment feeds 2*TT MFMAs and every token fragment RT of them (register blocking cuts the L2
+// traffic of the operand re-reads by RT resp. TT); blockIdx.y walks the token-tile groups, so the chip is filled
+// by tokens as well as by features and the weights are re-read from L2 / Infinity Cache, not HBM.  Per output the
+// accumulation order is the 16-row kernel's (k ascending, hi then lo; K-slices summed in order): bit-identical.
+template <int NKR, int RT, int TT, class Ep>
+__global__ void __launch_bounds__(640)
+k_rows_gemm(const bf16_t* __restrict__ W, int N16, int K32, int ksplit, const int* __restrict__ done,
+            const bf16_t* __restrict__ X, size_t plane, int MT, Ep ep)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (done && *done) return;
+    const int lane = threadIdx.x & 63;
+    const int ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rt0 = blockIdx.x * RT, mt0 = blockIdx.y * TT;
+    const int kt0 = ks * NKR;
+    const bf16_t* wp[RT]; const bf16_t* xp[TT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) wp[i] = W + ((size_t)min(rt0 + i, N16 - 1) * K32 + kt0) * 512 + lane * 8;
+#pragma unroll
+    for (int j = 0; j < TT; ++j) xp[j] = X + ((size_t)min(mt0 + j, MT - 1) * K32 + kt0) * 512 + lane * 8;
+    f32x4_t acc[RT][TT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < TT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    constexpr int G = 4;
+#pragma unroll
+    for (int kg = 0; kg < NKR; kg += G) {
+        bf16x8_t a[RT][G], xh[TT][G], xl[TT][G];
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+#pragma unroll
+            for (int j = 0; j < TT; ++j) { xh[j][u] = ld_frag(xp[j] + (size_t)(kg + u) * 512); xl[j][u] = ld_frag(xp[j] + plane + (size_t)(kg + u) * 512); }
+#pragma unroll
+            for (int i = 0; i < RT; ++i) a[i][u] = ld_frag(wp[i] + (size_t)(kg + u) * 512);
+        }
+#pragma unroll
+        for (int u = 0; u < G; ++u)
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int j = 0; j < TT; ++j) { acc[i][j] = mfma16(a[i][u], xh[j][u], acc[i][j]); acc[i][j] = mfma16(a[i][u], xl[j][u], acc[i][j]); }
+    }
+    if (ksplit > 1) {
+        float4* red = reinterpret_cast<float4*>(smem);
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int j = 0; j < TT; ++j)
+                red[((i * TT + j) * ksplit + ks) * 64 + lane] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        __syncthreads();
+        for (int e = threadIdx.x; e < RT * TT * 64; e += blockDim.x) {
+            const int t = e >> 6, l2 = e & 63, i = t / TT, j = t - i * TT;
+            f32x4_t sacc = {0.f, 0.f, 0.f, 0.f};
+            for (int k2 = 0; k2 < ksplit; ++k2) {
+                const float4 p = red[(t * ksplit + k2) * 64 + l2];
+                sacc[0] += p.x; sacc[1] += p.y; sacc[2] += p.z; sacc[3] += p.w;
+            }
+            if (rt0 + i < N16 && mt0 + j < MT) ep.store4((mt0 + j) * 16 + (l2 & 15), (rt0 + i) * 16 + 4 * (l2 >> 4), sacc);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int j = 0; j < TT; ++j)
+                if (rt0 + i < N16 && mt0 + j < MT) ep.store4((mt0 + j) * 16 + (lane & 15), (rt0 + i) * 16 + 4 * (lane >> 4), acc[i][j]);
+    }
+}
+
 // ---- host-side launch plan -------------------------------------------------------------------
 static const int* g_skinny_done = nullptr;     // device flags checked by every launch of this translation unit
 static const int* g_skinny_skip = nullptr;
@@ -337,17 +407,38 @@ static inline hipError_t launch_skinny(hipStream_t st, const bf16_t* W, int N16,
     return launch_skinny_u<4>(st, W, N16, K32, p, ld, ep);
 }
 
+template <int NKR, class Ep>
+static inline hipError_t launch_skinny_mt_nk(hipStream_t st, const bf16_t* W, int N16, int K32, const SkinnyPlan& p,
+                                             const bf16_t* X, size_t plane, int MT, const Ep& ep) {
+    static const int mt_tiled = skinny_env("WM_ROWS_GEMM_MIN_TILES", 3);      // token tiles from which the register-blocked kernel runs
+    if (MT >= mt_tiled) {
+        // RT x TT register tile: 4 x 2 while a K-slice batch fits the register file, 2 x 2 for 16-fragment slices' bigger blocks
+        constexpr int RT = 4, TT = 2;
+        const dim3 grid((N16 + RT - 1) / RT, (MT + TT - 1) / TT);
+        const size_t lds = p.ksplit > 1 ? (size_t)RT * TT * p.ksplit * 1024 : 0;
+        auto kern = k_rows_gemm<NKR, RT, TT, Ep>;
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(64 * p.ksplit), lds, st, W, N16, K32, p.ksplit, g_skinny_done, X, plane, MT, ep);
+        return hipGetLastError();
+    }
+    const int grid = (N16 + p.rt - 1) / p.rt, threads = 64 * p.ksplit * p.rt;
+    const size_t lds = p.ksplit > 1 ? (size_t)p.rt * p.ksplit * 1024 : 0;
+    hipLaunchKernelGGL((k_skinny_gemm_mt<NKR, Ep>), dim3(grid), dim3(threads), lds, st, W, N16, K32, p.ksplit, p.rt, g_skinny_done, X, plane, MT, ep);
+    return hipGetLastError();
+}
+
 template <class Ep>
 static inline hipError_t launch_skinny_mt(hipStream_t st, const bf16_t* W, int N16, int K32, const SkinnyPlan& p,
                                           const bf16_t* X, size_t plane, int MT, const Ep& ep) {
-    const int grid = (N16 + p.rt - 1) / p.rt, threads = 64 * p.ksplit * p.rt, nk = K32 / p.ksplit;
-    const size_t lds = p.ksplit > 1 ? (size_t)p.rt * p.ksplit * 1024 : 0;
-    if (nk == 16) hipLaunchKernelGGL((k_skinny_gemm_mt<16, Ep>), dim3(grid), dim3(threads), lds, st, W, N16, K32, p.ksplit, p.rt, g_skinny_done, X, plane, MT, ep);
-    else if (nk == 12) hipLaunchKernelGGL((k_skinny_gemm_mt<12, Ep>), dim3(grid), dim3(threads), lds, st, W, N16, K32, p.ksplit, p.rt, g_skinny_done, X, plane, MT, ep);
-    else if (nk == 8) hipLaunchKernelGGL((k_skinny_gemm_mt<8, Ep>), dim3(grid), dim3(threads), lds, st, W, N16, K32, p.ksplit, p.rt, g_skinny_done, X, plane, MT, ep);
-    else if (nk == 4) hipLaunchKernelGGL((k_skinny_gemm_mt<4, Ep>), dim3(grid), dim3(threads), lds, st, W, N16, K32, p.ksplit, p.rt, g_skinny_done, X, plane, MT, ep);
-    else return hipErrorInvalidConfiguration;
-    return hipGetLastError();
+    const int nk = K32 / p.ksplit;
+    if (nk == 16) return launch_skinny_mt_nk<16>(st, W, N16, K32, p, X, plane, MT, ep);
+    if (nk == 12) return launch_skinny_mt_nk<12>(st, W, N16, K32, p, X, plane, MT, ep);
+    if (nk == 8) return launch_skinny_mt_nk<8>(st, W, N16, K32, p, X, plane, MT, ep);
+    if (nk == 4) return launch_skinny_mt_nk<4>(st, W, N16, K32, p, X, plane, MT, ep);
+    return hipErrorInvalidConfiguration;
 }
 
 // out = X (R token rows, packed hi/lo planes in global memory) times W^T (N = 16*N16 features, K = 32*K32)
