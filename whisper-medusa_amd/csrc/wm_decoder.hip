@@ -121,13 +121,21 @@ struct KVStep { bf16x8_t k00, k01, k10, k11, v[4]; };        // one 32-key step:
 struct AttnAcc { float m_run, l_run; f32x4_t o[4]; };
 
 // 8 fully coalesced 16-B-per-lane loads: K rows are 128-B lines, the V^T fragments of a step are 4 contiguous KiB
+// NT: the cross K/V of a (stream, head) is read by one block once per pass — stream it past the caches (nt policy)
+template <bool NT>
 __device__ __forceinline__ void kv_load(KVStep& t, const bf16_t* kp, const bf16_t* vp, int kb, int c, int g, int lane)
 {
     const bf16_t* kr = kp + (size_t)(kb + c) * 64 + g * 8;
-    t.k00 = ld_frag(kr); t.k01 = ld_frag(kr + 32); t.k10 = ld_frag(kr + 16 * 64); t.k11 = ld_frag(kr + 16 * 64 + 32);
     const bf16_t* vr = vp + ((size_t)(kb >> 5) * 256 + lane) * 8;
+    if (NT) {
+        t.k00 = ld_frag_nt(kr); t.k01 = ld_frag_nt(kr + 32); t.k10 = ld_frag_nt(kr + 16 * 64); t.k11 = ld_frag_nt(kr + 16 * 64 + 32);
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) t.v[dt] = ld_frag(vr + dt * 512);
+        for (int dt = 0; dt < 4; ++dt) t.v[dt] = ld_frag_nt(vr + dt * 512);
+    } else {
+        t.k00 = ld_frag(kr); t.k01 = ld_frag(kr + 32); t.k10 = ld_frag(kr + 16 * 64); t.k11 = ld_frag(kr + 16 * 64 + 32);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) t.v[dt] = ld_frag(vr + dt * 512);
+    }
 }
 
 // scores of 32 keys x 16 queries, online softmax, O^T += V^T P^T
@@ -168,7 +176,7 @@ __device__ __forceinline__ void attn_step(AttnAcc& st, const KVStep& t, const bf
     }
 }
 
-template <bool CROSS>
+template <bool CROSS, bool NT>
 __global__ void __launch_bounds__(256)
 k_attn_mfma(const float* __restrict__ q, const bf16_t* __restrict__ kmat, const bf16_t* __restrict__ vtmat,
             const int* __restrict__ base, bf16_t* __restrict__ xout, size_t xplane, float* __restrict__ ml, float* __restrict__ po,
@@ -197,13 +205,13 @@ k_attn_mfma(const float* __restrict__ q, const bf16_t* __restrict__ kmat, const 
 
     // K/V do not depend on q: the first loads go out before anything else.  Self: wave w walks the 32-key steps
     // w, w+4, ... with the next step in flight.  Cross: a wave owns 64 keys (two steps) of every split and keeps the
-    // whole NEXT split (16 KiB per wave) in flight while it works on this one — bytes in flight, not occupancy, is what
-    // the cross-K/V stream needs.
+    // same two steps of the NEXT split in flight while it works on this one (16 KiB per wave, 3 blocks per CU): bytes in
+    // flight are what the cross-K/V stream needs.
     KVStep c0 = {}, c1 = {};
     int kb = CROSS ? sp0 * 256 + w * 64 : 32 * w;
     int kend = CROSS ? min(S, kb + 64) : min(b0 + Mper, rows_alloc);
-    if (kb < kend) kv_load(c0, kp, vp, kb, c, g, lane);
-    if (CROSS && kb + 32 < kend) kv_load(c1, kp, vp, kb + 32, c, g, lane);
+    if (kb < kend) kv_load<NT>(c0, kp, vp, kb, c, g, lane);
+    if (CROSS && kb + 32 < kend) kv_load<NT>(c1, kp, vp, kb + 32, c, g, lane);
     bf16x8_t qhi[2], qlo[2];
     {
         float qv[8];
@@ -231,19 +239,18 @@ k_attn_mfma(const float* __restrict__ q, const bf16_t* __restrict__ kmat, const 
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) st.o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         if (CROSS) {
-            KVStep n0 = c0, n1 = c1;
-            const int nkb = (sp + 1) * 256 + w * 64, nkend = min(S, nkb + 64);
-            if (sp + 1 < sp1 && nkb < nkend) kv_load(n0, kp, vp, nkb, c, g, lane);
-            if (sp + 1 < sp1 && nkb + 32 < nkend) kv_load(n1, kp, vp, nkb + 32, c, g, lane);
+            // each step's registers are refilled with the same step of the NEXT split as soon as its math has issued
+            const int nkb = (sp + 1) * 256 + w * 64, nkend = (sp + 1 < sp1) ? min(S, nkb + 64) : 0;
             if (kb < kend) attn_step(st, c0, qhi, qlo, kb, g, limit);
+            if (nkb < nkend) kv_load<NT>(c0, kp, vp, nkb, c, g, lane);
             if (kb + 32 < kend) attn_step(st, c1, qhi, qlo, kb + 32, g, limit);
-            c0 = n0; c1 = n1; kb = nkb; kend = nkend;
+            if (nkb + 32 < nkend) kv_load<NT>(c1, kp, vp, nkb + 32, c, g, lane);
+            kb = nkb; kend = nkend;
         } else {
             for (; kb < kend; kb += 128) {
-                KVStep n0 = c0;
-                if (kb + 128 < kend) kv_load(n0, kp, vp, kb + 128, c, g, lane);
-                attn_step(st, c0, qhi, qlo, kb, g, limit);
-                c0 = n0;
+                const bool second = CROSS ? false : ((kb >> 7) & 1);        // two register sets alternate: the next step is in flight
+                if (kb + 128 < kend) { if (second) kv_load<NT>(c0, kp, vp, kb + 128, c, g, lane); else kv_load<NT>(c1, kp, vp, kb + 128, c, g, lane); }
+                if (second) attn_step(st, c1, qhi, qlo, kb, g, limit); else attn_step(st, c0, qhi, qlo, kb, g, limit);
             }
         }
         const float m_run = st.m_run, l_run = st.l_run;
@@ -557,7 +564,7 @@ __global__ void k_accept_vanilla1(GenDev gp, int B, const int* __restrict__ amax
 static inline int xattn_blocks_per_head(int NS, int heads_total)
 {
     static const int target = [] { const char* v = std::getenv("WM_XATTN_TARGET_BLOCKS"); return v ? std::atoi(v) : 768; }();
-    int gx = (target + heads_total - 1) / heads_total;
+    int gx = (target + heads_total / 2) / heads_total;       // ~768 resident block slots (3 per CU): one round when possible
     gx = std::max(1, std::min(gx, NS));
     int spb = std::min((NS + gx - 1) / gx, WM_XATTN_SPB_MAX);
     return (NS + spb - 1) / spb;
@@ -581,7 +588,7 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
                               EpQKVDec{ctx->qbuf, kc, vc, w.qkv_b, base, Mper, d, H, ctx->Tal, R}, ctx->xbuf, xpl));
     if (kv_only) return WM_OK;
     // 2. causal self-attention over the contiguous cache
-    hipLaunchKernelGGL(k_attn_mfma<false>, dim3(1, H, nb), dim3(256), 0, st, ctx->qbuf, kc, vc, base, ctx->xbuf, xpl,
+    hipLaunchKernelGGL((k_attn_mfma<false, false>), dim3(1, H, nb), dim3(256), 0, st, ctx->qbuf, kc, vc, base, ctx->xbuf, xpl,
                        nullptr, nullptr, nullptr, g_skinny_done, g_skinny_skip, sskip, Mper, H, ctx->Tal, 0, 1, K32);
     WM_HIP(hipGetLastError());
     // 3. out_proj + residual
@@ -590,8 +597,13 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
     WM_HIP(launch_skinny_norm(st, w.cq_w, d / 16, K32, h, w.ln2_w, w.ln2_b, d, R, 1, 0, 1, EpF32{ctx->qbuf, w.cq_b, d, R, 0.125f},
                               ctx->xbuf, xpl));
     // 5. cross-attention over the encoder K/V, 256 keys per block
-    hipLaunchKernelGGL(k_attn_mfma<true>, dim3(xattn_blocks_per_head(ctx->NS, H * nb), H, nb), dim3(256), 0, st, ctx->qbuf, kx, vx, base, ctx->xbuf, xpl,
-                       ctx->cml, ctx->co, ctx->ticket, g_skinny_done, g_skinny_skip, sskip, Mper, H, ctx->Spad, ctx->S, ctx->NS, K32);
+    static const bool xattn_nt = [] { const char* v = std::getenv("WM_XATTN_NT"); return v ? std::atoi(v) != 0 : true; }();
+    if (xattn_nt)
+        hipLaunchKernelGGL((k_attn_mfma<true, true>), dim3(xattn_blocks_per_head(ctx->NS, H * nb), H, nb), dim3(256), 0, st, ctx->qbuf, kx, vx, base, ctx->xbuf, xpl,
+                           ctx->cml, ctx->co, ctx->ticket, g_skinny_done, g_skinny_skip, sskip, Mper, H, ctx->Spad, ctx->S, ctx->NS, K32);
+    else
+        hipLaunchKernelGGL((k_attn_mfma<true, false>), dim3(xattn_blocks_per_head(ctx->NS, H * nb), H, nb), dim3(256), 0, st, ctx->qbuf, kx, vx, base, ctx->xbuf, xpl,
+                           ctx->cml, ctx->co, ctx->ticket, g_skinny_done, g_skinny_skip, sskip, Mper, H, ctx->Spad, ctx->S, ctx->NS, K32);
     WM_HIP(hipGetLastError());
     // 6. out_proj + residual
     WM_HIP(launch_skinny_rows(st, w.cout_w, d / 16, K32, R, ctx->xbuf, xpl, EpResidual{h, w.cout_b, d, R}));
