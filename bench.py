@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--logit-std", type=float, default=4.5,
                     help="std of the vocabulary logits of the random-init checkpoint; 4.5 gives ~3.5 tokens/iteration "
                          "under typical acceptance, close to the ~3 implied by the reference's x1.5 speed-up")
+    ap.add_argument("--micro-batches", type=int, default=1,
+                    help="decode the per-GPU batch as this many concurrent micro-batches (whisper_medusa/pool.py); 1 = one context")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=6)
     args = ap.parse_args()
@@ -111,9 +113,17 @@ def main():
     gp = synth.bench_gen_params(cfg, max_new_tokens=args.max_new, accept_mode=ACCEPT_TYPICAL)
     step_no = [0]
 
+    pool = None
+    if args.micro_batches > 1:
+        from whisper_medusa.pool import ContextPool
+        pool = ContextPool(cfg, blob, offs, args.micro_batches, B)
+
     def step():
         wav = wavs[step_no[0] % n_sets]
         step_no[0] += 1
+        if pool is not None:
+            seqs = pool.run(wav, gp, from_wav=True)
+            return sum(len(s) - len(gp.prompt) for s in seqs), pool.last_stats
         feats = eng.logmel(wav)
         eng.encode(feats)
         seqs = eng.decode(gp, B)
@@ -144,6 +154,8 @@ def main():
 
     # ---- anchor: vanilla greedy decoding on the same engine / clips / budget (one untimed-region step) ----
     gpv = synth.bench_gen_params(cfg, max_new_tokens=args.max_new, vanilla=True)
+    if pool is not None:
+        eng.encode(eng.logmel(wavs[0]))      # the timed steps ran on the pool's contexts
     eng.decode(gpv, B)                       # warm
     eng.decode(gpv, B)
     stv = eng.stats()
@@ -172,7 +184,8 @@ def main():
         "config": {"workload": f"whisper-{args.model} + medusa-{args.heads} K={cfg.medusa_num_heads}, "
                                f"{B} x 30 s clip(s) per GPU, log-mel+encoder+decode, max_new_tokens={args.max_new}, "
                                f"typical acceptance (T=1.0), hipGraph decode loop, random-init weights (logit_std={args.logit_std})",
-                   "streams_per_gpu": B, "parallelism": f"dp{world}", "max_new_tokens": args.max_new},
+                   "streams_per_gpu": B, "micro_batches": args.micro_batches, "parallelism": f"dp{world}",
+                   "max_new_tokens": args.max_new},
         "tokens_per_sec_per_gpu": round(tokens_all / elapsed / world, 2),
         "rtf": round(elapsed / audio_s, 6), "x_realtime": round(audio_s / elapsed, 2),
         "decode_tokens_per_sec_per_gpu": round(tokens / (ms_dec * 1e-3), 2),

@@ -176,6 +176,58 @@ def test_many_streams_batched_path(gpu):
     eng.close()
 
 
+def test_micro_batches_match_single_context(gpu):
+    """7 ragged clips through generate() as 1, 2 and 3 concurrent micro-batches (own context + HIP stream each,
+    whisper_medusa/pool.py): identical ids, and equal to the oracle for the first streams."""
+    cfg = MedusaConfig.micro(K=4)
+    sd = synth.synth_state_dict(cfg, seed=11)
+    model = WhisperMedusaModel(cfg, sd, device=gpu, max_batch=7)
+    n = cfg.n_mel_frames * 160
+    feats = model.extract_features([clip_for(cfg, i)[: n // (1 + i % 2)] for i in range(7)])
+    one = model.generate(feats, max_new_tokens=28)
+    st1 = dict(model.last_stats)
+    for mb in (2, 3):
+        model.set_micro_batches(mb)
+        out = model.generate(feats, max_new_tokens=28)
+        assert torch.equal(out, one), mb
+        assert model.last_stats["micro_batches"] == mb
+        assert model.last_stats["tokens_emitted"] == st1["tokens_emitted"]
+        assert model.last_stats["accept_hist"] == st1["accept_hist"]
+    model.set_micro_batches(1)
+    orc = Oracle(cfg, sd, sim="bf16")
+    gp = model._gen_params(None, None, None, 28, None, None, False, None, None, None, None, None)
+    model.engine.encode(feats)
+    enc = model.engine.encoder_output(7)
+    P = len(gp.prompt)
+    for b in range(2):
+        ref = orc.decode(enc[b], gp).ids
+        want = ref[: ref.index(gp.eos_token_id) + 1] if gp.eos_token_id in ref[P:] else ref
+        got = one[b].tolist()
+        assert got[: len(want)] == want and all(t == gp.pad_token_id for t in got[len(want):])
+    model.engine.close()
+
+
+def test_wide_batch_token_tile_gemm(gpu):
+    """20 streams x (K+1 = 11) = 220 verify rows = 14 token tiles: the register-blocked token-tile GEMM, multi-split
+    cross-attention blocks and the per-stream hidden-state carry, against single-stream runs of the same engine."""
+    cfg = MedusaConfig.micro(K=10)
+    sd = synth.synth_state_dict(cfg, seed=12)
+    B = 20
+    model = WhisperMedusaModel(cfg, sd, device=gpu, max_batch=B)
+    eng = model.engine
+    n = cfg.n_mel_frames * 160
+    feats = model.extract_features([clip_for(cfg, i)[: n // (1 + i % 3)] for i in range(B)])
+    gp = golden_gen_params(cfg, ACCEPT_TYPICAL, 30)
+    eng.encode(feats)
+    both = eng.decode(gp, B)
+    st = eng.stats()
+    assert sum(st["accept_hist"][1:]) > 0                      # some stream carried its hidden state
+    for b in (0, 1, 7, 13, 19):
+        eng.encode(feats[b: b + 1].contiguous())
+        assert eng.decode(gp, 1)[0] == both[b], b
+    eng.close()
+
+
 def test_generate_api_end_to_end(rig):
     """from wav: log-mel -> encoder -> decode through the drop-in generate() (README.md:101-142 call shape)."""
     feats = rig.model.extract_features(rig.wavs[:1])

@@ -157,3 +157,25 @@ def test_checkpoint_directory_roundtrip_cpu(tmp_path):
     b1, o1 = weights.build_blob(cfg, sd)
     b2, o2 = weights.build_blob(cfg2, sd2)           # tied proj_out falls back to embed_tokens
     assert torch.equal(b1, b2) and o1.tolist() == o2.tolist()
+
+
+def test_pool_sharding_and_stats_merge():
+    """whisper_medusa/pool.py host logic: contiguous balanced shards, whole-batch statistics."""
+    from whisper_medusa.pool import merge_stats, shard_bounds
+    assert shard_bounds(32, 2) == [(0, 16), (16, 32)]
+    assert shard_bounds(7, 3) == [(0, 3), (3, 5), (5, 7)]
+    assert shard_bounds(2, 4) == [(0, 1), (1, 2)]
+    assert shard_bounds(1, 1) == [(0, 1)]
+    for n in range(1, 40):
+        for parts in range(1, 6):
+            b = shard_bounds(n, parts)
+            assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(len(b) - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert min(sizes) >= 1 and max(sizes) - min(sizes) <= 1
+    a = dict(iterations=10, iterations_launched=12, tokens_emitted=100, accept_hist=[5, 3, 2], ms_logmel=0.1, ms_encode=2.0,
+             ms_decode=30.0, graph_replays=9)
+    b = dict(iterations=14, iterations_launched=16, tokens_emitted=90, accept_hist=[6, 1, 7], ms_logmel=0.2, ms_encode=1.0,
+             ms_decode=40.0, graph_replays=13)
+    m = merge_stats([a, b])
+    assert m["iterations"] == 14 and m["iterations_launched"] == 28 and m["tokens_emitted"] == 190
+    assert m["accept_hist"] == [11, 4, 9] and m["ms_decode"] == 40.0 and m["ms_encode"] == 2.0 and m["micro_batches"] == 2

@@ -44,6 +44,27 @@ __device__ __host__ __forceinline__ size_t vfrag_index(int key, int dim) {
     return ((size_t)((key >> 5) * 4 + (dim >> 4)) * 64 + (dim & 15) + 16 * (rr >> 2)) * 8 + (r >> 4) * 4 + (rr & 3);
 }
 
+// Reductions over the four 16-lane rows of a wavefront (lanes c, c+16, c+32, c+48), every lane gets the result:
+// gfx950's v_permlane16_swap / v_permlane32_swap exchange rows in the VALU (a few cycles) where __shfl_xor(.,16|32)
+// goes through the LDS crossbar (ds_bpermute, ~100 cycles of latency on the critical path of every softmax step and
+// LayerNorm).  Same operand pairing as the xor-16-then-xor-32 butterfly: bit-identical results.
+__device__ __forceinline__ float rows4_sum(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float y = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const unsigned w = __float_as_uint(y);
+    const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ float rows4_max(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float y = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const unsigned w = __float_as_uint(y);
+    const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

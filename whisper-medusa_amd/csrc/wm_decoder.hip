@@ -151,8 +151,7 @@ __device__ __forceinline__ void attn_step(AttnAcc& st, const KVStep& t, const bf
         if (kb + 16 + 4 * g + r >= limit) s1[r] = -INFINITY;
     }
     float mx = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = rows4_max(mx);
     const float m_new = fmaxf(st.m_run, mx);
     const float alpha = (m_new == -INFINITY) ? 1.f : __expf(st.m_run - m_new);
     float p[8], rs = 0.f;
@@ -162,8 +161,7 @@ __device__ __forceinline__ void attn_step(AttnAcc& st, const KVStep& t, const bf
         p[4 + r] = (m_new == -INFINITY) ? 0.f : __expf(s1[r] - m_new);
         rs += p[r] + p[4 + r];
     }
-    rs += __shfl_xor(rs, 16, 64);
-    rs += __shfl_xor(rs, 32, 64);
+    rs = rows4_sum(rs);
     st.l_run = st.l_run * alpha + rs;
     st.m_run = m_new;
     bf16x8_t phi, plo;

@@ -115,23 +115,46 @@ static inline hipError_t launch_gemm_tiled(hipStream_t st, const bf16_t* X, cons
 // =============================================================================================
 template <int QT>                 // QT x 16 queries per wave: every K / V^T fragment is reused by QT query tiles
 __global__ void __launch_bounds__(256)
-k_flash_enc(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kt, const bf16_t* __restrict__ Vt,
+k_flash_enc(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kt, const bf16_t* __restrict__ Vf,
             bf16_t* __restrict__ out, int S, int Spad, int H, int K32out)
 {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // The 4 waves of a block share the K / V of their (batch, head): a 64-key step = 8 K fragments + 8 V^T fragments
+    // (16 KiB) is brought in ONCE per block by LDS-DMA (each wave issues 4 of the 16 KiB-sized loads) into a 3-stage
+    // ring — two steps are in flight while one is consumed — and read back with lane-linear ds_read_b128.
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NST = 3, STAGE = 16 * 1024;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, c = lane & 15;
     const int hd = blockIdx.y, b = blockIdx.z;
     const size_t bh = (size_t)b * H + hd;
     const int q0 = (blockIdx.x * 4 + w) * 16 * QT;
+    const bf16_t* kbase = Kt + bh * Spad * 64;
+    const bf16_t* vbase = Vf + bh * 64 * Spad;
+    const int nsteps = (S + 63) >> 6;
+
+    auto stage_load = [&](int stage, int step) {
+        char* sb = smem + stage * STAGE;
+        const int kb = step * 64;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = 2 * w + i;                                   // K fragment f: key tile f >> 1, dims (f & 1) * 32 ..
+            glds16(kbase + (size_t)(kb + (f >> 1) * 16 + c) * 64 + (f & 1) * 32 + g * 8, sb + f * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = 2 * w + i;                                   // V^T fragment f of the step: contiguous in vfrag layout
+            glds16(vbase + ((size_t)(kb >> 5) * 256 + f * 64 + lane) * 8, sb + 8192 + f * 1024);
+        }
+    };
+    stage_load(0, 0);
+    if (nsteps > 1) stage_load(1, 1);
+
     bf16x8_t qb[QT][2];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         const bf16_t* qp = Q + (bh * Spad + q0 + t * 16 + c) * 64 + g * 8;
         qb[t][0] = ld_frag(qp); qb[t][1] = ld_frag(qp + 32);
     }
-    const bf16_t* kbase = Kt + bh * Spad * 64;
-    const bf16_t* vbase = Vt + bh * 64 * Spad;
-
     float m_run[QT], l_run[QT];
     f32x4_t o[QT][4];
 #pragma unroll
@@ -141,54 +164,57 @@ k_flash_enc(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kt, const b
         for (int dt = 0; dt < 4; ++dt) o[t][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
 
-    for (int kb = 0; kb < S; kb += 32) {
-        const bf16_t* kp = kbase + (size_t)(kb + c) * 64 + g * 8;
-        const bf16x8_t a00 = ld_frag(kp), a01 = ld_frag(kp + 32);
-        const bf16x8_t a10 = ld_frag(kp + 16 * 64), a11 = ld_frag(kp + 16 * 64 + 32);
-        bf16x8_t va[4];
+    for (int i = 0; i < nsteps; ++i) {
+        // stage i has landed when at most the 4 loads of stage i+1 are still outstanding (vmcnt counts in order)
+        if (i + 1 < nsteps) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                               // everyone's part landed; everyone is done with stage i-1
+        if (i + 2 < nsteps) stage_load((i + 2) % NST, i + 2);
+        const bf16_t* sb = reinterpret_cast<const bf16_t*>(smem + (i % NST) * STAGE);
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const bf16_t* vp = vbase + (size_t)(dt * 16 + c) * Spad + kb + 4 * g;
-            const uint2 lo = *reinterpret_cast<const uint2*>(vp), hi = *reinterpret_cast<const uint2*>(vp + 16);
-            uint4 vw; vw.x = lo.x; vw.y = lo.y; vw.z = hi.x; vw.w = hi.y;
-            va[dt] = __builtin_bit_cast(bf16x8_t, vw);
-        }
-        const bool tail = kb + 32 > S;
+        for (int hh = 0; hh < 2; ++hh) {
+            const int kb = i * 64 + hh * 32;
+            if (kb >= S) break;                                        // block-uniform
+            const bf16x8_t a00 = ld_frag(sb + ((4 * hh + 0) * 64 + lane) * 8), a01 = ld_frag(sb + ((4 * hh + 1) * 64 + lane) * 8);
+            const bf16x8_t a10 = ld_frag(sb + ((4 * hh + 2) * 64 + lane) * 8), a11 = ld_frag(sb + ((4 * hh + 3) * 64 + lane) * 8);
+            bf16x8_t va[4];
 #pragma unroll
-        for (int t = 0; t < QT; ++t) {
-            f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-            s0 = mfma16(a00, qb[t][0], s0); s0 = mfma16(a01, qb[t][1], s0);
-            s1 = mfma16(a10, qb[t][0], s1); s1 = mfma16(a11, qb[t][1], s1);
-            if (tail) {
+            for (int dt = 0; dt < 4; ++dt) va[dt] = ld_frag(sb + 4096 + ((4 * hh + dt) * 64 + lane) * 8);
+            const bool tail = kb + 32 > S;
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+                s0 = mfma16(a00, qb[t][0], s0); s0 = mfma16(a01, qb[t][1], s0);
+                s1 = mfma16(a10, qb[t][0], s1); s1 = mfma16(a11, qb[t][1], s1);
+                if (tail) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (kb + 4 * g + r >= S) s0[r] = -INFINITY;
+                        if (kb + 16 + 4 * g + r >= S) s1[r] = -INFINITY;
+                    }
+                }
+                float mx = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
+                mx = rows4_max(mx);
+                const float m_new = fmaxf(m_run[t], mx);
+                const float alpha = __expf(m_run[t] - m_new);
+                float p0[4], p1[4], rs = 0.f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (kb + 4 * g + r >= S) s0[r] = -INFINITY;
-                    if (kb + 16 + 4 * g + r >= S) s1[r] = -INFINITY;
+                    p0[r] = __expf(s0[r] - m_new); p1[r] = __expf(s1[r] - m_new);
+                    rs += p0[r] + p1[r];
                 }
-            }
-            float mx = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run[t], mx);
-            const float alpha = __expf(m_run[t] - m_new);
-            float p0[4], p1[4], rs = 0.f;
+                rs = rows4_sum(rs);
+                l_run[t] = l_run[t] * alpha + rs;
+                m_run[t] = m_new;
+                uint4 pw;
+                pw.x = pack_bf2(p0[0], p0[1]); pw.y = pack_bf2(p0[2], p0[3]);
+                pw.z = pack_bf2(p1[0], p1[1]); pw.w = pack_bf2(p1[2], p1[3]);
+                const bf16x8_t pb = __builtin_bit_cast(bf16x8_t, pw);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                p0[r] = __expf(s0[r] - m_new); p1[r] = __expf(s1[r] - m_new);
-                rs += p0[r] + p1[r];
-            }
-            rs += __shfl_xor(rs, 16, 64);
-            rs += __shfl_xor(rs, 32, 64);
-            l_run[t] = l_run[t] * alpha + rs;
-            m_run[t] = m_new;
-            uint4 pw;
-            pw.x = pack_bf2(p0[0], p0[1]); pw.y = pack_bf2(p0[2], p0[3]);
-            pw.z = pack_bf2(p1[0], p1[1]); pw.w = pack_bf2(p1[2], p1[3]);
-            const bf16x8_t pb = __builtin_bit_cast(bf16x8_t, pw);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                o[t][dt][0] *= alpha; o[t][dt][1] *= alpha; o[t][dt][2] *= alpha; o[t][dt][3] *= alpha;
-                o[t][dt] = mfma16(va[dt], pb, o[t][dt]);
+                for (int dt = 0; dt < 4; ++dt) {
+                    o[t][dt][0] *= alpha; o[t][dt][1] *= alpha; o[t][dt][2] *= alpha; o[t][dt][3] *= alpha;
+                    o[t][dt] = mfma16(va[dt], pb, o[t][dt]);
+                }
             }
         }
     }
@@ -402,9 +428,9 @@ int wm_enc_encode(wm_ctx* ctx, const float* feats, int B)
         WM_HIP(hipGetLastError());
         WM_HIP(launch_gemm_tiled(st, ctx->exn, w.qkv_w, M, 3 * d, K32, EpQKVEnc{ctx->eq, ctx->ek, ctx->evt, w.qkv_b, Spad, H, d}));
         if (B * (Spad / 128) * H >= 256 && Spad % 256 == 0)
-            hipLaunchKernelGGL(k_flash_enc<4>, dim3(Spad / 256, H, B), dim3(256), 0, st, ctx->eq, ctx->ek, ctx->evt, ctx->exn, S, Spad, H, K32);
+            hipLaunchKernelGGL(k_flash_enc<4>, dim3(Spad / 256, H, B), dim3(256), 3 * 16 * 1024, st, ctx->eq, ctx->ek, ctx->evt, ctx->exn, S, Spad, H, K32);
         else
-            hipLaunchKernelGGL(k_flash_enc<2>, dim3(Spad / 128, H, B), dim3(256), 0, st, ctx->eq, ctx->ek, ctx->evt, ctx->exn, S, Spad, H, K32);
+            hipLaunchKernelGGL(k_flash_enc<2>, dim3(Spad / 128, H, B), dim3(256), 3 * 16 * 1024, st, ctx->eq, ctx->ek, ctx->evt, ctx->exn, S, Spad, H, K32);
         WM_HIP(hipGetLastError());
         WM_HIP(launch_gemm_tiled(st, ctx->exn, w.out_w, M, d, K32, EpResidual{ctx->eh, w.out_b, d, M}));
         hipLaunchKernelGGL(k_enc_ln, dim3((M + 3) / 4), dim3(256), 0, st, ctx->eh, w.ln2_w, w.ln2_b, ctx->exn, K32, d, M);

@@ -125,7 +125,7 @@ struct EpConv2 {               // h = gelu(conv2) + embed_positions   (HF:modeli
     }
 };
 
-struct EpQKVEnc {              // q (x 64^-1/2), k as [b][h][s][64]; v transposed [b][h][64][s] for the PV MFMA operand
+struct EpQKVEnc {              // q (x 64^-1/2), k as [b][h][s][64]; v as V^T MFMA fragments per [b][h] (vfrag_index)
     static constexpr bool kPre = false;
     bf16_t* q; bf16_t* k; bf16_t* vt; const float* bias; int Spad, H, d;
     __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const {
@@ -140,8 +140,8 @@ struct EpQKVEnc {              // q (x 64^-1/2), k as [b][h][s][64]; v transpose
             *reinterpret_cast<uint2*>((isq ? q : k) + (((size_t)b * H + (c >> 6)) * Spad + s) * 64 + (c & 63)) = o;
         } else {
             const int c = n - 2 * d;
-            bf16_t* p = vt + (((size_t)b * H + (c >> 6)) * 64 + (c & 63)) * Spad + s;
-            p[0] = f2bf(x0); p[Spad] = f2bf(x1); p[2 * (size_t)Spad] = f2bf(x2); p[3 * (size_t)Spad] = f2bf(x3);
+            bf16_t* p = vt + ((size_t)b * H + (c >> 6)) * 64 * Spad + vfrag_index(s, c & 63);
+            p[0] = f2bf(x0); p[8] = f2bf(x1); p[16] = f2bf(x2); p[24] = f2bf(x3);
         }
     }
 };

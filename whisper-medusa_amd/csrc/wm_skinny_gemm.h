@@ -50,7 +50,7 @@ __device__ __forceinline__ void hilo8_to_lds(bf16_t* xh, bf16_t* xl, int q, floa
 // Threads walk the 16 x K tile in PACKED order (one 16-B chunk = 8 consecutive k of one row; with a block
 // size that is a multiple of 64 every chunk of a thread belongs to the same row r = tid & 15).  All global
 // loads of a thread are issued together (ONE memory round trip); LayerNorm statistics (single-pass sum and
-// sum of squares) come from the same registers: 2 xor-shuffles inside the wave, then a fixed-order sum of
+// sum of squares) come from the same registers: a 4-row permlane-swap reduction inside the wave, then a fixed-order sum of
 // the per-wave partials in LDS (deterministic).  LDS writes are lane-linear ds_write_b128.
 struct LdNorm {
     const float* h; const float* gamma; const float* beta;
@@ -98,8 +98,7 @@ struct LdNorm {
                 q2 += (v0[i].x * v0[i].x + v0[i].y * v0[i].y) + (v0[i].z * v0[i].z + v0[i].w * v0[i].w) +
                       (v1[i].x * v1[i].x + v1[i].y * v1[i].y) + (v1[i].z * v1[i].z + v1[i].w * v1[i].w);
             }
-            s += __shfl_xor(s, 16, 64); q2 += __shfl_xor(q2, 16, 64);
-            s += __shfl_xor(s, 32, 64); q2 += __shfl_xor(q2, 32, 64);
+            s = rows4_sum(s); q2 = rows4_sum(q2);
             if (lane < 16) part[wave * 16 + lane] = make_float2(s, q2);
             __syncthreads();
             float ts = 0.f, tq = 0.f;
@@ -354,8 +353,8 @@ k_rows_gemm(const bf16_t* __restrict__ W, int N16, int K32, int ksplit, const in
 }
 
 // ---- host-side launch plan -------------------------------------------------------------------
-static const int* g_skinny_done = nullptr;     // device flags checked by every launch of this translation unit
-static const int* g_skinny_skip = nullptr;
+static thread_local const int* g_skinny_done = nullptr;     // device flags checked by every launch of this translation unit
+static thread_local const int* g_skinny_skip = nullptr;
 struct SkinnyPlan { int ksplit, rt, U; };
 
 // K-slices of at most 16 fragments (so the batched kernel can hold a slice in registers) and, if possible,

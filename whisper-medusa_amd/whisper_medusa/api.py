@@ -39,6 +39,8 @@ class WhisperMedusaModel:
         self.generation_config = config          # posterior_threshold / alpha / token ids live on the config here
         self._sd = state_dict
         self._max_batch = max_batch
+        self._micro_batches = 1
+        self._pool = None
         self._engine: Optional[Engine] = None
         self._blob = None
         self.device = torch.device("cpu")
@@ -78,6 +80,7 @@ class WhisperMedusaModel:
         with torch.cuda.device(device):
             self._blob, self._offsets = _weights.build_blob(self.config, self._sd, device=device)
             self._engine = Engine(self.config, self._blob, self._offsets, max_batch=self._max_batch, device=device)
+        self._drop_pool()
         self.device = device
         return self
 
@@ -93,7 +96,30 @@ class WhisperMedusaModel:
             if self._engine is not None:
                 self._engine.close()
                 self._engine = Engine(self.config, self._blob, self._offsets, max_batch=max_batch, device=self.device)
+            self._drop_pool()
         return self
+
+    def set_micro_batches(self, n: int):
+        """Decode batches as ``n`` concurrent micro-batches (own engine context + HIP stream each, shared weights):
+        see ``pool.py``.  n = 1 (default) is the single-context path; tokens do not depend on n."""
+        if n < 1:
+            raise ValueError("micro_batches must be >= 1")
+        if n != self._micro_batches:
+            self._micro_batches = n
+            self._drop_pool()
+        return self
+
+    def _drop_pool(self):
+        if self._pool is not None:
+            self._pool.close()
+            self._pool = None
+
+    def _get_pool(self):
+        if self._pool is None:
+            from .pool import ContextPool
+            _ = self.engine                                         # raises when not on a HIP device
+            self._pool = ContextPool(self.config, self._blob, self._offsets, self._micro_batches, self._max_batch)
+        return self._pool
 
     @property
     def engine(self) -> Engine:
@@ -191,6 +217,11 @@ class WhisperMedusaModel:
                               kwargs.get("posterior_alpha"), kwargs.get("suppress_tokens"),
                               kwargs.get("begin_suppress_tokens"), prompt_ids)
         feats = input_features.to(self.device, torch.float32).contiguous()
+        if self._micro_batches > 1 and B >= 2:
+            pool = self._get_pool()
+            seqs = pool.run(feats, gp)                                      # F1..F14 per micro-batch, concurrently
+            self.last_stats = pool.last_stats
+            return self._pad(seqs, gp)
         eng = self.engine
         eng.encode(feats)                                                   # F1 + F2
         seqs = eng.decode(gp, B)                                            # F3..F14
