@@ -1,6 +1,7 @@
 // wm_encoder.hip — log-mel front end (F0), Whisper encoder (F1) and cross-K/V projection (F2).
 // MFMA-bound prefill: every matmul runs on v_mfma_f32_16x16x32_bf16 from packed operands.
 #include "wm_internal.h"
+#include <cstdlib>
 #include "wm_epilogues.h"
 
 // =============================================================================================
@@ -17,7 +18,14 @@ __device__ __forceinline__ void glds16(const bf16_t* gsrc, char* lds_wave_base)
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int BM, class Ep>      // BM = token rows per tile: 128 (default) or 64 (doubles the block count of the N=d GEMMs)
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// BM = token rows per tile: 128 (default) or 64 (doubles the block count of the N=d GEMMs).
+// NST = LDS ring stages: a stage (64 k of the X tile and of the 128-feature W tile) is filled by LDS-DMA; NST-1 stages
+// are in flight while one is consumed, and the consumer waits with a partial vmcnt for ITS stage only.  Grids of at
+// most one 64-row block per CU (one clip, N = d) run 4 stages; everywhere else two resident blocks x 2 stages measured
+// faster than one block x 3-4 stages (tests/microbench/enc_sweep.sh: occupancy beats ring depth).
+template <int BM, int NST, class Ep>
 __global__ void __launch_bounds__(256)
 k_gemm_tiled(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32, int tiles_m, int tiles_n, Ep ep)
 {
@@ -25,6 +33,7 @@ k_gemm_tiled(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32
     constexpr int XB = BM / 16 * 2;            // X fragments per stage (m-tiles x 2 k-tiles)
     constexpr int NB = XB + 16;                // + 16 W fragments (8 n-tiles x 2 k-tiles)
     constexpr int STAGE = NB * 1024;
+    constexpr int LPW = NB / 4;                // LDS-DMA loads per wave per stage
     constexpr int MJ = BM / 32;                // token tiles per wave
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -42,8 +51,8 @@ k_gemm_tiled(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32
     auto stage_load = [&](int stage, int kt2) {
         char* sb = smem + stage * STAGE;
 #pragma unroll
-        for (int i = 0; i < NB / 4; ++i) {
-            const int blk = w * (NB / 4) + i;          // 0..XB-1 X fragments, then 16 W fragments
+        for (int i = 0; i < LPW; ++i) {
+            const int blk = w * LPW + i;               // 0..XB-1 X fragments, then 16 W fragments
             const bool isx = blk < XB;
             const int bb = isx ? blk : blk - XB;
             const int t = bb >> 1, kk = bb & 1;
@@ -58,13 +67,19 @@ k_gemm_tiled(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32
 #pragma unroll
         for (int j = 0; j < MJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    stage_load(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st)
+        if (st < nkt) stage_load(st, st);
 
     for (int kt2 = 0; kt2 < nkt; ++kt2) {
-        if (kt2 + 1 < nkt) stage_load((kt2 + 1) & 1, kt2 + 1);
-        const bf16_t* xs = reinterpret_cast<const bf16_t*>(smem + (kt2 & 1) * STAGE);
+        // stages kt2 .. min(nkt-1, kt2+NST-2) are outstanding, in order: wait until only the younger ones remain
+        const int younger = min(nkt - 1, kt2 + NST - 2) - kt2;
+        if (NST >= 4 && younger >= 2) wait_vmcnt<2 * LPW>();
+        else if (NST >= 3 && younger >= 1) wait_vmcnt<LPW>();
+        else wait_vmcnt<0>();
+        __syncthreads();                       // every wave's part of stage kt2 landed; everyone is done with stage kt2-1
+        if (kt2 + NST - 1 < nkt) stage_load((kt2 + NST - 1) % NST, kt2 + NST - 1);
+        const bf16_t* xs = reinterpret_cast<const bf16_t*>(smem + (kt2 % NST) * STAGE);
         const bf16_t* ws = xs + XB * 512;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -78,8 +93,6 @@ k_gemm_tiled(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32
 #pragma unroll
                 for (int j = 0; j < MJ; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
     }
 
     const int m0 = tm * BM + wm * (BM / 2) + (lane & 15), n0 = tn * GT_BN + wn * 64 + 4 * (lane >> 4);
@@ -89,21 +102,36 @@ k_gemm_tiled(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32
         for (int j = 0; j < MJ; ++j) ep.store4(m0 + j * 16, n0 + i * 16, acc[i][j]);
 }
 
-template <int BM, class Ep>
+template <int BM, int NST, class Ep>
 static inline hipError_t launch_gemm_tiled_bm(hipStream_t st, const bf16_t* X, const bf16_t* W, int Mrows, int N, int K32, const Ep& ep)
 {
     const int tiles_m = Mrows / BM, tiles_n = N / GT_BN;
-    constexpr int lds = 2 * (BM / 16 * 2 + 16) * 1024;
-    hipLaunchKernelGGL((k_gemm_tiled<BM, Ep>), dim3(tiles_m * tiles_n), dim3(256), lds, st, X, W, K32, tiles_m, tiles_n, ep);
+    constexpr int lds = NST * (BM / 16 * 2 + 16) * 1024;
+    auto kern = k_gemm_tiled<BM, NST, Ep>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), lds, st, X, W, K32, tiles_m, tiles_n, ep);
     return hipGetLastError();
 }
 
 template <class Ep>
 static inline hipError_t launch_gemm_tiled(hipStream_t st, const bf16_t* X, const bf16_t* W, int Mrows, int N, int K32, const Ep& ep)
 {
+    static const int big_nst = [] { const char* v = std::getenv("WM_ENC_GEMM_STAGES"); return v ? std::atoi(v) : 2; }();
+    const int blocks128 = (Mrows / 128) * (N / GT_BN);
     // fewer than ~one block per CU with 128-row tiles: halve the tile to fill the chip
-    if ((Mrows / 128) * (N / GT_BN) < 200) return launch_gemm_tiled_bm<64>(st, X, W, Mrows, N, K32, ep);
-    return launch_gemm_tiled_bm<128>(st, X, W, Mrows, N, K32, ep);
+    if (blocks128 < 200) return launch_gemm_tiled_bm<64, 4>(st, X, W, Mrows, N, K32, ep);
+    static const int mid = [] { const char* v = std::getenv("WM_ENC_GEMM_MID"); return v ? std::atoi(v) : 2; }();
+    if (blocks128 <= 512) {                // 1-2 blocks per CU: measured best with 2 stages x 2 resident blocks (tests/microbench/enc_sweep.sh)
+        if (mid == 4) return launch_gemm_tiled_bm<128, 4>(st, X, W, Mrows, N, K32, ep);
+        if (mid == 3) return launch_gemm_tiled_bm<128, 3>(st, X, W, Mrows, N, K32, ep);
+        if (mid == 64) return launch_gemm_tiled_bm<64, 4>(st, X, W, Mrows, N, K32, ep);
+        return launch_gemm_tiled_bm<128, 2>(st, X, W, Mrows, N, K32, ep);
+    }
+    if (big_nst == 3) return launch_gemm_tiled_bm<128, 3>(st, X, W, Mrows, N, K32, ep);
+    return launch_gemm_tiled_bm<128, 2>(st, X, W, Mrows, N, K32, ep);
 }
 
 // =============================================================================================
