@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--micro-batches", type=int, default=1,
                     help="decode the per-GPU batch as this many concurrent micro-batches (whisper_medusa/pool.py); 1 = one context")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vanilla", action="store_true",
+                    help="skip the vanilla-greedy anchor (PMC passes: only Medusa iterations in the counter totals)")
     ap.add_argument("--cpu-iters", type=int, default=6)
     args = ap.parse_args()
 
@@ -153,14 +155,16 @@ def main():
     tokens_all = wd.sum_over_ranks(float(tokens), dev)
 
     # ---- anchor: vanilla greedy decoding on the same engine / clips / budget (one untimed-region step) ----
-    gpv = synth.bench_gen_params(cfg, max_new_tokens=args.max_new, vanilla=True)
-    if pool is not None:
-        eng.encode(eng.logmel(wavs[0]))      # the timed steps ran on the pool's contexts
-    eng.decode(gpv, B)                       # warm
-    eng.decode(gpv, B)
-    stv = eng.stats()
-    vanilla_tps = B * args.max_new / (stv["ms_decode"] * 1e-3)
-    vanilla_ms_step = stv["ms_decode"] / max(stv["iterations"], 1)
+    vanilla_tps = vanilla_ms_step = None
+    if not args.no_vanilla:
+        gpv = synth.bench_gen_params(cfg, max_new_tokens=args.max_new, vanilla=True)
+        if pool is not None:
+            eng.encode(eng.logmel(wavs[0]))      # the timed steps ran on the pool's contexts
+        eng.decode(gpv, B)                       # warm
+        eng.decode(gpv, B)
+        stv = eng.stats()
+        vanilla_tps = B * args.max_new / (stv["ms_decode"] * 1e-3)
+        vanilla_ms_step = stv["ms_decode"] / max(stv["iterations"], 1)
 
     if rank != 0:
         return
@@ -173,7 +177,8 @@ def main():
     mean_len = len(gp.prompt) + args.max_new / 2
     bytes_iter = decode_iter_bytes(cfg, B, mean_len)
     achieved = bytes_iter / (t_iter_ms * 1e-3) / 1e9
-    gemm_ms, gemm_bytes = eng.profile_layer_gemms(rows=min(16, B * (cfg.medusa_num_heads + 1)), reps=50)
+    gemm_rows = min(16, B * (cfg.medusa_num_heads + 1))
+    gemm_ms, gemm_bytes = (None, None) if args.no_vanilla else eng.profile_layer_gemms(rows=gemm_rows, reps=50)
     audio_s = args.steps * B * world * 30.0 * cfg.max_source_positions / 1500.0
     tok_per_iter = tokens / max(iters, 1) / B
     out = {
@@ -193,17 +198,19 @@ def main():
         "accept_hist": hist.tolist(), "graph_replays": int(replays),
         "ms_logmel_per_step": round(ms_mel / args.steps, 3), "ms_encode_per_step": round(ms_enc / args.steps, 3),
         "ms_decode_per_step": round(ms_dec / args.steps, 3), "weight_broadcast_s": round(t_bcast, 3),
-        "vanilla_anchor": {"tokens_per_sec_per_gpu": round(vanilla_tps, 2), "ms_per_token_step": round(vanilla_ms_step, 4),
+        "vanilla_anchor": None if vanilla_tps is None else
+                          {"tokens_per_sec_per_gpu": round(vanilla_tps, 2), "ms_per_token_step": round(vanilla_ms_step, 4),
                            "medusa_over_vanilla": round(tokens / (ms_dec * 1e-3) / vanilla_tps, 3)},
-        "roofline": {"bound": "hbm", "kernel": "decode iteration (base pass + verify pass, one hipGraph launch)",
+        "roofline": {"bound": "hbm", "kernel": "decode iteration (verify pass + base pass unless the hidden state was carried; hipGraph replays)",
                      "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
                      "traffic": traffic, "bytes_per_launch": round(bytes_iter), "ms_per_launch": round(t_iter_ms, 4),
                      "prefill": {"bound": "mfma", "tflops_per_clip": round(prefill_flops(cfg) / 1e12, 3),
                                  "achieved": round(prefill_flops(cfg) * B / (ms_enc / args.steps * 1e-3) / 1e12, 1),
                                  "peak": 2500.0, "unit": "TFLOP/s",
                                  "frac": round(prefill_flops(cfg) * B / (ms_enc / args.steps * 1e-3) / 2.5e15, 4)},
-                     "layer_gemms": {"rows": min(32, B * (cfg.medusa_num_heads + 1)), "ms": round(gemm_ms, 5),
-                                     "bytes": round(gemm_bytes), "achieved_gbs": round(gemm_bytes / (gemm_ms * 1e-3) / 1e9, 1)}},
+                     "layer_gemms": None if gemm_ms is None else
+                                    {"rows": gemm_rows, "ms": round(gemm_ms, 5), "bytes": round(gemm_bytes),
+                                     "achieved_gbs": round(gemm_bytes / (gemm_ms * 1e-3) / 1e9, 1)}},
     }
 
     # ---- CPU baseline: the oracle (a port of the reference algorithm) on the host cores, bounded sample ----

@@ -1,6 +1,8 @@
 """HBM traffic per decode iteration from a `rocprofv3 --pmc FETCH_SIZE --kernel-trace` run of bench.py.
 FETCH_SIZE is reported in KB; on gfx950 it counts 64 B per 128-B request for wide coalesced streams, i.e.
-HALF of the bytes (MI355X_MICROARCH.md §HBM) -> multiply by 2.  python tests/pmc_summary.py <db> [out.md]"""
+HALF of the bytes (MI355X_MICROARCH.md §HBM) -> multiply by 2.  python tests/pmc_summary.py <db> [out.md [out.json]]
+Run bench.py with --no-vanilla so that every decode-path byte belongs to a Medusa iteration."""
+import json
 import re
 import sqlite3
 import sys
@@ -24,3 +26,9 @@ out = "\n".join(lines)
 print(out)
 if len(sys.argv) > 2:
     open(sys.argv[2], "w").write(out + "\n")
+if len(sys.argv) > 3 and n_iter and not n_van:
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vanilla (MI355X)",
+               "correction": "FETCH_SIZE x 2 (gfx950 counts 64 B per 128-B request on wide coalesced streams, MI355X_MICROARCH.md HBM section)",
+               "medusa_iterations": n_iter, "medusa_iteration_bytes": round(2 * tot * 1024 * 1024 / n_iter),
+               "note": "host-driven hidden-state carry: an iteration is a verify pass plus a base pass only when the previous accept length was 0",
+               "config": "whisper-large-v2 + medusa-linear K=10, batch 1"}, open(sys.argv[3], "w"), indent=1)
