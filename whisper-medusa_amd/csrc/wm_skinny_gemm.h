@@ -229,60 +229,7 @@ k_ln_tiles(LdNorm ld, bf16_t* __restrict__ xg, size_t plane, const int* __restri
     ld.prepare_to(xg + off, xg + plane + off, smem, blockIdx.x * 16);
 }
 
-// Weight-stationary variant for many token rows: a wave keeps its NKR weight fragments (its whole K-slice) in
-// registers and walks the MT 16-row token tiles, reading their packed hi/lo fragments from L2.  Per output the
-// accumulation order (k ascending, hi then lo; then K-slices in order) is exactly the 16-row kernel's.
-template <int NKR, class Ep>
-__global__ void __launch_bounds__(640)
-k_skinny_gemm_mt(const bf16_t* __restrict__ W, int N16, int K32, int ksplit, int rt_per_wg, const int* __restrict__ done,
-                 const bf16_t* __restrict__ X, size_t plane, int MT, Ep ep)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (done && *done) return;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int ks = wave % ksplit, rtl = wave / ksplit;
-    const int rt = blockIdx.x * rt_per_wg + rtl;
-    float4* red = reinterpret_cast<float4*>(smem);
-    const int kt0 = ks * NKR;
-    const bool active = rt < N16;
-    const bf16_t* wp = W + ((size_t)(active ? rt : 0) * K32 + kt0) * 512 + lane * 8;
-    bf16x8_t a[NKR];
-#pragma unroll
-    for (int u = 0; u < NKR; ++u) a[u] = ld_frag_nt(wp + (size_t)u * 512);
-    constexpr int G = (NKR % 8 == 0) ? 8 : 4;
-    for (int mt = 0; mt < MT; ++mt) {
-        const bf16_t* xp = X + ((size_t)(mt * K32 + kt0) * 64 + lane) * 8;
-        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kg = 0; kg < NKR; kg += G) {
-            bf16x8_t xh[G], xl[G];
-#pragma unroll
-            for (int u = 0; u < G; ++u) { xh[u] = ld_frag(xp + (size_t)(kg + u) * 512); xl[u] = ld_frag(xp + plane + (size_t)(kg + u) * 512); }
-#pragma unroll
-            for (int u = 0; u < G; ++u) { acc = mfma16(a[kg + u], xh[u], acc); acc = mfma16(a[kg + u], xl[u], acc); }
-        }
-        if (ksplit > 1) {
-            red[(rtl * ksplit + ks) * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-            __syncthreads();
-            for (int e = threadIdx.x; e < rt_per_wg * 64; e += blockDim.x) {
-                const int rtl2 = e >> 6, l2 = e & 63;
-                f32x4_t sacc = {0.f, 0.f, 0.f, 0.f};
-                for (int k2 = 0; k2 < ksplit; ++k2) {
-                    const float4 p = red[(rtl2 * ksplit + k2) * 64 + l2];
-                    sacc[0] += p.x; sacc[1] += p.y; sacc[2] += p.z; sacc[3] += p.w;
-                }
-                const int rt2 = blockIdx.x * rt_per_wg + rtl2;
-                if (rt2 < N16) ep.store4(mt * 16 + (l2 & 15), rt2 * 16 + 4 * (l2 >> 4), sacc);
-            }
-            __syncthreads();
-        } else if (active) {
-            ep.store4(mt * 16 + (lane & 15), rt * 16 + 4 * (lane >> 4), acc);
-        }
-    }
-}
-
-// Many token tiles (verify pass of a large batch): a wave owns RT weight row tiles x TT token tiles x ONE K-slice,
+// More than 16 token rows (several streams): a wave owns RT weight row tiles x TT token tiles x ONE K-slice,
 // so every weight fragment feeds 2*TT MFMAs and every token fragment RT of them (register blocking cuts the L2
 // traffic of the operand re-reads by RT resp. TT); blockIdx.y walks the token-tile groups, so the chip is filled
 // by tokens as well as by features and the weights are re-read from L2 / Infinity Cache, not HBM.  Per output the
@@ -357,7 +304,7 @@ static thread_local const int* g_skinny_done = nullptr;     // device flags chec
 static thread_local const int* g_skinny_skip = nullptr;
 struct SkinnyPlan { int ksplit, rt, U; };
 
-// K-slices of at most 16 fragments (so the batched kernel can hold a slice in registers) and, if possible,
+// K-slices of at most 16 fragments and, if possible,
 // >= 1024 waves.  The plan depends only on (N16, K32, loader kind): 16-row and batched launches of one GEMM
 // share it, which is what makes their results bit-identical.
 static inline int skinny_env(const char* name, int dflt) {
@@ -406,27 +353,31 @@ static inline hipError_t launch_skinny(hipStream_t st, const bf16_t* W, int N16,
     return launch_skinny_u<4>(st, W, N16, K32, p, ld, ep);
 }
 
+template <int NKR, int RT, class Ep>
+static inline hipError_t launch_rows_gemm(hipStream_t st, const bf16_t* W, int N16, int K32, const SkinnyPlan& p,
+                                          const bf16_t* X, size_t plane, int MT, const Ep& ep) {
+    constexpr int TT = 2;
+    const dim3 grid((N16 + RT - 1) / RT, (MT + TT - 1) / TT);
+    const size_t lds = p.ksplit > 1 ? (size_t)RT * TT * p.ksplit * 1024 : 0;
+    auto kern = k_rows_gemm<NKR, RT, TT, Ep>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(64 * p.ksplit), lds, st, W, N16, K32, p.ksplit, g_skinny_done, X, plane, MT, ep);
+    return hipGetLastError();
+}
+
 template <int NKR, class Ep>
 static inline hipError_t launch_skinny_mt_nk(hipStream_t st, const bf16_t* W, int N16, int K32, const SkinnyPlan& p,
                                              const bf16_t* X, size_t plane, int MT, const Ep& ep) {
-    static const int mt_tiled = skinny_env("WM_ROWS_GEMM_MIN_TILES", 3);      // token tiles from which the register-blocked kernel runs
-    if (MT >= mt_tiled) {
-        // RT x TT register tile: 4 x 2 while a K-slice batch fits the register file, 2 x 2 for 16-fragment slices' bigger blocks
-        constexpr int RT = 4, TT = 2;
-        const dim3 grid((N16 + RT - 1) / RT, (MT + TT - 1) / TT);
-        const size_t lds = p.ksplit > 1 ? (size_t)RT * TT * p.ksplit * 1024 : 0;
-        auto kern = k_rows_gemm<NKR, RT, TT, Ep>;
-        if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-        }
-        hipLaunchKernelGGL(kern, grid, dim3(64 * p.ksplit), lds, st, W, N16, K32, p.ksplit, g_skinny_done, X, plane, MT, ep);
-        return hipGetLastError();
-    }
-    const int grid = (N16 + p.rt - 1) / p.rt, threads = 64 * p.ksplit * p.rt;
-    const size_t lds = p.ksplit > 1 ? (size_t)p.rt * p.ksplit * 1024 : 0;
-    hipLaunchKernelGGL((k_skinny_gemm_mt<NKR, Ep>), dim3(grid), dim3(threads), lds, st, W, N16, K32, p.ksplit, p.rt, g_skinny_done, X, plane, MT, ep);
-    return hipGetLastError();
+    static const int min_blocks = skinny_env("WM_ROWS_GEMM_MIN_BLOCKS", 200);
+    // weight row tiles per wave: as many as still leave ~one block per CU (register blocking divides the L2 re-reads
+    // of the token operand; with few token tiles the chip has to be filled by features instead).  Same results.
+    const int groups = (MT + 1) / 2;
+    if (((N16 + 3) / 4) * groups >= min_blocks) return launch_rows_gemm<NKR, 4>(st, W, N16, K32, p, X, plane, MT, ep);
+    if (((N16 + 1) / 2) * groups >= min_blocks) return launch_rows_gemm<NKR, 2>(st, W, N16, K32, p, X, plane, MT, ep);
+    return launch_rows_gemm<NKR, 1>(st, W, N16, K32, p, X, plane, MT, ep);
 }
 
 template <class Ep>
@@ -455,7 +406,7 @@ static inline bool skinny_norm_fusable(int N16, int K32) {
 }
 
 // LayerNorm-fused GEMM over R token rows.  R <= 16: one fused launch.  R > 16: the same LayerNorm code writes
-// the packed hi/lo operand to `xscr` (global), then the weight-stationary batched kernel runs.  The fused loader
+// the packed hi/lo operand to `xscr` (global), then the register-blocked token-tile kernel runs.  The fused loader
 // needs the whole 16 x K tile in one batch of the block's threads (true for every Whisper size).
 template <class Ep>
 static inline hipError_t launch_skinny_norm(hipStream_t st, const bf16_t* W, int N16, int K32, const float* h, const float* gamma,
@@ -469,6 +420,5 @@ static inline hipError_t launch_skinny_norm(hipStream_t st, const bf16_t* W, int
     hipLaunchKernelGGL(k_ln_tiles, dim3(MT), dim3(64 * p.ksplit * p.rt), LdNorm::scratch_bytes(K32), st, ld, xscr, plane, g_skinny_done);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    SkinnyPlan q = p; q.rt = (p.ksplit == 1) ? 4 : 1;
-    return launch_skinny_mt(st, W, N16, K32, q, xscr, plane, MT, ep);
+    return launch_skinny_mt(st, W, N16, K32, p, xscr, plane, MT, ep);
 }
