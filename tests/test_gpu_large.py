@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 def large(gpu):
     cfg = MedusaConfig.large_v2("base_head", K=10)
     sd = synth.synth_state_dict(cfg, seed=0, device=str(gpu))
-    model = WhisperMedusaModel(cfg, sd, device=gpu, max_batch=2)
+    model = WhisperMedusaModel(cfg, sd, device=gpu, max_batch=12)
     wav = np.stack([synth.synth_clip(i) for i in range(2)])
     feats = model.extract_features(wav)
     yield cfg, sd, model, feats
@@ -40,6 +40,32 @@ def test_large_greedy_equals_vanilla_and_batch_consistency(large):
     assert alone == both[1]
     st = eng.stats()
     assert st["graph_replays"] > 0          # the steady state ran as hipGraph replays
+
+
+def test_large_twelve_streams_equal_single_stream_runs(large):
+    """12 streams x 11 verify rows = 132 rows (9 token tiles) at the real shape: the register-blocked token-tile GEMM
+    (RT = 4 and 2, 8- and 16-fragment K-slices), cross-attention blocks walking two key splits each and the per-stream
+    hidden-state carry must give every stream exactly the tokens of its own single-stream run."""
+    cfg, sd, model, _ = large
+    eng = model.engine
+    n = cfg.n_mel_frames * 160
+    wav = np.stack([synth.synth_clip(20 + i, n) for i in range(12)])
+    wav[3, n // 2:] = 0.0                                     # ragged content
+    feats = model.extract_features(wav)
+    gp = synth.bench_gen_params(cfg, max_new_tokens=40, accept_mode=ACCEPT_TYPICAL)
+    eng.encode(feats)
+    both = eng.decode(gp, 12)
+    st = eng.stats()
+    assert sum(st["accept_hist"][1:]) > 0
+    for b in (0, 3, 7, 11):
+        eng.encode(feats[b: b + 1].contiguous())
+        assert eng.decode(gp, 1)[0] == both[b], b
+    model.set_micro_batches(2)                                # 2 contexts x 6 streams, concurrently
+    out = model.generate(feats, max_new_tokens=40, exponential_decay_length_penalty=(140, 1.01), suppress_tokens=gp.suppress_tokens)
+    model.set_micro_batches(1)
+    for b in range(12):
+        got = out[b].tolist()
+        assert got[: len(both[b])] == both[b] and all(t == gp.pad_token_id for t in got[len(both[b]):]), b
 
 
 def test_large_prompt_pass_against_oracle(large):
