@@ -10,7 +10,10 @@
  * Conventions: all functions return 0 on success, <0 on error (wm_last_error(ctx) gives the
  * text; WM_ERR_* below).  Handles are opaque.  Pointers marked DEV are device (HBM)
  * pointers, HOST are host pointers.  One context = one GPU + one HIP stream; a context is
- * not thread-safe, distinct contexts are independent.  Nothing here takes a torch type.
+ * not thread-safe, distinct contexts are independent (and may run concurrently from different host threads).
+ * Ordering: the work runs on the context's own stream; device inputs must be complete before the call (the caller
+ * synchronises whatever produced them) and every entry point returns after its work has finished, so outputs can be
+ * read from any stream.  Nothing here takes a torch type.
  */
 #ifndef WM_H_
 #define WM_H_
@@ -100,6 +103,15 @@ int wm_create(const wm_config* cfg, const wm_weights* w, int device, void* hip_s
 void wm_destroy(wm_ctx* ctx);
 const char* wm_last_error(const wm_ctx* ctx);     /* ctx may be NULL: last create error */
 int wm_abi_version(void);
+
+/* ---- audio front door (replaces what the reference's callers do with torchaudio before the
+ * feature extractor: `input_speech.mean(dim=0)` and `torchaudio.transforms.Resample(sr, 16000)`, README.md:120-125,
+ * eval_whisper_medusa.py:41-45).  Channel-mean downmix + windowed-sinc polyphase resampling with torchaudio 2.2.2's
+ * default filter (sinc_interp_hann, lowpass_filter_width 6, rolloff 0.99).
+ * in: DEV float32 [B][channels][n_in]; out: DEV float32 [B][wm_resample_len(n_in, sr_in, sr_out)].
+ * sr_in == sr_out: downmix only. */
+int64_t wm_resample_len(int64_t n_in, int sr_in, int sr_out);    /* ceil(n_in * sr_out / sr_in) */
+int wm_resample(wm_ctx* ctx, const float* in, int B, int channels, int n_in, int sr_in, int sr_out, float* out);
 
 /* ---- F0 log-mel (replaces WhisperProcessor.__call__, eval_whisper_medusa.py:46-50) ----
  * wav: DEV float32 [B][n_samples] already padded/trimmed to n_samples = 320*n_ctx (480000).

@@ -84,6 +84,51 @@ def mel_filter_bank(n_mels: int = 80, n_fft: int = 400, sr: int = 16000, fmax: f
     return fb * enorm[None, :]
 
 
+def resample_sinc_hann(wave: np.ndarray, orig_freq: int, new_freq: int, lowpass_filter_width: int = 6,
+                       rolloff: float = 0.99) -> np.ndarray:
+    """``torchaudio.transforms.Resample(orig_freq, new_freq)`` with its defaults, applied to float32 ``[..., n]``.
+
+    Call sites in the reference: README.md:120-125, eval_whisper_medusa.py:41-45.  The arithmetic lives in
+    torchaudio==2.2.2 (requirements.txt:6; functional/functional.py ``_get_sinc_resample_kernel`` /
+    ``_apply_sinc_resample_kernel``), which is neither under /root/reference nor installed here: this restates the
+    published algorithm with the same torch primitives in the same order — **parity unpinned** for this function
+    (tests check it against independent properties and scipy's polyphase resampler instead).
+    Details that matter for bit-level agreement with torchaudio: the tap grid ``idx`` is float64, the phase offset
+    ``arange(0, -new, -1) / new`` is a float32 quotient that is then promoted, the kernel is rounded to float32 last,
+    and the convolution is an fp32 ``conv1d`` with stride ``orig`` over the clip padded by (width, width + orig)."""
+    import math
+    g = math.gcd(int(orig_freq), int(new_freq))
+    x = torch.from_numpy(np.ascontiguousarray(wave, dtype=np.float32))
+    if orig_freq == new_freq:
+        return x.numpy()
+    orig, new = int(orig_freq) // g, int(new_freq) // g
+    base_freq = min(orig, new) * rolloff
+    width = math.ceil(lowpass_filter_width * orig / base_freq)
+    idx = torch.arange(-width, width + orig, dtype=torch.float64)[None, None] / orig
+    t = torch.arange(0, -new, -1)[:, None, None] / new + idx
+    t = t * base_freq
+    t = t.clamp(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    scale = base_freq / orig
+    kernels = torch.where(t == 0, torch.tensor(1.0).to(t), t.sin() / t)
+    kernels = (kernels * (window * scale)).to(torch.float32)
+    shape = x.shape
+    x2 = x.reshape(-1, shape[-1])
+    num_wavs, length = x2.shape
+    x2 = torch.nn.functional.pad(x2, (width, width + orig))
+    res = torch.nn.functional.conv1d(x2[:, None], kernels, stride=orig)
+    res = res.transpose(1, 2).reshape(num_wavs, -1)
+    target_length = int(math.ceil(new * length / orig))
+    res = res[..., :target_length]
+    return res.reshape(shape[:-1] + res.shape[-1:]).numpy()
+
+
+def downmix_mono(wave: np.ndarray) -> np.ndarray:
+    """``input_speech.mean(dim=0)`` for a multi-channel clip [channels, n] (reference README.md:121-122)."""
+    return torch.from_numpy(np.ascontiguousarray(wave, dtype=np.float32)).mean(dim=0).numpy()
+
+
 def log_mel(wav: np.ndarray, n_mels: int = 80, n_samples: int = 480000) -> np.ndarray:
     """wav [n] float -> [n_mels, n_samples/160] float32.  Pad/trim to ``n_samples``, reflect-pad
     STFT (n_fft 400, hop 160, periodic Hann), power, drop the last frame, mel, log10, clamp

@@ -228,6 +228,51 @@ def test_wide_batch_token_tile_gemm(gpu):
     eng.close()
 
 
+@pytest.mark.parametrize("sr", [44100, 48000, 22050, 8000, 11025])
+def test_audio_front_door_resample_matches_oracle(gpu, sr):
+    """wm_resample (channel mean + torchaudio-default windowed-sinc resampling) vs the oracle's restatement on the
+    same seeded clips: fp32 both sides, only the summation order of <= 500 taps differs -> 5e-6 absolute on |x| <= 1."""
+    from oracle.whisper_medusa_oracle import downmix_mono, resample_sinc_hann
+    cfg = MedusaConfig.micro(K=4)
+    model = WhisperMedusaModel(cfg, synth.synth_state_dict(cfg, seed=11), device=gpu, max_batch=2)
+    rng = np.random.default_rng(sr)
+    n = 3 * sr + 211                                          # ragged length, several output frames + a partial one
+    for ch in (1, 2, 3):
+        x = np.clip(0.3 * rng.standard_normal((2, ch, n)), -1, 1).astype(np.float32)
+        got = model.engine.resample(torch.from_numpy(x).to(gpu), sr, 16000).cpu().numpy()
+        want = np.stack([resample_sinc_hann(downmix_mono(x[b]), sr, 16000) for b in range(2)])
+        assert got.shape == want.shape == (2, -(-16000 * n // sr))
+        assert np.abs(got - want).max() <= 5e-6, (ch, float(np.abs(got - want).max()))
+    # same rate: downmix only, exact
+    x = rng.standard_normal((2, 2, 1000)).astype(np.float32)
+    got = model.engine.resample(torch.from_numpy(x).to(gpu), 16000, 16000).cpu().numpy()
+    assert np.array_equal(got, np.stack([downmix_mono(x[b]) for b in range(2)]))
+    model.engine.close()
+
+
+def test_features_from_a_stereo_44k_wav_file(gpu, tmp_path):
+    """file -> decode -> downmix -> resample -> log-mel on the engine == the oracle's chain (README.md:120-130 call shape)."""
+    from oracle.whisper_medusa_oracle import downmix_mono, resample_sinc_hann
+    from whisper_medusa.audio import read_wav, write_wav
+    cfg = MedusaConfig.micro(K=4)
+    model = WhisperMedusaModel(cfg, synth.synth_state_dict(cfg, seed=11), device=gpu, max_batch=1)
+    sr = 44100
+    n16 = cfg.n_mel_frames * 160
+    n = int(n16 * sr / 16000 * 0.8)                            # 80 % of the model's window: the rest is zero padding
+    t = np.arange(n) / sr
+    x = np.stack([0.4 * np.sin(2 * np.pi * 523.25 * t), 0.3 * np.sin(2 * np.pi * 1760.0 * t + 1.0)]).astype(np.float32)
+    x += 0.01 * np.random.default_rng(5).standard_normal(x.shape).astype(np.float32)
+    path = tmp_path / "clip.wav"
+    write_wav(path, x, sr)
+    got = model.features_from_file(str(path)).cpu().numpy()
+    pcm, sr2 = read_wav(path)
+    mono16 = resample_sinc_hann(downmix_mono(pcm), sr2, 16000)
+    buf = np.zeros(n16, np.float32); buf[: min(len(mono16), n16)] = mono16[:n16]
+    want = log_mel(buf, cfg.num_mel_bins, n16)[None]
+    assert got.shape == want.shape and np.abs(got - want).max() <= 2e-3
+    model.engine.close()
+
+
 def test_generate_api_end_to_end(rig):
     """from wav: log-mel -> encoder -> decode through the drop-in generate() (README.md:101-142 call shape)."""
     feats = rig.model.extract_features(rig.wavs[:1])

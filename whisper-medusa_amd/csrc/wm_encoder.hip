@@ -1,7 +1,10 @@
 // wm_encoder.hip — log-mel front end (F0), Whisper encoder (F1) and cross-K/V projection (F2).
 // MFMA-bound prefill: every matmul runs on v_mfma_f32_16x16x32_bf16 from packed operands.
 #include "wm_internal.h"
+#include <algorithm>
+#include <cmath>
 #include <cstdlib>
+#include <vector>
 #include "wm_epilogues.h"
 
 // =============================================================================================
@@ -406,8 +409,120 @@ __global__ void k_logmel_norm(float* __restrict__ feats, const int* __restrict__
 }
 
 // =============================================================================================
+// Audio front door: channel-mean downmix + windowed-sinc polyphase resampling to the model
+// rate — what the reference's callers do with torchaudio before the feature extractor (README.md:120-125,
+// eval_whisper_medusa.py:41-45; algorithm: torchaudio==2.2.2 functional.py _get_sinc_resample_kernel /
+// _apply_sinc_resample_kernel, sinc_interp_hann, lowpass_filter_width 6, rolloff 0.99).
+//   out[f*nw + j] = sum_k table[k][j] * xpad[f*og + k],   xpad[p] = mean_c in[c][p - width]  (0 outside the clip)
+// One block = one output frame f (nw samples): the og + 2*width inputs it needs are downmixed into LDS once,
+// threads walk j (table is stored [k][j]: coalesced; the LDS read is a broadcast).
+// =============================================================================================
+__global__ void __launch_bounds__(256)
+k_resample(const float* __restrict__ in, const float* __restrict__ table, float* __restrict__ out, int channels, int n_in,
+           int og, int nw, int width, int K, int n_out)
+{
+    extern __shared__ float s_x[];
+    const int f = blockIdx.x, b = blockIdx.y;
+    const float* src = in + (size_t)b * channels * n_in;
+    const float inv = 1.0f / (float)channels;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        const long p = (long)f * og + k - width;
+        float v = 0.f;
+        if (p >= 0 && p < n_in) {
+            for (int c = 0; c < channels; ++c) v += src[(size_t)c * n_in + p];
+            if (channels > 1) v *= inv;
+        }
+        s_x[k] = v;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < nw; j += blockDim.x) {
+        const long o = (long)f * nw + j;
+        if (o >= n_out) break;
+        float acc = 0.f;
+        for (int k = 0; k < K; ++k) acc = fmaf(table[(size_t)k * nw + j], s_x[k], acc);
+        out[(size_t)b * n_out + o] = acc;
+    }
+}
+
+__global__ void k_downmix(const float* __restrict__ in, float* __restrict__ out, int channels, int n)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (i >= n) return;
+    float v = 0.f;
+    for (int c = 0; c < channels; ++c) v += in[((size_t)b * channels + c) * n + i];
+    out[(size_t)b * n + i] = channels > 1 ? v * (1.0f / (float)channels) : v;
+}
+
+// =============================================================================================
 // host side
 // =============================================================================================
+static int gcd_int(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
+
+long wm_enc_resample_len(long n_in, int sr_in, int sr_out)
+{
+    if (n_in < 0 || sr_in < 1 || sr_out < 1) return -1;
+    const int g = gcd_int(sr_in, sr_out);
+    const long og = sr_in / g, nw = sr_out / g;
+    return (nw * n_in + og - 1) / og;                 // ceil(new_freq * length / orig_freq)
+}
+
+// filter bank of torchaudio's Resample(sr_in, sr_out) defaults, computed like its float64 path (the phase offset
+// j / new_freq is a float32 quotient there: `torch.arange(0, -new, -1) / new` is float32 before it meets the float64
+// index grid), rounded to float32 at the end; stored [k][j].
+static void build_resample_table(int og, int nw, int& width, std::vector<float>& tab)
+{
+    const double lowpass_filter_width = 6.0, rolloff = 0.99, pi = 3.14159265358979323846;
+    const double base = (double)std::min(og, nw) * rolloff;
+    width = (int)std::ceil(lowpass_filter_width * og / base);
+    const int K = 2 * width + og;
+    tab.assign((size_t)K * nw, 0.f);
+    for (int j = 0; j < nw; ++j) {
+        const double off = (double)((float)(-j) / (float)nw);
+        for (int k = 0; k < K; ++k) {
+            double t = (off + (double)(k - width) / (double)og) * base;
+            t = std::min(std::max(t, -lowpass_filter_width), lowpass_filter_width);
+            const double c = std::cos(t * pi / lowpass_filter_width / 2.0);
+            const double window = c * c;
+            t *= pi;
+            const double sinc = (t == 0.0) ? 1.0 : std::sin(t) / t;
+            tab[(size_t)k * nw + j] = (float)(sinc * (window * (base / og)));
+        }
+    }
+}
+
+int wm_enc_resample(wm_ctx* ctx, const float* in, int B, int channels, int n_in, int sr_in, int sr_out, float* out)
+{
+    hipStream_t st = ctx->stream;
+    if (B < 1 || channels < 1 || n_in < 1 || sr_in < 1 || sr_out < 1) { ctx->err = "wm_resample: bad arguments"; return WM_ERR_ARG; }
+    const int g = gcd_int(sr_in, sr_out), og = sr_in / g, nw = sr_out / g;
+    if (og == nw) {                                   // same rate: torchaudio returns the input; only the downmix is left
+        hipLaunchKernelGGL(k_downmix, dim3((unsigned)((n_in + 255) / 256), B), dim3(256), 0, st, in, out, channels, n_in);
+        WM_HIP(hipGetLastError());
+        WM_HIP(hipStreamSynchronize(st));             // like wm_logmel: the result is complete when the call returns
+        return WM_OK;
+    }
+    if (ctx->rs_og != og || ctx->rs_nw != nw) {
+        std::vector<float> tab;
+        int width = 0;
+        build_resample_table(og, nw, width, tab);
+        if ((size_t)(2 * width + og) * sizeof(float) > 60 * 1024) { ctx->err = "wm_resample: rate ratio needs a filter longer than 15360 taps"; return WM_ERR_ARG; }
+        WM_HIP(hipStreamSynchronize(st));
+        if (ctx->rs_table) { WM_HIP(hipFree(ctx->rs_table)); ctx->rs_table = nullptr; }
+        WM_HIP(hipMalloc(&ctx->rs_table, tab.size() * sizeof(float)));
+        WM_HIP(hipMemcpy(ctx->rs_table, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+        ctx->rs_og = og; ctx->rs_nw = nw; ctx->rs_width = width;
+    }
+    const int K = 2 * ctx->rs_width + og;
+    const long n_out = wm_enc_resample_len(n_in, sr_in, sr_out);
+    const long frames = (n_out + nw - 1) / nw;
+    hipLaunchKernelGGL(k_resample, dim3((unsigned)frames, B), dim3(256), K * sizeof(float), st, in, ctx->rs_table, out, channels, n_in,
+                       og, nw, ctx->rs_width, K, (int)n_out);
+    WM_HIP(hipGetLastError());
+    WM_HIP(hipStreamSynchronize(st));                 // like wm_logmel: the result is complete when the call returns
+    return WM_OK;
+}
+
 int wm_enc_logmel(wm_ctx* ctx, const float* wav, int B, int n_samples, float* feats)
 {
     hipStream_t st = ctx->stream;

@@ -34,7 +34,7 @@ extern "C" void wm_destroy(wm_ctx* ctx)
                     ctx->enc_out, ctx->kx, ctx->vx, ctx->kc, ctx->vc, ctx->h, ctx->hblk, ctx->hf, ctx->qbuf, ctx->xbuf, ctx->fbuf,
                     ctx->ybuf, ctx->cml, ctx->co, ctx->ticket, ctx->logits, ctx->amax, ctx->pc, ctx->part1, ctx->part2, ctx->ids, ctx->L, ctx->kvlen,
                     ctx->finished, ctx->cand, ctx->niter, ctx->hist, ctx->supmask, ctx->exppen, ctx->tap_tok, ctx->done,
-                    ctx->hf_keep, ctx->carry};
+                    ctx->hf_keep, ctx->carry, ctx->rs_table};
     for (void* b : bufs) if (b) hipFree(b);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
@@ -165,6 +165,15 @@ extern "C" int wm_create(const wm_config* cfg, const wm_weights* w, int device, 
 }
 
 extern "C" int wm_sync(wm_ctx* ctx) { WM_HIP(hipSetDevice(ctx->device)); WM_HIP(hipStreamSynchronize(ctx->stream)); return WM_OK; }
+
+extern "C" int64_t wm_resample_len(int64_t n_in, int sr_in, int sr_out) { return wm_enc_resample_len((long)n_in, sr_in, sr_out); }
+
+extern "C" int wm_resample(wm_ctx* ctx, const float* in, int B, int channels, int n_in, int sr_in, int sr_out, float* out)
+{
+    if (!ctx || !in || !out) return WM_ERR_ARG;
+    WM_HIP(hipSetDevice(ctx->device));
+    return wm_enc_resample(ctx, in, B, channels, n_in, sr_in, sr_out, out);
+}
 
 extern "C" int wm_logmel(wm_ctx* ctx, const float* wav, int B, int n_samples, float* feats)
 {

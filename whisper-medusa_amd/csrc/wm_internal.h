@@ -78,6 +78,7 @@ struct wm_ctx {
     int* carry = nullptr;                                                   // [maxB] next base pass is redundant
     bool fuse = true;
     bool host_carry = false;                                                // single-stream runs: the host skips the base pass
+    float* rs_table = nullptr; int rs_og = 0, rs_nw = 0, rs_width = 0;     // cached resampling filter bank [taps][phases]
     bool dev_carry = false;                                                 // several streams: per-stream carry flags on the device
     int *hostflags = nullptr, *hostflags_dev = nullptr;                     // host-mapped {carry, finished}
     hipGraphExec_t graph_base = nullptr;
@@ -110,6 +111,8 @@ struct wm_ctx {
 };
 
 // implemented in wm_encoder.hip
+long wm_enc_resample_len(long n_in, int sr_in, int sr_out);
+int wm_enc_resample(wm_ctx* ctx, const float* in, int B, int channels, int n_in, int sr_in, int sr_out, float* out);
 int wm_enc_logmel(wm_ctx* ctx, const float* wav, int B, int n_samples, float* feats);
 int wm_enc_encode(wm_ctx* ctx, const float* feats, int B);
 // implemented in wm_decoder.hip

@@ -131,20 +131,34 @@ class WhisperMedusaModel:
         return self.config.medusa_choices
 
     # ---- F0 ---------------------------------------------------------------------------------
-    def extract_features(self, wav: Union[np.ndarray, torch.Tensor, Sequence[np.ndarray]]) -> torch.Tensor:
-        """16 kHz mono waveform(s) -> log-mel ``input_features`` [B, 80, 3000] on the GPU; pads / trims
-        to 30 s like ``WhisperFeatureExtractor`` (eval_whisper_medusa.py:46-50)."""
+    def extract_features(self, wav: Union[np.ndarray, torch.Tensor, Sequence[np.ndarray]], sampling_rate: int = 16000) -> torch.Tensor:
+        """waveform(s) -> log-mel ``input_features`` [B, 80, 3000] on the GPU; pads / trims to 30 s like
+        ``WhisperFeatureExtractor`` (eval_whisper_medusa.py:46-50).  Clips in a list are mono [n] or multi-channel
+        [channels, n] (a bare 2-D array is a batch of mono clips); anything that is not 16 kHz mono first goes through the audio front door on the GPU
+        (channel mean + torchaudio-default resampling, README.md:120-125 of the reference)."""
         n = 160 * self.config.n_mel_frames
         if isinstance(wav, (list, tuple)):
             clips = [np.asarray(w, dtype=np.float32) for w in wav]
         else:
             a = wav.detach().cpu().numpy() if isinstance(wav, torch.Tensor) else np.asarray(wav)
-            clips = [a.astype(np.float32)] if a.ndim == 1 else [r.astype(np.float32) for r in a]
-        buf = np.zeros((len(clips), n), dtype=np.float32)
+            a = a.astype(np.float32)
+            clips = [a] if a.ndim == 1 else [r for r in a]          # 2-D array = batch of mono clips; multi-channel clips go in a list
+        buf = torch.zeros(len(clips), n, dtype=torch.float32, device=self.device)
         for i, c in enumerate(clips):
-            m = min(len(c), n)
-            buf[i, :m] = c[:m]
-        return self.engine.logmel(torch.from_numpy(buf).to(self.device))
+            if c.ndim == 2 or sampling_rate != 16000:
+                t = torch.from_numpy(np.atleast_2d(c)[None]).to(self.device)         # [1, channels, n_in]
+                r = self.engine.resample(t, sampling_rate, 16000)[0]
+            else:
+                r = torch.from_numpy(c).to(self.device)
+            m = min(r.numel(), n)
+            buf[i, :m] = r[:m]
+        return self.engine.logmel(buf)
+
+    def features_from_file(self, path: str) -> torch.Tensor:
+        """PCM WAV file -> ``input_features`` [1, 80, 3000] (decode, downmix, resample, log-mel)."""
+        from .audio import read_wav
+        x, sr = read_wav(path)
+        return self.extract_features([x], sampling_rate=sr)
 
     # ---- generate ---------------------------------------------------------------------------
     def _gen_params(self, language, task, exponential_decay_length_penalty, max_new_tokens, max_length,

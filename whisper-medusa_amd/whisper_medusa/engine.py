@@ -48,7 +48,7 @@ class WmStats(C.Structure):
                 ("graph_replays", C.c_int32)]
 
 
-EXPORTS = ["wm_create", "wm_destroy", "wm_last_error", "wm_abi_version", "wm_logmel", "wm_encode",
+EXPORTS = ["wm_create", "wm_destroy", "wm_last_error", "wm_abi_version", "wm_resample_len", "wm_resample", "wm_logmel", "wm_encode",
            "wm_decode_begin", "wm_decode_run", "wm_get_tokens", "wm_get_stats", "wm_sync",
            "wm_get_encoder_output", "wm_forward_logits", "wm_get_cross_kv", "wm_profile_kernel"]
 
@@ -70,6 +70,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.wm_destroy.argtypes = [vp]; lib.wm_destroy.restype = None
     lib.wm_last_error.argtypes = [vp]; lib.wm_last_error.restype = C.c_char_p
     lib.wm_abi_version.argtypes = []
+    lib.wm_resample_len.argtypes = [C.c_int64, i32, i32]; lib.wm_resample_len.restype = C.c_int64
+    lib.wm_resample.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
     lib.wm_logmel.argtypes = [vp, vp, i32, i32, vp]
     lib.wm_encode.argtypes = [vp, vp, i32]
     lib.wm_decode_begin.argtypes = [vp, C.POINTER(WmGenParams), i32]
@@ -142,12 +144,36 @@ class Engine:
                 raise ValueError(f"{what}: {msg}")
             raise RuntimeError(f"{what} failed ({rc}): {msg}")
 
+    def _inputs_ready(self):
+        """The context runs on its own HIP stream: tensors PyTorch is still producing on its stream must be complete
+        before the engine reads them (pageable H2D copies return before the DMA lands, kernels are asynchronous)."""
+        torch.cuda.current_stream(self.device).synchronize()
+
+    # ---- audio front door -----------------------------------------------------------------
+    def resample(self, wav: torch.Tensor, sr_in: int, sr_out: int = 16000) -> torch.Tensor:
+        """wav [B, channels, n] (or [B, n]) float32 on the GPU -> mono [B, ceil(n * sr_out / sr_in)] at ``sr_out``:
+        channel mean + torchaudio-default windowed-sinc resampling (README.md:120-125 of the reference)."""
+        wav = wav.to(self.device, torch.float32)
+        if wav.dim() == 2:
+            wav = wav[:, None, :]
+        wav = wav.contiguous()
+        B, ch, n = wav.shape
+        n_out = int(self.lib.wm_resample_len(n, int(sr_in), int(sr_out)))
+        if n_out < 1:
+            raise ValueError("resample: empty input or bad sampling rates")
+        out = torch.empty(B, n_out, dtype=torch.float32, device=wav.device)
+        self._inputs_ready()
+        self._check(self.lib.wm_resample(self.h, C.c_void_p(wav.data_ptr()), B, ch, n, int(sr_in), int(sr_out),
+                                         C.c_void_p(out.data_ptr())), "wm_resample")
+        return out
+
     # ---- F0 -------------------------------------------------------------------------------
     def logmel(self, wav: torch.Tensor) -> torch.Tensor:
         """wav [B, 160*2*n_ctx] float32 on the GPU -> features [B, n_mels, 2*n_ctx]."""
         wav = wav.to(self.device, torch.float32).contiguous()
         B, n = wav.shape
         feats = torch.empty(B, self.cfg.num_mel_bins, self.cfg.n_mel_frames, dtype=torch.float32, device=wav.device)
+        self._inputs_ready()
         self._check(self.lib.wm_logmel(self.h, C.c_void_p(wav.data_ptr()), B, n, C.c_void_p(feats.data_ptr())), "wm_logmel")
         return feats
 
@@ -158,6 +184,7 @@ class Engine:
         if tuple(feats.shape[1:]) != (self.cfg.num_mel_bins, self.cfg.n_mel_frames):
             raise ValueError(f"Whisper expects the mel input features to be of length {self.cfg.n_mel_frames}, "
                              f"but found {feats.shape[-1]}")
+        self._inputs_ready()
         self._check(self.lib.wm_encode(self.h, C.c_void_p(feats.data_ptr()), B), "wm_encode")
         self._B = B
 
