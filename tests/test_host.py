@@ -179,3 +179,22 @@ def test_pool_sharding_and_stats_merge():
     m = merge_stats([a, b])
     assert m["iterations"] == 14 and m["iterations_launched"] == 28 and m["tokens_emitted"] == 190
     assert m["accept_hist"] == [11, 4, 9] and m["ms_decode"] == 40.0 and m["ms_encode"] == 2.0 and m["micro_batches"] == 2
+
+
+def test_save_pretrained_round_trip(tmp_path):
+    """checkpoint tooling: save_pretrained writes the reference's layout, from_pretrained reads it back."""
+    import torch
+    from whisper_medusa import WhisperMedusaModel, synth
+    from whisper_medusa.config import MedusaConfig
+    from whisper_medusa.weights import load_state_dict_from_dir
+    cfg = MedusaConfig.micro(K=4, heads_type="medusa_block")
+    sd = synth.synth_state_dict(cfg, seed=3)
+    m = WhisperMedusaModel(cfg, sd)                        # CPU-side object: no engine until .to("cuda")
+    for safe in (True, False):
+        d = tmp_path / ("st" if safe else "bin")
+        m.save_pretrained(str(d), safe_serialization=safe)
+        back = load_state_dict_from_dir(str(d))
+        assert "whisper_model.proj_out.weight" not in back and set(back) == set(sd) - {"whisper_model.proj_out.weight"}
+        assert all(torch.equal(back[k], sd[k].cpu()) for k in back)
+        m2 = WhisperMedusaModel.from_pretrained(str(d))
+        assert m2.config.to_dict() == cfg.to_dict()

@@ -56,6 +56,22 @@ class WhisperMedusaModel:
         sd = _weights.load_state_dict_from_dir(pretrained_model_name_or_path)
         return cls(config, sd, device=device, max_batch=max_batch)
 
+    def save_pretrained(self, save_directory: str, safe_serialization: bool = True) -> None:
+        """``config.json`` + ``model.safetensors`` with the reference's parameter names (what its Trainer writes,
+        trainer.py:45-51; the tied ``proj_out.weight`` is dropped like HF does) — re-loadable by ``from_pretrained`` here
+        and by the reference.  Needs the state dict (models built with ``from_blob`` only hold the packed blob)."""
+        import os
+        if not self._sd:
+            raise RuntimeError("save_pretrained needs the parameter state dict; this model was built from a packed blob")
+        os.makedirs(save_directory, exist_ok=True)
+        self.config.save_pretrained(save_directory)
+        sd = {k: v.detach().cpu().contiguous().clone() for k, v in self._sd.items() if k != "whisper_model.proj_out.weight"}
+        if safe_serialization:
+            from safetensors.torch import save_file
+            save_file(sd, os.path.join(save_directory, "model.safetensors"), metadata={"format": "pt"})
+        else:
+            torch.save(sd, os.path.join(save_directory, "pytorch_model.bin"))
+
     @classmethod
     def from_blob(cls, config: MedusaConfig, blob: torch.Tensor, offsets: np.ndarray, max_batch: int = 1):
         """Build directly from a packed parameter blob already resident on a GPU (the path the
