@@ -289,6 +289,29 @@ def test_generate_api_end_to_end(rig):
     rig.encode()
 
 
+def test_streamer_receives_every_iteration(rig):
+    """generate(streamer=...) hands over the prompt, then the tokens of each iteration, then end() (model.py:1034-1035,
+    :758-759, :795-796); concatenated they are the returned sequence."""
+    class Collect:
+        def __init__(self): self.chunks, self.ended = [], False
+        def put(self, t): self.chunks.append(t.flatten().tolist())
+        def end(self): self.ended = True
+    feats = rig.model.extract_features(rig.wavs[:1])
+    plain = rig.model.generate(feats, max_new_tokens=24, exponential_decay_length_penalty=(6, 1.3))
+    iters = rig.model.last_stats["iterations"]
+    st = Collect()
+    out = rig.model.generate(feats, max_new_tokens=24, exponential_decay_length_penalty=(6, 1.3), streamer=st)
+    assert torch.equal(out, plain) and st.ended
+    assert st.chunks[0] == synth.default_prompt(rig.cfg) and len(st.chunks) == 1 + iters
+    flat = [t for c in st.chunks for t in c]
+    got = out[0].tolist()
+    assert flat[: len(got)] == got                         # tokens past the first EOS are stripped from the returned tensor only
+    assert all(1 <= len(c) <= rig.cfg.medusa_num_heads + 1 for c in st.chunks[1:])
+    with pytest.raises(ValueError):
+        rig.model.generate(rig.model.extract_features(rig.wavs), streamer=Collect())
+    rig.encode()
+
+
 def test_runs_to_the_hard_length_limit(gpu):
     """No EOS, no max_new_tokens: decoding stops by the reference's `L + K >= max_length` rule (model.py:789-793)
     with the KV cache and position table used up to their last rows."""

@@ -254,7 +254,16 @@ class WhisperMedusaModel:
             return self._pad(seqs, gp)
         eng = self.engine
         eng.encode(feats)                                                   # F1 + F2
-        seqs = eng.decode(gp, B)                                            # F3..F14
+        streamer = kwargs.get("streamer")
+        if streamer is not None:
+            # model.py:1034-1035 (prompt), :758-759 (tokens of every iteration), :795-796 (end); HF streamers are batch-1
+            if B != 1:
+                raise ValueError("streamer only supports batch size 1")
+            streamer.put(torch.tensor([gp.prompt], dtype=torch.long))
+            seqs = eng.decode(gp, B, on_iteration=lambda new: streamer.put(torch.tensor(new[0], dtype=torch.long)))
+            streamer.end()
+        else:
+            seqs = eng.decode(gp, B)                                        # F3..F14
         self.last_stats = eng.stats()
         return self._pad(seqs, gp)
 

@@ -189,7 +189,7 @@ class Engine:
         self._B = B
 
     # ---- F3..F14 ------------------------------------------------------------------------------
-    def decode(self, gp: GenParams, B: int, max_iters: int = 1 << 30) -> List[List[int]]:
+    def decode(self, gp: GenParams, B: int, max_iters: int = 1 << 30, on_iteration=None) -> List[List[int]]:
         prompt, sup, bsup = _i32arr(gp.prompt), _i32arr(gp.suppress_tokens), _i32arr(gp.begin_suppress_tokens)
         g = WmGenParams(prompt, len(gp.prompt), gp.eos_token_id, gp.pad_token_id, sup, len(gp.suppress_tokens),
                         bsup, len(gp.begin_suppress_tokens), gp.max_length, gp.hard_max_length,
@@ -199,7 +199,20 @@ class Engine:
                         gp.accept_mode, 1 if gp.vanilla else 0)
         self._check(self.lib.wm_decode_begin(self.h, C.byref(g), B), "wm_decode_begin")
         left = C.c_int32(0)
-        self._check(self.lib.wm_decode_run(self.h, max_iters, C.byref(left)), "wm_decode_run")
+        if on_iteration is None:
+            self._check(self.lib.wm_decode_run(self.h, max_iters, C.byref(left)), "wm_decode_run")
+            return [self.tokens(b) for b in range(B)]
+        # streaming: one iteration per call, the tokens each stream gained are handed over as they appear
+        seen = [len(gp.prompt)] * B
+        it = 0
+        while it < max_iters:
+            self._check(self.lib.wm_decode_run(self.h, 1, C.byref(left)), "wm_decode_run")
+            it += 1
+            cur = [self.tokens(b) for b in range(B)]
+            on_iteration([cur[b][seen[b]:] for b in range(B)])
+            seen = [len(c) for c in cur]
+            if left.value == 0:
+                break
         return [self.tokens(b) for b in range(B)]
 
     def tokens(self, stream: int) -> List[int]:
