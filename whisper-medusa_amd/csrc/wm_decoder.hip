@@ -469,6 +469,18 @@ __global__ void k_select_argmax(const float* __restrict__ part1, int nrows, int 
     amax[out_row0 + row] = mi;
 }
 
+// batched hidden-state carry, Medusa-Block: rows of carrying streams take the saved block-layer output
+__global__ void k_rows_take_carried(float* __restrict__ dst, const float* __restrict__ keep, const int* __restrict__ carry, int d, int M,
+                                    const int* __restrict__ done)
+{
+    if (done && *done) return;
+    const int m = blockIdx.x;
+    if (m >= M || !carry[m]) return;
+    const float4* sp = reinterpret_cast<const float4*>(keep + (size_t)m * d);
+    float4* dp = reinterpret_cast<float4*>(dst + (size_t)m * d);
+    for (int j = threadIdx.x; j < (d >> 2); j += blockDim.x) dp[j] = sp[j];
+}
+
 // candidates of the base pass: cand[s][i] = argmax of head i   (medusa_utils.py:446-458, top-1 chain)
 __global__ void k_set_cand(const int* __restrict__ amax, int* __restrict__ cand, int rps, int n)
 {
@@ -486,7 +498,7 @@ __global__ void k_accept(GenDev gp, const int* __restrict__ cand, const int* __r
                          const float* __restrict__ part2, int* __restrict__ ids, int* __restrict__ L, int* __restrict__ kvlen,
                          int* __restrict__ finished, int* __restrict__ niter, long long* __restrict__ hist, int* __restrict__ done, int B,
                          int* __restrict__ carry, const float* __restrict__ hf, float* __restrict__ hf_keep, int d,
-                         int* __restrict__ hostflags)
+                         int* __restrict__ hostflags, const float* __restrict__ hb, float* __restrict__ hb_keep)
 {
     const int s = blockIdx.x, lane = threadIdx.x;
     if (finished[s]) return;
@@ -523,6 +535,11 @@ __global__ void k_accept(GenDev gp, const int* __restrict__ cand, const int* __r
         const float4* srcp = reinterpret_cast<const float4*>(hf + (size_t)(s * rps + a) * d);
         float4* dstp = reinterpret_cast<float4*>(hf_keep + (size_t)s * d);
         for (int j = lane; j < (d >> 2); j += 64) dstp[j] = srcp[j];
+        if (hb) {                  // Medusa-Block: the heads read the extra layer's output of that row (model.py:1414-1417)
+            const float4* bs = reinterpret_cast<const float4*>(hb + (size_t)(s * rps + a) * d);
+            float4* bd = reinterpret_cast<float4*>(hb_keep + (size_t)s * d);
+            for (int j = lane; j < (d >> 2); j += 64) bd[j] = bs[j];
+        }
     }
     if (lane == 0) {
         const int Ln = Lcur + n_emit;
@@ -658,8 +675,18 @@ int wm_dec_stage_final(wm_ctx* ctx, int b0, int nb, int Mper, int mode, int medu
     g_skinny_skip = nullptr;                               // heads / vocabulary projection always run
     ctx->hf_cur = hf;
     if (ctx->block && !ctx->gp.vanilla) {
-        int rc = dec_layer(ctx, ctx->dec[ctx->nkv - 1], ctx->nkv - 1, ctx->hblk, b0, nb, Mper, base, !medusa);
+        // verify pass (medusa disabled): the reference needs only the layer's K/V (model.py:1410-1413); with the hidden-state
+        // carry on, the layer runs completely so that row a's output can serve the next iteration's heads
+        const bool carrying = ctx->host_carry || ctx->dev_carry;
+        const bool kv_only = !medusa && !carrying;
+        const int* sskip = (mode == 0 && Mper == 1 && ctx->dev_carry) ? ctx->carry + b0 : nullptr;
+        int rc = dec_layer(ctx, ctx->dec[ctx->nkv - 1], ctx->nkv - 1, ctx->hblk, b0, nb, Mper, base, kv_only, sskip);
         if (rc) return rc;
+        if (sskip) {
+            hipLaunchKernelGGL(k_rows_take_carried, dim3(R), dim3(256), 0, st, ctx->hblk + (size_t)b0 * d, ctx->hb_keep + (size_t)b0 * d,
+                               sskip, d, R, g_skinny_done);
+            WM_HIP(hipGetLastError());
+        }
     }
     return WM_OK;
 }
@@ -773,7 +800,8 @@ int wm_dec_iter_rest(wm_ctx* ctx, int Mper_base)
     // dev_carry (several streams) it goes to hf_keep[stream] and the next base pass's final LayerNorm selects it.
     hipLaunchKernelGGL(k_accept, dim3(B), dim3(64), 0, st, gp, ctx->cand, ctx->amax, ctx->pc, ctx->part2, ctx->ids, ctx->L,
                        ctx->kvlen, ctx->finished, ctx->niter, ctx->hist, ctx->done, B, (carry || ctx->dev_carry) ? ctx->carry : nullptr, ctx->hf,
-                       carry ? ctx->hf : ctx->hf_keep, ctx->d, carry ? ctx->hostflags_dev : nullptr);
+                       carry ? ctx->hf : ctx->hf_keep, ctx->d, carry ? ctx->hostflags_dev : nullptr,
+                       ctx->block ? ctx->hblk : nullptr, carry ? ctx->hblk : ctx->hb_keep);
     WM_HIP(hipGetLastError());
     return WM_OK;
 }

@@ -34,7 +34,7 @@ extern "C" void wm_destroy(wm_ctx* ctx)
                     ctx->enc_out, ctx->kx, ctx->vx, ctx->kc, ctx->vc, ctx->h, ctx->hblk, ctx->hf, ctx->qbuf, ctx->xbuf, ctx->fbuf,
                     ctx->ybuf, ctx->cml, ctx->co, ctx->ticket, ctx->logits, ctx->amax, ctx->pc, ctx->part1, ctx->part2, ctx->ids, ctx->L, ctx->kvlen,
                     ctx->finished, ctx->cand, ctx->niter, ctx->hist, ctx->supmask, ctx->exppen, ctx->tap_tok, ctx->done,
-                    ctx->hf_keep, ctx->carry, ctx->rs_table};
+                    ctx->hf_keep, ctx->hb_keep, ctx->carry, ctx->rs_table};
     for (void* b : bufs) if (b) hipFree(b);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
@@ -130,6 +130,7 @@ extern "C" int wm_create(const wm_config* cfg, const wm_weights* w, int device, 
     CREATE_HIP(dev_alloc(&ctx->hblk, RW * d, st));
     CREATE_HIP(dev_alloc(&ctx->hf, RW * d, st));
     CREATE_HIP(dev_alloc(&ctx->hf_keep, B * d, st));
+    CREATE_HIP(dev_alloc(&ctx->hb_keep, B * d, st));
     CREATE_HIP(dev_alloc(&ctx->carry, B, st));
     CREATE_HIP(dev_alloc(&ctx->qbuf, RW * d, st));
     CREATE_HIP(dev_alloc(&ctx->xbuf, 2 * RW * d, st));          // hi + lo planes
@@ -212,8 +213,8 @@ extern "C" int wm_decode_begin(wm_ctx* ctx, const wm_gen_params* gp, int B)
     g.inv_temp = (gp->accept_mode == WM_ACCEPT_TYPICAL && gp->temperature > 0.f) ? 1.0f / gp->temperature : 1.0f;
     g.accept_mode = gp->accept_mode; g.vanilla = gp->vanilla; g.K = K; g.V = ctx->V; g.Vpad = ctx->Vpad; g.Tids = Tids;
     ctx->fuse = std::getenv("WM_NO_CARRY") == nullptr;
-    ctx->host_carry = ctx->fuse && !ctx->block && B == 1 && !gp->vanilla;
-    ctx->dev_carry = ctx->fuse && !ctx->block && B > 1 && !gp->vanilla;
+    ctx->host_carry = ctx->fuse && B == 1 && !gp->vanilla;
+    ctx->dev_carry = ctx->fuse && B > 1 && !gp->vanilla;
     g.fuse = ctx->host_carry ? 1 : (ctx->dev_carry ? 2 : 0);
     const bool same = ctx->graph && ctx->graph_B == B && std::memcmp(&g, &ctx->gp, sizeof(GenDev)) == 0;
     if (!same && ctx->graph) { hipGraphExecDestroy(ctx->graph); ctx->graph = nullptr; }

@@ -74,6 +74,7 @@ struct wm_ctx {
 
     // ---- decode row scratch (<= WM_MAX_ROWS_SKINNY rows per chunk) ----
     float *h = nullptr, *hblk = nullptr, *hf = nullptr, *qbuf = nullptr;    // hf: [maxB*16][d] post-final-LN rows
+    float *hb_keep = nullptr;                                               // Medusa-Block: carried block-layer output row per stream
     float *hf_cur = nullptr, *hf_keep = nullptr;                            // current chunk's rows; carried row per stream
     int* carry = nullptr;                                                   // [maxB] next base pass is redundant
     bool fuse = true;
