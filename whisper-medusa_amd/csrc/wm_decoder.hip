@@ -178,10 +178,10 @@ template <bool CROSS, bool NT>
 __global__ void __launch_bounds__(256)
 k_attn_mfma(const float* __restrict__ q, const bf16_t* __restrict__ kmat, const bf16_t* __restrict__ vtmat,
             const int* __restrict__ base, bf16_t* __restrict__ xout, size_t xplane, float* __restrict__ ml, float* __restrict__ po,
-            int* __restrict__ ticket, const int* __restrict__ done, const int* __restrict__ skip, const int* __restrict__ sskip,
+            int* __restrict__ ticket, const int* __restrict__ done, const int* __restrict__ sskip,
             int Mper, int H, int rows_alloc, int S, int NS, int K32)
 {
-    if ((done && *done) || (skip && *skip)) return;
+    if (done && *done) return;
     // per-stream skip: the stream carried its hidden state, this base-pass row is not used (its K/V reads are saved)
     if (sskip && sskip[blockIdx.z]) return;
     __shared__ float s_m[4][16], s_l[4][16];
@@ -604,7 +604,7 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
     if (kv_only) return WM_OK;
     // 2. causal self-attention over the contiguous cache
     hipLaunchKernelGGL((k_attn_mfma<false, false>), dim3(1, H, nb), dim3(256), 0, st, ctx->qbuf, kc, vc, base, ctx->xbuf, xpl,
-                       nullptr, nullptr, nullptr, g_skinny_done, g_skinny_skip, sskip, Mper, H, ctx->Tal, 0, 1, K32);
+                       nullptr, nullptr, nullptr, g_skinny_done, sskip, Mper, H, ctx->Tal, 0, 1, K32);
     WM_HIP(hipGetLastError());
     // 3. out_proj + residual
     WM_HIP(launch_skinny_rows(st, w.out_w, d / 16, K32, R, ctx->xbuf, xpl, EpResidual{h, w.out_b, d, R}));
@@ -615,10 +615,10 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
     static const bool xattn_nt = [] { const char* v = std::getenv("WM_XATTN_NT"); return v ? std::atoi(v) != 0 : true; }();
     if (xattn_nt)
         hipLaunchKernelGGL((k_attn_mfma<true, true>), dim3(xattn_blocks_per_head(ctx->NS, H * nb), H, nb), dim3(256), 0, st, ctx->qbuf, kx, vx, base, ctx->xbuf, xpl,
-                           ctx->cml, ctx->co, ctx->ticket, g_skinny_done, g_skinny_skip, sskip, Mper, H, ctx->Spad, ctx->S, ctx->NS, K32);
+                           ctx->cml, ctx->co, ctx->ticket, g_skinny_done, sskip, Mper, H, ctx->Spad, ctx->S, ctx->NS, K32);
     else
         hipLaunchKernelGGL((k_attn_mfma<true, false>), dim3(xattn_blocks_per_head(ctx->NS, H * nb), H, nb), dim3(256), 0, st, ctx->qbuf, kx, vx, base, ctx->xbuf, xpl,
-                           ctx->cml, ctx->co, ctx->ticket, g_skinny_done, g_skinny_skip, sskip, Mper, H, ctx->Spad, ctx->S, ctx->NS, K32);
+                           ctx->cml, ctx->co, ctx->ticket, g_skinny_done, sskip, Mper, H, ctx->Spad, ctx->S, ctx->NS, K32);
     WM_HIP(hipGetLastError());
     // 6. out_proj + residual
     WM_HIP(launch_skinny_rows(st, w.cout_w, d / 16, K32, R, ctx->xbuf, xpl, EpResidual{h, w.cout_b, d, R}));
@@ -637,7 +637,6 @@ int wm_dec_stage_layers(wm_ctx* ctx, int b0, int nb, int Mper, int mode)
 {
     hipStream_t st = ctx->stream;
     g_skinny_done = ctx->use_done ? ctx->done : nullptr;
-    g_skinny_skip = nullptr;
     const int d = ctx->d, R = nb * Mper;
     const int* base = (mode == 0 ? ctx->kvlen : ctx->L) + b0;
     if (R > ctx->Rcap || Mper > 16) { ctx->err = "decode pass exceeds the row capacity of the context"; return WM_ERR_ARG; }
@@ -670,9 +669,8 @@ int wm_dec_stage_final(wm_ctx* ctx, int b0, int nb, int Mper, int mode, int medu
     float* hf = ctx->hf + (size_t)b0 * Mper * d;          // rows of this chunk; persists until the stream's next pass
     hipLaunchKernelGGL(k_rows_norm, dim3((R + 3) / 4), dim3(256), 0, st, ctx->h, 1, 0, ctx->dec_lnf_w, ctx->dec_lnf_b, 1,
                        hf, ctx->block ? ctx->hblk : nullptr, nullptr, (size_t)0, K32, 1, 0, d, R,
-                       (mode == 0 && Mper == 1 && ctx->dev_carry) ? ctx->carry + b0 : g_skinny_skip, ctx->hf_keep + (size_t)b0 * d);
+                       (mode == 0 && Mper == 1 && ctx->dev_carry) ? ctx->carry + b0 : nullptr, ctx->hf_keep + (size_t)b0 * d);
     WM_HIP(hipGetLastError());
-    g_skinny_skip = nullptr;                               // heads / vocabulary projection always run
     ctx->hf_cur = hf;
     if (ctx->block && !ctx->gp.vanilla) {
         // verify pass (medusa disabled): the reference needs only the layer's K/V (model.py:1410-1413); with the hidden-state
@@ -775,7 +773,7 @@ int wm_dec_iter_rest(wm_ctx* ctx, int Mper_base)
     const GenDev gp = ctx->gp;
     const bool carry = ctx->host_carry;
     ctx->hf_cur = ctx->hf;
-    g_skinny_done = ctx->use_done ? ctx->done : nullptr; g_skinny_skip = nullptr;
+    g_skinny_done = ctx->use_done ? ctx->done : nullptr;
     int rc = wm_dec_stage_heads(ctx, nb, Mper_base, Mper_base - 1, 1);
     if (rc) return rc;
     hipLaunchKernelGGL(k_select1, dim3(SEL_SP, nb * rps), dim3(256), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen, ctx->L, rps, ctx->part1);
@@ -810,7 +808,7 @@ int wm_dec_iter_rest(wm_ctx* ctx, int Mper_base)
 int wm_dec_profile(wm_ctx* ctx, int kernel, int rows, int reps, float* ms, double* bytes)
 {
     if (kernel != 0 || rows < 1 || rows > 16) { ctx->err = "wm_profile_kernel: bad arguments"; return WM_ERR_ARG; }
-    g_skinny_done = nullptr; g_skinny_skip = nullptr;
+    g_skinny_done = nullptr;
     hipStream_t st = ctx->stream;
     const int d = ctx->d, K32 = d / 32, R = rows, H = ctx->H, F32 = ctx->ffn / 32;
     const size_t xpl = (size_t)ctx->Rcap * d, fpl = (size_t)ctx->Rcap * ctx->ffn;

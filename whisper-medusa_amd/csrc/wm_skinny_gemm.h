@@ -132,12 +132,11 @@ struct LdNorm {
 template <int U, class Ld, class Ep>
 __global__ void __launch_bounds__(640)
 k_skinny_gemm(const bf16_t* __restrict__ W, int N16, int K32, int ksplit, int rt_per_wg, const int* __restrict__ done,
-              const int* __restrict__ skip, Ld ld, Ep ep)
+              Ld ld, Ep ep)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // done: every stream finished (the rest of this replay is a no-op); skip: this base pass is redundant because
-    // the previous verify pass already produced the hidden state of its token (hidden-state carry)
-    if ((done && *done) || (skip && *skip)) return;
+    // done: every stream finished (the rest of this replay is a no-op)
+    if (done && *done) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ks = wave % ksplit, rtl = wave / ksplit;
@@ -300,8 +299,7 @@ k_rows_gemm(const bf16_t* __restrict__ W, int N16, int K32, int ksplit, const in
 }
 
 // ---- host-side launch plan -------------------------------------------------------------------
-static thread_local const int* g_skinny_done = nullptr;     // device flags checked by every launch of this translation unit
-static thread_local const int* g_skinny_skip = nullptr;
+static thread_local const int* g_skinny_done = nullptr;     // device flag checked by every launch of this translation unit
 struct SkinnyPlan { int ksplit, rt, U; };
 
 // K-slices of at most 16 fragments and, if possible,
@@ -343,7 +341,7 @@ static inline hipError_t launch_skinny_u(hipStream_t st, const bf16_t* W, int N1
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, W, N16, K32, p.ksplit, p.rt, g_skinny_done, g_skinny_skip, ld, ep);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, W, N16, K32, p.ksplit, p.rt, g_skinny_done, ld, ep);
     return hipGetLastError();
 }
 
