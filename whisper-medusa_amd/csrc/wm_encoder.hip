@@ -25,31 +25,37 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 
 // BM = token rows per tile: 128 (default) or 64 (doubles the block count of the N=d GEMMs).
 // NST = LDS ring stages: a stage (64 k of the X tile and of the 128-feature W tile) is filled by LDS-DMA; NST-1 stages
-// are in flight while one is consumed, and the consumer waits with a partial vmcnt for ITS stage only.  Grids of at
-// most one 64-row block per CU (one clip, N = d) run 4 stages; everywhere else two resident blocks x 2 stages measured
-// faster than one block x 3-4 stages (tests/microbench/enc_sweep.sh: occupancy beats ring depth).
-template <int BM, int NST, class Ep>
-__global__ void __launch_bounds__(256)
+// are in flight while one is consumed, and the consumer waits with a partial vmcnt for ITS stage only.
+// KS = K-split groups inside the block: group g (4 waves, its own LDS ring) walks the g-th part of the K loop and the
+// partial tiles are added in group order through LDS at the end (deterministic).  One clip gives the N = d GEMMs one
+// 64-row block per CU at most: KS = 2 doubles the waves per CU and halves the dependent K loop (FC2: 80 -> 40 steps).
+// Everywhere else two resident blocks x 2 stages measured faster than one block x 3-4 stages
+// (tests/microbench/enc_sweep.sh: occupancy beats ring depth).
+template <int BM, int NST, int KS, class Ep>
+__global__ void __launch_bounds__(256 * KS)
 k_gemm_tiled(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32, int tiles_m, int tiles_n, Ep ep)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];
     constexpr int XB = BM / 16 * 2;            // X fragments per stage (m-tiles x 2 k-tiles)
     constexpr int NB = XB + 16;                // + 16 W fragments (8 n-tiles x 2 k-tiles)
     constexpr int STAGE = NB * 1024;
     constexpr int LPW = NB / 4;                // LDS-DMA loads per wave per stage
     constexpr int MJ = BM / 32;                // token tiles per wave
     const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wa = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wa >> 2, w = wa & 3;
     const int wn = w >> 1, wm = w & 1;
+    char* smem = smem_all + grp * (NST * STAGE);
     // XCD-aware remap: consecutive tiles of one weight panel stay on one XCD's L2
     int bid = blockIdx.x;
     const int nwg = tiles_m * tiles_n;
     if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
     const int tn = bid / tiles_m, tm = bid - tn * tiles_m;
 
+    const int nkt = (K32 >> 1) / KS;           // k-steps of this group (the launcher checks divisibility)
+    const int k0 = grp * nkt;
     const bf16_t* xg = X + (size_t)tm * (BM / 16) * K32 * 512 + lane * 8;
     const bf16_t* wg = W + (size_t)tn * 8 * K32 * 512 + lane * 8;
-    const int nkt = K32 >> 1;
 
     auto stage_load = [&](int stage, int kt2) {
         char* sb = smem + stage * STAGE;
@@ -59,7 +65,7 @@ k_gemm_tiled(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32
             const bool isx = blk < XB;
             const int bb = isx ? blk : blk - XB;
             const int t = bb >> 1, kk = bb & 1;
-            const bf16_t* src = (isx ? xg : wg) + ((size_t)t * K32 + kt2 * 2 + kk) * 512;
+            const bf16_t* src = (isx ? xg : wg) + ((size_t)t * K32 + (k0 + kt2) * 2 + kk) * 512;
             glds16(src, sb + blk * 1024);
         }
     };
@@ -98,6 +104,28 @@ k_gemm_tiled(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32
         }
     }
 
+    if (KS > 1) {                              // partial tiles of groups 1.. go through LDS, group 0 adds them in order
+        __syncthreads();                       // the rings are no longer read
+        float4* red = reinterpret_cast<float4*>(smem_all);
+        if (grp > 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < MJ; ++j)
+                    red[((((grp - 1) * 4 + w) * 4 + i) * MJ + j) * 64 + lane] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+        __syncthreads();
+        if (grp > 0) return;
+        for (int g2 = 1; g2 < KS; ++g2)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < MJ; ++j) {
+                    const float4 p = red[((((g2 - 1) * 4 + w) * 4 + i) * MJ + j) * 64 + lane];
+                    acc[i][j][0] += p.x; acc[i][j][1] += p.y; acc[i][j][2] += p.z; acc[i][j][3] += p.w;
+                }
+    }
+
     const int m0 = tm * BM + wm * (BM / 2) + (lane & 15), n0 = tn * GT_BN + wn * 64 + 4 * (lane >> 4);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -105,17 +133,17 @@ k_gemm_tiled(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32
         for (int j = 0; j < MJ; ++j) ep.store4(m0 + j * 16, n0 + i * 16, acc[i][j]);
 }
 
-template <int BM, int NST, class Ep>
+template <int BM, int NST, int KS, class Ep>
 static inline hipError_t launch_gemm_tiled_bm(hipStream_t st, const bf16_t* X, const bf16_t* W, int Mrows, int N, int K32, const Ep& ep)
 {
     const int tiles_m = Mrows / BM, tiles_n = N / GT_BN;
-    constexpr int lds = NST * (BM / 16 * 2 + 16) * 1024;
-    auto kern = k_gemm_tiled<BM, NST, Ep>;
+    constexpr int lds = KS * NST * (BM / 16 * 2 + 16) * 1024;
+    auto kern = k_gemm_tiled<BM, NST, KS, Ep>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), lds, st, X, W, K32, tiles_m, tiles_n, ep);
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256 * KS), lds, st, X, W, K32, tiles_m, tiles_n, ep);
     return hipGetLastError();
 }
 
@@ -123,18 +151,15 @@ template <class Ep>
 static inline hipError_t launch_gemm_tiled(hipStream_t st, const bf16_t* X, const bf16_t* W, int Mrows, int N, int K32, const Ep& ep)
 {
     static const int big_nst = [] { const char* v = std::getenv("WM_ENC_GEMM_STAGES"); return v ? std::atoi(v) : 2; }();
+    static const int small_ks = [] { const char* v = std::getenv("WM_ENC_GEMM_KSPLIT"); return v ? std::atoi(v) : 2; }();
     const int blocks128 = (Mrows / 128) * (N / GT_BN);
-    // fewer than ~one block per CU with 128-row tiles: halve the tile to fill the chip
-    if (blocks128 < 200) return launch_gemm_tiled_bm<64, 4>(st, X, W, Mrows, N, K32, ep);
-    static const int mid = [] { const char* v = std::getenv("WM_ENC_GEMM_MID"); return v ? std::atoi(v) : 2; }();
-    if (blocks128 <= 512) {                // 1-2 blocks per CU: measured best with 2 stages x 2 resident blocks (tests/microbench/enc_sweep.sh)
-        if (mid == 4) return launch_gemm_tiled_bm<128, 4>(st, X, W, Mrows, N, K32, ep);
-        if (mid == 3) return launch_gemm_tiled_bm<128, 3>(st, X, W, Mrows, N, K32, ep);
-        if (mid == 64) return launch_gemm_tiled_bm<64, 4>(st, X, W, Mrows, N, K32, ep);
-        return launch_gemm_tiled_bm<128, 2>(st, X, W, Mrows, N, K32, ep);
+    // fewer than ~one block per CU with 128-row tiles: halve the tile to fill the chip and split K inside the block
+    if (blocks128 < 200) {
+        if (small_ks == 2 && (K32 >> 1) % 2 == 0 && (K32 >> 1) >= 8) return launch_gemm_tiled_bm<64, 3, 2>(st, X, W, Mrows, N, K32, ep);
+        return launch_gemm_tiled_bm<64, 4, 1>(st, X, W, Mrows, N, K32, ep);
     }
-    if (big_nst == 3) return launch_gemm_tiled_bm<128, 3>(st, X, W, Mrows, N, K32, ep);
-    return launch_gemm_tiled_bm<128, 2>(st, X, W, Mrows, N, K32, ep);
+    if (big_nst == 3) return launch_gemm_tiled_bm<128, 3, 1>(st, X, W, Mrows, N, K32, ep);
+    return launch_gemm_tiled_bm<128, 2, 1>(st, X, W, Mrows, N, K32, ep);
 }
 
 // =============================================================================================
