@@ -140,6 +140,28 @@ def test_greedy_mode_equals_vanilla(rig):
         assert van[b] == ref.ids
 
 
+def test_hidden_state_carry_is_bit_identical_to_two_passes(rig, monkeypatch):
+    """WM_NO_CARRY=1 runs base pass + verify pass every iteration (the reference's schedule); the default schedule carries
+    row a of the verify pass instead (host-driven at B = 1, per-stream flags at B > 1, Block: with the extra layer's
+    output).  Same tokens, same accept histogram, fewer passes."""
+    gp = golden_gen_params(rig.cfg, ACCEPT_TYPICAL, 30)
+    runs = {}
+    for carry in (True, False):
+        if carry:
+            monkeypatch.delenv("WM_NO_CARRY", raising=False)
+        else:
+            monkeypatch.setenv("WM_NO_CARRY", "1")
+        rig.encode()
+        both = rig.eng.decode(gp, rig.B)
+        st = rig.eng.stats()
+        rig.eng.encode(torch.from_numpy(rig.feats[:1]).to(rig.dev))
+        one = rig.eng.decode(gp, 1)[0]
+        runs[carry] = (both, st["accept_hist"], st["iterations"], one)
+    monkeypatch.delenv("WM_NO_CARRY", raising=False)
+    assert runs[True] == runs[False]
+    rig.encode()
+
+
 def test_batch_equals_independent_streams(rig):
     """B streams decoded together == each stream decoded alone (reference semantics: batch-1 runs)."""
     gp = golden_gen_params(rig.cfg, ACCEPT_TYPICAL, 30)
