@@ -29,22 +29,24 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 
-def decode_iter_bytes(cfg, B, mean_len):
+def decode_iter_bytes(cfg, B, mean_len, dec_fp8=False):
     """Algorithmic HBM bytes of one Medusa iteration: weights of the base pass (K+1 heads)
-    + weights of the verify pass (1 head) + per stream 2 x cross-KV + self-KV read in both passes."""
+    + weights of the verify pass (1 head) + per stream 2 x cross-KV + self-KV read in both passes.
+    ``dec_fp8``: the decoder-layer matrices are 1 byte per parameter (+ 4 bytes per output row of scales)."""
     d, f, L, V, K = cfg.d_model, cfg.decoder_ffn_dim, cfg.decoder_layers, cfg.vocab_size, cfg.medusa_num_heads
     layer = 6 * d * d + 2 * d * f            # q,k,v,out, cross-q, cross-out + fc1, fc2 (cross k/v proj not re-read)
+    lb = (1.0 * layer + 4.0 * (7 * d + f)) if dec_fp8 else 2.0 * layer          # bytes of one layer's matrices
     if cfg.is_block:
-        w_a = (L + 1) * layer + V * d + K * d * d
-        w_v = L * layer + V * d + 3 * d * d  # block runs only its qkv projection in the verify pass
+        w_a = (L + 1) * lb + 2.0 * (V * d + K * d * d)
+        w_v = L * lb + (lb * 3 * d * d / layer) + 2.0 * V * d   # block runs only its qkv projection in the verify pass
         nkv = L + 1
     else:
-        w_a = L * layer + V * d + (K + 1) * d * d
-        w_v = L * layer + V * d + d * d
+        w_a = L * lb + 2.0 * (V * d + (K + 1) * d * d)
+        w_v = L * lb + 2.0 * (V * d + d * d)
         nkv = L
     X = nkv * 2 * cfg.max_source_positions * d * 2
     skv = 2 * (nkv * 2 * mean_len * d * 2)
-    return 2.0 * (w_a + w_v) + B * (2.0 * X + skv)
+    return (w_a + w_v) + B * (2.0 * X + skv)
 
 
 def prefill_flops(cfg):
@@ -70,6 +72,8 @@ def main():
                          "under typical acceptance, close to the ~3 implied by the reference's x1.5 speed-up")
     ap.add_argument("--micro-batches", type=int, default=1,
                     help="decode the per-GPU batch as this many concurrent micro-batches (whisper_medusa/pool.py); 1 = one context")
+    ap.add_argument("--fp8-weights", action="store_true",
+                    help="BASELINE configs[4]: decoder-layer matrices as fp8 e4m3 + per-row scale (bf16 hi/lo MFMA on the widened fragments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vanilla", action="store_true",
                     help="skip the vanilla-greedy anchor (PMC passes: only Medusa iterations in the counter totals)")
@@ -99,12 +103,12 @@ def main():
     blob = offs = sd = None
     if rank == 0:
         sd = synth.synth_state_dict(cfg, seed=0, device=str(dev), logit_std=args.logit_std)
-        blob, offs = weights.build_blob(cfg, sd, device=dev)
+        blob, offs = weights.build_blob(cfg, sd, device=dev, dec_fp8=args.fp8_weights)
     t0 = time.time()
     blob, offs = wd.broadcast_blob(blob, offs, device=dev)
     torch.cuda.synchronize()
     t_bcast = time.time() - t0
-    model = WhisperMedusaModel.from_blob(cfg, blob, offs, max_batch=B)
+    model = WhisperMedusaModel.from_blob(cfg, blob, offs, max_batch=B, dec_weight_fp8=args.fp8_weights)
     eng = model.engine
 
     # ---- inputs resident in HBM ----
@@ -118,7 +122,7 @@ def main():
     pool = None
     if args.micro_batches > 1:
         from whisper_medusa.pool import ContextPool
-        pool = ContextPool(cfg, blob, offs, args.micro_batches, B)
+        pool = ContextPool(cfg, blob, offs, args.micro_batches, B, dec_weight_fp8=args.fp8_weights)
 
     def step():
         wav = wavs[step_no[0] % n_sets]
@@ -171,11 +175,11 @@ def main():
 
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if args.model == "large-v2" and B == 1 and args.heads == "linear" and os.path.exists(tpath):
+    if args.model == "large-v2" and B == 1 and args.heads == "linear" and not args.fp8_weights and os.path.exists(tpath):
         traffic = json.load(open(tpath))["medusa_iteration_bytes"]      # PMC FETCH_SIZE x2, see profiles/
     t_iter_ms = ms_dec / max(iters, 1)
     mean_len = len(gp.prompt) + args.max_new / 2
-    bytes_iter = decode_iter_bytes(cfg, B, mean_len)
+    bytes_iter = decode_iter_bytes(cfg, B, mean_len, args.fp8_weights)
     achieved = bytes_iter / (t_iter_ms * 1e-3) / 1e9
     gemm_rows = min(16, B * (cfg.medusa_num_heads + 1))
     gemm_ms, gemm_bytes = (None, None) if args.no_vanilla else eng.profile_layer_gemms(rows=gemm_rows, reps=50)
@@ -185,11 +189,11 @@ def main():
         "metric": "decoded_tokens_per_sec", "value": round(tokens_all / elapsed, 2), "unit": "tokens/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "vs_baseline": None, "dtype": "bf16" if not args.fp8_weights else "bf16 (fp8 e4m3 decoder-layer weights)", "data": "synthetic",
         "config": {"workload": f"whisper-{args.model} + medusa-{args.heads} K={cfg.medusa_num_heads}, "
                                f"{B} x 30 s clip(s) per GPU, log-mel+encoder+decode, max_new_tokens={args.max_new}, "
                                f"typical acceptance (T=1.0), hipGraph decode loop, random-init weights (logit_std={args.logit_std})",
-                   "streams_per_gpu": B, "micro_batches": args.micro_batches, "parallelism": f"dp{world}",
+                   "streams_per_gpu": B, "micro_batches": args.micro_batches, "fp8_decoder_weights": bool(args.fp8_weights), "parallelism": f"dp{world}",
                    "max_new_tokens": args.max_new},
         "tokens_per_sec_per_gpu": round(tokens_all / elapsed / world, 2),
         "rtf": round(elapsed / audio_s, 6), "x_realtime": round(audio_s / elapsed, 2),
@@ -220,7 +224,7 @@ def main():
             torch.set_num_threads(min(os.cpu_count() or 1, 64))
             enc = eng.encoder_output(1)[0]
             sd_cpu = {k: v.float().cpu() for k, v in sd.items()}
-            orc = Oracle(cfg, sd_cpu, sim="fp32")
+            orc = Oracle(cfg, sd_cpu, sim="fp32", dec_fp8=args.fp8_weights)
             tc = time.perf_counter()
             r = orc.decode(enc, gp, max_iters=args.cpu_iters)
             dt = time.perf_counter() - tc

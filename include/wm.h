@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define WM_ABI_VERSION 1
+#define WM_ABI_VERSION 2
 
 #define WM_OK 0
 #define WM_ERR_ARG (-1)      /* bad argument / unsupported configuration (reference: ValueError, model.py:225-229) */
@@ -55,6 +55,8 @@ typedef struct wm_config {
     int32_t medusa_heads;       /* K = medusa_num_heads, <= 15; chain tree medusa_choices=[1]*(K+1) */
     int32_t heads_type;         /* WM_HEADS_* */
     int32_t max_batch;          /* streams the context is sized for */
+    int32_t dec_weight_fp8;     /* 1: the six matrices of every decoder layer are fp8 e4m3 (OCP) in the packed layout, with one fp32
+                                 * scale per output row appended to the table (BASELINE.json configs[4]); 0: bf16 */
 } wm_config;
 
 /* Packed parameter blob (layout: whisper_medusa/weights.py).  The blob

@@ -204,13 +204,25 @@ class DecodeResult:
 class Oracle:
     """Functional Whisper-Medusa over a plain state dict (reference key layout)."""
 
-    def __init__(self, cfg, sd: Dict[str, torch.Tensor], sim: str = "fp32"):
+    def __init__(self, cfg, sd: Dict[str, torch.Tensor], sim: str = "fp32", dec_fp8: bool = False):
         assert sim in ("fp32", "bf16")
         self.cfg, self.sim = cfg, sim
         self.sd = {k: v.detach().to(torch.float32).cpu() for k, v in sd.items()}
         self.H = cfg.d_model // HEAD_DIM
         if "whisper_model.proj_out.weight" not in self.sd:
             self.sd["whisper_model.proj_out.weight"] = self.sd["whisper_model.model.decoder.embed_tokens.weight"]
+        # BASELINE.json configs[4] (fp8 weights; not a reference feature): the self-attention q/k/v/out, cross-attention q/out
+        # and MLP matrices of every decoder layer (and of the Medusa block) are W[n][k] = scale[n] * q[n][k], q in fp8 e4m3
+        # (round to nearest even), scale[n] = max_k |W[n][k]| / 448; a product is (x @ q^T) * scale.
+        self.q8: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
+        if dec_fp8:
+            for k, w in self.sd.items():
+                layer = k.startswith("whisper_model.model.decoder.layers.") or k.startswith("medusa_block.")
+                if layer and k.endswith(".weight") and w.dim() == 2 and not (k.endswith("encoder_attn.k_proj.weight") or k.endswith("encoder_attn.v_proj.weight")):
+                    amax = w.abs().amax(dim=1)
+                    scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+                    q = (w / scale[:, None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32)
+                    self.q8[k[: -len(".weight")]] = (q, scale)
 
     # ---- small helpers --------------------------------------------------------------
     def _r(self, x):           # rounding point of the engine contract (encoder operands, KV / encoder-output storage)
@@ -223,7 +235,12 @@ class Oracle:
         return hi + _bf16(x - hi)
 
     def _lin(self, x, prefix, bias=True, dec=False):
-        y = (self._rd(x) if dec else self._r(x)) @ self.sd[prefix + ".weight"].t()
+        xr = self._rd(x) if dec else self._r(x)
+        if prefix in self.q8:
+            q, scale = self.q8[prefix]
+            y = (xr @ q.t()) * scale
+        else:
+            y = xr @ self.sd[prefix + ".weight"].t()
         if bias and (prefix + ".bias") in self.sd:
             y = y + self.sd[prefix + ".bias"]
         return y

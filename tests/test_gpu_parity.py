@@ -295,6 +295,40 @@ def test_features_from_a_stereo_44k_wav_file(gpu, tmp_path):
     model.engine.close()
 
 
+@pytest.mark.parametrize("heads", ["base_head", "medusa_block"])
+def test_fp8_decoder_weights_match_the_fp8_oracle(gpu, heads):
+    """BASELINE configs[4]: decoder-layer matrices stored as fp8 e4m3 + per-row scale.  The engine widens them to bf16 in
+    registers (exact) and scales the fp32 accumulator, the oracle computes (x @ q^T) * scale: token ids bit-exact, logits
+    within the bf16-path tolerance; B = 1 (fused 16-row GEMM) and 6 streams (token-tile GEMM)."""
+    cfg = MedusaConfig.micro(K=4, heads_type=heads)
+    sd = synth.synth_state_dict(cfg, seed=21)
+    model = WhisperMedusaModel(cfg, sd, device=gpu, max_batch=6, dec_weight_fp8=True)
+    ref16 = WhisperMedusaModel(cfg, sd, device=gpu, max_batch=1)
+    eng = model.engine
+    orc = Oracle(cfg, sd, sim="bf16", dec_fp8=True)
+    n = cfg.n_mel_frames * 160
+    feats = model.extract_features([clip_for(cfg, i)[: n // (1 + i % 2)] for i in range(6)])
+    eng.encode(feats)
+    enc = eng.encoder_output(6)
+    prompt = synth.default_prompt(cfg)
+    z = eng.forward_logits([prompt], 0, False)[:, 0]
+    ref = orc.decoder_pass(orc.new_state(enc[0]), prompt, 0, disable_medusa=False)
+    assert (z - ref).abs().max() <= 2e-3 * max(1.0, float(ref.abs().max()))
+    ref16.engine.encode(feats[:1].contiguous())
+    z16 = ref16.engine.forward_logits([prompt], 0, False)[:, 0]
+    assert (z - z16).abs().max() > 1e-3                        # it really is a different (quantised) model
+    for mode in (ACCEPT_TYPICAL, ACCEPT_GREEDY):
+        gp = golden_gen_params(cfg, mode, 30)
+        eng.encode(feats)
+        both = eng.decode(gp, 6)
+        for b in range(6):
+            if b < 3:
+                assert orc.decode(enc[b], gp).ids == both[b], (mode, b)
+            eng.encode(feats[b: b + 1].contiguous())
+            assert eng.decode(gp, 1)[0] == both[b], (mode, b)
+    eng.close(); ref16.engine.close()
+
+
 def test_generate_api_end_to_end(rig):
     """from wav: log-mel -> encoder -> decode through the drop-in generate() (README.md:101-142 call shape)."""
     feats = rig.model.extract_features(rig.wavs[:1])

@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     lib = ctypes.CDLL(built_lib)
     for name in declared:
         assert hasattr(lib, name), f"libwm.so does not export {name}"
-    assert lib.wm_abi_version() == 1
+    assert lib.wm_abi_version() == 2
     from whisper_medusa import engine
     assert sorted(engine.EXPORTS) == declared
     engine.load_library()          # prototypes resolve
@@ -198,3 +198,36 @@ def test_save_pretrained_round_trip(tmp_path):
         assert all(torch.equal(back[k], sd[k].cpu()) for k in back)
         m2 = WhisperMedusaModel.from_pretrained(str(d))
         assert m2.config.to_dict() == cfg.to_dict()
+
+
+def test_fp8_row_quantiser_and_blob_layout():
+    """BASELINE configs[4]: per-row e4m3 quantisation of the decoder-layer matrices; packed fp8 tiles + appended scales."""
+    import torch
+    from whisper_medusa import synth
+    from whisper_medusa.config import MedusaConfig
+    from whisper_medusa.weights import (build_blob, n_table_entries, pack_matrix, pack_matrix_fp8, quantize_rows_e4m3,
+                                        unpack_matrix)
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(48, 64, generator=g) * torch.logspace(-3, 1, 48)[:, None]
+    w[5] = 0.0
+    q, sc = quantize_rows_e4m3(w)
+    assert q.dtype == torch.float8_e4m3fn and sc.shape == (48,) and sc[5] == 1.0
+    deq = q.to(torch.float32) * sc[:, None]
+    assert torch.all(deq[5] == 0)
+    amax = w.abs().amax(1, keepdim=True)
+    assert (deq - w).abs().max() <= (amax / 448 * 16).max()            # half a step of the top binade [256, 448]: 16 * scale
+    rel = ((deq - w).abs() / w.abs().clamp_min(1e-30))[w.abs() > amax / 16]
+    assert rel.max() <= 2.0 ** -4 + 1e-6                               # 3 mantissa bits, round to nearest
+    assert torch.equal(q.to(torch.float32).abs().amax(1)[sc != 1.0], torch.full((47,), 448.0))
+    # same element order as the bf16 packed layout, one byte per element
+    pf = pack_matrix_fp8(q)
+    pb = pack_matrix(q.to(torch.float32))
+    assert pf.dtype == torch.uint8 and pf.numel() == 48 * 64
+    assert torch.equal(pf.view(torch.float8_e4m3fn).to(torch.float32), pb.to(torch.float32))
+    assert torch.equal(unpack_matrix(pb, 48, 64).to(torch.float32), q.to(torch.float32))
+    cfg = MedusaConfig.micro(K=4, heads_type="medusa_block")
+    sd = synth.synth_state_dict(cfg, seed=1)
+    b16, o16 = build_blob(cfg, sd)
+    b8, o8 = build_blob(cfg, sd, dec_fp8=True)
+    assert len(o8) == n_table_entries(cfg, True) == len(o16) + 6 * cfg.n_kv_layers
+    assert b8.numel() < b16.numel()

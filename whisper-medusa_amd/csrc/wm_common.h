@@ -91,6 +91,30 @@ __device__ __forceinline__ bf16x8_t ld_frag_nt(const bf16_t* p) {    // streamed
     return __builtin_bit_cast(bf16x8_t, __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p)));
 }
 
+// Weight fragment of the weight-streaming GEMMs: bf16 (16 B per lane) or fp8 e4m3 (8 B per lane, the matrix's per-row
+// scale is applied to the fp32 accumulator afterwards).  The fp8 tile has the packed layout of the bf16 one — element
+// index = the same number, one byte per element — and is widened to bf16 exactly (every e4m3 value is a bf16 value), so
+// the MFMA and the hi/lo token operand are those of the bf16 path.
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+template <bool W8>
+__device__ __forceinline__ bf16x8_t ld_wfrag(const bf16_t* W, size_t elem) {
+    if constexpr (W8) {
+        const u32x2_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(reinterpret_cast<const unsigned char*>(W) + elem));
+        const f32x2_t a = __builtin_amdgcn_cvt_pk_f32_fp8(v[0], false), b = __builtin_amdgcn_cvt_pk_f32_fp8(v[0], true);
+        const f32x2_t c = __builtin_amdgcn_cvt_pk_f32_fp8(v[1], false), d = __builtin_amdgcn_cvt_pk_f32_fp8(v[1], true);
+        uint4 r;
+        r.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf16x2_t)); r.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(b, bf16x2_t));
+        r.z = __builtin_bit_cast(uint32_t, __builtin_convertvector(c, bf16x2_t)); r.w = __builtin_bit_cast(uint32_t, __builtin_convertvector(d, bf16x2_t));
+        return __builtin_bit_cast(bf16x8_t, r);
+    } else {
+        return ld_frag_nt(W + elem);
+    }
+}
+__device__ __forceinline__ f32x4_t scale4(f32x4_t v, const float* wscale, int n) {       // n % 4 == 0
+    const float4 s = *reinterpret_cast<const float4*>(wscale + n);
+    return f32x4_t{v[0] * s.x, v[1] * s.y, v[2] * s.z, v[3] * s.w};
+}
+
 // store 4 consecutive values as a bf16 hi/lo pair (x = hi + lo keeps ~17 mantissa bits)
 __device__ __forceinline__ void st_hilo4(bf16_t* hi, bf16_t* lo, float4 y)
 {

@@ -76,7 +76,8 @@ extern "C" int wm_create(const wm_config* cfg, const wm_weights* w, int device, 
     if (ctx->NS > 16 || ctx->H > 32) { g_create_err = "wm_create: n_ctx > 4096 or more than 32 heads unsupported"; wm_destroy(ctx); return WM_ERR_ARG; }
 
     // ---- parameter table ----
-    const int n_expected = 19 + 12 * cfg->enc_layers + 18 * ctx->nkv;
+    const bool w8 = cfg->dec_weight_fp8 != 0;
+    const int n_expected = 19 + 12 * cfg->enc_layers + 18 * ctx->nkv + (w8 ? 6 * ctx->nkv : 0);
     if (w->n_offsets != n_expected || !w->blob || !w->offsets) {
         g_create_err = "wm_create: weight table has " + std::to_string(w->n_offsets) + " entries, expected " + std::to_string(n_expected);
         wm_destroy(ctx); return WM_ERR_ARG;
@@ -103,6 +104,8 @@ extern "C" int wm_create(const wm_config* cfg, const wm_weights* w, int device, 
         e.ln2_w = F(); e.ln2_b = F(); e.cq_w = Hh(); e.cq_b = F(); e.cout_w = Hh(); e.cout_b = F();
         e.ln3_w = F(); e.ln3_b = F(); e.fc1_w = Hh(); e.fc1_b = F(); e.fc2_w = Hh(); e.fc2_b = F();
     }
+    if (w8)                                    // fp8 e4m3 decoder-layer matrices: one fp32 scale per output row, appended to the table
+        for (auto& e : ctx->dec) { e.qkv_s = F(); e.out_s = F(); e.cq_s = F(); e.cout_s = F(); e.fc1_s = F(); e.fc2_s = F(); }
 
     // ---- HBM allocation ----
     hipStream_t st = ctx->stream;

@@ -21,7 +21,8 @@ struct EncLayerW {
 };
 struct DecLayerW {
     const float *ln1_w, *ln1_b, *qkv_b, *out_b, *ln2_w, *ln2_b, *cq_b, *cout_b, *ln3_w, *ln3_b, *fc1_b, *fc2_b;
-    const bf16_t *qkv_w, *out_w, *cq_w, *cout_w, *fc1_w, *fc2_w;
+    const bf16_t *qkv_w, *out_w, *cq_w, *cout_w, *fc1_w, *fc2_w;     // packed bf16 — or packed fp8 e4m3 when the scales below are set
+    const float *qkv_s = nullptr, *out_s = nullptr, *cq_s = nullptr, *cout_s = nullptr, *fc1_s = nullptr, *fc2_s = nullptr;
 };
 
 // scalars every decode kernel may need (passed by value)

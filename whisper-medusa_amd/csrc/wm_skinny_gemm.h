@@ -129,10 +129,10 @@ struct LdNorm {
     }
 };
 
-template <int U, class Ld, class Ep>
+template <int U, bool W8, class Ld, class Ep>
 __global__ void __launch_bounds__(640)
-k_skinny_gemm(const bf16_t* __restrict__ W, int N16, int K32, int ksplit, int rt_per_wg, const int* __restrict__ done,
-              Ld ld, Ep ep)
+k_skinny_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int N16, int K32, int ksplit, int rt_per_wg,
+              const int* __restrict__ done, Ld ld, Ep ep)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // done: every stream finished (the rest of this replay is a no-op)
@@ -144,12 +144,12 @@ k_skinny_gemm(const bf16_t* __restrict__ W, int N16, int K32, int ksplit, int rt
     float4* red = reinterpret_cast<float4*>(smem + Ld::lds_bytes(K32));
     const int nk = K32 / ksplit, kt0 = ks * nk;
     const bool active = rt < N16;
-    const bf16_t* wp = W + ((size_t)(active ? rt : 0) * K32 + kt0) * 512 + lane * 8;
+    const size_t wp = ((size_t)(active ? rt : 0) * K32 + kt0) * 512 + lane * 8;     // element index (bf16: 2 B, fp8: 1 B per element)
 
     // first round of the weight stream goes out before the token operand exists
     bf16x8_t a[U], xh[U], xl[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) a[u] = ld_frag_nt(wp + (size_t)u * 512);
+    for (int u = 0; u < U; ++u) a[u] = ld_wfrag<W8>(W, wp + (size_t)u * 512);
 
     // epilogue operand (residual + bias) of the element this thread will finish: fetched under the weight stream
     float4 pre = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -176,7 +176,7 @@ k_skinny_gemm(const bf16_t* __restrict__ W, int N16, int K32, int ksplit, int rt
         const bool more = (kk + U) < nk;                      // wave-uniform
         if (more) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) an[u] = ld_frag_nt(wp + (size_t)(kk + U + u) * 512);
+            for (int u = 0; u < U; ++u) an[u] = ld_wfrag<W8>(W, wp + (size_t)(kk + U + u) * 512);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -206,11 +206,13 @@ k_skinny_gemm(const bf16_t* __restrict__ W, int N16, int K32, int ksplit, int rt
             }
             const int rt2 = blockIdx.x * rt_per_wg + rtl2;
             if (rt2 < N16) {
+                if constexpr (W8) s = scale4(s, wscale, rt2 * 16 + 4 * (l2 >> 4));
                 if constexpr (Ep::kPre) ep.store4p(l2 & 15, rt2 * 16 + 4 * (l2 >> 4), s, pre);
                 else ep.store4(l2 & 15, rt2 * 16 + 4 * (l2 >> 4), s);
             }
         }
     } else if (active) {
+        if constexpr (W8) acc = scale4(acc, wscale, rt * 16 + 4 * (lane >> 4));
         if constexpr (Ep::kPre) ep.store4p(lane & 15, rt * 16 + 4 * (lane >> 4), acc, pre);
         else ep.store4(lane & 15, rt * 16 + 4 * (lane >> 4), acc);
     }
@@ -233,9 +235,9 @@ k_ln_tiles(LdNorm ld, bf16_t* __restrict__ xg, size_t plane, const int* __restri
 // traffic of the operand re-reads by RT resp. TT); blockIdx.y walks the token-tile groups, so the chip is filled
 // by tokens as well as by features and the weights are re-read from L2 / Infinity Cache, not HBM.  Per output the
 // accumulation order is the 16-row kernel's (k ascending, hi then lo; K-slices summed in order): bit-identical.
-template <int NKR, int RT, int TT, class Ep>
+template <int NKR, int RT, int TT, bool W8, class Ep>
 __global__ void __launch_bounds__(640)
-k_rows_gemm(const bf16_t* __restrict__ W, int N16, int K32, int ksplit, const int* __restrict__ done,
+k_rows_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int N16, int K32, int ksplit, const int* __restrict__ done,
             const bf16_t* __restrict__ X, size_t plane, int MT, Ep ep)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -244,9 +246,9 @@ k_rows_gemm(const bf16_t* __restrict__ W, int N16, int K32, int ksplit, const in
     const int ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rt0 = blockIdx.x * RT, mt0 = blockIdx.y * TT;
     const int kt0 = ks * NKR;
-    const bf16_t* wp[RT]; const bf16_t* xp[TT];
+    size_t wp[RT]; const bf16_t* xp[TT];
 #pragma unroll
-    for (int i = 0; i < RT; ++i) wp[i] = W + ((size_t)min(rt0 + i, N16 - 1) * K32 + kt0) * 512 + lane * 8;
+    for (int i = 0; i < RT; ++i) wp[i] = ((size_t)min(rt0 + i, N16 - 1) * K32 + kt0) * 512 + lane * 8;
 #pragma unroll
     for (int j = 0; j < TT; ++j) xp[j] = X + ((size_t)min(mt0 + j, MT - 1) * K32 + kt0) * 512 + lane * 8;
     f32x4_t acc[RT][TT];
@@ -263,7 +265,7 @@ k_rows_gemm(const bf16_t* __restrict__ W, int N16, int K32, int ksplit, const in
 #pragma unroll
             for (int j = 0; j < TT; ++j) { xh[j][u] = ld_frag(xp[j] + (size_t)(kg + u) * 512); xl[j][u] = ld_frag(xp[j] + plane + (size_t)(kg + u) * 512); }
 #pragma unroll
-            for (int i = 0; i < RT; ++i) a[i][u] = ld_frag(wp[i] + (size_t)(kg + u) * 512);
+            for (int i = 0; i < RT; ++i) a[i][u] = ld_wfrag<W8>(W, wp[i] + (size_t)(kg + u) * 512);
         }
 #pragma unroll
         for (int u = 0; u < G; ++u)
@@ -287,14 +289,20 @@ k_rows_gemm(const bf16_t* __restrict__ W, int N16, int K32, int ksplit, const in
                 const float4 p = red[(t * ksplit + k2) * 64 + l2];
                 sacc[0] += p.x; sacc[1] += p.y; sacc[2] += p.z; sacc[3] += p.w;
             }
-            if (rt0 + i < N16 && mt0 + j < MT) ep.store4((mt0 + j) * 16 + (l2 & 15), (rt0 + i) * 16 + 4 * (l2 >> 4), sacc);
+            if (rt0 + i < N16 && mt0 + j < MT) {
+                if constexpr (W8) sacc = scale4(sacc, wscale, (rt0 + i) * 16 + 4 * (l2 >> 4));
+                ep.store4((mt0 + j) * 16 + (l2 & 15), (rt0 + i) * 16 + 4 * (l2 >> 4), sacc);
+            }
         }
     } else {
 #pragma unroll
         for (int i = 0; i < RT; ++i)
 #pragma unroll
             for (int j = 0; j < TT; ++j)
-                if (rt0 + i < N16 && mt0 + j < MT) ep.store4((mt0 + j) * 16 + (lane & 15), (rt0 + i) * 16 + 4 * (lane >> 4), acc[i][j]);
+                if (rt0 + i < N16 && mt0 + j < MT) {
+                    if constexpr (W8) acc[i][j] = scale4(acc[i][j], wscale, (rt0 + i) * 16 + 4 * (lane >> 4));
+                    ep.store4((mt0 + j) * 16 + (lane & 15), (rt0 + i) * 16 + 4 * (lane >> 4), acc[i][j]);
+                }
     }
 }
 
@@ -330,44 +338,56 @@ static inline SkinnyPlan skinny_plan(int N16, int K32, bool lds_loader) {
     return p;
 }
 
-template <int U, class Ld, class Ep>
-static inline hipError_t launch_skinny_u(hipStream_t st, const bf16_t* W, int N16, int K32, const SkinnyPlan& p,
-                                         const Ld& ld, const Ep& ep) {
+// a weight matrix in the packed layout: bf16 (scale == nullptr) or fp8 e4m3 with one fp32 scale per output row
+struct WRef {
+    const bf16_t* w; const float* scale;
+    WRef(const bf16_t* w_, const float* scale_ = nullptr) : w(w_), scale(scale_) {}
+};
+
+template <int U, bool W8, class Ld, class Ep>
+static inline hipError_t launch_skinny_u(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p, const Ld& ld, const Ep& ep) {
     const int grid = (N16 + p.rt - 1) / p.rt;
     const int threads = 64 * p.ksplit * p.rt;
     const size_t lds = Ld::lds_bytes(K32) + (p.ksplit > 1 ? (size_t)p.rt * p.ksplit * 1024 : 0);
-    auto kern = k_skinny_gemm<U, Ld, Ep>;
+    auto kern = k_skinny_gemm<U, W8, Ld, Ep>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, W, N16, K32, p.ksplit, p.rt, g_skinny_done, ld, ep);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, W.w, W.scale, N16, K32, p.ksplit, p.rt, g_skinny_done, ld, ep);
     return hipGetLastError();
 }
 
 template <class Ld, class Ep>
-static inline hipError_t launch_skinny(hipStream_t st, const bf16_t* W, int N16, int K32, const SkinnyPlan& p, const Ld& ld, const Ep& ep) {
-    if (p.U == 8) return launch_skinny_u<8>(st, W, N16, K32, p, ld, ep);
-    return launch_skinny_u<4>(st, W, N16, K32, p, ld, ep);
+static inline hipError_t launch_skinny(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p, const Ld& ld, const Ep& ep) {
+    if (W.scale) return p.U == 8 ? launch_skinny_u<8, true>(st, W, N16, K32, p, ld, ep) : launch_skinny_u<4, true>(st, W, N16, K32, p, ld, ep);
+    return p.U == 8 ? launch_skinny_u<8, false>(st, W, N16, K32, p, ld, ep) : launch_skinny_u<4, false>(st, W, N16, K32, p, ld, ep);
 }
 
-template <int NKR, int RT, class Ep>
-static inline hipError_t launch_rows_gemm(hipStream_t st, const bf16_t* W, int N16, int K32, const SkinnyPlan& p,
-                                          const bf16_t* X, size_t plane, int MT, const Ep& ep) {
+template <int NKR, int RT, bool W8, class Ep>
+static inline hipError_t launch_rows_gemm_w(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p,
+                                            const bf16_t* X, size_t plane, int MT, const Ep& ep) {
     constexpr int TT = 2;
     const dim3 grid((N16 + RT - 1) / RT, (MT + TT - 1) / TT);
     const size_t lds = p.ksplit > 1 ? (size_t)RT * TT * p.ksplit * 1024 : 0;
-    auto kern = k_rows_gemm<NKR, RT, TT, Ep>;
+    auto kern = k_rows_gemm<NKR, RT, TT, W8, Ep>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(64 * p.ksplit), lds, st, W, N16, K32, p.ksplit, g_skinny_done, X, plane, MT, ep);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * p.ksplit), lds, st, W.w, W.scale, N16, K32, p.ksplit, g_skinny_done, X, plane, MT, ep);
     return hipGetLastError();
 }
 
+template <int NKR, int RT, class Ep>
+static inline hipError_t launch_rows_gemm(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p,
+                                          const bf16_t* X, size_t plane, int MT, const Ep& ep) {
+    if (W.scale) return launch_rows_gemm_w<NKR, RT, true>(st, W, N16, K32, p, X, plane, MT, ep);
+    return launch_rows_gemm_w<NKR, RT, false>(st, W, N16, K32, p, X, plane, MT, ep);
+}
+
 template <int NKR, class Ep>
-static inline hipError_t launch_skinny_mt_nk(hipStream_t st, const bf16_t* W, int N16, int K32, const SkinnyPlan& p,
+static inline hipError_t launch_skinny_mt_nk(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p,
                                              const bf16_t* X, size_t plane, int MT, const Ep& ep) {
     static const int min_blocks = skinny_env("WM_ROWS_GEMM_MIN_BLOCKS", 200);
     // weight row tiles per wave: as many as still leave ~one block per CU (register blocking divides the L2 re-reads
@@ -379,7 +399,7 @@ static inline hipError_t launch_skinny_mt_nk(hipStream_t st, const bf16_t* W, in
 }
 
 template <class Ep>
-static inline hipError_t launch_skinny_mt(hipStream_t st, const bf16_t* W, int N16, int K32, const SkinnyPlan& p,
+static inline hipError_t launch_skinny_mt(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p,
                                           const bf16_t* X, size_t plane, int MT, const Ep& ep) {
     const int nk = K32 / p.ksplit;
     if (nk == 16) return launch_skinny_mt_nk<16>(st, W, N16, K32, p, X, plane, MT, ep);
@@ -391,7 +411,7 @@ static inline hipError_t launch_skinny_mt(hipStream_t st, const bf16_t* W, int N
 
 // out = X (R token rows, packed hi/lo planes in global memory) times W^T (N = 16*N16 features, K = 32*K32)
 template <class Ep>
-static inline hipError_t launch_skinny_rows(hipStream_t st, const bf16_t* W, int N16, int K32, int R, const bf16_t* X, size_t plane,
+static inline hipError_t launch_skinny_rows(hipStream_t st, WRef W, int N16, int K32, int R, const bf16_t* X, size_t plane,
                                             const Ep& ep) {
     const SkinnyPlan p = skinny_plan(N16, K32, false);
     if (R <= 16) return launch_skinny(st, W, N16, K32, p, LdPacked{X, K32, plane}, ep);
@@ -407,7 +427,7 @@ static inline bool skinny_norm_fusable(int N16, int K32) {
 // the packed hi/lo operand to `xscr` (global), then the register-blocked token-tile kernel runs.  The fused loader
 // needs the whole 16 x K tile in one batch of the block's threads (true for every Whisper size).
 template <class Ep>
-static inline hipError_t launch_skinny_norm(hipStream_t st, const bf16_t* W, int N16, int K32, const float* h, const float* gamma,
+static inline hipError_t launch_skinny_norm(hipStream_t st, WRef W, int N16, int K32, const float* h, const float* gamma,
                                             const float* beta, int d, int R, int row_mul, int row_off, int do_norm, const Ep& ep,
                                             bf16_t* xscr, size_t plane) {
     if (!skinny_norm_fusable(N16, K32)) return hipErrorInvalidConfiguration;

@@ -34,11 +34,12 @@ class MedusaForwardOutput:
 
 class WhisperMedusaModel:
     def __init__(self, config: MedusaConfig, state_dict: Dict[str, torch.Tensor], device: Union[str, torch.device, None] = None,
-                 max_batch: int = 1):
+                 max_batch: int = 1, dec_weight_fp8: bool = False):
         self.config = config
         self.generation_config = config          # posterior_threshold / alpha / token ids live on the config here
         self._sd = state_dict
         self._max_batch = max_batch
+        self._fp8 = bool(dec_weight_fp8)         # decoder-layer matrices stored as fp8 e4m3 + per-row scale (BASELINE configs[4])
         self._micro_batches = 1
         self._pool = None
         self._engine: Optional[Engine] = None
@@ -49,12 +50,12 @@ class WhisperMedusaModel:
 
     # ---- construction ---------------------------------------------------------------------
     @classmethod
-    def from_pretrained(cls, pretrained_model_name_or_path, *args, device=None, max_batch: int = 1, **kwargs):
+    def from_pretrained(cls, pretrained_model_name_or_path, *args, device=None, max_batch: int = 1, dec_weight_fp8: bool = False, **kwargs):
         """Load ``config.json`` + ``model.safetensors`` from a local checkpoint directory
         (reference model.py:265-291; there is no hub access in this environment)."""
         config = MedusaConfig.from_pretrained(pretrained_model_name_or_path)
         sd = _weights.load_state_dict_from_dir(pretrained_model_name_or_path)
-        return cls(config, sd, device=device, max_batch=max_batch)
+        return cls(config, sd, device=device, max_batch=max_batch, dec_weight_fp8=dec_weight_fp8)
 
     def save_pretrained(self, save_directory: str, safe_serialization: bool = True) -> None:
         """``config.json`` + ``model.safetensors`` with the reference's parameter names (what its Trainer writes,
@@ -73,13 +74,13 @@ class WhisperMedusaModel:
             torch.save(sd, os.path.join(save_directory, "pytorch_model.bin"))
 
     @classmethod
-    def from_blob(cls, config: MedusaConfig, blob: torch.Tensor, offsets: np.ndarray, max_batch: int = 1):
+    def from_blob(cls, config: MedusaConfig, blob: torch.Tensor, offsets: np.ndarray, max_batch: int = 1, dec_weight_fp8: bool = False):
         """Build directly from a packed parameter blob already resident on a GPU (the path the
         8-GPU data-parallel launcher uses after the RCCL broadcast, ``dist.py``)."""
-        self = cls(config, {}, device=None, max_batch=max_batch)
+        self = cls(config, {}, device=None, max_batch=max_batch, dec_weight_fp8=dec_weight_fp8)
         self._blob, self._offsets = blob, offsets
         self.device = blob.device
-        self._engine = Engine(config, blob, offsets, max_batch=max_batch, device=blob.device)
+        self._engine = Engine(config, blob, offsets, max_batch=max_batch, device=blob.device, dec_weight_fp8=dec_weight_fp8)
         return self
 
     def to(self, device):
@@ -94,8 +95,8 @@ class WhisperMedusaModel:
         if self._engine is not None and self.device == device:
             return self
         with torch.cuda.device(device):
-            self._blob, self._offsets = _weights.build_blob(self.config, self._sd, device=device)
-            self._engine = Engine(self.config, self._blob, self._offsets, max_batch=self._max_batch, device=device)
+            self._blob, self._offsets = _weights.build_blob(self.config, self._sd, device=device, dec_fp8=self._fp8)
+            self._engine = Engine(self.config, self._blob, self._offsets, max_batch=self._max_batch, device=device, dec_weight_fp8=self._fp8)
         self._drop_pool()
         self.device = device
         return self
@@ -111,7 +112,7 @@ class WhisperMedusaModel:
             self._max_batch = max_batch
             if self._engine is not None:
                 self._engine.close()
-                self._engine = Engine(self.config, self._blob, self._offsets, max_batch=max_batch, device=self.device)
+                self._engine = Engine(self.config, self._blob, self._offsets, max_batch=max_batch, device=self.device, dec_weight_fp8=self._fp8)
             self._drop_pool()
         return self
 
@@ -134,7 +135,7 @@ class WhisperMedusaModel:
         if self._pool is None:
             from .pool import ContextPool
             _ = self.engine                                         # raises when not on a HIP device
-            self._pool = ContextPool(self.config, self._blob, self._offsets, self._micro_batches, self._max_batch)
+            self._pool = ContextPool(self.config, self._blob, self._offsets, self._micro_batches, self._max_batch, self._fp8)
         return self._pool
 
     @property

@@ -16,13 +16,13 @@ from .config import MedusaConfig, GenParams, HEADS_BLOCK
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwm.so")
-WM_ABI_VERSION = 1
+WM_ABI_VERSION = 2
 
 
 class WmConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "abi_version", "d_model", "enc_layers", "dec_layers", "n_heads", "ffn_dim", "vocab", "n_mels",
-        "n_ctx", "n_tgt", "medusa_heads", "heads_type", "max_batch")]
+        "n_ctx", "n_tgt", "medusa_heads", "heads_type", "max_batch", "dec_weight_fp8")]
 
 
 class WmWeights(C.Structure):
@@ -102,7 +102,7 @@ class Engine:
     """One context = one GPU.  ``blob`` is the packed parameter tensor (uint8, on that GPU)."""
 
     def __init__(self, cfg: MedusaConfig, blob: torch.Tensor, offsets: np.ndarray, max_batch: int = 1,
-                 device: Optional[torch.device] = None):
+                 device: Optional[torch.device] = None, dec_weight_fp8: bool = False):
         if not torch.cuda.is_available():
             raise RuntimeError("no HIP device visible: the Whisper-Medusa engine has no CPU path")
         self.lib = load_library()
@@ -116,7 +116,7 @@ class Engine:
         c = WmConfig(WM_ABI_VERSION, cfg.d_model, cfg.encoder_layers, cfg.decoder_layers, cfg.n_heads,
                      cfg.decoder_ffn_dim, cfg.vocab_size, cfg.num_mel_bins, cfg.max_source_positions,
                      cfg.max_target_positions, cfg.medusa_num_heads,
-                     1 if cfg.medusa_heads_type == HEADS_BLOCK else 0, self.max_batch)
+                     1 if cfg.medusa_heads_type == HEADS_BLOCK else 0, self.max_batch, 1 if dec_weight_fp8 else 0)
         w = WmWeights(C.c_void_p(blob.data_ptr()), blob.numel(),
                       self._offsets.ctypes.data_as(C.POINTER(C.c_uint64)), len(self._offsets))
         self.stream = torch.cuda.current_stream(self.device)

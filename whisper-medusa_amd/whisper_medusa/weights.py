@@ -37,6 +37,29 @@ def unpack_matrix(p: torch.Tensor, n: int, k: int) -> torch.Tensor:
     return t.view(n, k)
 
 
+FP8_MAX = 448.0                  # largest finite e4m3 (OCP "fn") magnitude
+
+
+def quantize_rows_e4m3(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Per-output-row symmetric fp8 quantisation (BASELINE.json configs[4]): W[n][k] ~= scale[n] * q[n][k] with
+    scale[n] = max_k |W[n][k]| / 448 and q rounded to nearest-even e4m3.  Returns (q as float8_e4m3fn [N, K], fp32 scale [N])."""
+    # always on the CPU: GPU elementwise kernels turn `x / 448` into `x * (1 / 448)`, which moves a scale by one ulp and
+    # flips round-to-nearest ties of q — the quantised checkpoint must not depend on where it was packed
+    w = w.detach().to("cpu", torch.float32)
+    amax = w.abs().amax(dim=1)
+    scale = torch.where(amax > 0, amax / FP8_MAX, torch.ones_like(amax))
+    q = (w / scale[:, None]).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn)
+    return q, scale
+
+
+def pack_matrix_fp8(q: torch.Tensor) -> torch.Tensor:
+    """float8_e4m3fn [N, K] -> uint8 in the packed fragment layout [N/16][K/32][64][8] (one byte per element)."""
+    n, k = q.shape
+    assert n % 16 == 0 and k % 32 == 0, (n, k)
+    t = q.view(torch.uint8).view(n // 16, 16, k // 32, 4, 8)
+    return t.permute(0, 2, 3, 1, 4).contiguous().view(-1)
+
+
 def _pad2(w: torch.Tensor, n: int, k: int) -> torch.Tensor:
     if w.shape == (n, k):
         return w
@@ -45,8 +68,9 @@ def _pad2(w: torch.Tensor, n: int, k: int) -> torch.Tensor:
     return out
 
 
-def canonical_tensors(cfg: MedusaConfig, sd: Dict[str, torch.Tensor], device) -> List[torch.Tensor]:
-    """The parameter list in the engine's canonical order; each entry is a flat fp32 or bf16 tensor."""
+def canonical_tensors(cfg: MedusaConfig, sd: Dict[str, torch.Tensor], device, dec_fp8: bool = False) -> List[torch.Tensor]:
+    """The parameter list in the engine's canonical order; each entry is a flat fp32 / bf16 (/ uint8 fp8) tensor.
+    ``dec_fp8``: the six matrices of every decoder layer are stored as fp8 e4m3 and their per-row scales are appended."""
     d, dev = cfg.d_model, device
     f32 = lambda t: t.detach().to(dev, torch.float32).contiguous().view(-1)
     mat = lambda t: pack_matrix(t.detach().to(dev, torch.float32))
@@ -75,13 +99,22 @@ def canonical_tensors(cfg: MedusaConfig, sd: Dict[str, torch.Tensor], device) ->
                                        sd[p + ".encoder_attn.v_proj.weight"].to(dev, torch.float32)], 0) for p in kv_prefixes], 0)),
             torch.cat([torch.cat([zeros(d), f32(sd[p + ".encoder_attn.v_proj.bias"])]) for p in kv_prefixes])]
 
-    def qkv(p):
+    scales: List[torch.Tensor] = []
+
+    def wmat(w, fp8):
+        if not fp8:
+            return mat(w)
+        q, sc = quantize_rows_e4m3(w)
+        scales.append(sc.to(dev).contiguous())
+        return pack_matrix_fp8(q).to(dev)
+
+    def qkv(p, fp8=False):
         w = torch.cat([sd[p + ".q_proj.weight"], sd[p + ".k_proj.weight"], sd[p + ".v_proj.weight"]], 0)
         b = torch.cat([f32(sd[p + ".q_proj.bias"]), zeros(d), f32(sd[p + ".v_proj.bias"])])       # k_proj has no bias
-        return [mat(w), b]
+        return [wmat(w, fp8), b]
 
-    def lin(p):
-        return [mat(sd[p + ".weight"]), f32(sd[p + ".bias"])]
+    def lin(p, fp8=False):
+        return [wmat(sd[p + ".weight"], fp8), f32(sd[p + ".bias"])]
 
     def ln(p):
         return [f32(sd[p + ".weight"]), f32(sd[p + ".bias"])]
@@ -91,20 +124,20 @@ def canonical_tensors(cfg: MedusaConfig, sd: Dict[str, torch.Tensor], device) ->
         out += ln(p + ".self_attn_layer_norm") + qkv(p + ".self_attn") + lin(p + ".self_attn.out_proj")
         out += ln(p + ".final_layer_norm") + lin(p + ".fc1") + lin(p + ".fc2")
     for p in kv_prefixes:
-        out += ln(p + ".self_attn_layer_norm") + qkv(p + ".self_attn") + lin(p + ".self_attn.out_proj")
-        out += ln(p + ".encoder_attn_layer_norm") + lin(p + ".encoder_attn.q_proj") + lin(p + ".encoder_attn.out_proj")
-        out += ln(p + ".final_layer_norm") + lin(p + ".fc1") + lin(p + ".fc2")
-    return out
+        out += ln(p + ".self_attn_layer_norm") + qkv(p + ".self_attn", dec_fp8) + lin(p + ".self_attn.out_proj", dec_fp8)
+        out += ln(p + ".encoder_attn_layer_norm") + lin(p + ".encoder_attn.q_proj", dec_fp8) + lin(p + ".encoder_attn.out_proj", dec_fp8)
+        out += ln(p + ".final_layer_norm") + lin(p + ".fc1", dec_fp8) + lin(p + ".fc2", dec_fp8)
+    return out + scales          # fp8: 6 scale vectors per decoder layer, in launch order (qkv, out, cq, cout, fc1, fc2)
 
 
-def n_table_entries(cfg: MedusaConfig) -> int:
-    return 19 + 12 * cfg.encoder_layers + 18 * cfg.n_kv_layers
+def n_table_entries(cfg: MedusaConfig, dec_fp8: bool = False) -> int:
+    return 19 + 12 * cfg.encoder_layers + 18 * cfg.n_kv_layers + (6 * cfg.n_kv_layers if dec_fp8 else 0)
 
 
-def build_blob(cfg: MedusaConfig, sd: Dict[str, torch.Tensor], device="cpu") -> Tuple[torch.Tensor, np.ndarray]:
+def build_blob(cfg: MedusaConfig, sd: Dict[str, torch.Tensor], device="cpu", dec_fp8: bool = False) -> Tuple[torch.Tensor, np.ndarray]:
     """-> (uint8 blob on ``device``, uint64 offsets[n_table_entries])."""
-    tensors = canonical_tensors(cfg, sd, device)
-    assert len(tensors) == n_table_entries(cfg), (len(tensors), n_table_entries(cfg))
+    tensors = canonical_tensors(cfg, sd, device, dec_fp8)
+    assert len(tensors) == n_table_entries(cfg, dec_fp8), (len(tensors), n_table_entries(cfg, dec_fp8))
     offsets, total = [], 0
     for t in tensors:
         offsets.append(total)
