@@ -342,6 +342,12 @@ def test_generate_api_end_to_end(rig):
     want = ref.ids[: ref.ids.index(gp.eos_token_id) + 1] if gp.eos_token_id in ref.ids[P:] else ref.ids
     assert out[0].tolist() == want
     assert rig.model.last_stats["iterations"] == ref.n_iters
+    d = rig.model.generate(feats, max_new_tokens=24, exponential_decay_length_penalty=(6, 1.3), return_dict_in_generate=True)
+    assert set(d) == {"sequences"} and torch.equal(d["sequences"], out)
+    d = rig.model.generate(feats, max_new_tokens=24, exponential_decay_length_penalty=(6, 1.3), return_segments=True)
+    assert torch.equal(d["sequences"], out) and len(d["segments"]) == 1 and torch.equal(d["segments"][0][0]["result"], out[0])
+    with pytest.raises(NotImplementedError):
+        rig.model.generate(feats, return_token_timestamps=True)
     rig.encode()
 
 

@@ -248,11 +248,13 @@ class WhisperMedusaModel:
                               kwargs.get("posterior_alpha"), kwargs.get("suppress_tokens"),
                               kwargs.get("begin_suppress_tokens"), prompt_ids)
         feats = input_features.to(self.device, torch.float32).contiguous()
+        if return_token_timestamps:
+            raise NotImplementedError("token timestamps are not supported with medusa")
         if self._micro_batches > 1 and B >= 2:
             pool = self._get_pool()
             seqs = pool.run(feats, gp)                                      # F1..F14 per micro-batch, concurrently
             self.last_stats = pool.last_stats
-            return self._pad(seqs, gp)
+            return self._outputs(seqs, gp, return_dict_in_generate, return_segments)
         eng = self.engine
         eng.encode(feats)                                                   # F1 + F2
         streamer = kwargs.get("streamer")
@@ -266,7 +268,21 @@ class WhisperMedusaModel:
         else:
             seqs = eng.decode(gp, B)                                        # F3..F14
         self.last_stats = eng.stats()
-        return self._pad(seqs, gp)
+        return self._outputs(seqs, gp, return_dict_in_generate, return_segments)
+
+    def _outputs(self, seqs, gp, return_dict_in_generate, return_segments):
+        """Default: the padded LongTensor.  ``return_dict_in_generate`` / ``return_segments``: the reference's dict form
+        ``{"sequences": ..., ["segments": ...]}`` (model.py:1747-1779; one segment per clip, short-form only)."""
+        t = self._pad(seqs, gp)
+        if not return_dict_in_generate and not return_segments:
+            return t
+        out = {"sequences": t}
+        if return_segments:
+            P = len(gp.prompt)
+            out["segments"] = [[{"start": torch.tensor(0.0), "end": torch.tensor(30.0 * self.config.max_source_positions / 1500.0),
+                                 "tokens": t[i, P:][t[i, P:] != gp.pad_token_id] if gp.pad_token_id != gp.eos_token_id else t[i, P:],
+                                 "result": t[i]}] for i in range(t.shape[0])]
+        return out
 
     def _pad(self, seqs: List[List[int]], gp: GenParams) -> torch.Tensor:
         """G3: strip trailing pad/eos beyond the first EOS, right-pad to a tensor (model.py:1929-1973,1747-1762)."""
