@@ -96,10 +96,12 @@ __device__ __forceinline__ bf16x8_t ld_frag_nt(const bf16_t* p) {    // streamed
 // index = the same number, one byte per element — and is widened to bf16 exactly (every e4m3 value is a bf16 value), so
 // the MFMA and the hi/lo token operand are those of the bf16 path.
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
-template <bool W8>
+// NT: streamed once per pass (single-stream GEMMs) -> nt policy; re-read by other token-tile groups (batched GEMM) -> default
+template <bool W8, bool NT>
 __device__ __forceinline__ bf16x8_t ld_wfrag(const bf16_t* W, size_t elem) {
     if constexpr (W8) {
-        const u32x2_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(reinterpret_cast<const unsigned char*>(W) + elem));
+        const u32x2_t* p8 = reinterpret_cast<const u32x2_t*>(reinterpret_cast<const unsigned char*>(W) + elem);
+        const u32x2_t v = NT ? __builtin_nontemporal_load(p8) : *p8;
         const f32x2_t a = __builtin_amdgcn_cvt_pk_f32_fp8(v[0], false), b = __builtin_amdgcn_cvt_pk_f32_fp8(v[0], true);
         const f32x2_t c = __builtin_amdgcn_cvt_pk_f32_fp8(v[1], false), d = __builtin_amdgcn_cvt_pk_f32_fp8(v[1], true);
         uint4 r;
@@ -107,7 +109,7 @@ __device__ __forceinline__ bf16x8_t ld_wfrag(const bf16_t* W, size_t elem) {
         r.z = __builtin_bit_cast(uint32_t, __builtin_convertvector(c, bf16x2_t)); r.w = __builtin_bit_cast(uint32_t, __builtin_convertvector(d, bf16x2_t));
         return __builtin_bit_cast(bf16x8_t, r);
     } else {
-        return ld_frag_nt(W + elem);
+        return NT ? ld_frag_nt(W + elem) : ld_frag(W + elem);
     }
 }
 __device__ __forceinline__ f32x4_t scale4(f32x4_t v, const float* wscale, int n) {       // n % 4 == 0

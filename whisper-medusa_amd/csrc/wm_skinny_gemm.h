@@ -149,7 +149,7 @@ k_skinny_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, in
     // first round of the weight stream goes out before the token operand exists
     bf16x8_t a[U], xh[U], xl[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) a[u] = ld_wfrag<W8>(W, wp + (size_t)u * 512);
+    for (int u = 0; u < U; ++u) a[u] = ld_wfrag<W8, true>(W, wp + (size_t)u * 512);
 
     // epilogue operand (residual + bias) of the element this thread will finish: fetched under the weight stream
     float4 pre = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -176,7 +176,7 @@ k_skinny_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, in
         const bool more = (kk + U) < nk;                      // wave-uniform
         if (more) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) an[u] = ld_wfrag<W8>(W, wp + (size_t)(kk + U + u) * 512);
+            for (int u = 0; u < U; ++u) an[u] = ld_wfrag<W8, true>(W, wp + (size_t)(kk + U + u) * 512);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -265,7 +265,7 @@ k_rows_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int 
 #pragma unroll
             for (int j = 0; j < TT; ++j) { xh[j][u] = ld_frag(xp[j] + (size_t)(kg + u) * 512); xl[j][u] = ld_frag(xp[j] + plane + (size_t)(kg + u) * 512); }
 #pragma unroll
-            for (int i = 0; i < RT; ++i) a[i][u] = ld_wfrag<W8>(W, wp[i] + (size_t)(kg + u) * 512);
+            for (int i = 0; i < RT; ++i) a[i][u] = ld_wfrag<W8, false>(W, wp[i] + (size_t)(kg + u) * 512);
         }
 #pragma unroll
         for (int u = 0; u < G; ++u)
