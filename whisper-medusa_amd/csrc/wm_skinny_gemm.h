@@ -389,8 +389,8 @@ static inline hipError_t launch_rows_gemm(hipStream_t st, WRef W, int N16, int K
 template <int NKR, class Ep>
 static inline hipError_t launch_skinny_mt_nk(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p,
                                              const bf16_t* X, size_t plane, int MT, const Ep& ep) {
-    static const int min_blocks = skinny_env("WM_ROWS_GEMM_MIN_BLOCKS", 200);
-    // weight row tiles per wave: as many as still leave ~one block per CU (register blocking divides the L2 re-reads
+    static const int min_blocks = skinny_env("WM_ROWS_GEMM_MIN_BLOCKS", 400);
+    // weight row tiles per wave: as many as still leave >= 400 blocks (~1.5 per CU; swept 100..800 at 8 and 32 streams) (register blocking divides the L2 re-reads
     // of the token operand; with few token tiles the chip has to be filled by features instead).  Same results.
     const int groups = (MT + 1) / 2;
     if (((N16 + 3) / 4) * groups >= min_blocks) return launch_rows_gemm<NKR, 4>(st, W, N16, K32, p, X, plane, MT, ep);
