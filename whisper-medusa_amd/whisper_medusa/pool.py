@@ -7,8 +7,11 @@ micro-batches and drives every context from its own host thread (ctypes releases
 never interact — the engine's results do not depend on batch composition — so the tokens are those of a single
 context run (tests/test_gpu_parity.py::test_micro_batches_match_single_context).
 
-Measured on MI355X, whisper-large-v2 + Medusa-Linear K=10, 32 clips (tests/microbench/two_ctx.py): 1 x 32 streams
-5.96 k tokens/s, 2 x 16 streams 6.76 k tokens/s; 64 clips as 2 x 32: 8.2 k tokens/s.
+Measured on MI355X, whisper-large-v2 + Medusa-Linear K=10 (tests/microbench/two_ctx.py, bench.py --micro-batches):
+32 clips: 1 x 32 streams 6.9 k tokens/s, 2 x 16 streams 7.3-7.7 k; 64 clips as 2 x 32: 8.2 k; 2 clips as 2 x 1 (each
+context then runs the host-driven single-stream schedule): 1.77 k vs 1.33 k batched.  It does NOT help in between
+(4 x 1: 1.6 k vs 2.6 k batched, 2 x 4: 3.3 k vs 3.9 k): more host threads synchronising every iteration, and every
+context re-streams the weights.  Two contexts is the useful setting.
 """
 from __future__ import annotations
 
