@@ -1,0 +1,35 @@
+"""bench.py's algorithmic byte / FLOP figures (what roofline.achieved is priced on) against SURVEY.md §8d."""
+import importlib.util
+import os
+
+from helpers import ROOT, MedusaConfig
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_decode_iteration_bytes_match_the_survey_figures():
+    b = _bench()
+    lin = MedusaConfig.large_v2("base_head", K=10)
+    blk = MedusaConfig.large_v2("medusa_block", K=10)
+    # W_a = 1.638 GB, W_v = 1.605 GB, X = 245.76 MB / stream / pass, S_kv = 0.328 MB x len (both passes)
+    one = b.decode_iter_bytes(lin, 1, 64)
+    assert abs(one - (1.638e9 + 1.605e9 + 2 * 245.76e6 + 0.328e6 * 64)) / one < 5e-3
+    assert abs(one - 3.75e9) / 3.75e9 < 0.01                       # "B=1 Linear: ~3.76 GB/iter"
+    b32 = b.decode_iter_bytes(lin, 32, 64)
+    assert abs(b32 - 19.6e9) / 19.6e9 < 0.03                       # "B=32 Linear: ~19.6 GB/iter"
+    assert b.decode_iter_bytes(blk, 1, 64) > one                    # the extra layer and its cross-KV
+    # fp8 decoder-layer weights: the layer matrices shrink to one byte per parameter, everything else stays
+    f8 = b.decode_iter_bytes(lin, 1, 64, True)
+    layer_params = 32 * (6 * 1280 * 1280 + 2 * 1280 * 5120)
+    assert abs((one - f8) - 2 * (layer_params - 4 * 32 * (7 * 1280 + 5120))) / one < 1e-3
+
+
+def test_prefill_flops_match_the_survey_figure():
+    b = _bench()
+    lin = MedusaConfig.large_v2("base_head", K=10)
+    assert abs(b.prefill_flops(lin) - 2.59e12) / 2.59e12 < 0.01    # encoder 2.273 + cross-KV projection 0.315 TFLOP
