@@ -87,7 +87,7 @@ def main():
     assert world == args.gpus or (world == 1 and args.gpus == 1), f"WORLD_SIZE={world} but --gpus {args.gpus}"
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a HIP device: the engine has no CPU path")
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", local % torch.cuda.device_count())     # a launcher may narrow the visible devices per rank
     torch.cuda.set_device(dev)
 
     heads = "medusa_block" if args.heads == "block" else "base_head"
