@@ -7,6 +7,8 @@ Tolerances (engine contract = oracle sim="bf16": bf16 GEMM operands / KV cache, 
   decoder logits    max |d| <= 6e-2, mean |d| <= 4e-3           (given the SAME encoder output)
   token ids         bit-exact against the oracle run on the engine's encoder output
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -187,7 +189,7 @@ def test_many_streams_batched_path(gpu):
     eng.encode(feats)
     both = eng.decode(gp, 8)
     st = eng.stats()
-    assert sum(st["accept_hist"]) >= 8 and st["graph_replays"] > 0
+    assert sum(st["accept_hist"]) >= 8 and (st["graph_replays"] > 0 or os.environ.get("WM_NO_GRAPH"))
     orc = Oracle(cfg, sd, sim="bf16")
     enc = eng.encoder_output(8)
     for b in range(8):
