@@ -7,9 +7,12 @@ Runs only in the build container (needs ``/root/reference``; the GPU box has no 
 What is executed from the reference (nothing is copied):
   * ``whisper_medusa/models/medusa_utils.py`` imported by path: ``generate_medusa_buffers``,
     ``generate_candidates``, ``evaluate_posterior`` (both branches);
-  * ``WhisperMedusaModel.forward()`` (Medusa-Linear) under the import stubs of SURVEY.md
+  * ``WhisperMedusaModel.forward()`` (Medusa-Linear AND Medusa-Block) under the import stubs of SURVEY.md
     Appendix B, driven cache-free (full ``decoder_input_ids`` each call) — mathematically the
-    cached path because of causal masking;
+    cached path because of causal masking.  Medusa-Block needs two more shims for transformers 5.x
+    (``build_ref``): ``_forward_medusa_block`` (model.py:1361-1380) has no branch for the ``EncoderDecoderCache``
+    HF now always returns, so the name it tests against is swapped for a pass-through class, and
+    ``WhisperDecoderLayer`` now returns a tensor where the reference indexes a tuple (model.py:1414);
   * HF's own ``SuppressTokensLogitsProcessor`` / ``SuppressTokensAtBeginLogitsProcessor`` /
     ``ExponentialDecayLengthPenalty`` as the processor list the reference builds
     (model.py:1168-1207, :1106-1116).
@@ -78,7 +81,8 @@ def _import_reference_package():
     return ref_model, ref_cfg
 
 
-def build_ref_linear(cfg: MedusaConfig, sd):
+def build_ref(cfg: MedusaConfig, sd):
+    """The reference's own ``WhisperMedusaModel`` (either head type) with the seeded checkpoint loaded."""
     from transformers import WhisperConfig
     ref_model, ref_cfg = _import_reference_package()
     hf_cfg = WhisperConfig(
@@ -95,11 +99,30 @@ def build_ref_linear(cfg: MedusaConfig, sd):
     mcfg = ref_cfg.MedusaConfig(
         medusa_num_heads=cfg.medusa_num_heads, medusa_num_layers=1, medusa_hidden_size=cfg.d_model,
         whisper_model_name="dummy", medusa_choices=[1] * (cfg.medusa_num_heads + 1),
-        medusa_heads_type="base_head")
+        medusa_heads_type=cfg.medusa_heads_type)
     model = ref_model.WhisperMedusaModel(mcfg).eval()
     missing, unexpected = model.load_state_dict(sd, strict=False)
     assert not unexpected, unexpected
     assert all("proj_out" in m or "embed_positions" in m for m in missing), missing
+    if cfg.is_block:
+        real_edc = ref_model.EncoderDecoderCache
+
+        class _PassThroughCache:            # `isinstance(hf_cache, _PassThroughCache)` is False -> model.py:1365-1370 runs and
+            def __new__(cls, self_cache, cross_cache=None):     # "wraps" the cache HF already built: hand it through unchanged
+                return self_cache
+
+            @staticmethod
+            def from_legacy_cache(x):
+                return real_edc.from_legacy_cache(x)
+
+        ref_model.EncoderDecoderCache = _PassThroughCache
+        layer_forward = model.medusa_block.forward
+
+        def tuple_forward(*a, **k):         # transformers 4.49 returned (hidden_states, ...); model.py:1414 takes [0]
+            o = layer_forward(*a, **k)
+            return o if isinstance(o, tuple) else (o,)
+
+        model.medusa_block.forward = tuple_forward
     return model
 
 
@@ -118,16 +141,17 @@ def hf_processors(gp: GenParams):
 
 
 @torch.no_grad()
-def ref_medusa_loop(model, mu, enc, gp: GenParams, K: int):
+def ref_medusa_loop(model, mu, enc, gp: GenParams, K: int, use_cache: bool = False):
     """Semi-live end-to-end run: reference forward() + reference candidates/posterior; the glue
-    below restates model.py:634-793 (SURVEY.md §8c 'semi-live oracle')."""
+    below restates model.py:634-793 (SURVEY.md §8c 'semi-live oracle').  ``use_cache=True`` (Medusa-Block: model.py:1364
+    needs a cache object to exist) still is cache-free from the outside: no past is passed in, HF builds a fresh cache per call."""
     procs = hf_processors(gp)
     buffers = mu.generate_medusa_buffers([1] * (K + 1), device="cpu")
     ids = torch.tensor([gp.prompt], dtype=torch.long)
     accepts, first_logits = [], None
     while True:
         L = ids.shape[1]
-        out = model(encoder_outputs=(enc[None],), decoder_input_ids=ids, use_cache=False, return_dict=True)
+        out = model(encoder_outputs=(enc[None],), decoder_input_ids=ids, use_cache=use_cache, return_dict=True)
         logits = out.logits[:, :, -1:, :]                                   # [K+1, 1, 1, V] last row only
         if first_logits is None:
             first_logits = logits[:, 0, 0].clone()
@@ -135,7 +159,7 @@ def ref_medusa_loop(model, mu, enc, gp: GenParams, K: int):
         med = procs(ids, logits[1:].reshape(K, -1)).reshape(K, 1, 1, -1)    # model.py:656-665
         cands, tree_cands = mu.generate_candidates(med, orig, [1] * K, buffers["tree_indices"])
         full = torch.cat([ids, tree_cands], dim=1)                          # cache-free verify pass
-        vout = model(encoder_outputs=(enc[None],), decoder_input_ids=full, use_cache=False,
+        vout = model(encoder_outputs=(enc[None],), decoder_input_ids=full, use_cache=use_cache,
                      return_dict=True, disable_medusa=True)
         tree_logits = vout.logits[0][0, L:][buffers["retrieve_indices"]]    # medusa_utils.py:518-521
         proc = procs(ids, tree_logits.reshape(K + 1, -1)).reshape(1, K + 1, -1)
@@ -206,9 +230,9 @@ def gen_params_for(cfg, mode, max_new, suppress_eos=True, exp_decay=(6, 1.3)):
 
 
 def golden_model(tag, cfg, seed, mu, max_new):
-    """Reference forward()/loop outputs for one seeded Medusa-Linear checkpoint."""
+    """Reference forward()/loop outputs for one seeded checkpoint (Linear or Block heads)."""
     sd = synth.synth_state_dict(cfg, seed=seed)
-    model = build_ref_linear(cfg, sd)
+    model = build_ref(cfg, sd)
     orc = Oracle(cfg, sd, sim="fp32")
     wav = synth.synth_clip(0, n_samples=cfg.n_mel_frames * 160)
     feats = torch.from_numpy(log_mel(wav, cfg.num_mel_bins, cfg.n_mel_frames * 160))
@@ -219,7 +243,7 @@ def golden_model(tag, cfg, seed, mu, max_new):
     for mode, mname in ((ACCEPT_TYPICAL, "typical"), (ACCEPT_GREEDY, "greedy")):
         for eos_free, ename in ((True, "noeos"), (False, "eos")):
             gp = gen_params_for(cfg, mode, max_new, suppress_eos=eos_free)
-            ids, accepts, first_logits = ref_medusa_loop(model, mu, enc, gp, K)
+            ids, accepts, first_logits = ref_medusa_loop(model, mu, enc, gp, K, use_cache=cfg.is_block)
             key = f"{tag}_{mname}_{ename}"
             out[key + "_ids"] = np.array(ids)
             out[key + "_accepts"] = np.array(accepts)
@@ -242,7 +266,13 @@ def main():
     out.update(golden_model("micro10", MedusaConfig.micro(K=10, d_model=128, layers=2), 12, mu, max_new=40))
     out.update(golden_model("tiny", MedusaConfig.tiny_en(K=4), 0, mu, max_new=24))
     np.savez_compressed(os.path.join(GOLD, "reference_linear_runs.npz"), **out)
-    print("reference forward()/loop vectors written")
+    print("reference forward()/loop vectors written (Medusa-Linear)")
+    out = {}
+    out.update(golden_model("microblock", MedusaConfig.micro(K=4, heads_type="medusa_block"), 13, mu, max_new=40))
+    out.update(golden_model("micro10block", MedusaConfig.micro(K=10, heads_type="medusa_block", d_model=128, layers=2), 14, mu, max_new=40))
+    out.update(golden_model("tinyblock", MedusaConfig.tiny_en("medusa_block", K=4), 1, mu, max_new=24))
+    np.savez_compressed(os.path.join(GOLD, "reference_block_runs.npz"), **out)
+    print("reference forward()/loop vectors written (Medusa-Block)")
 
 
 if __name__ == "__main__":

@@ -21,6 +21,12 @@ GOLDEN_MODELS = {
     "micro10": (lambda: MedusaConfig.micro(K=10, d_model=128, layers=2), 12, 40),
     "tiny": (lambda: MedusaConfig.tiny_en(K=4), 0, 24),
 }
+# Medusa-Block runs minted from the reference's own Block forward (oracle/make_golden.py:build_ref shims)
+GOLDEN_BLOCK_MODELS = {
+    "microblock": (lambda: MedusaConfig.micro(K=4, heads_type="medusa_block"), 13, 40),
+    "micro10block": (lambda: MedusaConfig.micro(K=10, heads_type="medusa_block", d_model=128, layers=2), 14, 40),
+    "tinyblock": (lambda: MedusaConfig.tiny_en("medusa_block", K=4), 1, 24),
+}
 
 
 def golden_gen_params(cfg, mode, max_new, suppress_eos=True, exp_decay=(6, 1.3)):

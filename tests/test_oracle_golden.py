@@ -5,11 +5,11 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import GOLD, GOLDEN_MODELS, golden_gen_params, clip_for, synth, ACCEPT_TYPICAL, ACCEPT_GREEDY, GenParams, MedusaConfig
+from helpers import GOLD, GOLDEN_MODELS, GOLDEN_BLOCK_MODELS, golden_gen_params, clip_for, synth, ACCEPT_TYPICAL, ACCEPT_GREEDY, GenParams, MedusaConfig
 from oracle.whisper_medusa_oracle import Oracle, log_mel, mel_filter_bank, evaluate_posterior_chain, process_logits
 
 KAT = np.load(f"{GOLD}/medusa_utils_kat.npz")
-RUNS = np.load(f"{GOLD}/reference_linear_runs.npz")
+RUNS = {**np.load(f"{GOLD}/reference_linear_runs.npz"), **np.load(f"{GOLD}/reference_block_runs.npz")}
 
 
 def _gp(mode):
@@ -41,10 +41,10 @@ def test_generate_candidates_matches_reference():
     assert got.tolist() == KAT["cand_out"][0].tolist() == KAT["cand_tree_out"][0].tolist()
 
 
-@pytest.mark.parametrize("tag", list(GOLDEN_MODELS))
+@pytest.mark.parametrize("tag", list(GOLDEN_MODELS) + list(GOLDEN_BLOCK_MODELS))
 def test_decode_matches_reference_runs(tag):
-    """oracle.decode == reference forward() + reference candidates/posterior, token for token."""
-    mk, seed, max_new = GOLDEN_MODELS[tag]
+    """oracle.decode == reference forward() + reference candidates/posterior, token for token (Linear and Block heads)."""
+    mk, seed, max_new = {**GOLDEN_MODELS, **GOLDEN_BLOCK_MODELS}[tag]
     cfg = mk()
     sd = synth.synth_state_dict(cfg, seed=seed)
     orc = Oracle(cfg, sd, sim="fp32")
