@@ -18,13 +18,13 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 
 
 def _newest_src():
-    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "wm.h")]
+    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))] + [os.path.join(HERE, "..", "include", "wm.h")]
     return max(os.path.getmtime(f) for f in files)
 
 
-def _compile(src):
-    obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-    cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+def _compile(src, extra=(), suffix=""):
+    obj = os.path.join(CSRC, src.replace(".hip", suffix + ".o"))
+    cmd = [HIPCC] + FLAGS + list(extra) + ["-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -44,5 +44,21 @@ def build(force=False, verbose=True):
     return LIB
 
 
+def build_timeline(verbose=True):
+    """Debug variant with in-kernel timeline probes (-DWM_TIMELINE, csrc/wm_skinny_gemm.h): libwm_tl.so next to the product
+    library, loaded by tests/microbench/timeline.py through engine.load_library(path).  Never loaded by the product."""
+    lib = os.path.join(OUT_DIR, "libwm_tl.so")
+    with cf.ThreadPoolExecutor(len(SOURCES)) as ex:
+        objs = list(ex.map(lambda s: _compile(s, ("-DWM_TIMELINE",), "_tl"), SOURCES))
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    if verbose:
+        print(f"built {lib}")
+    return lib
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    if "--timeline" in sys.argv:
+        build_timeline()

@@ -179,9 +179,9 @@ __global__ void __launch_bounds__(256)
 k_attn_mfma(const float* __restrict__ q, const bf16_t* __restrict__ kmat, const bf16_t* __restrict__ vtmat,
             const int* __restrict__ base, bf16_t* __restrict__ xout, size_t xplane, float* __restrict__ ml, float* __restrict__ po,
             int* __restrict__ ticket, const int* __restrict__ done, const int* __restrict__ sskip,
-            int Mper, int H, int rows_alloc, int S, int NS, int K32)
+            int Mper, int H, int rows_alloc, int S, int NS, int K32 TL_ARG)
 {
-    if (done && *done) return;
+    TL_BEGIN
     // per-stream skip: the stream carried its hidden state, this base-pass row is not used (its K/V reads are saved)
     if (sskip && sskip[blockIdx.z]) return;
     __shared__ float s_m[4][16], s_l[4][16];
@@ -196,36 +196,35 @@ k_attn_mfma(const float* __restrict__ q, const bf16_t* __restrict__ kmat, const 
     const int spb = CROSS ? (NS + gridDim.x - 1) / gridDim.x : 1;
     const int sp0 = CROSS ? blockIdx.x * spb : 0, sp1 = CROSS ? min(NS, sp0 + spb) : 1;
 
-    const int b0 = CROSS ? 0 : base[s];
-    const int limit = CROSS ? S : min(b0 + c + 1, rows_alloc);            // keys < limit are visible to query c
     const bf16_t* kp = kmat + ((size_t)s * H + hd) * rows_alloc * 64;
     const bf16_t* vp = vtmat + ((size_t)s * H + hd) * 64 * rows_alloc;
 
-    // K/V do not depend on q: the first loads go out before anything else.  Self: wave w walks the 32-key steps
-    // w, w+4, ... with the next step in flight.  Cross: a wave owns 64 keys (two steps) of every split and keeps the
-    // same two steps of the NEXT split in flight while it works on this one (16 KiB per wave, 3 blocks per CU): bytes in
-    // flight are what the cross-K/V stream needs.
+    // The launch's memory batch goes out before anything is waited for: K/V do not depend on q nor on the cache length.
+    // Self: wave w walks the 32-key steps w, w+4, ... with the next step in flight; its first step is fetched whatever
+    // the length turns out to be (the rows exist: rows_alloc is a multiple of 32).  Cross: a wave owns 64 keys (two steps)
+    // of every split and keeps the same two steps of the NEXT split in flight while it works on this one (16 KiB per wave,
+    // 3 blocks per CU): bytes in flight are what the cross-K/V stream needs.  Then q (written by the previous launch).
     KVStep c0 = {}, c1 = {};
     int kb = CROSS ? sp0 * 256 + w * 64 : 32 * w;
-    int kend = CROSS ? min(S, kb + 64) : min(b0 + Mper, rows_alloc);
-    if (kb < kend) kv_load<NT>(c0, kp, vp, kb, c, g, lane);
-    if (CROSS && kb + 32 < kend) kv_load<NT>(c1, kp, vp, kb + 32, c, g, lane);
-    bf16x8_t qhi[2], qlo[2];
-    {
-        float qv[8];
+    if (CROSS ? (kb < S) : (kb < rows_alloc)) kv_load<NT>(c0, kp, vp, kb, c, g, lane);
+    if (CROSS && kb + 32 < S) kv_load<NT>(c1, kp, vp, kb + 32, c, g, lane);
+    float4 qraw[2][2];
 #pragma unroll
-        for (int ds = 0; ds < 2; ++ds) {
-            if (c < Mper) {
-                const float4* qp = reinterpret_cast<const float4*>(q + (size_t)(s * Mper + c) * d + hd * 64 + ds * 32 + g * 8);
-                const float4 u0 = qp[0], u1 = qp[1];
-                qv[0] = u0.x; qv[1] = u0.y; qv[2] = u0.z; qv[3] = u0.w; qv[4] = u1.x; qv[5] = u1.y; qv[6] = u1.z; qv[7] = u1.w;
-            } else {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) qv[i] = 0.f;
-            }
-            split_hilo8(qv, qhi[ds], qlo[ds]);
+    for (int ds = 0; ds < 2; ++ds) {
+        qraw[ds][0] = make_float4(0.f, 0.f, 0.f, 0.f); qraw[ds][1] = qraw[ds][0];
+        if (c < Mper) {
+            const float4* qp = reinterpret_cast<const float4*>(q + (size_t)(s * Mper + c) * d + hd * 64 + ds * 32 + g * 8);
+            qraw[ds][0] = qp[0]; qraw[ds][1] = qp[1];
         }
     }
+    const int b0 = CROSS ? 0 : base[s];
+    if (done && *done) return;          // all streams finished: checked after the batch went out (off the critical path)
+    const int limit = CROSS ? S : min(b0 + c + 1, rows_alloc);            // keys < limit are visible to query c
+    int kend = CROSS ? min(S, kb + 64) : min(b0 + Mper, rows_alloc);
+    bf16x8_t qhi[2], qlo[2];
+#pragma unroll
+    for (int ds = 0; ds < 2; ++ds) split_hilo8(qraw[ds][0], qraw[ds][1], qhi[ds], qlo[ds]);
+    TL_PREP
     const int qr = threadIdx.x >> 4, ch = (threadIdx.x & 15) * 4;
     const int row = s * Mper + qr;
     typedef unsigned long long u64;
@@ -287,12 +286,14 @@ k_attn_mfma(const float* __restrict__ q, const bf16_t* __restrict__ kmat, const 
         }
         if (sp + 1 < sp1) __syncthreads();                 // s_o / s_m / s_l are rewritten by the next split
     }
+    TL_MID
     if (!CROSS) {
         if (qr < Mper) {
             const float inv = 1.0f / L;
             const size_t oi = packed_index(row, hd * 64 + ch, K32);
             st_hilo4(xout + oi, xout + xplane + oi, make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv));
         }
+        TL_END
         return;
     }
     // ---- the last block of the (stream, head) merges all NS partials ----
@@ -309,40 +310,53 @@ k_attn_mfma(const float* __restrict__ q, const bf16_t* __restrict__ kmat, const 
             s_last = last;
         }
         __syncthreads();
-        if (!s_last) return;
+        if (!s_last) { TL_END return; }
     } else __syncthreads();
-    if (qr >= Mper) return;
-    {
+    if (qr < Mper) {
         const u64* mlp = reinterpret_cast<const u64*>(ml + ((size_t)row * H + hd) * NS * 2);
         const u64* op = reinterpret_cast<const u64*>(po + ((size_t)row * H + hd) * NS * 64 + ch);
-        float ms[16], ls[16];
-        float Mx = -INFINITY;
-        for (int sp = 0; sp < NS; ++sp) {
-            if (sp >= sp0 && sp < sp1) { ms[sp] = s_part[sp - sp0][qr][64]; ls[sp] = s_part[sp - sp0][qr][65]; }
-            else {
-                const u64 v = __hip_atomic_load(mlp + sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ms[sp] = __uint_as_float((unsigned)v); ls[sp] = __uint_as_float((unsigned)(v >> 32));
+        // every partial another block published is fetched in ONE batch (relaxed agent-scope loads bypass L1), then merged in
+        // split order; this block's own splits come from LDS
+        constexpr int NSM = 16;                    // wm_create: NS <= 16
+        u64 rml[NSM], ro0[NSM], ro1[NSM];
+#pragma unroll
+        for (int sp = 0; sp < NSM; ++sp) {
+            rml[sp] = 0; ro0[sp] = 0; ro1[sp] = 0;
+            if (sp < NS && !(sp >= sp0 && sp < sp1)) {
+                rml[sp] = __hip_atomic_load(mlp + sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ro0[sp] = __hip_atomic_load(op + (size_t)sp * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ro1[sp] = __hip_atomic_load(op + (size_t)sp * 32 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            Mx = fmaxf(Mx, ms[sp]);
+        }
+        float ms[NSM], ls[NSM];
+        float Mx = -INFINITY;
+#pragma unroll
+        for (int sp = 0; sp < NSM; ++sp) {
+            ms[sp] = -INFINITY; ls[sp] = 0.f;
+            if (sp < NS) {
+                if (sp >= sp0 && sp < sp1) { ms[sp] = s_part[sp - sp0][qr][64]; ls[sp] = s_part[sp - sp0][qr][65]; }
+                else { ms[sp] = __uint_as_float((unsigned)rml[sp]); ls[sp] = __uint_as_float((unsigned)(rml[sp] >> 32)); }
+                Mx = fmaxf(Mx, ms[sp]);
+            }
         }
         float Lt = 0.f; float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int sp = 0; sp < NS; ++sp) {
-            const float e = (ms[sp] == -INFINITY) ? 0.f : __expf(ms[sp] - Mx);
-            Lt += ls[sp] * e;
-            float4 ov;
-            if (sp >= sp0 && sp < sp1) ov = *reinterpret_cast<const float4*>(&s_part[sp - sp0][qr][ch]);
-            else {
-                const u64 v0 = __hip_atomic_load(op + (size_t)sp * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const u64 v1 = __hip_atomic_load(op + (size_t)sp * 32 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ov = make_float4(__uint_as_float((unsigned)v0), __uint_as_float((unsigned)(v0 >> 32)),
-                                 __uint_as_float((unsigned)v1), __uint_as_float((unsigned)(v1 >> 32)));
+#pragma unroll
+        for (int sp = 0; sp < NSM; ++sp) {
+            if (sp < NS) {
+                const float e = (ms[sp] == -INFINITY) ? 0.f : __expf(ms[sp] - Mx);
+                Lt += ls[sp] * e;
+                float4 ov;
+                if (sp >= sp0 && sp < sp1) ov = *reinterpret_cast<const float4*>(&s_part[sp - sp0][qr][ch]);
+                else ov = make_float4(__uint_as_float((unsigned)ro0[sp]), __uint_as_float((unsigned)(ro0[sp] >> 32)),
+                                      __uint_as_float((unsigned)ro1[sp]), __uint_as_float((unsigned)(ro1[sp] >> 32)));
+                o4.x += ov.x * e; o4.y += ov.y * e; o4.z += ov.z * e; o4.w += ov.w * e;
             }
-            o4.x += ov.x * e; o4.y += ov.y * e; o4.z += ov.z * e; o4.w += ov.w * e;
         }
         const float inv = 1.0f / Lt;
         const size_t oi = packed_index(row, hd * 64 + ch, K32);
         st_hilo4(xout + oi, xout + xplane + oi, make_float4(o4.x * inv, o4.y * inv, o4.z * inv, o4.w * inv));
     }
+    TL_END
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -599,16 +613,20 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
     const bf16_t* kx = ctx->kx + ((size_t)slot * ctx->Benc + b0) * H * ctx->Spad * 64;
     const bf16_t* vx = ctx->vx + ((size_t)slot * ctx->Benc + b0) * H * ctx->Spad * 64;
     // 1. LN1 + QKV; k rows / transposed v rows straight into the cache
+    TL_SET(slot * 16 + 1 + 8192 * Mper);
     WM_HIP(launch_skinny_norm(st, WRef{w.qkv_w, w.qkv_s}, 3 * d / 16, K32, h, w.ln1_w, w.ln1_b, d, R, 1, 0, 1,
                               EpQKVDec{ctx->qbuf, kc, vc, w.qkv_b, base, Mper, d, H, ctx->Tal, R}, ctx->xbuf, xpl));
     if (kv_only) return WM_OK;
     // 2. causal self-attention over the contiguous cache
+    TL_SET(slot * 16 + 2 + 8192 * Mper);
     hipLaunchKernelGGL((k_attn_mfma<false, false>), dim3(1, H, nb), dim3(256), 0, st, ctx->qbuf, kc, vc, base, ctx->xbuf, xpl,
-                       nullptr, nullptr, nullptr, g_skinny_done, sskip, Mper, H, ctx->Tal, 0, 1, K32);
+                       nullptr, nullptr, nullptr, g_skinny_done, sskip, Mper, H, ctx->Tal, 0, 1, K32 TL_PASS);
     WM_HIP(hipGetLastError());
     // 3. out_proj + residual
+    TL_SET(slot * 16 + 3 + 8192 * Mper);
     WM_HIP(launch_skinny_rows(st, WRef{w.out_w, w.out_s}, d / 16, K32, R, ctx->xbuf, xpl, EpResidual{h, w.out_b, d, R}));
     // 4. LN2 + cross-attention q
+    TL_SET(slot * 16 + 4 + 8192 * Mper);
     WM_HIP(launch_skinny_norm(st, WRef{w.cq_w, w.cq_s}, d / 16, K32, h, w.ln2_w, w.ln2_b, d, R, 1, 0, 1, EpF32{ctx->qbuf, w.cq_b, d, R, 0.125f},
                               ctx->xbuf, xpl));
     // 5. cross-attention over the encoder K/V, 256 keys per block
@@ -616,20 +634,24 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
     // mix): size the key-split grouping for the blocks that actually run
     static const int skip_div = [] { const char* v = std::getenv("WM_XATTN_SKIP_DIV"); return v ? std::max(1, std::atoi(v)) : 3; }();
     const int xheads = sskip ? std::max(1, H * nb / skip_div) : H * nb;
+    TL_SET(slot * 16 + 5 + 8192 * Mper);
     static const bool xattn_nt = [] { const char* v = std::getenv("WM_XATTN_NT"); return v ? std::atoi(v) != 0 : true; }();
     if (xattn_nt)
         hipLaunchKernelGGL((k_attn_mfma<true, true>), dim3(xattn_blocks_per_head(ctx->NS, xheads), H, nb), dim3(256), 0, st, ctx->qbuf, kx, vx, base, ctx->xbuf, xpl,
-                           ctx->cml, ctx->co, ctx->ticket, g_skinny_done, sskip, Mper, H, ctx->Spad, ctx->S, ctx->NS, K32);
+                           ctx->cml, ctx->co, ctx->ticket, g_skinny_done, sskip, Mper, H, ctx->Spad, ctx->S, ctx->NS, K32 TL_PASS);
     else
         hipLaunchKernelGGL((k_attn_mfma<true, false>), dim3(xattn_blocks_per_head(ctx->NS, xheads), H, nb), dim3(256), 0, st, ctx->qbuf, kx, vx, base, ctx->xbuf, xpl,
-                           ctx->cml, ctx->co, ctx->ticket, g_skinny_done, sskip, Mper, H, ctx->Spad, ctx->S, ctx->NS, K32);
+                           ctx->cml, ctx->co, ctx->ticket, g_skinny_done, sskip, Mper, H, ctx->Spad, ctx->S, ctx->NS, K32 TL_PASS);
     WM_HIP(hipGetLastError());
     // 6. out_proj + residual
+    TL_SET(slot * 16 + 6 + 8192 * Mper);
     WM_HIP(launch_skinny_rows(st, WRef{w.cout_w, w.cout_s}, d / 16, K32, R, ctx->xbuf, xpl, EpResidual{h, w.cout_b, d, R}));
     // 7. LN3 + fc1 + GELU
+    TL_SET(slot * 16 + 7 + 8192 * Mper);
     WM_HIP(launch_skinny_norm(st, WRef{w.fc1_w, w.fc1_s}, ctx->ffn / 16, K32, h, w.ln3_w, w.ln3_b, d, R, 1, 0, 1,
                               EpPackedAct<1>{ctx->fbuf, ctx->fbuf + fpl, w.fc1_b, F32, R}, ctx->xbuf, xpl));
     // 8. fc2 + residual
+    TL_SET(slot * 16 + 8 + 8192 * Mper);
     WM_HIP(launch_skinny_rows(st, WRef{w.fc2_w, w.fc2_s}, d / 16, F32, R, ctx->fbuf, fpl, EpResidual{h, w.fc2_b, d, R}));
     return WM_OK;
 }
@@ -698,6 +720,7 @@ int wm_dec_stage_final(wm_ctx* ctx, int b0, int nb, int Mper, int mode, int medu
 int wm_dec_stage_heads(wm_ctx* ctx, int nsel, int sel_mul, int sel_off, int medusa)
 {
     hipStream_t st = ctx->stream;
+    TL_SET(1000);
     const int d = ctx->d, K32 = d / 32, K = ctx->K;
     const int nout = medusa ? K + 1 : 1;
     const size_t ypl = (size_t)ctx->Rcap * d;
@@ -718,6 +741,7 @@ int wm_dec_stage_heads(wm_ctx* ctx, int nsel, int sel_mul, int sel_off, int medu
                                       ctx->xbuf, ypl));
     }
     // shared vocabulary projection (tied proj_out, model.py:1277)
+    TL_SET(1001);
     WM_HIP(launch_skinny_rows(st, ctx->vocab_w, ctx->Vpad / 16, K32, nsel * nout, ctx->ybuf, ypl,
                               EpF32{ctx->logits, nullptr, ctx->Vpad, nsel * nout, 1.0f}));
     return WM_OK;
@@ -843,3 +867,16 @@ int wm_dec_profile(wm_ctx* ctx, int kernel, int rows, int reps, float* ms, doubl
     *bytes = 2.0 * ((double)(3 + 1 + 1 + 1) * d * d + 2.0 * (double)d * ctx->ffn);
     return WM_OK;
 }
+
+#ifdef WM_TIMELINE
+// debug build only (libwm_tl.so): point the in-kernel timeline probes at a record buffer (DEV) and its append index (DEV)
+extern "C" int wm_debug_timeline(wm_ctx* ctx, void* buf, unsigned* idx, unsigned cap)
+{
+    WM_HIP(hipSetDevice(ctx->device));
+    TlRec* b = reinterpret_cast<TlRec*>(buf);
+    WM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tl_buf), &b, sizeof(b)));
+    WM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tl_idx), &idx, sizeof(idx)));
+    WM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tl_cap), &cap, sizeof(cap)));
+    return WM_OK;
+}
+#endif

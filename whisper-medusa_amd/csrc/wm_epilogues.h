@@ -5,93 +5,116 @@
 #pragma once
 #include "wm_common.h"
 
+// Decode epilogues come in two halves so that the weight-streaming GEMM can issue every global load of a launch in ONE
+// batch at kernel entry:  pre(m, n) only LOADS the operands the element needs (bias, residual, cache position) — no
+// arithmetic, so nothing waits on them while the weight stream is in flight —, fin(m, n, v, pre) does the arithmetic and the
+// store once the accumulator exists.  store4(m, n, v) = fin(m, n, v, pre(m, n)) for the kernels that do not prefetch.
+struct EpPre { float4 a, b; int i; };
+
 struct EpResidual {            // h[m][n] = (h[m][n] + bias[n]) + v      (out_proj / fc2 + residual, HF:modeling_whisper.py:396-413)
     float* h; const float* bias; int ld; int M;
-    static constexpr bool kPre = true;           // the (h + bias) operand can be fetched while the weights stream
-    __device__ __forceinline__ float4 pre4(int m, int n) const {
-        if (m >= M) return make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 o = *reinterpret_cast<const float4*>(h + (size_t)m * ld + n);
-        const float4 b = *reinterpret_cast<const float4*>(bias + n);
-        return make_float4(o.x + b.x, o.y + b.y, o.z + b.z, o.w + b.w);
+    __device__ __forceinline__ EpPre pre(int m, int n) const {
+        EpPre p; p.i = 0; p.a = make_float4(0.f, 0.f, 0.f, 0.f); p.b = p.a;
+        if (m < M) { p.a = *reinterpret_cast<const float4*>(h + (size_t)m * ld + n); p.b = *reinterpret_cast<const float4*>(bias + n); }
+        return p;
     }
-    __device__ __forceinline__ void store4p(int m, int n, f32x4_t v, float4 pre) const {
+    __device__ __forceinline__ void fin(int m, int n, f32x4_t v, const EpPre& p) const {
         if (m >= M) return;
-        *reinterpret_cast<float4*>(h + (size_t)m * ld + n) = make_float4(pre.x + v[0], pre.y + v[1], pre.z + v[2], pre.w + v[3]);
+        *reinterpret_cast<float4*>(h + (size_t)m * ld + n) =
+            make_float4((p.a.x + p.b.x) + v[0], (p.a.y + p.b.y) + v[1], (p.a.z + p.b.z) + v[2], (p.a.w + p.b.w) + v[3]);
     }
-    __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const { store4p(m, n, v, pre4(m, n)); }
+    __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const { fin(m, n, v, pre(m, n)); }
 };
 
 struct EpF32 {                 // out[m][n] = (v + bias[n]) * scale   (cross-attn q; vocabulary logits with bias == nullptr)
-    static constexpr bool kPre = false;
     float* out; const float* bias; int ld; int M; float scale;
-    __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const {
-        if (m >= M) return;
-        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (bias) b = *reinterpret_cast<const float4*>(bias + n);
-        *reinterpret_cast<float4*>(out + (size_t)m * ld + n) =
-            make_float4((v[0] + b.x) * scale, (v[1] + b.y) * scale, (v[2] + b.z) * scale, (v[3] + b.w) * scale);
+    __device__ __forceinline__ EpPre pre(int m, int n) const {
+        EpPre p; p.i = 0; p.a = make_float4(0.f, 0.f, 0.f, 0.f); p.b = p.a;
+        if (bias && m < M) p.a = *reinterpret_cast<const float4*>(bias + n);
+        return p;
     }
+    __device__ __forceinline__ void fin(int m, int n, f32x4_t v, const EpPre& p) const {
+        if (m >= M) return;
+        *reinterpret_cast<float4*>(out + (size_t)m * ld + n) =
+            make_float4((v[0] + p.a.x) * scale, (v[1] + p.a.y) * scale, (v[2] + p.a.z) * scale, (v[3] + p.a.w) * scale);
+    }
+    __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const { fin(m, n, v, pre(m, n)); }
 };
 
 template <int ACT>             // packed bf16 out = act(v + bias)   (fc1 + GELU -> next GEMM's operand)
 struct EpPackedAct {           // out_lo != nullptr: decoder path, value kept as a bf16 hi/lo pair
-    static constexpr bool kPre = false;
     bf16_t* out; bf16_t* out_lo; const float* bias; int K32out; int M;
-    __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const {
+    __device__ __forceinline__ EpPre pre(int m, int n) const {
+        EpPre p; p.i = 0; p.a = make_float4(0.f, 0.f, 0.f, 0.f); p.b = p.a;
+        if (m < M) p.a = *reinterpret_cast<const float4*>(bias + n);
+        return p;
+    }
+    __device__ __forceinline__ void fin(int m, int n, f32x4_t v, const EpPre& p) const {
         if (m >= M) return;
-        const float4 b = *reinterpret_cast<const float4*>(bias + n);
-        float x0 = v[0] + b.x, x1 = v[1] + b.y, x2 = v[2] + b.z, x3 = v[3] + b.w;
+        float x0 = v[0] + p.a.x, x1 = v[1] + p.a.y, x2 = v[2] + p.a.z, x3 = v[3] + p.a.w;
         if (ACT == 1) { x0 = gelu_erf(x0); x1 = gelu_erf(x1); x2 = gelu_erf(x2); x3 = gelu_erf(x3); }
         const size_t o = packed_index(m, n, K32out);
         if (out_lo) { st_hilo4(out + o, out_lo + o, make_float4(x0, x1, x2, x3)); return; }
         uint2 u; u.x = pack_bf2(x0, x1); u.y = pack_bf2(x2, x3);
         *reinterpret_cast<uint2*>(out + o) = u;
     }
+    __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const { fin(m, n, v, pre(m, n)); }
 };
 
 // Decoder self-attention projections: q (scaled, fp32) to a row buffer, k/v rows (bf16) straight
 // into the contiguous KV cache at position base[stream] + r   (HF:modeling_whisper.py:288-318; the
 // reference's per-iteration cat-compaction, model.py:378-402, becomes "overwrite rows >= kv_len").
 struct EpQKVDec {              // K cache [s][h][pos][64]; V cache [s][h] as V^T MFMA fragments (vfrag_index)
-    static constexpr bool kPre = false;
     float* q; bf16_t* kc; bf16_t* vc; const float* bias; const int* base;
     int Mper, d, H, Tal, M;
-    __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const {
+    __device__ __forceinline__ EpPre pre(int m, int n) const {
+        EpPre p; p.i = 0; p.a = make_float4(0.f, 0.f, 0.f, 0.f); p.b = p.a;
+        if (m < M) { p.a = *reinterpret_cast<const float4*>(bias + n); if (n >= d) p.i = base[m / Mper]; }
+        return p;
+    }
+    __device__ __forceinline__ void fin(int m, int n, f32x4_t v, const EpPre& p) const {
         if (m >= M) return;
-        const float4 b = *reinterpret_cast<const float4*>(bias + n);
-        const float x0 = v[0] + b.x, x1 = v[1] + b.y, x2 = v[2] + b.z, x3 = v[3] + b.w;
+        const float x0 = v[0] + p.a.x, x1 = v[1] + p.a.y, x2 = v[2] + p.a.z, x3 = v[3] + p.a.w;
         if (n < d) {
             *reinterpret_cast<float4*>(q + (size_t)m * d + n) = make_float4(x0 * 0.125f, x1 * 0.125f, x2 * 0.125f, x3 * 0.125f);
             return;
         }
         const int s = m / Mper, r = m - s * Mper;
-        int pos = base[s] + r; if (pos > Tal - 1) pos = Tal - 1;
+        int pos = p.i + r; if (pos > Tal - 1) pos = Tal - 1;
         if (n < 2 * d) {
             const int c = n - d;
             uint2 o; o.x = pack_bf2(x0, x1); o.y = pack_bf2(x2, x3);
             *reinterpret_cast<uint2*>(kc + (((size_t)s * H + (c >> 6)) * Tal + pos) * 64 + (c & 63)) = o;
         } else {
             const int c = n - 2 * d;
-            bf16_t* p = vc + ((size_t)s * H + (c >> 6)) * 64 * Tal + vfrag_index(pos, c & 63);     // dims c..c+3: lanes 8 elements apart
-            p[0] = f2bf(x0); p[8] = f2bf(x1); p[16] = f2bf(x2); p[24] = f2bf(x3);
+            bf16_t* pv = vc + ((size_t)s * H + (c >> 6)) * 64 * Tal + vfrag_index(pos, c & 63);     // dims c..c+3: lanes 8 elements apart
+            pv[0] = f2bf(x0); pv[8] = f2bf(x1); pv[16] = f2bf(x2); pv[24] = f2bf(x3);
         }
     }
+    __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const { fin(m, n, v, pre(m, n)); }
 };
 
 // Medusa residual heads: y = x + SiLU(W x + b) (model.py:180-210) for head k = n / d, written as
 // packed bf16 row  m*row_mul + row_off + k  of the vocabulary-projection operand.
 struct EpHead {
-    static constexpr bool kPre = false;
     bf16_t* y; bf16_t* y_lo; const float* hf; const float* bias; int d, K32, row_mul, row_off, M, src_mul, src_off;
-    __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const {
+    __device__ __forceinline__ EpPre pre(int m, int n) const {
+        EpPre p; p.i = 0; p.a = make_float4(0.f, 0.f, 0.f, 0.f); p.b = p.a;
+        if (m < M) {
+            const int k = n / d, c = n - k * d;
+            p.a = *reinterpret_cast<const float4*>(bias + n);
+            p.b = *reinterpret_cast<const float4*>(hf + (size_t)(m * src_mul + src_off) * d + c);
+        }
+        return p;
+    }
+    __device__ __forceinline__ void fin(int m, int n, f32x4_t v, const EpPre& p) const {
         if (m >= M) return;
         const int k = n / d, c = n - k * d;
-        const float4 b = *reinterpret_cast<const float4*>(bias + n);
-        const float4 x = *reinterpret_cast<const float4*>(hf + (size_t)(m * src_mul + src_off) * d + c);
         const size_t o = packed_index(m * row_mul + row_off + k, c, K32);
-        st_hilo4(y + o, y_lo + o, make_float4(x.x + silu(v[0] + b.x), x.y + silu(v[1] + b.y),
-                                               x.z + silu(v[2] + b.z), x.w + silu(v[3] + b.w)));
+        st_hilo4(y + o, y_lo + o, make_float4(p.b.x + silu(v[0] + p.a.x), p.b.y + silu(v[1] + p.a.y),
+                                               p.b.z + silu(v[2] + p.a.z), p.b.w + silu(v[3] + p.a.w)));
     }
+    __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const { fin(m, n, v, pre(m, n)); }
 };
 
 // ---- encoder -----------------------------------------------------------------------------

@@ -1,39 +1,103 @@
-// wm_skinny_gemm.h — weight-streaming MFMA GEMM for the decode step (token rows M <= 16).
+// wm_skinny_gemm.h — weight-streaming MFMA GEMM for the decode step (token rows M <= 16 per launch; more rows through
+// the token-tile kernel below).
 //
-//   out[m][n] = sum_k X[m][k] * W[n][k]          X: M x K activations, W: N x K weights (packed bf16)
+//   out[m][n] = sum_k X[m][k] * W[n][k]          X: M x K activations, W: N x K weights (packed bf16 or fp8 e4m3)
 //
-// The decode step is HBM-bound: every weight byte is read exactly once per pass, so the kernel is
-// organised around the weight stream.  One wavefront owns one 16-row weight tile x one K-slice: it
-// fetches 1-KiB packed fragments with fully coalesced non-temporal 16-B loads (the first round is
-// issued BEFORE the token operand is prepared, so HBM latency hides under the LayerNorm), multiplies
-// them against the M token rows with v_mfma_f32_16x16x32_bf16 (weights = A operand, tokens = B operand:
-// the idle token columns of a batch-1 pass cost nothing), and the KSPLIT waves of a row tile reduce
-// through LDS in a fixed order (deterministic).
+// The decode step is HBM-bound and, at one stream, LATENCY-bound: a pass is a chain of ~270 dependent launches, each of
+// which moves 3-13 MB.  The kernel is therefore organised around ONE memory round trip per launch:
+//   * every global load of the launch is issued in one batch at kernel entry, in the order the data is needed — the
+//     wave's whole K-slice of the weight stream (non-temporal 16-B loads, 1 KiB packed fragments), its slice of the token
+//     operand, the LayerNorm parameters (LDS-DMA, no registers) and the operands of the epilogue (bias, residual, cache
+//     position: wm_epilogues.h `pre`) — and nothing touches a loaded value before all of it is in flight;
+//   * one wavefront owns one 16-row weight tile x one K-slice (NK fragments, a template parameter: straight-line code, so
+//     the compiler's vmcnt bookkeeping is exact); weights are the MFMA A operand, tokens the B operand;
+//   * the token operand of a LayerNorm-fused GEMM never goes through LDS: a wave normalises exactly the fragments of its own
+//     K-slice, in registers, in MFMA B layout (only the per-row statistics cross waves, 8 bytes per row and slice);
+//   * rows >= M of the token tile are never loaded (exec-masked lanes): a 1-row base pass reads 1/16 of the operand;
+//   * the KSPLIT waves of a row tile reduce through LDS in a fixed order (deterministic).
 //
-// Activations are carried as a bf16 HI/LO PAIR (x = hi + lo, ~17 mantissa bits): two MFMAs per weight
-// fragment instead of one — free in a bandwidth-bound kernel — so decoder activations are never rounded
-// to 8 bits and the fp32-accumulate results match the oracle to ~1e-6 (no rounding-flip cascades).
+// Activations are carried as a bf16 HI/LO PAIR (x = hi + lo, ~17 mantissa bits): two MFMAs per weight fragment instead
+// of one — free in a bandwidth-bound kernel — so decoder activations are never rounded to 8 bits and the fp32-accumulate
+// results match the oracle to ~1e-6 (no rounding-flip cascades).
 //
-// Token operand LOADERS:
-//   LdPacked  — packed hi/lo planes in global memory (L2-resident), fragments prefetched in registers
-//   LdNorm    — fp32 residual rows -> LayerNorm (or identity) -> hi/lo fragments in LDS, fused
-// Results leave through a fused EPILOGUE functor (wm_epilogues.h).
+// Per output element the accumulation order is: K-slices in order, inside a slice k ascending, hi then lo.  The token-tile
+// kernel (R > 16 rows) keeps that order and shares the LayerNorm code, so a B-stream run is bit-identical to B
+// single-stream runs.
 #pragma once
+#include <algorithm>
 #include <cstdlib>
 #include "wm_common.h"
 #include "wm_epilogues.h"
 
-struct LdPacked {
-    const bf16_t* X; int K32; size_t plane;            // lo plane at X + plane
-    static constexpr bool kLds = false;
-    __host__ __device__ __forceinline__ static size_t lds_bytes(int) { return 0; }
-    __device__ __forceinline__ void prepare(char*) const {}
-    __device__ __forceinline__ bf16x8_t frag(const char*, int kt, int lane, int pl) const {
-        return ld_frag(X + (pl ? plane : 0) + ((size_t)kt * 64 + lane) * 8);
+// ---- optional in-kernel timeline (build with -DWM_TIMELINE -> libwm_tl.so; tests/microbench/timeline.py) ----------
+// Thread 0 of every block appends one record {tag, block, realtime at entry / exit (100 MHz, chip-wide), shader cycles from
+// entry to "operands ready", "products done" and exit}.  Not compiled into the product library.
+#ifdef WM_TIMELINE
+struct TlRec { unsigned tag, block; unsigned long long rt0, rt1; unsigned c_prep, c_mid, c_end, pad; };
+static __device__ TlRec* g_tl_buf = nullptr;
+static __device__ unsigned* g_tl_idx = nullptr;
+static __device__ unsigned g_tl_cap = 0;
+static thread_local int g_tl_tag = 0;              // host: tag of the next launch
+struct TlProbe {
+    unsigned long long rt0, c0; unsigned c_prep, c_mid; int tag;
+    __device__ __forceinline__ void begin(int t) { tag = t; rt0 = __builtin_amdgcn_s_memrealtime(); c0 = __builtin_readcyclecounter(); c_mid = 0; c_prep = 0; }
+    __device__ __forceinline__ void prep() { c_prep = (unsigned)(__builtin_readcyclecounter() - c0); }
+    __device__ __forceinline__ void mid() { c_mid = (unsigned)(__builtin_readcyclecounter() - c0); }
+    __device__ __forceinline__ void end() {
+        if (threadIdx.x != 0 || !g_tl_buf) return;
+        const unsigned c_end = (unsigned)(__builtin_readcyclecounter() - c0);
+        const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+        const unsigned i = atomicAdd(g_tl_idx, 1u);
+        if (i < g_tl_cap) g_tl_buf[i] = TlRec{(unsigned)tag, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), rt0, rt1, c_prep, c_mid, c_end, 0u};
     }
 };
+#define TL_ARG , int tl_tag
+#define TL_PASS , g_tl_tag
+#define TL_BEGIN TlProbe tl_; tl_.begin(tl_tag);
+#define TL_PREP tl_.prep();
+#define TL_MID tl_.mid();
+#define TL_END tl_.end();
+#define TL_SET(t) (g_tl_tag = (t))
+#else
+#define TL_ARG
+#define TL_PASS
+#define TL_BEGIN
+#define TL_PREP
+#define TL_MID
+#define TL_END
+#define TL_SET(t) ((void)0)
+#endif
 
-__device__ __forceinline__ void hilo8_to_lds(bf16_t* xh, bf16_t* xl, int q, float4 y0, float4 y1)
+// ---- weight fragments: raw load now, widen later (an fp8 fragment must not be converted before the batch is in flight) ----
+template <bool W8> struct WRaw { typedef u32x4_t type; };
+template <> struct WRaw<true> { typedef u32x2_t type; };
+
+template <bool W8, bool NT>
+__device__ __forceinline__ typename WRaw<W8>::type ld_wraw(const bf16_t* W, size_t elem) {
+    if constexpr (W8) {
+        const u32x2_t* p8 = reinterpret_cast<const u32x2_t*>(reinterpret_cast<const unsigned char*>(W) + elem);
+        return NT ? __builtin_nontemporal_load(p8) : *p8;
+    } else {
+        const u32x4_t* p = reinterpret_cast<const u32x4_t*>(W + elem);
+        return NT ? __builtin_nontemporal_load(p) : *p;
+    }
+}
+template <bool W8>
+__device__ __forceinline__ bf16x8_t w_expand(typename WRaw<W8>::type v) {
+    if constexpr (W8) {      // e4m3 -> bf16 is exact
+        const f32x2_t a = __builtin_amdgcn_cvt_pk_f32_fp8(v[0], false), b = __builtin_amdgcn_cvt_pk_f32_fp8(v[0], true);
+        const f32x2_t c = __builtin_amdgcn_cvt_pk_f32_fp8(v[1], false), d = __builtin_amdgcn_cvt_pk_f32_fp8(v[1], true);
+        uint4 r;
+        r.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf16x2_t)); r.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(b, bf16x2_t));
+        r.z = __builtin_bit_cast(uint32_t, __builtin_convertvector(c, bf16x2_t)); r.w = __builtin_bit_cast(uint32_t, __builtin_convertvector(d, bf16x2_t));
+        return __builtin_bit_cast(bf16x8_t, r);
+    } else {
+        return __builtin_bit_cast(bf16x8_t, v);
+    }
+}
+
+// 8 fp32 values -> bf16 hi / lo MFMA fragments
+__device__ __forceinline__ void split_hilo8(float4 y0, float4 y1, bf16x8_t& hi, bf16x8_t& lo)
 {
     uint4 h, l;
     h.x = pack_bf2(y0.x, y0.y); h.y = pack_bf2(y0.z, y0.w); h.z = pack_bf2(y1.x, y1.y); h.w = pack_bf2(y1.z, y1.w);
@@ -41,193 +105,219 @@ __device__ __forceinline__ void hilo8_to_lds(bf16_t* xh, bf16_t* xl, int q, floa
     l.y = pack_bf2(y0.z - __uint_as_float(h.y << 16), y0.w - __uint_as_float(h.y & 0xffff0000u));
     l.z = pack_bf2(y1.x - __uint_as_float(h.z << 16), y1.y - __uint_as_float(h.z & 0xffff0000u));
     l.w = pack_bf2(y1.z - __uint_as_float(h.w << 16), y1.w - __uint_as_float(h.w & 0xffff0000u));
-    reinterpret_cast<uint4*>(xh)[q] = h;          // chunk q = 16 B: lane-linear, bank-conflict-free
-    reinterpret_cast<uint4*>(xl)[q] = l;
+    hi = __builtin_bit_cast(bf16x8_t, h); lo = __builtin_bit_cast(bf16x8_t, l);
 }
 
-// fp32 rows -> (LayerNorm | identity) -> packed hi/lo fragments in LDS.  GEMM row r reads source row
-// r*row_mul + row_off (selects the last prompt row per stream on the first base pass).
-// Threads walk the 16 x K tile in PACKED order (one 16-B chunk = 8 consecutive k of one row; with a block
-// size that is a multiple of 64 every chunk of a thread belongs to the same row r = tid & 15).  All global
-// loads of a thread are issued together (ONE memory round trip); LayerNorm statistics (single-pass sum and
-// sum of squares) come from the same registers: a 4-row permlane-swap reduction inside the wave, then a fixed-order sum of
-// the per-wave partials in LDS (deterministic).  LDS writes are lane-linear ds_write_b128.
-struct LdNorm {
-    const float* h; const float* gamma; const float* beta;
-    int d, K32, M, row_mul, row_off, do_norm;
-    static constexpr bool kLds = true;
-    static constexpr int UB = 8;                 // packed chunks per thread per batch
-    __host__ __device__ __forceinline__ static size_t scratch_bytes(int K32) { return 2048 + (size_t)K32 * 256; }
-    __host__ __device__ __forceinline__ static size_t lds_bytes(int K32) { return (size_t)2 * K32 * 1024 + scratch_bytes(K32); }
+__device__ __forceinline__ void glds16_f(const float* gsrc, char* lds_wave_base)     // LDS-DMA, 16 B per lane
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
 
-    // requires K32 * 64 <= UB * blockDim.x (the whole 16 x K tile in one batch; checked by the launcher)
-    __device__ __forceinline__ void prepare(char* smem) const {
-        bf16_t* xh = reinterpret_cast<bf16_t*>(smem);
-        prepare_to(xh, xh + (size_t)K32 * 512, smem + (size_t)2 * K32 * 1024, 0);
-    }
-    // rows row0 .. row0+15 of the GEMM -> fragments at xh / xl (LDS for the fused GEMM, global memory for the
-    // batched path: the arithmetic and its order are the same, so both give bit-identical operands)
-    __device__ __forceinline__ void prepare_to(bf16_t* xh, bf16_t* xl, char* scratch, int row0) const {
-        float2* part = reinterpret_cast<float2*>(scratch);                              // [waves <= 16][16 rows]
-        float* gb = reinterpret_cast<float*>(scratch + 2048);                           // gamma[d] then beta[d]
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-        const int nv = d >> 2, nq = K32 * 64, T = blockDim.x;
-        const int r = lane & 15;                 // the row of every chunk this thread touches
-        const int g8 = (lane >> 4) * 8;
-        const bool rvalid = row0 + r < M;
-        const float* hrow = h + (size_t)((row0 + r) * row_mul + row_off) * d + g8;
-        float4 v0[UB], v1[UB];
+// ---- token operand: packed hi/lo planes in global memory (written by the previous kernel's epilogue) ------------
+struct LdPacked {
+    const bf16_t* X; int K32; size_t plane; int M;           // lo plane at X + plane; rows >= M are not read
+    static constexpr bool kNorm = false;
+    template <int NB> struct Regs { bf16x8_t h[NB], l[NB]; };
+    __host__ __device__ int lds_bytes() const { return 0; }
+    template <int NB>
+    __device__ __forceinline__ void issue(Regs<NB>& r, char*, int kt0, int lane, int = 0) const {
+        const bool rv = (lane & 15) < M;
+        const bf16x8_t z = __builtin_bit_cast(bf16x8_t, make_uint4(0u, 0u, 0u, 0u));
 #pragma unroll
-        for (int i = 0; i < UB; ++i) {
-            const int q = threadIdx.x + i * T;
-            if (q < nq && rvalid) {
-                const float4* src = reinterpret_cast<const float4*>(hrow + (q >> 6) * 32);
-                v0[i] = src[0]; v1[i] = src[1];
-            } else { v0[i] = make_float4(0.f, 0.f, 0.f, 0.f); v1[i] = v0[i]; }
+        for (int u = 0; u < NB; ++u) {
+            const bf16_t* p = X + ((size_t)(kt0 + u) * 64 + lane) * 8;
+            r.h[u] = z; r.l[u] = z;
+            if (rv) { r.h[u] = ld_frag(p); r.l[u] = ld_frag(p + plane); }
         }
-        float mean = 0.f, rstd = 1.f;
-        if (do_norm) {
-            for (int c = threadIdx.x; c < nv; c += T) {
-                reinterpret_cast<float4*>(gb)[c] = reinterpret_cast<const float4*>(gamma)[c];
-                reinterpret_cast<float4*>(gb + d)[c] = reinterpret_cast<const float4*>(beta)[c];
-            }
-            float s = 0.f, q2 = 0.f;
-#pragma unroll
-            for (int i = 0; i < UB; ++i) {
-                s += (v0[i].x + v0[i].y) + (v0[i].z + v0[i].w) + (v1[i].x + v1[i].y) + (v1[i].z + v1[i].w);
-                q2 += (v0[i].x * v0[i].x + v0[i].y * v0[i].y) + (v0[i].z * v0[i].z + v0[i].w * v0[i].w) +
-                      (v1[i].x * v1[i].x + v1[i].y * v1[i].y) + (v1[i].z * v1[i].z + v1[i].w * v1[i].w);
-            }
-            s = rows4_sum(s); q2 = rows4_sum(q2);
-            if (lane < 16) part[wave * 16 + lane] = make_float2(s, q2);
-            __syncthreads();
-            float ts = 0.f, tq = 0.f;
-            for (int w = 0; w < nw; ++w) { const float2 p = part[w * 16 + r]; ts += p.x; tq += p.y; }
-            mean = ts / (float)d;
-            rstd = rsqrtf(fmaxf(tq / (float)d - mean * mean, 0.f) + 1e-5f);
-        }
-        const bool norm_row = do_norm && rvalid;
-#pragma unroll
-        for (int i = 0; i < UB; ++i) {
-            const int q = threadIdx.x + i * T, k0 = (q >> 6) * 32 + g8;
-            if (q >= nq) continue;
-            float4 y0 = v0[i], y1 = v1[i];
-            if (norm_row) {
-                const float4 g0 = *reinterpret_cast<const float4*>(gb + k0), g1 = *reinterpret_cast<const float4*>(gb + k0 + 4);
-                const float4 b0 = *reinterpret_cast<const float4*>(gb + d + k0), b1 = *reinterpret_cast<const float4*>(gb + d + k0 + 4);
-                y0.x = (y0.x - mean) * rstd * g0.x + b0.x; y0.y = (y0.y - mean) * rstd * g0.y + b0.y;
-                y0.z = (y0.z - mean) * rstd * g0.z + b0.z; y0.w = (y0.w - mean) * rstd * g0.w + b0.w;
-                y1.x = (y1.x - mean) * rstd * g1.x + b1.x; y1.y = (y1.y - mean) * rstd * g1.y + b1.y;
-                y1.z = (y1.z - mean) * rstd * g1.z + b1.z; y1.w = (y1.w - mean) * rstd * g1.w + b1.w;
-            }
-            hilo8_to_lds(xh, xl, q, y0, y1);
-        }
-        __syncthreads();
     }
-    __device__ __forceinline__ bf16x8_t frag(const char* smem, int kt, int lane, int pl) const {
-        return ld_frag(reinterpret_cast<const bf16_t*>(smem) + ((size_t)(pl * K32 + kt) * 64 + lane) * 8);
-    }
+    template <int NB> __device__ __forceinline__ void stats(Regs<NB>&, char*, int, int, bool, int) const {}
+    template <int NB>
+    __device__ __forceinline__ void frag(const Regs<NB>& r, const char*, int u, int, int, bf16x8_t& bh, bf16x8_t& bl) const { bh = r.h[u]; bl = r.l[u]; }
 };
 
-template <int U, bool W8, class Ld, class Ep>
+// ---- token operand: fp32 residual rows -> LayerNorm (or identity) -> hi/lo fragments, in registers -------------------
+// GEMM row r reads source row r*row_mul + row_off (selects the last prompt row per stream on the first base pass).
+// A wave owns the k-tiles of ITS K-slice: lane (r = lane & 15, g = lane >> 4) holds h[r][32 kt + 8 g .. + 8] for each of
+// them — exactly the B fragment the MFMA wants once normalised.  Statistics (single-pass sum and sum of squares): per lane
+// over its k-tiles in order, 4-group permlane-swap butterfly inside the wave, then the K-slices' partials are summed in
+// slice order through LDS.  gamma / beta are staged once per block by LDS-DMA.  The token-tile path (k_ln_tiles) runs the
+// same code with the same slicing: bit-identical operands.
+template <bool NORM>           // NORM = false: identity (the Medusa heads read the post-LN rows as they are)
+struct LdNormT {
+    const float* h; const float* gamma; const float* beta;
+    int d, K32, M, row_mul, row_off;
+    static constexpr bool kNorm = true;
+    static constexpr bool do_norm = NORM;
+    template <int NB> struct Regs { float4 v0[NB], v1[NB]; float mean, rstd; };
+    __host__ __device__ int lds_bytes() const { return 2 * d * (int)sizeof(float) + 2048; }   // gamma, beta, statistics
+
+    template <int NB>
+    __device__ __forceinline__ void issue(Regs<NB>& r, char* smem, int kt0, int lane, int row0 = 0) const {
+        const int rr = lane & 15, g8 = (lane >> 4) * 8;
+        const bool rv = row0 + rr < M;
+        const float* hrow = h + (size_t)((row0 + rr) * row_mul + row_off) * d + (size_t)kt0 * 32 + g8;
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            r.v0[u] = make_float4(0.f, 0.f, 0.f, 0.f); r.v1[u] = r.v0[u];
+            if (rv) { const float4* src = reinterpret_cast<const float4*>(hrow + u * 32); r.v0[u] = src[0]; r.v1[u] = src[1]; }
+        }
+        if constexpr (NORM) {       // gamma | beta -> LDS, 1 KiB pieces (256 floats) spread over the block's waves
+            const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6, np = (2 * d + 255) >> 8;
+            for (int p = wave; p < np; p += nw) {
+                const int idx = p * 256 + lane * 4;
+                if (idx < 2 * d) glds16_f(idx < d ? gamma + idx : beta + (idx - d), smem + (size_t)p * 1024);
+            }
+        }
+    }
+    // per-row statistics over the whole row: needs every K-slice -> LDS exchange (contains the block barrier, which also
+    // makes the LDS-DMA'd gamma / beta visible).  `leader`: this wave publishes its slice's partial (one wave per slice).
+    template <int NB>
+    __device__ __forceinline__ void stats(Regs<NB>& r, char* smem, int ks, int ksplit, bool leader, int lane) const {
+        r.mean = 0.f; r.rstd = 1.f;
+        if constexpr (!NORM) return;
+        float2* part = reinterpret_cast<float2*>(smem + (size_t)2 * d * sizeof(float));      // [ksplit <= 16][16 rows]
+        float s = 0.f, q2 = 0.f;
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const float4 a = r.v0[u], b = r.v1[u];
+            s += ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w));
+            q2 += ((a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w)) + ((b.x * b.x + b.y * b.y) + (b.z * b.z + b.w * b.w));
+        }
+        s = rows4_sum(s); q2 = rows4_sum(q2);
+        if (leader && lane < 16) part[ks * 16 + lane] = make_float2(s, q2);
+        __syncthreads();
+        float ts = 0.f, tq = 0.f;
+        for (int k2 = 0; k2 < ksplit; ++k2) { const float2 p = part[k2 * 16 + (lane & 15)]; ts += p.x; tq += p.y; }
+        r.mean = ts / (float)d;
+        r.rstd = rsqrtf(fmaxf(tq / (float)d - r.mean * r.mean, 0.f) + 1e-5f);
+    }
+    template <int NB>
+    __device__ __forceinline__ void frag(const Regs<NB>& r, const char* smem, int u, int kt, int lane, bf16x8_t& bh, bf16x8_t& bl) const {
+        float4 y0 = r.v0[u], y1 = r.v1[u];
+        if constexpr (NORM) {
+            const float* gb = reinterpret_cast<const float*>(smem) + kt * 32 + (lane >> 4) * 8;
+            const float4 g0 = *reinterpret_cast<const float4*>(gb), g1 = *reinterpret_cast<const float4*>(gb + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(gb + d), b1 = *reinterpret_cast<const float4*>(gb + d + 4);
+            const float m = r.mean, rs = r.rstd;
+            y0.x = __builtin_fmaf((y0.x - m) * rs, g0.x, b0.x); y0.y = __builtin_fmaf((y0.y - m) * rs, g0.y, b0.y);
+            y0.z = __builtin_fmaf((y0.z - m) * rs, g0.z, b0.z); y0.w = __builtin_fmaf((y0.w - m) * rs, g0.w, b0.w);
+            y1.x = __builtin_fmaf((y1.x - m) * rs, g1.x, b1.x); y1.y = __builtin_fmaf((y1.y - m) * rs, g1.y, b1.y);
+            y1.z = __builtin_fmaf((y1.z - m) * rs, g1.z, b1.z); y1.w = __builtin_fmaf((y1.w - m) * rs, g1.w, b1.w);
+        }
+        split_hilo8(y0, y1, bh, bl);
+    }
+};
+typedef LdNormT<true> LdNorm;
+typedef LdNormT<false> LdIdent;
+
+// NK = fragments of a wave's K-slice; ksplit * NK == K32.  XB = token-operand fragments held at a time (NK, or NK / 2
+// when the slice is long: the second half is issued as soon as the first has been consumed).
+template <int NK, bool W8, class Ld, class Ep>
 __global__ void __launch_bounds__(640)
-k_skinny_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int N16, int K32, int ksplit, int rt_per_wg,
-              const int* __restrict__ done, Ld ld, Ep ep)
+k_skinny_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int N16, int K32, int ksplit, int rt_per_wg, int ks_magic,
+              const int* __restrict__ done, Ld ld, Ep ep TL_ARG)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // done: every stream finished (the rest of this replay is a no-op)
-    if (done && *done) return;
+    TL_BEGIN
+    constexpr int XB = (NK > 8 && !Ld::kNorm) ? NK / 2 : NK;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int ks = wave % ksplit, rtl = wave / ksplit;
+    const int rtl = (wave * ks_magic) >> 8, ks = wave - rtl * ksplit;          // wave / ksplit, wave % ksplit (waves <= 16)
     const int rt = blockIdx.x * rt_per_wg + rtl;
-    float4* red = reinterpret_cast<float4*>(smem + Ld::lds_bytes(K32));
-    const int nk = K32 / ksplit, kt0 = ks * nk;
+    const int kt0 = ks * NK;
     const bool active = rt < N16;
     const size_t wp = ((size_t)(active ? rt : 0) * K32 + kt0) * 512 + lane * 8;     // element index (bf16: 2 B, fp8: 1 B per element)
 
-    // first round of the weight stream goes out before the token operand exists
-    bf16x8_t a[U], xh[U], xl[U];
+    // ---- the launch's memory batch: weights, token operand, LayerNorm parameters, epilogue operands ----
+    typename WRaw<W8>::type a[NK];
 #pragma unroll
-    for (int u = 0; u < U; ++u) a[u] = ld_wfrag<W8, true>(W, wp + (size_t)u * 512);
-
-    // epilogue operand (residual + bias) of the element this thread will finish: fetched under the weight stream
-    float4 pre = make_float4(0.f, 0.f, 0.f, 0.f);
-    int em = 0, en = 0; bool edo = false;
-    if constexpr (Ep::kPre) {
-        if (ksplit > 1) {
-            if (threadIdx.x < rt_per_wg * 64) {
-                const int rt2 = blockIdx.x * rt_per_wg + (threadIdx.x >> 6);
-                em = lane & 15; en = rt2 * 16 + 4 * (lane >> 4); edo = rt2 < N16;
-            }
-        } else { em = lane & 15; en = rt * 16 + 4 * (lane >> 4); edo = active; }
-        if (edo) pre = ep.pre4(em, en);
+    for (int u = 0; u < NK; ++u) a[u] = ld_wraw<W8, true>(W, wp + (size_t)u * 512);
+    typename Ld::template Regs<XB> xr;
+    ld.template issue<XB>(xr, smem, kt0, lane);
+    EpPre pre; pre.i = 0; pre.a = make_float4(0.f, 0.f, 0.f, 0.f); pre.b = pre.a;
+    float4 wsc = make_float4(1.f, 1.f, 1.f, 1.f);
+    // the element this thread will finish: with K-slices, waves 0 .. rt_per_wg-1 finish row tile (wave), else every wave its own
+    const int rtf = (ksplit > 1) ? blockIdx.x * rt_per_wg + wave : rt;
+    const int em = lane & 15, en = rtf * 16 + 4 * (lane >> 4);
+    const bool edo = ((ksplit > 1) ? (wave < rt_per_wg) : true) && rtf < N16;
+    if (edo) {
+        pre = ep.pre(em, en);
+        if constexpr (W8) wsc = *reinterpret_cast<const float4*>(wscale + en);
     }
+    // done: every stream finished (the rest of this replay is a no-op).  Checked after the batch went out: the flag's
+    // latency overlaps the stream instead of heading every launch of the dependent chain.
+    if (done && *done) return;
 
-    ld.prepare(smem);
+    ld.template stats<XB>(xr, smem, ks, ksplit, rtl == 0, lane);
+    TL_PREP
 
-    if (!Ld::kLds) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) { xh[u] = ld.frag(smem, kt0 + u, lane, 0); xl[u] = ld.frag(smem, kt0 + u, lane, 1); }
-    }
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    for (int kk = 0; kk < nk; kk += U) {
-        bf16x8_t an[U];
-        const bool more = (kk + U) < nk;                      // wave-uniform
-        if (more) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) an[u] = ld_wfrag<W8, true>(W, wp + (size_t)(kk + U + u) * 512);
-        }
+    for (int u = 0; u < XB; ++u) {
+        bf16x8_t bh, bl;
+        ld.template frag<XB>(xr, smem, u, kt0 + u, lane, bh, bl);
+        const bf16x8_t av = w_expand<W8>(a[u]);
+        acc = mfma16(av, bh, acc);
+        acc = mfma16(av, bl, acc);
+    }
+    if constexpr (XB < NK) {
+        ld.template issue<XB>(xr, smem, kt0 + XB, lane);
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const bf16x8_t bh = Ld::kLds ? ld.frag(smem, kt0 + kk + u, lane, 0) : xh[u];
-            const bf16x8_t bl = Ld::kLds ? ld.frag(smem, kt0 + kk + u, lane, 1) : xl[u];
-            acc = mfma16(a[u], bh, acc);
-            acc = mfma16(a[u], bl, acc);
-        }
-        if (more) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                a[u] = an[u];
-                if (!Ld::kLds) { xh[u] = ld.frag(smem, kt0 + kk + U + u, lane, 0); xl[u] = ld.frag(smem, kt0 + kk + U + u, lane, 1); }
-            }
+        for (int u = 0; u < XB; ++u) {
+            bf16x8_t bh, bl;
+            ld.template frag<XB>(xr, smem, u, kt0 + XB + u, lane, bh, bl);
+            const bf16x8_t av = w_expand<W8>(a[XB + u]);
+            acc = mfma16(av, bh, acc);
+            acc = mfma16(av, bl, acc);
         }
     }
+    TL_MID
 
     if (ksplit > 1) {
+        float4* red = reinterpret_cast<float4*>(smem + ld.lds_bytes());
         red[(rtl * ksplit + ks) * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
         __syncthreads();
-        if (threadIdx.x < rt_per_wg * 64) {              // blockDim >= 64 * rt_per_wg: one output quad per thread
-            const int rtl2 = threadIdx.x >> 6, l2 = lane;
+        if (edo) {
             f32x4_t s = {0.f, 0.f, 0.f, 0.f};
             for (int k2 = 0; k2 < ksplit; ++k2) {
-                const float4 p = red[(rtl2 * ksplit + k2) * 64 + l2];
+                const float4 p = red[(wave * ksplit + k2) * 64 + lane];
                 s[0] += p.x; s[1] += p.y; s[2] += p.z; s[3] += p.w;
             }
-            const int rt2 = blockIdx.x * rt_per_wg + rtl2;
-            if (rt2 < N16) {
-                if constexpr (W8) s = scale4(s, wscale, rt2 * 16 + 4 * (l2 >> 4));
-                if constexpr (Ep::kPre) ep.store4p(l2 & 15, rt2 * 16 + 4 * (l2 >> 4), s, pre);
-                else ep.store4(l2 & 15, rt2 * 16 + 4 * (l2 >> 4), s);
-            }
+            if constexpr (W8) s = f32x4_t{s[0] * wsc.x, s[1] * wsc.y, s[2] * wsc.z, s[3] * wsc.w};
+            ep.fin(em, en, s, pre);
         }
-    } else if (active) {
-        if constexpr (W8) acc = scale4(acc, wscale, rt * 16 + 4 * (lane >> 4));
-        if constexpr (Ep::kPre) ep.store4p(lane & 15, rt * 16 + 4 * (lane >> 4), acc, pre);
-        else ep.store4(lane & 15, rt * 16 + 4 * (lane >> 4), acc);
+    } else if (edo) {
+        if constexpr (W8) acc = f32x4_t{acc[0] * wsc.x, acc[1] * wsc.y, acc[2] * wsc.z, acc[3] * wsc.w};
+        ep.fin(em, en, acc, pre);
     }
+    TL_END
 }
 
 // ---- batched path (token rows R > 16) ----------------------------------------------------------
-// LayerNorm of all row tiles to global packed hi/lo planes: the SAME code as the fused loader, run with the
-// same block size, so the operand bits equal those of a 16-row launch.
+// LayerNorm of all row tiles to global packed hi/lo planes: the SAME code as the fused loader with the same K-slicing
+// (one wave per slice), so the operand bits equal those of a 16-row launch.
+template <int NK, class Ld>
 __global__ void __launch_bounds__(640)
-k_ln_tiles(LdNorm ld, bf16_t* __restrict__ xg, size_t plane, const int* __restrict__ done)
+k_ln_tiles(Ld ld, int ksplit, bf16_t* __restrict__ xg, size_t plane, const int* __restrict__ done)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (done && *done) return;
-    const size_t off = (size_t)blockIdx.x * ld.K32 * 512;
-    ld.prepare_to(xg + off, xg + plane + off, smem, blockIdx.x * 16);
+    const int lane = threadIdx.x & 63;
+    const int ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kt0 = ks * NK;
+    typename Ld::template Regs<NK> xr;
+    ld.template issue<NK>(xr, smem, kt0, lane, blockIdx.x * 16);
+    ld.template stats<NK>(xr, smem, ks, ksplit, true, lane);
+    bf16_t* dst = xg + (size_t)blockIdx.x * ld.K32 * 512;
+#pragma unroll
+    for (int u = 0; u < NK; ++u) {
+        bf16x8_t bh, bl;
+        ld.template frag<NK>(xr, smem, u, kt0 + u, lane, bh, bl);
+        const size_t o = ((size_t)(kt0 + u) * 64 + lane) * 8;
+        *reinterpret_cast<uint4*>(dst + o) = __builtin_bit_cast(uint4, bh);
+        *reinterpret_cast<uint4*>(dst + plane + o) = __builtin_bit_cast(uint4, bl);
+    }
 }
 
 // More than 16 token rows (several streams): a wave owns RT weight row tiles x TT token tiles x ONE K-slice,
@@ -308,22 +398,23 @@ k_rows_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int 
 
 // ---- host-side launch plan -------------------------------------------------------------------
 static thread_local const int* g_skinny_done = nullptr;     // device flag checked by every launch of this translation unit
-struct SkinnyPlan { int ksplit, rt, U; };
+struct SkinnyPlan { int ksplit, rt, nk; };
 
-// K-slices of at most 16 fragments and, if possible,
-// >= 1024 waves.  The plan depends only on (N16, K32, loader kind): 16-row and batched launches of one GEMM
-// share it, which is what makes their results bit-identical.
+// K-slices of at most 16 fragments (8 when the token operand is normalised in registers) and, if possible, >= 1024 waves.
+// The plan depends only on (N16, K32, loader kind): 16-row and batched launches of one GEMM share it, which is what makes
+// their results bit-identical.  nk = K32 / ksplit is always one of {4, 8, 12, 16}.
 static inline int skinny_env(const char* name, int dflt) {
     const char* v = std::getenv(name);
     return v ? std::atoi(v) : dflt;
 }
-static inline SkinnyPlan skinny_plan(int N16, int K32, bool lds_loader) {
+static inline SkinnyPlan skinny_plan(int N16, int K32, bool norm_loader) {
     static const int cap = skinny_env("WM_PLAN_WAVE_CAP", 10);          // tuning knobs (bench sweeps); defaults are the shipped plan
     static const int target = skinny_env("WM_PLAN_TARGET_WAVES", 1024);
-    static const int nkmax = skinny_env("WM_PLAN_NK_MAX", 16);
-    static const int rt2 = skinny_env("WM_PLAN_RT2", 1);
-    SkinnyPlan p; p.U = (K32 % 8 == 0) ? 8 : 4;
-    const int q = K32 / p.U;                // candidate ksplit must divide q
+    static const int nkmax_env = skinny_env("WM_PLAN_NK_MAX", 16);
+    const int nkmax = norm_loader ? std::min(nkmax_env, 8) : nkmax_env;
+    SkinnyPlan p;
+    const int U = (K32 % 8 == 0) ? 8 : 4;
+    const int q = K32 / U;                  // candidate ksplit must divide q
     int best = 1;
     for (int s = 1; s <= cap && s <= q; ++s) {      // <= 10 waves per block (launch bound 640 threads)
         if (q % s) continue;
@@ -331,10 +422,8 @@ static inline SkinnyPlan skinny_plan(int N16, int K32, bool lds_loader) {
         if ((long)N16 * s >= target && K32 / s <= nkmax) break;
     }
     p.ksplit = best;
+    p.nk = K32 / best;
     p.rt = (best == 1) ? 4 : 1;
-    // LDS loaders hold the whole 16 x K operand (one block per CU): when there are more row tiles than CUs,
-    // let two tiles share one block (and one LayerNorm) instead of running a second round of blocks
-    if (rt2 && lds_loader && best > 1 && best <= 5 && N16 > 256) p.rt = 2;
     return p;
 }
 
@@ -344,24 +433,38 @@ struct WRef {
     WRef(const bf16_t* w_, const float* scale_ = nullptr) : w(w_), scale(scale_) {}
 };
 
-template <int U, bool W8, class Ld, class Ep>
-static inline hipError_t launch_skinny_u(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p, const Ld& ld, const Ep& ep) {
+template <int NK, bool W8, class Ld, class Ep>
+static inline hipError_t launch_skinny_nk(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p, const Ld& ld, const Ep& ep) {
     const int grid = (N16 + p.rt - 1) / p.rt;
     const int threads = 64 * p.ksplit * p.rt;
-    const size_t lds = Ld::lds_bytes(K32) + (p.ksplit > 1 ? (size_t)p.rt * p.ksplit * 1024 : 0);
-    auto kern = k_skinny_gemm<U, W8, Ld, Ep>;
+    const size_t lds = (size_t)ld.lds_bytes() + (p.ksplit > 1 ? (size_t)p.rt * p.ksplit * 1024 : 0);
+    const int magic = (256 + p.ksplit - 1) / p.ksplit;         // (wave * magic) >> 8 == wave / ksplit for wave < 16
+    auto kern = k_skinny_gemm<NK, W8, Ld, Ep>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, W.w, W.scale, N16, K32, p.ksplit, p.rt, g_skinny_done, ld, ep);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, W.w, W.scale, N16, K32, p.ksplit, p.rt, magic, g_skinny_done, ld, ep TL_PASS);
     return hipGetLastError();
+}
+
+template <bool W8, class Ld, class Ep>
+static inline hipError_t launch_skinny_w(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p, const Ld& ld, const Ep& ep) {
+    if (p.ksplit * p.rt > 10 || p.ksplit * p.nk != K32 || (Ld::kNorm && p.nk > 8)) return hipErrorInvalidConfiguration;
+    switch (p.nk) {
+        case 4: return launch_skinny_nk<4, W8>(st, W, N16, K32, p, ld, ep);
+        case 8: return launch_skinny_nk<8, W8>(st, W, N16, K32, p, ld, ep);
+        case 12: if constexpr (!Ld::kNorm) return launch_skinny_nk<12, W8>(st, W, N16, K32, p, ld, ep); break;
+        case 16: if constexpr (!Ld::kNorm) return launch_skinny_nk<16, W8>(st, W, N16, K32, p, ld, ep); break;
+        default: break;
+    }
+    return hipErrorInvalidConfiguration;
 }
 
 template <class Ld, class Ep>
 static inline hipError_t launch_skinny(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p, const Ld& ld, const Ep& ep) {
-    if (W.scale) return p.U == 8 ? launch_skinny_u<8, true>(st, W, N16, K32, p, ld, ep) : launch_skinny_u<4, true>(st, W, N16, K32, p, ld, ep);
-    return p.U == 8 ? launch_skinny_u<8, false>(st, W, N16, K32, p, ld, ep) : launch_skinny_u<4, false>(st, W, N16, K32, p, ld, ep);
+    if (W.scale) return launch_skinny_w<true>(st, W, N16, K32, p, ld, ep);
+    return launch_skinny_w<false>(st, W, N16, K32, p, ld, ep);
 }
 
 template <int NKR, int RT, bool W8, class Ep>
@@ -401,11 +504,10 @@ static inline hipError_t launch_skinny_mt_nk(hipStream_t st, WRef W, int N16, in
 template <class Ep>
 static inline hipError_t launch_skinny_mt(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p,
                                           const bf16_t* X, size_t plane, int MT, const Ep& ep) {
-    const int nk = K32 / p.ksplit;
-    if (nk == 16) return launch_skinny_mt_nk<16>(st, W, N16, K32, p, X, plane, MT, ep);
-    if (nk == 12) return launch_skinny_mt_nk<12>(st, W, N16, K32, p, X, plane, MT, ep);
-    if (nk == 8) return launch_skinny_mt_nk<8>(st, W, N16, K32, p, X, plane, MT, ep);
-    if (nk == 4) return launch_skinny_mt_nk<4>(st, W, N16, K32, p, X, plane, MT, ep);
+    if (p.nk == 16) return launch_skinny_mt_nk<16>(st, W, N16, K32, p, X, plane, MT, ep);
+    if (p.nk == 12) return launch_skinny_mt_nk<12>(st, W, N16, K32, p, X, plane, MT, ep);
+    if (p.nk == 8) return launch_skinny_mt_nk<8>(st, W, N16, K32, p, X, plane, MT, ep);
+    if (p.nk == 4) return launch_skinny_mt_nk<4>(st, W, N16, K32, p, X, plane, MT, ep);
     return hipErrorInvalidConfiguration;
 }
 
@@ -414,29 +516,31 @@ template <class Ep>
 static inline hipError_t launch_skinny_rows(hipStream_t st, WRef W, int N16, int K32, int R, const bf16_t* X, size_t plane,
                                             const Ep& ep) {
     const SkinnyPlan p = skinny_plan(N16, K32, false);
-    if (R <= 16) return launch_skinny(st, W, N16, K32, p, LdPacked{X, K32, plane}, ep);
+    if (R <= 16) return launch_skinny(st, W, N16, K32, p, LdPacked{X, K32, plane, R}, ep);
     return launch_skinny_mt(st, W, N16, K32, p, X, plane, (R + 15) / 16, ep);
 }
 
-static inline bool skinny_norm_fusable(int N16, int K32) {
+template <class Ld, class Ep>
+static inline hipError_t launch_skinny_norm_t(hipStream_t st, WRef W, int N16, int K32, const Ld& ld, const Ep& ep, bf16_t* xscr, size_t plane) {
     const SkinnyPlan p = skinny_plan(N16, K32, true);
-    return K32 <= LdNorm::UB * p.ksplit * p.rt;
+    const int R = ld.M;
+    if (p.nk > 8 || K32 * 32 != ld.d) return hipErrorInvalidConfiguration;
+    if (R <= 16) return launch_skinny(st, W, N16, K32, p, ld, ep);
+    const int MT = (R + 15) / 16;
+    if (p.nk == 8) hipLaunchKernelGGL((k_ln_tiles<8, Ld>), dim3(MT), dim3(64 * p.ksplit), ld.lds_bytes(), st, ld, p.ksplit, xscr, plane, g_skinny_done);
+    else if (p.nk == 4) hipLaunchKernelGGL((k_ln_tiles<4, Ld>), dim3(MT), dim3(64 * p.ksplit), ld.lds_bytes(), st, ld, p.ksplit, xscr, plane, g_skinny_done);
+    else return hipErrorInvalidConfiguration;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return launch_skinny_mt(st, W, N16, K32, p, xscr, plane, MT, ep);
 }
 
 // LayerNorm-fused GEMM over R token rows.  R <= 16: one fused launch.  R > 16: the same LayerNorm code writes
-// the packed hi/lo operand to `xscr` (global), then the register-blocked token-tile kernel runs.  The fused loader
-// needs the whole 16 x K tile in one batch of the block's threads (true for every Whisper size).
+// the packed hi/lo operand to `xscr` (global), then the register-blocked token-tile kernel runs.
 template <class Ep>
 static inline hipError_t launch_skinny_norm(hipStream_t st, WRef W, int N16, int K32, const float* h, const float* gamma,
                                             const float* beta, int d, int R, int row_mul, int row_off, int do_norm, const Ep& ep,
                                             bf16_t* xscr, size_t plane) {
-    if (!skinny_norm_fusable(N16, K32)) return hipErrorInvalidConfiguration;
-    const SkinnyPlan p = skinny_plan(N16, K32, true);
-    const LdNorm ld{h, gamma, beta, d, K32, R, row_mul, row_off, do_norm};
-    if (R <= 16) return launch_skinny(st, W, N16, K32, p, ld, ep);
-    const int MT = (R + 15) / 16;
-    hipLaunchKernelGGL(k_ln_tiles, dim3(MT), dim3(64 * p.ksplit * p.rt), LdNorm::scratch_bytes(K32), st, ld, xscr, plane, g_skinny_done);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    return launch_skinny_mt(st, W, N16, K32, p, xscr, plane, MT, ep);
+    if (do_norm) return launch_skinny_norm_t(st, W, N16, K32, LdNorm{h, gamma, beta, d, K32, R, row_mul, row_off}, ep, xscr, plane);
+    return launch_skinny_norm_t(st, W, N16, K32, LdIdent{h, gamma, beta, d, K32, R, row_mul, row_off}, ep, xscr, plane);
 }

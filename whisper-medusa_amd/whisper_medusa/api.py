@@ -94,8 +94,17 @@ class WhisperMedusaModel:
             device = torch.device("cuda", torch.cuda.current_device())
         if self._engine is not None and self.device == device:
             return self
+        self._drop_pool()
+        if self._engine is not None:
+            self._engine.close()                                   # frees its KV caches / scratch before the new context allocates
+            self._engine = None
         with torch.cuda.device(device):
-            self._blob, self._offsets = _weights.build_blob(self.config, self._sd, device=device, dec_fp8=self._fp8)
+            if self._sd:
+                self._blob, self._offsets = _weights.build_blob(self.config, self._sd, device=device, dec_fp8=self._fp8)
+            elif self._blob is not None:
+                self._blob = self._blob.to(device)                 # built with from_blob: move the packed blob itself
+            else:
+                raise RuntimeError("model has neither a state dict nor a packed blob to place on the device")
             self._engine = Engine(self.config, self._blob, self._offsets, max_batch=self._max_batch, device=device, dec_weight_fp8=self._fp8)
         self._drop_pool()
         self.device = device
@@ -160,6 +169,8 @@ class WhisperMedusaModel:
             a = wav.detach().cpu().numpy() if isinstance(wav, torch.Tensor) else np.asarray(wav)
             a = a.astype(np.float32)
             clips = [a] if a.ndim == 1 else [r for r in a]          # 2-D array = batch of mono clips; multi-channel clips go in a list
+        if len(clips) > self._max_batch:
+            self.set_max_batch(len(clips))                          # wm_logmel checks B <= max_batch
         buf = torch.zeros(len(clips), n, dtype=torch.float32, device=self.device)
         for i, c in enumerate(clips):
             if c.ndim == 2 or sampling_rate != 16000:

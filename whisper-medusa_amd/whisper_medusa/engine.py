@@ -15,7 +15,7 @@ import torch
 from .config import MedusaConfig, GenParams, HEADS_BLOCK
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwm.so")
+LIB_PATH = os.path.join(_HERE, "libwm.so")      # the product library; tests/microbench scripts may point WM_LIB at a debug build
 WM_ABI_VERSION = 2
 
 
@@ -60,7 +60,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("WM_LIB") or LIB_PATH
     if not os.path.exists(p):
         raise RuntimeError(f"{p} not found: build the HIP engine first (python whisper-medusa_amd/build.py). "
                            "There is no CPU fallback.")
@@ -84,7 +84,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.wm_get_cross_kv.argtypes = [vp, i32, i32, i32, f32p, f32p]
     lib.wm_profile_kernel.argtypes = [vp, i32, i32, i32, f32p, C.POINTER(C.c_double)]
     for name in EXPORTS:
-        if name not in ("wm_destroy", "wm_last_error"):
+        if name not in ("wm_destroy", "wm_last_error", "wm_resample_len"):      # wm_resample_len returns int64 (set above)
             getattr(lib, name).restype = i32
     if lib.wm_abi_version() != WM_ABI_VERSION:
         raise RuntimeError("libwm.so ABI version mismatch")
@@ -119,9 +119,10 @@ class Engine:
                      1 if cfg.medusa_heads_type == HEADS_BLOCK else 0, self.max_batch, 1 if dec_weight_fp8 else 0)
         w = WmWeights(C.c_void_p(blob.data_ptr()), blob.numel(),
                       self._offsets.ctypes.data_as(C.POINTER(C.c_uint64)), len(self._offsets))
-        self.stream = torch.cuda.current_stream(self.device)
+        # every context owns a private non-blocking HIP stream (NULL -> wm_create makes one): several contexts built under
+        # one torch.cuda.stream(s) block must not capture graphs on / launch into the same stream from different host threads
         h = C.c_void_p()
-        rc = self.lib.wm_create(C.byref(c), C.byref(w), self.device.index or 0, C.c_void_p(self.stream.cuda_stream), C.byref(h))
+        rc = self.lib.wm_create(C.byref(c), C.byref(w), self.device.index or 0, C.c_void_p(None), C.byref(h))
         if rc != 0:
             raise RuntimeError(f"wm_create failed ({rc}): {self.lib.wm_last_error(None).decode()}")
         self.h = h
@@ -193,7 +194,7 @@ class Engine:
         prompt, sup, bsup = _i32arr(gp.prompt), _i32arr(gp.suppress_tokens), _i32arr(gp.begin_suppress_tokens)
         g = WmGenParams(prompt, len(gp.prompt), gp.eos_token_id, gp.pad_token_id, sup, len(gp.suppress_tokens),
                         bsup, len(gp.begin_suppress_tokens), gp.max_length, gp.hard_max_length,
-                        gp.exp_decay[0] if gp.exp_decay is not None else -1,
+                        int(gp.exp_decay[0]) if gp.exp_decay is not None else -1,      # the eval CLI parses the start as float
                         float(gp.exp_decay[1]) if gp.exp_decay is not None else 1.0,
                         gp.posterior_threshold, gp.posterior_alpha, gp.temperature if gp.temperature else 0.0,
                         gp.accept_mode, 1 if gp.vanilla else 0)
