@@ -58,6 +58,124 @@ def prefill_flops(cfg):
     return L * per_layer + conv + cross
 
 
+def kernels_sha():
+    """sha1 over the HIP sources: a PMC traffic file measured on other kernels is refused as stale."""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "whisper-medusa_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def median(v):
+    v = sorted(v)
+    return v[len(v) // 2]
+
+
+def cpu_baseline_leg(cfg, sd, eng, gp, wav0, engine_ids, n_iters, fp8, full_budget):
+    """The oracle (a CPU port of the reference algorithm, oracle/) on the host cores of this box, SURVEY.md §8d: split
+    log-mel / encoder / decode timers, 1 warm-up + 3 timed runs each, median.  The decode sample is `n_iters` Medusa iterations
+    (the whole 128-token budget with --cpu-full).  Parity: the oracle in the engine's numeric contract (sim="bf16"), fed with
+    the engine's encoder output, must emit exactly the engine's token ids for those iterations."""
+    from oracle.whisper_medusa_oracle import Oracle, log_mel
+    ncore = min(os.cpu_count() or 1, 64)
+    torch.set_num_threads(ncore)
+    sd_cpu = {k: v.float().cpu() for k, v in sd.items()}
+    orc = Oracle(cfg, sd_cpu, sim="fp32", dec_fp8=fp8)             # the reference's default dtype
+    n = cfg.n_mel_frames * 160
+    wav = wav0.cpu().numpy()
+
+    def timed(fn, reps=3):
+        fn()                                                         # warm-up
+        ts = []
+        for _ in range(reps):
+            t = time.perf_counter(); r = fn(); ts.append(time.perf_counter() - t)
+        return median(ts), r
+    t_mel, feats = timed(lambda: log_mel(wav, cfg.num_mel_bins, n))
+    t_enc, _ = timed(lambda: orc.encode(torch.from_numpy(feats)), reps=3)
+    enc = eng.encoder_output(1)[0]                                   # decode legs start from the GPU encoder output
+    iters = None if full_budget else n_iters
+    t_dec, r = timed(lambda: orc.decode(enc, gp, max_iters=iters))
+    ntok = len(r.ids) - len(gp.prompt)
+    # parity on the same iterations, engine contract
+    orc16 = Oracle(cfg, sd_cpu, sim="bf16", dec_fp8=fp8)
+    r16 = orc16.decode(enc, gp, max_iters=iters)
+    ok = engine_ids[: len(r16.ids)] == r16.ids
+    first = next((i for i, (a, b) in enumerate(zip(engine_ids, r16.ids)) if a != b), min(len(engine_ids), len(r16.ids)))
+    agree32 = next((i for i, (a, b) in enumerate(zip(engine_ids, r.ids)) if a != b), min(len(engine_ids), len(r.ids))) - len(gp.prompt)
+    audio_s = 30.0 * cfg.max_source_positions / 1500.0
+    return {"value": round(ntok / t_dec, 3), "unit": "tokens/s", "cores": ncore, "kind": "port",
+            "sample": f"oracle (PyTorch CPU fp32 restatement of the reference loop) on clip 0, 1 warm-up + 3 runs, median: log-mel "
+                      f"{t_mel:.2f} s, encoder {t_enc:.2f} s, decode (cross-KV projection + {r.n_iters} Medusa iterations = {ntok} tokens, "
+                      f"from the GPU encoder output) {t_dec:.2f} s",
+            "s_logmel": round(t_mel, 3), "s_encoder": round(t_enc, 3), "s_decode_sample": round(t_dec, 3),
+            "decode_sample_iters": r.n_iters, "decode_sample_tokens": ntok,
+            "whole_clip_rtf_estimate": round((t_mel + t_enc + t_dec * (gp.max_length - len(gp.prompt)) / max(ntok, 1)) / audio_s, 3),
+            "parity_checked": bool(ok), "parity_tokens_compared": len(r16.ids) - len(gp.prompt),
+            "parity_first_divergence": None if ok else first - len(gp.prompt),
+            "fp32_oracle_agrees_for_tokens": agree32}
+
+
+def acceptance_sensitivity(eng, cfg, gp_base, B, max_new):
+    """Decode-only tokens/s with the accept length of every iteration FORCED to a (wm.h force_accept): the cost side of the
+    headline, independent of what the random-init heads happen to accept.  a = 0 is the floor (2 tokens, 2 passes per iteration)."""
+    import copy
+    out = {}
+    for a in (0, 1, 2, 3, 5, cfg.medusa_num_heads):
+        g = copy.copy(gp_base); g.force_accept = a
+        eng.decode(g, B)
+        st = eng.stats()
+        out[f"a={a}"] = {"tokens_per_sec": round(st["tokens_emitted"] / (st["ms_decode"] * 1e-3), 1),
+                         "ms_per_iteration": round(st["ms_decode"] / max(st["iterations"], 1), 4),
+                         "tokens_per_iteration": round(st["tokens_emitted"] / max(st["iterations"], 1) / B, 3)}
+    return out
+
+
+def extra_config(name, heads, B, fp8, dev, logit_std, max_new, steps=2):
+    """One more BASELINE.json config measured in the same process (B streams, one context): whole-step tokens/s, decode
+    iteration time, vanilla anchor, roofline fractions."""
+    from whisper_medusa import MedusaConfig, WhisperMedusaModel, ACCEPT_TYPICAL, synth, weights
+    cfg = MedusaConfig.large_v2(heads, K=10)
+    sd = synth.synth_state_dict(cfg, seed=0, device=str(dev), logit_std=logit_std)
+    blob, offs = weights.build_blob(cfg, sd, device=dev, dec_fp8=fp8)
+    del sd
+    model = WhisperMedusaModel.from_blob(cfg, blob, offs, max_batch=B, dec_weight_fp8=fp8)
+    eng = model.engine
+    n_samp = cfg.n_mel_frames * 160
+    wav = torch.from_numpy(np.stack([synth.synth_clip(500 + j, n_samp) for j in range(B)])).to(dev)
+    gp = synth.bench_gen_params(cfg, max_new_tokens=max_new, accept_mode=ACCEPT_TYPICAL)
+
+    def step():
+        eng.encode(eng.logmel(wav))
+        seqs = eng.decode(gp, B)
+        return sum(len(s) - len(gp.prompt) for s in seqs), eng.stats()
+    step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    tok = it = 0; ms_dec = ms_enc = 0.0
+    for _ in range(steps):
+        n, st = step(); tok += n; it += st["iterations"]; ms_dec += st["ms_decode"]; ms_enc += st["ms_encode"]
+    torch.cuda.synchronize(); el = time.perf_counter() - t0
+    gpv = synth.bench_gen_params(cfg, max_new_tokens=max_new, vanilla=True)
+    eng.decode(gpv, B); eng.decode(gpv, B)
+    stv = eng.stats()
+    van = B * max_new / (stv["ms_decode"] * 1e-3)
+    t_iter = ms_dec / max(it, 1)
+    bytes_iter = decode_iter_bytes(cfg, B, len(gp.prompt) + max_new / 2, fp8)
+    out = {"config": name, "streams": B, "heads": heads, "fp8_decoder_weights": fp8, "steps": steps,
+           "tokens_per_sec": round(tok / el, 1), "decode_tokens_per_sec": round(tok / (ms_dec * 1e-3), 1),
+           "ms_per_iteration": round(t_iter, 4), "tokens_per_iteration": round(tok / max(it, 1) / B, 3),
+           "vanilla_tokens_per_sec": round(van, 1), "medusa_over_vanilla": round(tok / (ms_dec * 1e-3) / van, 3),
+           "roofline_frac_hbm": round(bytes_iter / (t_iter * 1e-3) / 8e12, 4),
+           "prefill_tflops": round(prefill_flops(cfg) * B / (ms_enc / steps * 1e-3) / 1e12, 1),
+           "prefill_frac_mfma": round(prefill_flops(cfg) * B / (ms_enc / steps * 1e-3) / 2.5e15, 4)}
+    eng.close()
+    del model, blob
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,7 +195,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vanilla", action="store_true",
                     help="skip the vanilla-greedy anchor (PMC passes: only Medusa iterations in the counter totals)")
-    ap.add_argument("--cpu-iters", type=int, default=6)
+    ap.add_argument("--cpu-iters", type=int, default=8, help="Medusa iterations of the CPU-baseline decode sample")
+    ap.add_argument("--cpu-full", action="store_true", help="CPU baseline decodes the whole max-new budget (minutes)")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip the BASELINE configs[2] (Block, 32 streams) and configs[4] (fp8, 32 streams) legs and the sensitivity rows")
     args = ap.parse_args()
 
     from whisper_medusa import MedusaConfig, WhisperMedusaModel, ACCEPT_TYPICAL
@@ -173,10 +294,16 @@ def main():
     if rank != 0:
         return
 
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    # HBM traffic per iteration from the PMC pass (profiles/): only if that pass was taken on THESE kernels (sha over csrc/)
+    traffic = None; traffic_src = None
+    tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     if args.model == "large-v2" and B == 1 and args.heads == "linear" and not args.fp8_weights and os.path.exists(tpath):
-        traffic = json.load(open(tpath))["medusa_iteration_bytes"]      # PMC FETCH_SIZE x2, see profiles/
+        tj = json.load(open(tpath))
+        if tj.get("kernels_sha") == kernels_sha():
+            traffic = tj["medusa_iteration_bytes"]      # PMC FETCH_SIZE x2, see profiles/
+            traffic_src = {"file": "profiles/r02_pmc_traffic.json", "command": tj.get("command"), "kernels_sha": tj.get("kernels_sha")}
+        else:
+            traffic_src = {"file": "profiles/r02_pmc_traffic.json", "stale": True, "file_kernels_sha": tj.get("kernels_sha"), "kernels_sha": kernels_sha()}
     t_iter_ms = ms_dec / max(iters, 1)
     mean_len = len(gp.prompt) + args.max_new / 2
     bytes_iter = decode_iter_bytes(cfg, B, mean_len, args.fp8_weights)
@@ -207,7 +334,7 @@ def main():
                            "medusa_over_vanilla": round(tokens / (ms_dec * 1e-3) / vanilla_tps, 3)},
         "roofline": {"bound": "hbm", "kernel": "decode iteration (verify pass + base pass unless the hidden state was carried; hipGraph replays)",
                      "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
-                     "traffic": traffic, "bytes_per_launch": round(bytes_iter), "ms_per_launch": round(t_iter_ms, 4),
+                     "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": round(bytes_iter), "ms_per_launch": round(t_iter_ms, 4),
                      "prefill": {"bound": "mfma", "tflops_per_clip": round(prefill_flops(cfg) / 1e12, 3),
                                  "achieved": round(prefill_flops(cfg) * B / (ms_enc / args.steps * 1e-3) / 1e12, 1),
                                  "peak": 2500.0, "unit": "TFLOP/s",
@@ -217,26 +344,32 @@ def main():
                                      "achieved_gbs": round(gemm_bytes / (gemm_ms * 1e-3) / 1e9, 1)}},
     }
 
+    # ---- acceptance sensitivity + the other single-GPU BASELINE configs (untimed by the driver, same process) ----
+    if not args.no_extra_configs and world == 1 and not args.no_vanilla:
+        try:
+            out["acceptance_sensitivity"] = acceptance_sensitivity(eng, cfg, gp, B, args.max_new)
+        except Exception as e:  # noqa: BLE001
+            out["acceptance_sensitivity"] = {"failed": repr(e)}
+        if args.model == "large-v2" and B == 1 and args.heads == "linear" and not args.fp8_weights:
+            extra = []
+            for name, heads_x, Bx, fp8x in (("configs[2] large-v2 + Medusa-Block K=10, 32 streams", "medusa_block", 32, False),
+                                            ("configs[1] shape at 32 streams (Medusa-Linear)", "base_head", 32, False),
+                                            ("configs[4] fp8 decoder weights + Medusa-Linear, 32 streams", "base_head", 32, True)):
+                try:
+                    extra.append(extra_config(name, heads_x, Bx, fp8x, dev, args.logit_std, args.max_new))
+                except Exception as e:  # noqa: BLE001
+                    extra.append({"config": name, "failed": repr(e)})
+            out["configs"] = extra
+
     # ---- CPU baseline: the oracle (a port of the reference algorithm) on the host cores, bounded sample ----
     if not args.no_cpu_baseline and world == 1:
         try:
-            from oracle.whisper_medusa_oracle import Oracle
-            torch.set_num_threads(min(os.cpu_count() or 1, 64))
-            enc = eng.encoder_output(1)[0]
-            sd_cpu = {k: v.float().cpu() for k, v in sd.items()}
-            orc = Oracle(cfg, sd_cpu, sim="fp32", dec_fp8=args.fp8_weights)
-            tc = time.perf_counter()
-            r = orc.decode(enc, gp, max_iters=args.cpu_iters)
-            dt = time.perf_counter() - tc
-            ntok = len(r.ids) - len(gp.prompt)
-            out["cpu_baseline"] = {"value": round(ntok / dt, 3), "unit": "tokens/s", "cores": torch.get_num_threads(),
-                                   "kind": "port",
-                                   "sample": f"oracle (PyTorch CPU fp32 restatement of the reference loop) on clip 0: cross-KV "
-                                             f"projection + {args.cpu_iters} Medusa iterations ({ntok} tokens) from the GPU "
-                                             f"encoder output, {dt:.1f} s"}
+            eng.encode(eng.logmel(wavs[0][:1].contiguous()))
+            ids0 = eng.decode(gp, 1)[0]
+            out["cpu_baseline"] = cpu_baseline_leg(cfg, sd, eng, gp, wavs[0][0], ids0, args.cpu_iters, args.fp8_weights, args.cpu_full)
         except Exception as e:  # noqa: BLE001
             out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
-                                   "sample": f"failed: {e!r}"}
+                                   "sample": f"failed: {e!r}", "parity_checked": False}
     print(json.dumps(out), flush=True)
 
 

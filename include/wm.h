@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define WM_ABI_VERSION 2
+#define WM_ABI_VERSION 3
 
 #define WM_OK 0
 #define WM_ERR_ARG (-1)      /* bad argument / unsupported configuration (reference: ValueError, model.py:225-229) */
@@ -88,6 +88,9 @@ typedef struct wm_gen_params {
     float temperature;              /* divides verify logits in typical mode (1.0 via generate()) */
     int32_t accept_mode;            /* WM_ACCEPT_* */
     int32_t vanilla;                /* 1 = plain greedy decoding on the base head (anchor measurement) */
+    int32_t force_accept;           /* measurement knob (bench.py acceptance-sensitivity rows): >= 0 forces every iteration's accept
+                                     * length to min(force_accept, K) whatever the posterior says — the tokens are then meaningless,
+                                     * the cost of an iteration at that acceptance is not; < 0 = off (always, outside benchmarks) */
 } wm_gen_params;
 
 typedef struct wm_stats {

@@ -425,3 +425,60 @@ def test_from_pretrained_checkpoint_directory(gpu, tmp_path):
     fw = model(input_features=feats, decoder_input_ids=torch.tensor([synth.default_prompt(cfg)]))
     assert fw.logits.shape == (5, 1, 2, cfg.vocab_size)                  # [K+1, B, T, V] like the reference forward()
     model.engine.close(); ref_model.engine.close()
+
+
+def _first_div(a, b):
+    return next((i for i, (x, y) in enumerate(zip(a, b)) if x != y), min(len(a), len(b)))
+
+
+@pytest.mark.parametrize("mode", [ACCEPT_GREEDY, ACCEPT_TYPICAL])
+def test_token_agreement_with_the_pinned_fp32_oracle_end_to_end(gpu, mode, capsys):
+    """Cross-mode evidence: audio -> tokens on the engine (bf16 parameters and KV cache, bf16 encoder
+    operands, hi/lo decoder operands: DESIGN.md §2) against the PINNED oracle mode — sim="fp32", the one reproduced from the
+    reference's own code in tests/test_oracle_golden.py — running its OWN log-mel and encoder, on 16 clips of tiny.en shape.
+    Nothing is shared between the two sides but the checkpoint and the waveform.  Reports, per clip, how many generated ids
+    agree before the first divergence and the oracle's decision margins at that point; asserts floors on the agreement.
+    (The bf16-contract oracle fed with the engine's encoder output agrees bit-exactly: test_decode_tokens_bit_exact.)"""
+    cfg = MedusaConfig.tiny_en(K=4)
+    sd = synth.synth_state_dict(cfg, seed=0)
+    N = 16
+    model = WhisperMedusaModel(cfg, sd, device=gpu, max_batch=N)
+    orc32 = Oracle(cfg, sd, sim="fp32")
+    n = cfg.n_mel_frames * 160
+    wavs = [synth.synth_clip(200 + i, n) for i in range(N)]
+    gp = golden_gen_params(cfg, mode, 32)
+    feats = model.extract_features(wavs)
+    model.engine.encode(feats)
+    got = model.engine.decode(gp, N)
+    P = len(gp.prompt)
+    rows, agree, total = [], 0, 0
+    for i in range(N):
+        ref = orc32.transcribe(wavs[i], gp, trace=True)
+        f = _first_div(got[i], ref.ids)
+        ngen = len(ref.ids) - P
+        agree += f - P; total += ngen
+        margin = ""
+        if f < len(ref.ids):
+            # the oracle iteration that emitted the first differing id: its closest accept/reject call and its top-2 margin
+            pos, it = P, None
+            for t in ref.trace:
+                if pos + len(t["emit"]) > f:
+                    it = t
+                    break
+                pos += len(t["emit"])
+            if it is not None:
+                top2 = torch.topk(it["v"][0], 2).values
+                m_acc = float((it["p_c"] - it["thr"]).abs().min()) if "p_c" in it else float("nan")
+                margin = f"top-2 logit margin {float(top2[0] - top2[1]):.4f}, min |p_c - thr| {m_acc:.5f}"
+        rows.append((i, f - P, ngen, margin))
+    with capsys.disabled():
+        print(f"\nengine (bf16 contract) vs pinned fp32 oracle, end to end, tiny.en K=4, mode {'typical' if mode == ACCEPT_TYPICAL else 'exact-match'}:")
+        for i, f, ngen, margin in rows:
+            print(f"  clip {i:2d}: {f:2d} / {ngen} generated ids agree before the first divergence  {margin}")
+        print(f"  total {agree} / {total} = {agree / max(total, 1):.3f}")
+    full = sum(1 for _, f, ngen, _ in rows if f == ngen)
+    # floors (measured values are printed above and recorded in DESIGN.md §2): the two sides never disagree on the first token,
+    # and a clear majority of the generated ids is reproduced although no rounding point is shared
+    assert all(f >= 1 for _, f, _, _ in rows)
+    assert agree >= 0.5 * total, (agree, total, full)
+    model.engine.close()

@@ -115,7 +115,8 @@ __device__ __forceinline__ void split_hilo8(const float* x, bf16x8_t& hi, bf16x8
     hi = __builtin_bit_cast(bf16x8_t, h); lo = __builtin_bit_cast(bf16x8_t, l);
 }
 
-#define WM_XATTN_SPB_MAX 6          // key splits one block may walk (LDS copy of its partials)
+#define WM_XATTN_NS_MAX 8           // key splits of 256 encoder frames per (stream, head): n_ctx <= 2048 (Whisper: 1500 -> 6)
+#define WM_XATTN_SPB_MAX WM_XATTN_NS_MAX   // a block may walk all of them (LDS copy of its partials)
 
 struct KVStep { bf16x8_t k00, k01, k10, k11, v[4]; };        // one 32-key step: K rows as A fragments, V^T fragments
 struct AttnAcc { float m_run, l_run; f32x4_t o[4]; };
@@ -313,43 +314,45 @@ k_attn_mfma(const float* __restrict__ q, const bf16_t* __restrict__ kmat, const 
         if (!s_last) { TL_END return; }
     } else __syncthreads();
     if (qr < Mper) {
-        const u64* mlp = reinterpret_cast<const u64*>(ml + ((size_t)row * H + hd) * NS * 2);
-        const u64* op = reinterpret_cast<const u64*>(po + ((size_t)row * H + hd) * NS * 64 + ch);
-        // every partial another block published is fetched in ONE batch (relaxed agent-scope loads bypass L1), then merged in
-        // split order; this block's own splits come from LDS
-        constexpr int NSM = 16;                    // wm_create: NS <= 16
-        u64 rml[NSM], ro0[NSM], ro1[NSM];
+        // merge the NS partials in split order (the same arithmetic whether they come from LDS or from other blocks)
+        float ms[WM_XATTN_NS_MAX], ls[WM_XATTN_NS_MAX]; float4 ov[WM_XATTN_NS_MAX];
+        if (gridDim.x > 1) {
+            // every partial (this block's own included: they were published above) is fetched in ONE batch of relaxed
+            // agent-scope loads (L1 bypass) — one memory round trip for the last-arriving block instead of one per split
+            const u64* mlp = reinterpret_cast<const u64*>(ml + ((size_t)row * H + hd) * NS * 2);
+            const u64* op = reinterpret_cast<const u64*>(po + ((size_t)row * H + hd) * NS * 64 + ch);
+            u64 rml[WM_XATTN_NS_MAX], ro0[WM_XATTN_NS_MAX], ro1[WM_XATTN_NS_MAX];
 #pragma unroll
-        for (int sp = 0; sp < NSM; ++sp) {
-            rml[sp] = 0; ro0[sp] = 0; ro1[sp] = 0;
-            if (sp < NS && !(sp >= sp0 && sp < sp1)) {
-                rml[sp] = __hip_atomic_load(mlp + sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ro0[sp] = __hip_atomic_load(op + (size_t)sp * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ro1[sp] = __hip_atomic_load(op + (size_t)sp * 32 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int sp = 0; sp < WM_XATTN_NS_MAX; ++sp) {
+                const int spc = min(sp, NS - 1);            // clamped: loads stay unconditional (straight-line, one batch)
+                rml[sp] = __hip_atomic_load(mlp + spc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ro0[sp] = __hip_atomic_load(op + (size_t)spc * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ro1[sp] = __hip_atomic_load(op + (size_t)spc * 32 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int sp = 0; sp < WM_XATTN_NS_MAX; ++sp) {
+                ms[sp] = __uint_as_float((unsigned)rml[sp]); ls[sp] = __uint_as_float((unsigned)(rml[sp] >> 32));
+                ov[sp] = make_float4(__uint_as_float((unsigned)ro0[sp]), __uint_as_float((unsigned)(ro0[sp] >> 32)),
+                                     __uint_as_float((unsigned)ro1[sp]), __uint_as_float((unsigned)(ro1[sp] >> 32)));
+            }
+        } else {
+#pragma unroll
+            for (int sp = 0; sp < WM_XATTN_NS_MAX; ++sp) {
+                const int spc = min(sp, NS - 1);
+                ms[sp] = s_part[spc][qr][64]; ls[sp] = s_part[spc][qr][65];
+                ov[sp] = *reinterpret_cast<const float4*>(&s_part[spc][qr][ch]);
             }
         }
-        float ms[NSM], ls[NSM];
         float Mx = -INFINITY;
 #pragma unroll
-        for (int sp = 0; sp < NSM; ++sp) {
-            ms[sp] = -INFINITY; ls[sp] = 0.f;
-            if (sp < NS) {
-                if (sp >= sp0 && sp < sp1) { ms[sp] = s_part[sp - sp0][qr][64]; ls[sp] = s_part[sp - sp0][qr][65]; }
-                else { ms[sp] = __uint_as_float((unsigned)rml[sp]); ls[sp] = __uint_as_float((unsigned)(rml[sp] >> 32)); }
-                Mx = fmaxf(Mx, ms[sp]);
-            }
-        }
+        for (int sp = 0; sp < WM_XATTN_NS_MAX; ++sp) if (sp < NS) Mx = fmaxf(Mx, ms[sp]);
         float Lt = 0.f; float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int sp = 0; sp < NSM; ++sp) {
+        for (int sp = 0; sp < WM_XATTN_NS_MAX; ++sp) {
             if (sp < NS) {
                 const float e = (ms[sp] == -INFINITY) ? 0.f : __expf(ms[sp] - Mx);
                 Lt += ls[sp] * e;
-                float4 ov;
-                if (sp >= sp0 && sp < sp1) ov = *reinterpret_cast<const float4*>(&s_part[sp - sp0][qr][ch]);
-                else ov = make_float4(__uint_as_float((unsigned)ro0[sp]), __uint_as_float((unsigned)(ro0[sp] >> 32)),
-                                      __uint_as_float((unsigned)ro1[sp]), __uint_as_float((unsigned)(ro1[sp] >> 32)));
-                o4.x += ov.x * e; o4.y += ov.y * e; o4.z += ov.z * e; o4.w += ov.w * e;
+                o4.x += ov[sp].x * e; o4.y += ov[sp].y * e; o4.z += ov[sp].z * e; o4.w += ov[sp].w * e;
             }
         }
         const float inv = 1.0f / Lt;
@@ -533,6 +536,7 @@ __global__ void k_accept(GenDev gp, const int* __restrict__ cand, const int* __r
     const unsigned long long inv = ~m;
     int a = (inv == 0ull) ? 64 : (__ffsll((long long)inv) - 1);
     if (a > K) a = K;
+    if (gp.force_accept >= 0) a = min(gp.force_accept, K);        // benchmark knob (wm.h): iteration cost at a given acceptance
     const int Lcur = L[s];
     const int n_emit = (a == 0) ? 2 : a + 1;
     int tok = -1;
@@ -599,11 +603,75 @@ static inline int xattn_blocks_per_head(int NS, int heads_total)
     return (NS + spb - 1) / spb;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Side-stream prefetch (WM_PREFETCH=1).  The single-stream decode chain is latency-bound: every launch starts with an HBM
+// round trip for its weights (1.2 us + bytes / 5 TB/s, in-kernel timeline profiles/r02_timeline_*.md) although HBM idles
+// most of the time.  A second stream therefore runs two kernels AHEAD of the chain and touches the bytes the consumer's
+// block b will read from a block b of its own — the dispatcher places block b of either kernel on XCD b % 8, so the lines
+// land in the L2 the consumer reads through (a different placement only makes it an Infinity-Cache hit instead).  Pure
+// hint: results cannot change; the chain never waits for it (joined once per pass so that stream capture closes).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_prefetch(const char* __restrict__ p, size_t chunk, size_t total, int* __restrict__ sink)
+{
+    const size_t lo = (size_t)blockIdx.x * chunk, hi = min(lo + chunk, total);
+    unsigned acc = 0;
+    for (size_t i = lo + (size_t)threadIdx.x * 16; i < hi; i += 256 * 16) {
+        const uint4 v = *reinterpret_cast<const uint4*>(p + i);
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x9e3779b9u && threadIdx.x == 1023) sink[0] = (int)acc;       // never true: keeps the loads alive
+}
+// cross K/V of one layer for the blocks of the cross-attention launch (same grid: x = key-split group, y = head, z = stream)
+__global__ void __launch_bounds__(256)
+k_prefetch_kv(const char* __restrict__ k, const char* __restrict__ v, size_t head_bytes, size_t chunk, int* __restrict__ sink)
+{
+    const size_t base = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * head_bytes + (size_t)blockIdx.x * chunk;
+    const size_t n = min(chunk, head_bytes - min(head_bytes, (size_t)blockIdx.x * chunk));
+    unsigned acc = 0;
+    for (size_t i = (size_t)threadIdx.x * 16; i < n; i += 256 * 16) {
+        const uint4 a = *reinterpret_cast<const uint4*>(k + base + i);
+        const uint4 b = *reinterpret_cast<const uint4*>(v + base + i);
+        acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w;
+    }
+    if (acc == 0x9e3779b9u && threadIdx.x == 1023) sink[0] = (int)acc;
+}
+
+// fork: the prefetch launched next may start once everything enqueued on the main stream so far has finished
+static int pf_fork(wm_ctx* ctx)
+{
+    WM_HIP(hipEventRecord(ctx->pf_fork, ctx->stream));
+    WM_HIP(hipStreamWaitEvent(ctx->pf_stream, ctx->pf_fork, 0));
+    ctx->pf_open = true;
+    return WM_OK;
+}
+// the weights the skinny GEMM for (W, N16, K32, loader kind) reads, block for block
+static int pf_gemm(wm_ctx* ctx, const bf16_t* W, bool fp8, int N16, int K32, bool norm_loader)
+{
+    if (!ctx->prefetch || !W) return WM_OK;
+    int rc = pf_fork(ctx);
+    if (rc) return rc;
+    const SkinnyPlan p = skinny_plan(N16, K32, norm_loader);
+    const int per_block = p.rt * p.RT, grid = (N16 + per_block - 1) / per_block;
+    const size_t tile = (size_t)K32 * 512 * (fp8 ? 1 : 2);
+    hipLaunchKernelGGL(k_prefetch, dim3(grid), dim3(256), 0, ctx->pf_stream, reinterpret_cast<const char*>(W), tile * per_block, tile * N16, ctx->pf_sink);
+    WM_HIP(hipGetLastError());
+    return WM_OK;
+}
+static int pf_join(wm_ctx* ctx)
+{
+    if (!ctx->pf_open) return WM_OK;
+    WM_HIP(hipEventRecord(ctx->pf_join, ctx->pf_stream));
+    WM_HIP(hipStreamWaitEvent(ctx->stream, ctx->pf_join, 0));
+    ctx->pf_open = false;
+    return WM_OK;
+}
+
 // =============================================================================================
 // host side
 // =============================================================================================
 static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0, int nb, int Mper, const int* base, bool kv_only,
-                     const int* sskip = nullptr)
+                     const int* sskip = nullptr, const DecLayerW* next = nullptr)
 {
     hipStream_t st = ctx->stream;
     const int d = ctx->d, H = ctx->H, K32 = d / 32, R = nb * Mper, F32 = ctx->ffn / 32;
@@ -612,19 +680,37 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
     bf16_t* vc = ctx->vc + ((size_t)slot * ctx->maxB + b0) * H * ctx->Tal * 64;
     const bf16_t* kx = ctx->kx + ((size_t)slot * ctx->Benc + b0) * H * ctx->Spad * 64;
     const bf16_t* vx = ctx->vx + ((size_t)slot * ctx->Benc + b0) * H * ctx->Spad * 64;
+    // side-stream prefetch (single-tile passes): before launch k goes out, the operand of launch k+2 starts streaming into L2
+    const bool pf = ctx->prefetch && R <= 16 && !kv_only;
+    const bool f8 = w.qkv_s != nullptr;
+#define WM_PF(call) do { if (pf) { int rc_ = (call); if (rc_) return rc_; } } while (0)
+    WM_PF(pf_gemm(ctx, w.out_w, f8, d / 16, K32, false));
     // 1. LN1 + QKV; k rows / transposed v rows straight into the cache
     TL_SET(slot * 16 + 1 + 8192 * Mper);
     WM_HIP(launch_skinny_norm(st, WRef{w.qkv_w, w.qkv_s}, 3 * d / 16, K32, h, w.ln1_w, w.ln1_b, d, R, 1, 0, 1,
                               EpQKVDec{ctx->qbuf, kc, vc, w.qkv_b, base, Mper, d, H, ctx->Tal, R}, ctx->xbuf, xpl));
     if (kv_only) return WM_OK;
+    WM_PF(pf_gemm(ctx, w.cq_w, f8, d / 16, K32, true));
     // 2. causal self-attention over the contiguous cache
     TL_SET(slot * 16 + 2 + 8192 * Mper);
     hipLaunchKernelGGL((k_attn_mfma<false, false>), dim3(1, H, nb), dim3(256), 0, st, ctx->qbuf, kc, vc, base, ctx->xbuf, xpl,
                        nullptr, nullptr, nullptr, g_skinny_done, sskip, Mper, H, ctx->Tal, 0, 1, K32 TL_PASS);
     WM_HIP(hipGetLastError());
+    static const int skip_div = [] { const char* v = std::getenv("WM_XATTN_SKIP_DIV"); return v ? std::max(1, std::atoi(v)) : 3; }();
+    const int xheads = sskip ? std::max(1, H * nb / skip_div) : H * nb;
+    const int xgrid = xattn_blocks_per_head(ctx->NS, xheads);
+    if (pf) {
+        int rc_ = pf_fork(ctx);
+        if (rc_) return rc_;
+        const int spb = (ctx->NS + xgrid - 1) / xgrid;
+        hipLaunchKernelGGL(k_prefetch_kv, dim3(xgrid, H, nb), dim3(256), 0, ctx->pf_stream, reinterpret_cast<const char*>(kx),
+                           reinterpret_cast<const char*>(vx), (size_t)ctx->Spad * 128, (size_t)spb * 256 * 128, ctx->pf_sink);
+        WM_HIP(hipGetLastError());
+    }
     // 3. out_proj + residual
     TL_SET(slot * 16 + 3 + 8192 * Mper);
     WM_HIP(launch_skinny_rows(st, WRef{w.out_w, w.out_s}, d / 16, K32, R, ctx->xbuf, xpl, EpResidual{h, w.out_b, d, R}));
+    WM_PF(pf_gemm(ctx, w.cout_w, f8, d / 16, K32, false));
     // 4. LN2 + cross-attention q
     TL_SET(slot * 16 + 4 + 8192 * Mper);
     WM_HIP(launch_skinny_norm(st, WRef{w.cq_w, w.cq_s}, d / 16, K32, h, w.ln2_w, w.ln2_b, d, R, 1, 0, 1, EpF32{ctx->qbuf, w.cq_b, d, R, 0.125f},
@@ -632,20 +718,21 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
     // 5. cross-attention over the encoder K/V, 256 keys per block
     // a base pass with per-stream carry skips the blocks of carrying streams (about half of them at the measured acceptance
     // mix): size the key-split grouping for the blocks that actually run
-    static const int skip_div = [] { const char* v = std::getenv("WM_XATTN_SKIP_DIV"); return v ? std::max(1, std::atoi(v)) : 3; }();
-    const int xheads = sskip ? std::max(1, H * nb / skip_div) : H * nb;
+    WM_PF(pf_gemm(ctx, w.fc1_w, f8, ctx->ffn / 16, K32, true));
     TL_SET(slot * 16 + 5 + 8192 * Mper);
     static const bool xattn_nt = [] { const char* v = std::getenv("WM_XATTN_NT"); return v ? std::atoi(v) != 0 : true; }();
     if (xattn_nt)
-        hipLaunchKernelGGL((k_attn_mfma<true, true>), dim3(xattn_blocks_per_head(ctx->NS, xheads), H, nb), dim3(256), 0, st, ctx->qbuf, kx, vx, base, ctx->xbuf, xpl,
+        hipLaunchKernelGGL((k_attn_mfma<true, true>), dim3(xgrid, H, nb), dim3(256), 0, st, ctx->qbuf, kx, vx, base, ctx->xbuf, xpl,
                            ctx->cml, ctx->co, ctx->ticket, g_skinny_done, sskip, Mper, H, ctx->Spad, ctx->S, ctx->NS, K32 TL_PASS);
     else
-        hipLaunchKernelGGL((k_attn_mfma<true, false>), dim3(xattn_blocks_per_head(ctx->NS, xheads), H, nb), dim3(256), 0, st, ctx->qbuf, kx, vx, base, ctx->xbuf, xpl,
+        hipLaunchKernelGGL((k_attn_mfma<true, false>), dim3(xgrid, H, nb), dim3(256), 0, st, ctx->qbuf, kx, vx, base, ctx->xbuf, xpl,
                            ctx->cml, ctx->co, ctx->ticket, g_skinny_done, sskip, Mper, H, ctx->Spad, ctx->S, ctx->NS, K32 TL_PASS);
     WM_HIP(hipGetLastError());
+    WM_PF(pf_gemm(ctx, w.fc2_w, f8, d / 16, F32, false));
     // 6. out_proj + residual
     TL_SET(slot * 16 + 6 + 8192 * Mper);
     WM_HIP(launch_skinny_rows(st, WRef{w.cout_w, w.cout_s}, d / 16, K32, R, ctx->xbuf, xpl, EpResidual{h, w.cout_b, d, R}));
+    if (next) WM_PF(pf_gemm(ctx, next->qkv_w, f8, 3 * d / 16, K32, true));
     // 7. LN3 + fc1 + GELU
     TL_SET(slot * 16 + 7 + 8192 * Mper);
     WM_HIP(launch_skinny_norm(st, WRef{w.fc1_w, w.fc1_s}, ctx->ffn / 16, K32, h, w.ln3_w, w.ln3_b, d, R, 1, 0, 1,
@@ -653,6 +740,7 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
     // 8. fc2 + residual
     TL_SET(slot * 16 + 8 + 8192 * Mper);
     WM_HIP(launch_skinny_rows(st, WRef{w.fc2_w, w.fc2_s}, d / 16, F32, R, ctx->fbuf, fpl, EpResidual{h, w.fc2_b, d, R}));
+#undef WM_PF
     return WM_OK;
 }
 
@@ -678,10 +766,10 @@ int wm_dec_stage_layers(wm_ctx* ctx, int b0, int nb, int Mper, int mode)
     // (the weights are streamed once for everybody) but its attention blocks exit, saving their K/V reads
     const int* sskip = (mode == 0 && Mper == 1 && ctx->dev_carry) ? ctx->carry + b0 : nullptr;
     for (int l = 0; l < ctx->cfg.dec_layers; ++l) {
-        int rc = dec_layer(ctx, ctx->dec[l], l, ctx->h, b0, nb, Mper, base, false, sskip);
+        int rc = dec_layer(ctx, ctx->dec[l], l, ctx->h, b0, nb, Mper, base, false, sskip, l + 1 < ctx->cfg.dec_layers ? &ctx->dec[l + 1] : nullptr);
         if (rc) return rc;
     }
-    return WM_OK;
+    return pf_join(ctx);
 }
 
 // ---- stage 2: final LayerNorm for all rows (-> hf); Medusa-Block: the extra decoder layer on the
@@ -705,6 +793,8 @@ int wm_dec_stage_final(wm_ctx* ctx, int b0, int nb, int Mper, int mode, int medu
         const bool kv_only = !medusa && !carrying;
         const int* sskip = (mode == 0 && Mper == 1 && ctx->dev_carry) ? ctx->carry + b0 : nullptr;
         int rc = dec_layer(ctx, ctx->dec[ctx->nkv - 1], ctx->nkv - 1, ctx->hblk, b0, nb, Mper, base, kv_only, sskip);
+        if (rc) return rc;
+        rc = pf_join(ctx);
         if (rc) return rc;
         if (sskip) {
             hipLaunchKernelGGL(k_rows_take_carried, dim3(R), dim3(256), 0, st, ctx->hblk + (size_t)b0 * d, ctx->hb_keep + (size_t)b0 * d,

@@ -34,10 +34,13 @@ extern "C" void wm_destroy(wm_ctx* ctx)
                     ctx->enc_out, ctx->kx, ctx->vx, ctx->kc, ctx->vc, ctx->h, ctx->hblk, ctx->hf, ctx->qbuf, ctx->xbuf, ctx->fbuf,
                     ctx->ybuf, ctx->cml, ctx->co, ctx->ticket, ctx->logits, ctx->amax, ctx->pc, ctx->part1, ctx->part2, ctx->ids, ctx->L, ctx->kvlen,
                     ctx->finished, ctx->cand, ctx->niter, ctx->hist, ctx->supmask, ctx->exppen, ctx->tap_tok, ctx->done,
-                    ctx->hf_keep, ctx->hb_keep, ctx->carry, ctx->rs_table};
+                    ctx->hf_keep, ctx->hb_keep, ctx->carry, ctx->rs_table, ctx->pf_sink};
     for (void* b : bufs) if (b) hipFree(b);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
+    if (ctx->pf_fork) hipEventDestroy(ctx->pf_fork);
+    if (ctx->pf_join) hipEventDestroy(ctx->pf_join);
+    if (ctx->pf_stream) { hipStreamSynchronize(ctx->pf_stream); hipStreamDestroy(ctx->pf_stream); }
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -62,6 +65,10 @@ extern "C" int wm_create(const wm_config* cfg, const wm_weights* w, int device, 
     else { CREATE_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->own_stream = true; }
     CREATE_HIP(hipEventCreate(&ctx->ev0));
     CREATE_HIP(hipEventCreate(&ctx->ev1));
+    CREATE_HIP(hipStreamCreateWithFlags(&ctx->pf_stream, hipStreamNonBlocking));
+    CREATE_HIP(hipEventCreateWithFlags(&ctx->pf_fork, hipEventDisableTiming));
+    CREATE_HIP(hipEventCreateWithFlags(&ctx->pf_join, hipEventDisableTiming));
+    { const char* v = std::getenv("WM_PREFETCH"); ctx->prefetch = v && std::atoi(v) != 0; }
 
     const int d = ctx->d = cfg->d_model;
     ctx->H = cfg->n_heads; ctx->ffn = cfg->ffn_dim; ctx->V = cfg->vocab; ctx->Vpad = rup(cfg->vocab, 128);
@@ -73,7 +80,7 @@ extern "C" int wm_create(const wm_config* cfg, const wm_weights* w, int device, 
     ctx->maxB = cfg->max_batch;
     ctx->K1pad = rup(3 * cfg->n_mels, 128);
     ctx->NS = (ctx->Spad + 255) / 256;
-    if (ctx->NS > 16 || ctx->H > 32) { g_create_err = "wm_create: n_ctx > 4096 or more than 32 heads unsupported"; wm_destroy(ctx); return WM_ERR_ARG; }
+    if (ctx->NS > 8 || ctx->H > 32) { g_create_err = "wm_create: n_ctx > 2048 or more than 32 heads unsupported"; wm_destroy(ctx); return WM_ERR_ARG; }
 
     // ---- parameter table ----
     const bool w8 = cfg->dec_weight_fp8 != 0;
@@ -159,6 +166,7 @@ extern "C" int wm_create(const wm_config* cfg, const wm_weights* w, int device, 
     CREATE_HIP(dev_alloc(&ctx->exppen, Tids + 1, st));
     CREATE_HIP(dev_alloc(&ctx->tap_tok, 16, st));
     CREATE_HIP(dev_alloc(&ctx->done, 4, st));
+    CREATE_HIP(dev_alloc(&ctx->pf_sink, 4, st));
     CREATE_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->hostflags), 64, hipHostMallocMapped));
     CREATE_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->hostflags_dev), ctx->hostflags, 0));
     ctx->hostflags[0] = ctx->hostflags[1] = 0;
@@ -214,6 +222,7 @@ extern "C" int wm_decode_begin(wm_ctx* ctx, const wm_gen_params* gp, int B)
     g.exp_start = gp->exp_decay_start >= 0 ? gp->exp_decay_start + P : -1;
     g.thr = gp->posterior_threshold; g.alpha = gp->posterior_alpha;
     g.inv_temp = (gp->accept_mode == WM_ACCEPT_TYPICAL && gp->temperature > 0.f) ? 1.0f / gp->temperature : 1.0f;
+    g.force_accept = gp->force_accept;
     g.accept_mode = gp->accept_mode; g.vanilla = gp->vanilla; g.K = K; g.V = ctx->V; g.Vpad = ctx->Vpad; g.Tids = Tids;
     ctx->fuse = std::getenv("WM_NO_CARRY") == nullptr;
     ctx->host_carry = ctx->fuse && B == 1 && !gp->vanilla;

@@ -29,7 +29,7 @@ struct DecLayerW {
 struct GenDev {
     int P, eos, pad, max_length, hard_max_length, exp_start /* absolute: start + P, or -1 */;
     float thr, alpha, inv_temp;
-    int accept_mode, vanilla, K, V, Vpad, Tids, fuse;
+    int accept_mode, vanilla, K, V, Vpad, Tids, fuse, force_accept;
 };
 
 struct wm_ctx {
@@ -109,6 +109,12 @@ struct wm_ctx {
     int graph_replays = 0;
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // side stream that warms the L2 / Infinity Cache with the NEXT kernels' weights and cross-K/V while the dependent chain runs
+    hipStream_t pf_stream = nullptr;
+    hipEvent_t pf_fork = nullptr, pf_join = nullptr;
+    int* pf_sink = nullptr;
+    bool prefetch = false;          // WM_PREFETCH
+    bool pf_open = false;           // the side stream has work that the main stream has not joined yet
     float ms_logmel = 0.f, ms_encode = 0.f, ms_decode = 0.f;
 };
 

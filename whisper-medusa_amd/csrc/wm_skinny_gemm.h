@@ -212,8 +212,10 @@ typedef LdNormT<true> LdNorm;
 typedef LdNormT<false> LdIdent;
 
 // NK = fragments of a wave's K-slice; ksplit * NK == K32.  XB = token-operand fragments held at a time (NK, or NK / 2
-// when the slice is long: the second half is issued as soon as the first has been consumed).
-template <int NK, bool W8, class Ld, class Ep>
+// when the slice is long: the second half is issued as soon as the first has been consumed).  RT = weight row tiles per
+// wave (register blocking: the token fragment — and, for LdNorm, its normalisation — is shared by RT tiles; used where one
+// tile per block would put more blocks than CUs on the chip).  RT > 1 needs ksplit >= RT.
+template <int NK, int RT, bool W8, class Ld, class Ep>
 __global__ void __launch_bounds__(640)
 k_skinny_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int N16, int K32, int ksplit, int rt_per_wg, int ks_magic,
               const int* __restrict__ done, Ld ld, Ep ep TL_ARG)
@@ -224,23 +226,26 @@ k_skinny_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, in
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rtl = (wave * ks_magic) >> 8, ks = wave - rtl * ksplit;          // wave / ksplit, wave % ksplit (waves <= 16)
-    const int rt = blockIdx.x * rt_per_wg + rtl;
+    const int tile0 = (blockIdx.x * rt_per_wg + rtl) * RT;                      // first of this wave's RT row tiles
     const int kt0 = ks * NK;
-    const bool active = rt < N16;
-    const size_t wp = ((size_t)(active ? rt : 0) * K32 + kt0) * 512 + lane * 8;     // element index (bf16: 2 B, fp8: 1 B per element)
 
     // ---- the launch's memory batch: weights, token operand, LayerNorm parameters, epilogue operands ----
-    typename WRaw<W8>::type a[NK];
+    typename WRaw<W8>::type a[RT][NK];
 #pragma unroll
-    for (int u = 0; u < NK; ++u) a[u] = ld_wraw<W8, true>(W, wp + (size_t)u * 512);
+    for (int i = 0; i < RT; ++i) {
+        const size_t wp = ((size_t)min(tile0 + i, N16 - 1) * K32 + kt0) * 512 + lane * 8;   // element index (bf16: 2 B, fp8: 1 B per element)
+#pragma unroll
+        for (int u = 0; u < NK; ++u) a[i][u] = ld_wraw<W8, true>(W, wp + (size_t)u * 512);
+    }
     typename Ld::template Regs<XB> xr;
     ld.template issue<XB>(xr, smem, kt0, lane);
     EpPre pre; pre.i = 0; pre.a = make_float4(0.f, 0.f, 0.f, 0.f); pre.b = pre.a;
     float4 wsc = make_float4(1.f, 1.f, 1.f, 1.f);
-    // the element this thread will finish: with K-slices, waves 0 .. rt_per_wg-1 finish row tile (wave), else every wave its own
-    const int rtf = (ksplit > 1) ? blockIdx.x * rt_per_wg + wave : rt;
-    const int em = lane & 15, en = rtf * 16 + 4 * (lane >> 4);
-    const bool edo = ((ksplit > 1) ? (wave < rt_per_wg) : true) && rtf < N16;
+    // the element this thread will finish: with K-slices, wave f < rt_per_wg * RT finishes the block's f-th row tile; without,
+    // every wave finishes its own tile (RT == 1 there)
+    const int tf = (ksplit > 1) ? blockIdx.x * rt_per_wg * RT + wave : tile0;
+    const int em = lane & 15, en = tf * 16 + 4 * (lane >> 4);
+    const bool edo = ((ksplit > 1) ? (wave < rt_per_wg * RT) : true) && tf < N16;
     if (edo) {
         pre = ep.pre(em, en);
         if constexpr (W8) wsc = *reinterpret_cast<const float4*>(wscale + en);
@@ -252,14 +257,19 @@ k_skinny_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, in
     ld.template stats<XB>(xr, smem, ks, ksplit, rtl == 0, lane);
     TL_PREP
 
-    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t acc[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < XB; ++u) {
         bf16x8_t bh, bl;
         ld.template frag<XB>(xr, smem, u, kt0 + u, lane, bh, bl);
-        const bf16x8_t av = w_expand<W8>(a[u]);
-        acc = mfma16(av, bh, acc);
-        acc = mfma16(av, bl, acc);
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            const bf16x8_t av = w_expand<W8>(a[i][u]);
+            acc[i] = mfma16(av, bh, acc[i]);
+            acc[i] = mfma16(av, bl, acc[i]);
+        }
     }
     if constexpr (XB < NK) {
         ld.template issue<XB>(xr, smem, kt0 + XB, lane);
@@ -267,16 +277,21 @@ k_skinny_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, in
         for (int u = 0; u < XB; ++u) {
             bf16x8_t bh, bl;
             ld.template frag<XB>(xr, smem, u, kt0 + XB + u, lane, bh, bl);
-            const bf16x8_t av = w_expand<W8>(a[XB + u]);
-            acc = mfma16(av, bh, acc);
-            acc = mfma16(av, bl, acc);
+#pragma unroll
+            for (int i = 0; i < RT; ++i) {
+                const bf16x8_t av = w_expand<W8>(a[i][XB + u]);
+                acc[i] = mfma16(av, bh, acc[i]);
+                acc[i] = mfma16(av, bl, acc[i]);
+            }
         }
     }
     TL_MID
 
     if (ksplit > 1) {
         float4* red = reinterpret_cast<float4*>(smem + ld.lds_bytes());
-        red[(rtl * ksplit + ks) * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+            red[((rtl * RT + i) * ksplit + ks) * 64 + lane] = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
         __syncthreads();
         if (edo) {
             f32x4_t s = {0.f, 0.f, 0.f, 0.f};
@@ -288,8 +303,8 @@ k_skinny_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, in
             ep.fin(em, en, s, pre);
         }
     } else if (edo) {
-        if constexpr (W8) acc = f32x4_t{acc[0] * wsc.x, acc[1] * wsc.y, acc[2] * wsc.z, acc[3] * wsc.w};
-        ep.fin(em, en, acc, pre);
+        if constexpr (W8) acc[0] = f32x4_t{acc[0][0] * wsc.x, acc[0][1] * wsc.y, acc[0][2] * wsc.z, acc[0][3] * wsc.w};
+        ep.fin(em, en, acc[0], pre);
     }
     TL_END
 }
@@ -398,7 +413,7 @@ k_rows_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int 
 
 // ---- host-side launch plan -------------------------------------------------------------------
 static thread_local const int* g_skinny_done = nullptr;     // device flag checked by every launch of this translation unit
-struct SkinnyPlan { int ksplit, rt, nk; };
+struct SkinnyPlan { int ksplit, rt, nk, RT; };      // rt: row-tile groups per block (waves), RT: row tiles per wave (registers)
 
 // K-slices of at most 16 fragments (8 when the token operand is normalised in registers) and, if possible, >= 1024 waves.
 // The plan depends only on (N16, K32, loader kind): 16-row and batched launches of one GEMM share it, which is what makes
@@ -424,6 +439,10 @@ static inline SkinnyPlan skinny_plan(int N16, int K32, bool norm_loader) {
     p.ksplit = best;
     p.nk = K32 / best;
     p.rt = (best == 1) ? 4 : 1;
+    // more row tiles than CUs: a second block on some CUs doubles their share of the launch's memory batch (the launch then
+    // waits for those CUs) — let a wave own two row tiles instead (the token fragment and its LayerNorm are shared)
+    static const int rt2 = skinny_env("WM_PLAN_RT2", 1);
+    p.RT = (rt2 && best >= 2 && p.nk <= 8 && N16 > 256 && N16 <= 1024) ? 2 : 1;
     return p;
 }
 
@@ -433,19 +452,27 @@ struct WRef {
     WRef(const bf16_t* w_, const float* scale_ = nullptr) : w(w_), scale(scale_) {}
 };
 
-template <int NK, bool W8, class Ld, class Ep>
-static inline hipError_t launch_skinny_nk(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p, const Ld& ld, const Ep& ep) {
-    const int grid = (N16 + p.rt - 1) / p.rt;
+template <int NK, int RT, bool W8, class Ld, class Ep>
+static inline hipError_t launch_skinny_nk_rt(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p, const Ld& ld, const Ep& ep) {
+    const int per_block = p.rt * RT;
+    const int grid = (N16 + per_block - 1) / per_block;
     const int threads = 64 * p.ksplit * p.rt;
-    const size_t lds = (size_t)ld.lds_bytes() + (p.ksplit > 1 ? (size_t)p.rt * p.ksplit * 1024 : 0);
+    const size_t lds = (size_t)ld.lds_bytes() + (p.ksplit > 1 ? (size_t)per_block * p.ksplit * 1024 : 0);
     const int magic = (256 + p.ksplit - 1) / p.ksplit;         // (wave * magic) >> 8 == wave / ksplit for wave < 16
-    auto kern = k_skinny_gemm<NK, W8, Ld, Ep>;
+    auto kern = k_skinny_gemm<NK, RT, W8, Ld, Ep>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, W.w, W.scale, N16, K32, p.ksplit, p.rt, magic, g_skinny_done, ld, ep TL_PASS);
     return hipGetLastError();
+}
+template <int NK, bool W8, class Ld, class Ep>
+static inline hipError_t launch_skinny_nk(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p, const Ld& ld, const Ep& ep) {
+    if constexpr (NK <= 8) {
+        if (p.RT == 2 && p.ksplit >= 2) return launch_skinny_nk_rt<NK, 2, W8>(st, W, N16, K32, p, ld, ep);
+    }
+    return launch_skinny_nk_rt<NK, 1, W8>(st, W, N16, K32, p, ld, ep);
 }
 
 template <bool W8, class Ld, class Ep>

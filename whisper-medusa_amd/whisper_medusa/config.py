@@ -183,6 +183,7 @@ class GenParams:
     accept_mode: int = ACCEPT_TYPICAL   # G4: generate() forces temperature=1.0 -> typical acceptance
     temperature: float = 1.0
     vanilla: bool = False            # anchor: plain greedy decoding with head 0 / base logits
+    force_accept: int = -1           # benchmark knob (wm.h): >= 0 forces the accept length of every iteration; -1 = off
 
     @property
     def begin_index(self) -> int:
