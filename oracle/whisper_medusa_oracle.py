@@ -404,6 +404,120 @@ class Oracle:
                 break
         return self._finish(res, ids, P, eos)
 
+    # ---- tie-aware parity ----------------------------------------------------------------------
+    @torch.no_grad()
+    def decode_following(self, enc: torch.Tensor, gp, engine_ids: List[int], tol_logit: float = 5e-4, tol_rel_p: float = 2e-3,
+                         max_iters: Optional[int] = None) -> Tuple[bool, List[dict], List[int]]:
+        """Parity check that survives numerical ties.  Two correct implementations of this loop agree on every decision
+        EXCEPT where the decision's own margin is below their numerical difference (fp32 summation order: ~1e-4 on logits of
+        scale ~6): an argmax between two logits 1e-4 apart, or `p_c > thr` with both sides equal to 1e-3 relative.  The loop is
+        chaotic after such a flip, so plain list equality reports a 'divergence' that is not an error.
+
+        This walks the oracle along the ENGINE's token sequence: at every decision whose margin is below the tolerance
+        (`tol_logit` absolute on processed logits, `tol_rel_p` relative on p_c vs thr) both outcomes are admissible and the one
+        that reproduces the engine's next tokens is taken; every other decision must match exactly.  Returns (ok, ties, ids):
+        `ties` lists the decisions that were resolved by following the engine (empty for a strictly identical run)."""
+        import itertools
+        cfg = self.cfg
+        K, P, eos = cfg.medusa_num_heads, len(gp.prompt), gp.eos_token_id
+        assert not gp.vanilla
+        st = self.new_state(enc)
+        ids = list(gp.prompt)
+        ties: List[dict] = []
+        n_it = 0
+        self.last_follow_accepts: List[int] = []
+        while True:
+            L, kv = len(ids), st["kv_len"]
+            z = self.decoder_pass(st, ids[kv:L], kv, disable_medusa=False, last_only=True)[:, 0]
+            st["kv_len"] = L
+            z = process_logits(z, L, gp)
+            top = torch.topk(z, 2, dim=-1)
+            opts = []
+            for k in range(K + 1):
+                m = float(top.values[k, 0] - top.values[k, 1])
+                opts.append([int(top.indices[k, 0])] + ([int(top.indices[k, 1])] if m < tol_logit else []))
+            n_combo = 1
+            for o in opts:
+                n_combo *= len(o)
+            combos = itertools.product(*opts) if n_combo <= 64 else [tuple(o[0] for o in opts)]
+            self_kv_snapshot = list(st["self_kv"])
+            matched = None
+            for cand_t in combos:
+                st["self_kv"] = list(self_kv_snapshot); st["kv_len"] = L
+                cand = torch.tensor(cand_t, dtype=torch.long)
+                v = self.decoder_pass(st, list(cand_t), L, disable_medusa=True)[0]
+                v = process_logits(v, L, gp)
+                # admissible accept lengths
+                if gp.accept_mode == 0 or gp.temperature == 0:
+                    vt = torch.topk(v[:-1], 2, dim=-1)
+                    ok = (cand[1:] == vt.indices[:, 0])
+                    tie = ((vt.values[:, 0] - vt.values[:, 1]) < tol_logit) & ((cand[1:] == vt.indices[:, 0]) | (cand[1:] == vt.indices[:, 1]))
+                else:
+                    p = torch.softmax(v[:-1] / gp.temperature, dim=-1)
+                    p_c = torch.gather(p, -1, cand[1:].unsqueeze(-1)).squeeze(-1)
+                    H = -torch.sum(p * torch.log(p + 1e-5), dim=-1)
+                    thr = torch.minimum(torch.full_like(H, gp.posterior_threshold), torch.exp(-H) * gp.posterior_alpha)
+                    ok = p_c > thr
+                    tie = (p_c - thr).abs() <= tol_rel_p * thr
+                a_set, a = [], 0
+                for i in range(K):
+                    if bool(tie[i]):
+                        a_set.append(a)                      # the tied candidate may be rejected here ...
+                        a += 1                               # ... or accepted
+                        continue
+                    if not bool(ok[i]):
+                        break
+                    a += 1
+                a_set.append(a)
+                for a in sorted(set(a_set), reverse=True):
+                    if a == 0:
+                        v0 = torch.topk(v[0], 2)
+                        seconds = [int(v0.indices[0])] + ([int(v0.indices[1])] if float(v0.values[0] - v0.values[1]) < tol_logit else [])
+                        emits = [[cand_t[0], s2] for s2 in seconds]
+                    else:
+                        emits = [list(cand_t[: a + 1])]
+                    for emit in emits:
+                        tail = engine_ids[L: L + len(emit)]
+                        if tail == emit[: len(tail)] and len(tail) > 0:
+                            matched = (cand_t, a, emit)
+                            break
+                    if matched:
+                        break
+                if matched:
+                    break
+            if matched is None:
+                st["self_kv"] = list(self_kv_snapshot)
+                return False, ties + [dict(L=L, reason="no admissible continuation reproduces the engine", engine=engine_ids[L: L + K + 1],
+                                           oracle_cand=[o[0] for o in opts])], ids
+            cand_t, a, emit = matched
+            strict_cand = tuple(o[0] for o in opts)
+            # was anything other than the strict outcome taken?
+            st_strict = None
+            if cand_t != strict_cand:
+                ties.append(dict(L=L, kind="candidate argmax", strict=list(strict_cand), taken=list(cand_t)))
+            else:
+                # strict accept length for this candidate set
+                a_strict = 0
+                for i in range(K):
+                    if not bool(ok[i]):
+                        break
+                    a_strict += 1
+                if a != a_strict:
+                    ties.append(dict(L=L, kind="accept", strict=a_strict, taken=a))
+                elif a == 0 and emit[1] != int(torch.argmax(v[0])):
+                    ties.append(dict(L=L, kind="verify argmax", strict=int(torch.argmax(v[0])), taken=emit[1]))
+            # state after the iteration (the verify pass of the matched candidate set is the one in st)
+            st["kv_len"] = L + 1 if a == 0 else L + a
+            ids += emit
+            self.last_follow_accepts.append(a)
+            n_it += 1
+            L = len(ids)
+            finished = (eos in emit) or (L >= gp.max_length) or (L + K >= gp.hard_max_length)
+            if finished or (max_iters is not None and n_it >= max_iters):
+                break
+        res = self._finish(DecodeResult(ids=[], new_tokens=[]), ids, P, eos)
+        return res.ids == engine_ids[: len(res.ids)] and (max_iters is not None or len(res.ids) == len(engine_ids)), ties, res.ids
+
     def _decode_vanilla(self, enc, gp, max_iters=None) -> DecodeResult:
         """Anchor: plain greedy decoding on head 0 / base logits, one token per pass."""
         P, eos = len(gp.prompt), gp.eos_token_id

@@ -42,3 +42,18 @@ def golden_gen_params(cfg, mode, max_new, suppress_eos=True, exp_decay=(6, 1.3))
 
 def clip_for(cfg, i=0):
     return synth.synth_clip(i, n_samples=cfg.n_mel_frames * 160)
+
+
+def check_tokens(orc, enc_b, gp, got, label="", max_ties=2, tol_logit=5e-4):
+    """Token parity of one engine run against the oracle: strictly identical ids, or — when the first difference sits at a
+    decision whose margin in the ORACLE is below the numerical difference of two correct implementations (an argmax between
+    logits < tol_logit apart, p_c within 2e-3 relative of the threshold) — identical along the engine's admissible branch
+    (oracle.decode_following).  Returns (accept lengths, ties); ties are printed: they are part of the evidence."""
+    ref = orc.decode(enc_b, gp)
+    if got == ref.ids:
+        return ref.accept_lengths, []
+    ok, ties, ids = orc.decode_following(enc_b, gp, got, tol_logit=tol_logit)
+    first = next((i for i, (a, b) in enumerate(zip(got, ref.ids)) if a != b), min(len(got), len(ref.ids)))
+    print(f"parity[{label}]: strict comparison differs at index {first}; numerical ties followed: {ties}")
+    assert ok and 0 < len(ties) <= max_ties and all("kind" in t for t in ties), (label, first, got, ref.ids, ties)
+    return list(orc.last_follow_accepts), ties

@@ -78,3 +78,24 @@ def test_resample_len_helper_of_the_c_abi(built_lib):
         for sr in RATES + [16000]:
             assert lib.wm_resample_len(n, sr, 16000) == math.ceil(16000 * n / sr)
     assert lib.wm_resample_len(10, 0, 16000) == -1
+
+
+def test_oracle_resampler_is_pinned_by_an_independent_float64_evaluation_of_the_published_kernel():
+    """tests/golden/resample_f64.npz: the torchaudio default-resampler formula y[n] = sum_m x[m] g(m/orig - n/new) evaluated
+    directly in float64 with exact rational sample times (oracle/make_resample_golden.py — no torch, no kernel table, no
+    conv1d).  The oracle restates torchaudio's implementation (float32 taps, float32 conv1d, float32 phase quotient i/new):
+    it must agree to float32 round-off.  Measured: <= 2.2e-7 where new | 2^k·5^j divides evenly (48 k, 32 k, 8 k), <= 2.1e-5
+    for the 441:x ratios, where torchaudio's float32 `arange(0, -new, -1) / new` phase offsets are inexact (6e-8 relative,
+    amplified by base_freq ~ 158 into the sinc argument) — a property of torchaudio the restatement keeps on purpose."""
+    import os
+    g = np.load(os.path.join(ROOT, "tests", "golden", "resample_f64.npz"))
+    for sr, bound in ((48000, 5e-7), (32000, 5e-7), (8000, 5e-7), (44100, 3e-5), (22050, 3e-5), (11025, 3e-5)):
+        x, want = g[f"x_{sr}"], g[f"y_{sr}"]
+        got = resample_sinc_hann(x, sr, 16000)
+        assert got.shape == want.shape and got.dtype == np.float32
+        assert np.abs(got - want).max() <= bound, (sr, float(np.abs(got - want).max()))
+    # and the script reproduces its own fixture (the golden file is not hand-edited)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mk", os.path.join(ROOT, "oracle", "make_resample_golden.py"))
+    mk = importlib.util.module_from_spec(spec); spec.loader.exec_module(mk)
+    assert np.array_equal(mk.resample_direct_f64(g["x_32000"], 32000, 16000), g["y_32000"])

@@ -5,7 +5,10 @@ Tolerances (engine contract = oracle sim="bf16": bf16 GEMM operands / KV cache, 
   log-mel           |d| <= 2e-3 on values in [-1, 2]           (fp32 DFT vs float64 FFT)
   encoder output    max |d| <= 0.12, mean |d| <= 6e-3 on O(1) values (bf16 rounding points can flip)
   decoder logits    max |d| <= 6e-2, mean |d| <= 4e-3           (given the SAME encoder output)
-  token ids         bit-exact against the oracle run on the engine's encoder output
+  token ids         bit-exact against the oracle run on the engine's encoder output — or, where the oracle's own decision
+                    margin is below the numerical difference of two correct implementations (argmax between logits < 5e-4
+                    apart, p_c within 2e-3 of the threshold), identical along the engine's admissible branch; such ties are
+                    printed (helpers.check_tokens / Oracle.decode_following)
 """
 import os
 
@@ -13,7 +16,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import MedusaConfig, synth, golden_gen_params, clip_for, ACCEPT_TYPICAL, ACCEPT_GREEDY
+from helpers import MedusaConfig, synth, golden_gen_params, clip_for, check_tokens, ACCEPT_TYPICAL, ACCEPT_GREEDY
 from oracle.whisper_medusa_oracle import Oracle, log_mel
 from whisper_medusa import WhisperMedusaModel
 
@@ -120,9 +123,8 @@ def test_decode_tokens_bit_exact(rig, mode, eos_free):
     st = rig.eng.stats()
     hist = np.zeros(rig.cfg.medusa_num_heads + 1, dtype=np.int64)
     for b in range(rig.B):
-        r = rig.orc.decode(rig.enc[b], gp)
-        assert seqs[b] == r.ids, (b, seqs[b], r.ids, r.accept_lengths)
-        for a in r.accept_lengths:
+        accepts, _ = check_tokens(rig.orc, rig.enc[b], gp, seqs[b], (b, mode, eos_free))
+        for a in accepts:
             hist[a] += 1
     assert st["accept_hist"] == hist.tolist()
     assert st["tokens_emitted"] >= sum(len(s) - len(gp.prompt) for s in seqs)
@@ -196,7 +198,7 @@ def test_many_streams_batched_path(gpu):
         eng.encode(feats[b: b + 1].contiguous())
         assert eng.decode(gp, 1)[0] == both[b], b
         if b < 3:
-            assert orc.decode(enc[b], gp).ids == both[b]
+            check_tokens(orc, enc[b], gp, both[b], ("many streams", b))
     eng.close()
 
 
@@ -325,7 +327,7 @@ def test_fp8_decoder_weights_match_the_fp8_oracle(gpu, heads):
         both = eng.decode(gp, 6)
         for b in range(6):
             if b < 3:
-                assert orc.decode(enc[b], gp).ids == both[b], (mode, b)
+                check_tokens(orc, enc[b], gp, both[b], ("fp8", mode, b))
             eng.encode(feats[b: b + 1].contiguous())
             assert eng.decode(gp, 1)[0] == both[b], (mode, b)
     eng.close(); ref16.engine.close()

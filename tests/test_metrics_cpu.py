@@ -68,3 +68,33 @@ def test_evaluate_loop_with_stub_model_and_tokenizer(tmp_path):
     assert (tmp_path / "o" / "r.csv").exists()
     evaluate_model(m, Tok(), data, regulation_factor=1)
     assert m.calls[-1][2] is None                          # factor 1 -> no length penalty (eval_whisper_medusa.py:52-58)
+
+
+def test_wer_cer_known_answers_worked_by_hand():
+    """Known-answer cases worked by hand from jiwer's documented transform chain (the reference's utils/metrics.py:5-71
+    composes: ExpandCommonEnglishContractions -> RemoveKaldiNonWords -> RemoveWhiteSpace(replace_by_space) ->
+    RemoveMultipleSpaces -> Strip -> RemovePunctuation -> ToLowerCase -> ReduceToListOfListOfWords / Chars) and jiwer's
+    measures (WER = (S + D + I) / N_ref over the whole corpus, Levenshtein alignment)."""
+    # 1. "I'm here, aren't I?" vs "i am here are not i": contractions expand on both sides, punctuation drops -> identical: 0 / 6
+    w, per = compute_wer(["I'm here, aren't I?"], ["i am here are not i"])
+    assert per == [0.0] and w == 0.0
+    # 2. ref "the quick brown fox jumps" (5 words), hyp "the quick brown box": 1 substitution (fox->box) + 1 deletion (jumps) = 2 / 5
+    w, per = compute_wer(["the quick brown box"], ["The quick brown fox jumps."])
+    assert per == [pytest.approx(0.4)] and w == pytest.approx(0.4)
+    # 3. insertion-only: ref "a b" hyp "a x y b" -> 2 insertions / 2 reference words = 1.0 (WER can exceed hits)
+    w, per = compute_wer(["a x y b"], ["a b"])
+    assert per == [pytest.approx(1.0)]
+    # 4. corpus WER pools edits and reference lengths: (2 + 2) / (5 + 2), NOT the mean of 0.4 and 1.0
+    w, per = compute_wer(["the quick brown box", "a x y b"], ["The quick brown fox jumps.", "a b"])
+    assert w == pytest.approx(4 / 7) and per == [pytest.approx(0.4), pytest.approx(1.0)]
+    # 5. Kaldi non-words vanish before scoring: "<unk> hello [noise] world" == "hello world"
+    w, per = compute_wer(["<unk> hello [noise] world"], ["hello world"])
+    assert per == [0.0]
+    # 6. CER on characters incl. the single spaces left after whitespace normalisation: ref "ab cd" (5 chars), hyp "ab  d" -> "ab d":
+    #    one deletion ('c') / 5
+    c, per = compute_cer(["ab  d"], ["ab cd"])
+    assert per == [pytest.approx(1 / 5)] and c == pytest.approx(1 / 5)
+    # 7. empty hypothesis: the reference maps "" to the token "EMPTY" on both sides before scoring (utils/metrics.py) ->
+    #    ref "hello world" (2 words) vs hyp "empty" (1 word): 1 substitution + 1 deletion = 2 / 2
+    w, per = compute_wer([""], ["hello world"])
+    assert per == [pytest.approx(1.0)]

@@ -180,8 +180,13 @@ __global__ void __launch_bounds__(256)
 k_attn_mfma(const float* __restrict__ q, const bf16_t* __restrict__ kmat, const bf16_t* __restrict__ vtmat,
             const int* __restrict__ base, bf16_t* __restrict__ xout, size_t xplane, float* __restrict__ ml, float* __restrict__ po,
             int* __restrict__ ticket, const int* __restrict__ done, const int* __restrict__ sskip,
-            int Mper, int H, int rows_alloc, int S, int NS, int K32 TL_ARG)
+            int Mper, int H, int rows_alloc, int S, int NS, int K32, int nbz, PfJob pf TL_ARG)
 {
+    if ((int)blockIdx.z >= nbz) {          // prefetch-only blocks (extra z slices): wm_skinny_gemm.h, PfJob
+        const int main_total = gridDim.x * gridDim.y * nbz;
+        pf_block(pf, main_total + (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * (blockIdx.z - nbz))) - pf_round8(main_total));
+        return;
+    }
     TL_BEGIN
     // per-stream skip: the stream carried its hidden state, this base-pass row is not used (its K/V reads are saved)
     if (sskip && sskip[blockIdx.z]) return;
@@ -603,70 +608,6 @@ static inline int xattn_blocks_per_head(int NS, int heads_total)
     return (NS + spb - 1) / spb;
 }
 
-// ---------------------------------------------------------------------------------------------
-// Side-stream prefetch (WM_PREFETCH=1).  The single-stream decode chain is latency-bound: every launch starts with an HBM
-// round trip for its weights (1.2 us + bytes / 5 TB/s, in-kernel timeline profiles/r02_timeline_*.md) although HBM idles
-// most of the time.  A second stream therefore runs two kernels AHEAD of the chain and touches the bytes the consumer's
-// block b will read from a block b of its own — the dispatcher places block b of either kernel on XCD b % 8, so the lines
-// land in the L2 the consumer reads through (a different placement only makes it an Infinity-Cache hit instead).  Pure
-// hint: results cannot change; the chain never waits for it (joined once per pass so that stream capture closes).
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-k_prefetch(const char* __restrict__ p, size_t chunk, size_t total, int* __restrict__ sink)
-{
-    const size_t lo = (size_t)blockIdx.x * chunk, hi = min(lo + chunk, total);
-    unsigned acc = 0;
-    for (size_t i = lo + (size_t)threadIdx.x * 16; i < hi; i += 256 * 16) {
-        const uint4 v = *reinterpret_cast<const uint4*>(p + i);
-        acc ^= v.x ^ v.y ^ v.z ^ v.w;
-    }
-    if (acc == 0x9e3779b9u && threadIdx.x == 1023) sink[0] = (int)acc;       // never true: keeps the loads alive
-}
-// cross K/V of one layer for the blocks of the cross-attention launch (same grid: x = key-split group, y = head, z = stream)
-__global__ void __launch_bounds__(256)
-k_prefetch_kv(const char* __restrict__ k, const char* __restrict__ v, size_t head_bytes, size_t chunk, int* __restrict__ sink)
-{
-    const size_t base = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * head_bytes + (size_t)blockIdx.x * chunk;
-    const size_t n = min(chunk, head_bytes - min(head_bytes, (size_t)blockIdx.x * chunk));
-    unsigned acc = 0;
-    for (size_t i = (size_t)threadIdx.x * 16; i < n; i += 256 * 16) {
-        const uint4 a = *reinterpret_cast<const uint4*>(k + base + i);
-        const uint4 b = *reinterpret_cast<const uint4*>(v + base + i);
-        acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w;
-    }
-    if (acc == 0x9e3779b9u && threadIdx.x == 1023) sink[0] = (int)acc;
-}
-
-// fork: the prefetch launched next may start once everything enqueued on the main stream so far has finished
-static int pf_fork(wm_ctx* ctx)
-{
-    WM_HIP(hipEventRecord(ctx->pf_fork, ctx->stream));
-    WM_HIP(hipStreamWaitEvent(ctx->pf_stream, ctx->pf_fork, 0));
-    ctx->pf_open = true;
-    return WM_OK;
-}
-// the weights the skinny GEMM for (W, N16, K32, loader kind) reads, block for block
-static int pf_gemm(wm_ctx* ctx, const bf16_t* W, bool fp8, int N16, int K32, bool norm_loader)
-{
-    if (!ctx->prefetch || !W) return WM_OK;
-    int rc = pf_fork(ctx);
-    if (rc) return rc;
-    const SkinnyPlan p = skinny_plan(N16, K32, norm_loader);
-    const int per_block = p.rt * p.RT, grid = (N16 + per_block - 1) / per_block;
-    const size_t tile = (size_t)K32 * 512 * (fp8 ? 1 : 2);
-    hipLaunchKernelGGL(k_prefetch, dim3(grid), dim3(256), 0, ctx->pf_stream, reinterpret_cast<const char*>(W), tile * per_block, tile * N16, ctx->pf_sink);
-    WM_HIP(hipGetLastError());
-    return WM_OK;
-}
-static int pf_join(wm_ctx* ctx)
-{
-    if (!ctx->pf_open) return WM_OK;
-    WM_HIP(hipEventRecord(ctx->pf_join, ctx->pf_stream));
-    WM_HIP(hipStreamWaitEvent(ctx->stream, ctx->pf_join, 0));
-    ctx->pf_open = false;
-    return WM_OK;
-}
-
 // =============================================================================================
 // host side
 // =============================================================================================
@@ -680,67 +621,72 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
     bf16_t* vc = ctx->vc + ((size_t)slot * ctx->maxB + b0) * H * ctx->Tal * 64;
     const bf16_t* kx = ctx->kx + ((size_t)slot * ctx->Benc + b0) * H * ctx->Spad * 64;
     const bf16_t* vx = ctx->vx + ((size_t)slot * ctx->Benc + b0) * H * ctx->Spad * 64;
-    // side-stream prefetch (single-tile passes): before launch k goes out, the operand of launch k+2 starts streaming into L2
+    // In-launch prefetch (single-tile passes, WM_PREFETCH != 0): launch k carries extra blocks that pull the operand of launch
+    // k+1 into L2 (wm_skinny_gemm.h PfJob).  The self-attention launch is tiny, so LN1+QKV fetches for the launch after it.
     const bool pf = ctx->prefetch && R <= 16 && !kv_only;
     const bool f8 = w.qkv_s != nullptr;
-#define WM_PF(call) do { if (pf) { int rc_ = (call); if (rc_) return rc_; } } while (0)
-    WM_PF(pf_gemm(ctx, w.out_w, f8, d / 16, K32, false));
+    static const int skip_div = [] { const char* v = std::getenv("WM_XATTN_SKIP_DIV"); return v ? std::max(1, std::atoi(v)) : 3; }();
+    const int xheads = sskip ? std::max(1, H * nb / skip_div) : H * nb;
+    const int xgrid = xattn_blocks_per_head(ctx->NS, xheads);
     // 1. LN1 + QKV; k rows / transposed v rows straight into the cache
+    if (pf) g_pf_job = pf_for_gemm(w.out_w, f8, d / 16, K32, false);
     TL_SET(slot * 16 + 1 + 8192 * Mper);
     WM_HIP(launch_skinny_norm(st, WRef{w.qkv_w, w.qkv_s}, 3 * d / 16, K32, h, w.ln1_w, w.ln1_b, d, R, 1, 0, 1,
                               EpQKVDec{ctx->qbuf, kc, vc, w.qkv_b, base, Mper, d, H, ctx->Tal, R}, ctx->xbuf, xpl));
     if (kv_only) return WM_OK;
-    WM_PF(pf_gemm(ctx, w.cq_w, f8, d / 16, K32, true));
     // 2. causal self-attention over the contiguous cache
     TL_SET(slot * 16 + 2 + 8192 * Mper);
     hipLaunchKernelGGL((k_attn_mfma<false, false>), dim3(1, H, nb), dim3(256), 0, st, ctx->qbuf, kc, vc, base, ctx->xbuf, xpl,
-                       nullptr, nullptr, nullptr, g_skinny_done, sskip, Mper, H, ctx->Tal, 0, 1, K32 TL_PASS);
+                       nullptr, nullptr, nullptr, g_skinny_done, sskip, Mper, H, ctx->Tal, 0, 1, K32, nb, PfJob{nullptr, nullptr, 0u, 0u, 0ull} TL_PASS);
     WM_HIP(hipGetLastError());
-    static const int skip_div = [] { const char* v = std::getenv("WM_XATTN_SKIP_DIV"); return v ? std::max(1, std::atoi(v)) : 3; }();
-    const int xheads = sskip ? std::max(1, H * nb / skip_div) : H * nb;
-    const int xgrid = xattn_blocks_per_head(ctx->NS, xheads);
-    if (pf) {
-        int rc_ = pf_fork(ctx);
-        if (rc_) return rc_;
-        const int spb = (ctx->NS + xgrid - 1) / xgrid;
-        hipLaunchKernelGGL(k_prefetch_kv, dim3(xgrid, H, nb), dim3(256), 0, ctx->pf_stream, reinterpret_cast<const char*>(kx),
-                           reinterpret_cast<const char*>(vx), (size_t)ctx->Spad * 128, (size_t)spb * 256 * 128, ctx->pf_sink);
-        WM_HIP(hipGetLastError());
-    }
     // 3. out_proj + residual
+    if (pf) g_pf_job = pf_for_gemm(w.cq_w, f8, d / 16, K32, true);
     TL_SET(slot * 16 + 3 + 8192 * Mper);
     WM_HIP(launch_skinny_rows(st, WRef{w.out_w, w.out_s}, d / 16, K32, R, ctx->xbuf, xpl, EpResidual{h, w.out_b, d, R}));
-    WM_PF(pf_gemm(ctx, w.cout_w, f8, d / 16, K32, false));
-    // 4. LN2 + cross-attention q
+    // 4. LN2 + cross-attention q   (carries the cross K/V of this layer: job j = what cross-attention block j reads, K and V
+    //    at the same offsets — the key splits of a (stream, head) are contiguous when every block walks the same number)
+    if (pf && ctx->NS % xgrid == 0 && ctx->Spad == ctx->NS * 256) {
+        const unsigned jb = (unsigned)(ctx->NS / xgrid) * 256 * 128;
+        g_pf_job = PfJob{reinterpret_cast<const char*>(kx), reinterpret_cast<const char*>(vx), jb, (unsigned)(xgrid * H * nb),
+                         (unsigned long long)H * nb * ctx->Spad * 128};
+    }
     TL_SET(slot * 16 + 4 + 8192 * Mper);
     WM_HIP(launch_skinny_norm(st, WRef{w.cq_w, w.cq_s}, d / 16, K32, h, w.ln2_w, w.ln2_b, d, R, 1, 0, 1, EpF32{ctx->qbuf, w.cq_b, d, R, 0.125f},
                               ctx->xbuf, xpl));
     // 5. cross-attention over the encoder K/V, 256 keys per block
     // a base pass with per-stream carry skips the blocks of carrying streams (about half of them at the measured acceptance
-    // mix): size the key-split grouping for the blocks that actually run
-    WM_PF(pf_gemm(ctx, w.fc1_w, f8, ctx->ffn / 16, K32, true));
-    TL_SET(slot * 16 + 5 + 8192 * Mper);
-    static const bool xattn_nt = [] { const char* v = std::getenv("WM_XATTN_NT"); return v ? std::atoi(v) != 0 : true; }();
-    if (xattn_nt)
-        hipLaunchKernelGGL((k_attn_mfma<true, true>), dim3(xgrid, H, nb), dim3(256), 0, st, ctx->qbuf, kx, vx, base, ctx->xbuf, xpl,
-                           ctx->cml, ctx->co, ctx->ticket, g_skinny_done, sskip, Mper, H, ctx->Spad, ctx->S, ctx->NS, K32 TL_PASS);
-    else
-        hipLaunchKernelGGL((k_attn_mfma<true, false>), dim3(xgrid, H, nb), dim3(256), 0, st, ctx->qbuf, kx, vx, base, ctx->xbuf, xpl,
-                           ctx->cml, ctx->co, ctx->ticket, g_skinny_done, sskip, Mper, H, ctx->Spad, ctx->S, ctx->NS, K32 TL_PASS);
-    WM_HIP(hipGetLastError());
-    WM_PF(pf_gemm(ctx, w.fc2_w, f8, d / 16, F32, false));
+    // mix): the key-split grouping is sized for the blocks that actually run
+    {
+        PfJob xpf{nullptr, nullptr, 0u, 0u, 0ull};
+        int zs = nb;
+        if (pf) {
+            xpf = pf_for_gemm(w.cout_w, f8, d / 16, K32, false);
+            const int main_total = xgrid * H * nb;
+            zs = nb + (pf_round8(main_total) - main_total + (int)xpf.n_jobs + xgrid * H - 1) / (xgrid * H);
+        }
+        TL_SET(slot * 16 + 5 + 8192 * Mper);
+        static const bool xattn_nt = [] { const char* v = std::getenv("WM_XATTN_NT"); return v ? std::atoi(v) != 0 : true; }();
+        if (xattn_nt)
+            hipLaunchKernelGGL((k_attn_mfma<true, true>), dim3(xgrid, H, zs), dim3(256), 0, st, ctx->qbuf, kx, vx, base, ctx->xbuf, xpl,
+                               ctx->cml, ctx->co, ctx->ticket, g_skinny_done, sskip, Mper, H, ctx->Spad, ctx->S, ctx->NS, K32, nb, xpf TL_PASS);
+        else
+            hipLaunchKernelGGL((k_attn_mfma<true, false>), dim3(xgrid, H, zs), dim3(256), 0, st, ctx->qbuf, kx, vx, base, ctx->xbuf, xpl,
+                               ctx->cml, ctx->co, ctx->ticket, g_skinny_done, sskip, Mper, H, ctx->Spad, ctx->S, ctx->NS, K32, nb, xpf TL_PASS);
+        WM_HIP(hipGetLastError());
+    }
     // 6. out_proj + residual
+    if (pf) g_pf_job = pf_for_gemm(w.fc1_w, f8, ctx->ffn / 16, K32, true);
     TL_SET(slot * 16 + 6 + 8192 * Mper);
     WM_HIP(launch_skinny_rows(st, WRef{w.cout_w, w.cout_s}, d / 16, K32, R, ctx->xbuf, xpl, EpResidual{h, w.cout_b, d, R}));
-    if (next) WM_PF(pf_gemm(ctx, next->qkv_w, f8, 3 * d / 16, K32, true));
     // 7. LN3 + fc1 + GELU
+    if (pf) g_pf_job = pf_for_gemm(w.fc2_w, f8, d / 16, F32, false);
     TL_SET(slot * 16 + 7 + 8192 * Mper);
     WM_HIP(launch_skinny_norm(st, WRef{w.fc1_w, w.fc1_s}, ctx->ffn / 16, K32, h, w.ln3_w, w.ln3_b, d, R, 1, 0, 1,
                               EpPackedAct<1>{ctx->fbuf, ctx->fbuf + fpl, w.fc1_b, F32, R}, ctx->xbuf, xpl));
     // 8. fc2 + residual
+    if (pf && next) g_pf_job = pf_for_gemm(next->qkv_w, f8, 3 * d / 16, K32, true);
     TL_SET(slot * 16 + 8 + 8192 * Mper);
     WM_HIP(launch_skinny_rows(st, WRef{w.fc2_w, w.fc2_s}, d / 16, F32, R, ctx->fbuf, fpl, EpResidual{h, w.fc2_b, d, R}));
-#undef WM_PF
     return WM_OK;
 }
 
@@ -769,7 +715,7 @@ int wm_dec_stage_layers(wm_ctx* ctx, int b0, int nb, int Mper, int mode)
         int rc = dec_layer(ctx, ctx->dec[l], l, ctx->h, b0, nb, Mper, base, false, sskip, l + 1 < ctx->cfg.dec_layers ? &ctx->dec[l + 1] : nullptr);
         if (rc) return rc;
     }
-    return pf_join(ctx);
+    return WM_OK;
 }
 
 // ---- stage 2: final LayerNorm for all rows (-> hf); Medusa-Block: the extra decoder layer on the
@@ -793,8 +739,6 @@ int wm_dec_stage_final(wm_ctx* ctx, int b0, int nb, int Mper, int mode, int medu
         const bool kv_only = !medusa && !carrying;
         const int* sskip = (mode == 0 && Mper == 1 && ctx->dev_carry) ? ctx->carry + b0 : nullptr;
         int rc = dec_layer(ctx, ctx->dec[ctx->nkv - 1], ctx->nkv - 1, ctx->hblk, b0, nb, Mper, base, kv_only, sskip);
-        if (rc) return rc;
-        rc = pf_join(ctx);
         if (rc) return rc;
         if (sskip) {
             hipLaunchKernelGGL(k_rows_take_carried, dim3(R), dim3(256), 0, st, ctx->hblk + (size_t)b0 * d, ctx->hb_keep + (size_t)b0 * d,

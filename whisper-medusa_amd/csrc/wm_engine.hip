@@ -34,13 +34,10 @@ extern "C" void wm_destroy(wm_ctx* ctx)
                     ctx->enc_out, ctx->kx, ctx->vx, ctx->kc, ctx->vc, ctx->h, ctx->hblk, ctx->hf, ctx->qbuf, ctx->xbuf, ctx->fbuf,
                     ctx->ybuf, ctx->cml, ctx->co, ctx->ticket, ctx->logits, ctx->amax, ctx->pc, ctx->part1, ctx->part2, ctx->ids, ctx->L, ctx->kvlen,
                     ctx->finished, ctx->cand, ctx->niter, ctx->hist, ctx->supmask, ctx->exppen, ctx->tap_tok, ctx->done,
-                    ctx->hf_keep, ctx->hb_keep, ctx->carry, ctx->rs_table, ctx->pf_sink};
+                    ctx->hf_keep, ctx->hb_keep, ctx->carry, ctx->rs_table};
     for (void* b : bufs) if (b) hipFree(b);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
-    if (ctx->pf_fork) hipEventDestroy(ctx->pf_fork);
-    if (ctx->pf_join) hipEventDestroy(ctx->pf_join);
-    if (ctx->pf_stream) { hipStreamSynchronize(ctx->pf_stream); hipStreamDestroy(ctx->pf_stream); }
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -65,10 +62,7 @@ extern "C" int wm_create(const wm_config* cfg, const wm_weights* w, int device, 
     else { CREATE_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->own_stream = true; }
     CREATE_HIP(hipEventCreate(&ctx->ev0));
     CREATE_HIP(hipEventCreate(&ctx->ev1));
-    CREATE_HIP(hipStreamCreateWithFlags(&ctx->pf_stream, hipStreamNonBlocking));
-    CREATE_HIP(hipEventCreateWithFlags(&ctx->pf_fork, hipEventDisableTiming));
-    CREATE_HIP(hipEventCreateWithFlags(&ctx->pf_join, hipEventDisableTiming));
-    { const char* v = std::getenv("WM_PREFETCH"); ctx->prefetch = v && std::atoi(v) != 0; }
+    { const char* v = std::getenv("WM_PREFETCH"); ctx->prefetch = !(v && std::atoi(v) == 0); }
 
     const int d = ctx->d = cfg->d_model;
     ctx->H = cfg->n_heads; ctx->ffn = cfg->ffn_dim; ctx->V = cfg->vocab; ctx->Vpad = rup(cfg->vocab, 128);
@@ -166,7 +160,6 @@ extern "C" int wm_create(const wm_config* cfg, const wm_weights* w, int device, 
     CREATE_HIP(dev_alloc(&ctx->exppen, Tids + 1, st));
     CREATE_HIP(dev_alloc(&ctx->tap_tok, 16, st));
     CREATE_HIP(dev_alloc(&ctx->done, 4, st));
-    CREATE_HIP(dev_alloc(&ctx->pf_sink, 4, st));
     CREATE_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->hostflags), 64, hipHostMallocMapped));
     CREATE_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->hostflags_dev), ctx->hostflags, 0));
     ctx->hostflags[0] = ctx->hostflags[1] = 0;

@@ -109,12 +109,7 @@ struct wm_ctx {
     int graph_replays = 0;
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    // side stream that warms the L2 / Infinity Cache with the NEXT kernels' weights and cross-K/V while the dependent chain runs
-    hipStream_t pf_stream = nullptr;
-    hipEvent_t pf_fork = nullptr, pf_join = nullptr;
-    int* pf_sink = nullptr;
-    bool prefetch = false;          // WM_PREFETCH
-    bool pf_open = false;           // the side stream has work that the main stream has not joined yet
+    bool prefetch = true;           // in-launch next-operand prefetch blocks (WM_PREFETCH=0 turns them off)
     float ms_logmel = 0.f, ms_encode = 0.f, ms_decode = 0.f;
 };
 

@@ -114,6 +114,31 @@ __device__ __forceinline__ void glds16_f(const float* gsrc, char* lds_wave_base)
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// ---- next-launch prefetch riding on this launch --------------------------------------------------------------------
+// The single-stream chain is latency-bound and HBM idles most of the time.  A launch may therefore carry extra blocks that
+// do nothing but touch the bytes the NEXT launch's blocks will read (its weights, or the cross K/V), so that those find them
+// in L2: job j = what block j of the consumer reads, fetched by the extra block whose global id is congruent to j modulo 8
+// — the dispatcher places block b on XCD b % 8 (observed, MI355X_MICROARCH.md), i.e. into the L2 the consumer reads through;
+// another placement only turns the L2 hit into an Infinity-Cache hit.  A pure hint: results cannot change, nothing waits.
+// (Tried first as a second stream inside the hipGraph: the fork/join event nodes raised every launch boundary from 1.9 to
+// 12-14 us — profiles/r02_timeline_sidestream_prefetch.md.)
+struct PfJob { const char* p0; const char* p1; unsigned job_bytes; unsigned n_jobs; unsigned long long total; };
+static thread_local PfJob g_pf_job = {nullptr, nullptr, 0u, 0u, 0ull};     // host: rides on the next launch, which clears it
+
+__device__ __forceinline__ void pf_block(const PfJob& pf, int job)
+{
+    if (job < 0 || job >= (int)pf.n_jobs) return;
+    const unsigned long long lo = (unsigned long long)job * pf.job_bytes;
+    const unsigned long long hi = min(lo + pf.job_bytes, pf.total);
+    u32x4_t sink;
+    for (unsigned long long i = lo + (unsigned long long)threadIdx.x * 16; i < hi; i += (unsigned long long)blockDim.x * 16) {
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sink) : "v"(pf.p0 + i) : "memory");
+        if (pf.p1) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sink) : "v"(pf.p1 + i) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__host__ __device__ __forceinline__ int pf_round8(int n) { return (n + 7) & ~7; }
+
 // ---- token operand: packed hi/lo planes in global memory (written by the previous kernel's epilogue) ------------
 struct LdPacked {
     const bf16_t* X; int K32; size_t plane; int M;           // lo plane at X + plane; rows >= M are not read
@@ -218,9 +243,10 @@ typedef LdNormT<false> LdIdent;
 template <int NK, int RT, bool W8, class Ld, class Ep>
 __global__ void __launch_bounds__(640)
 k_skinny_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int N16, int K32, int ksplit, int rt_per_wg, int ks_magic,
-              const int* __restrict__ done, Ld ld, Ep ep TL_ARG)
+              const int* __restrict__ done, Ld ld, Ep ep, int nmain, PfJob pf TL_ARG)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x >= nmain) { pf_block(pf, (int)blockIdx.x - pf_round8(nmain)); return; }      // prefetch-only blocks
     TL_BEGIN
     constexpr int XB = (NK > 8 && !Ld::kNorm) ? NK / 2 : NK;
     const int lane = threadIdx.x & 63;
@@ -446,6 +472,13 @@ static inline SkinnyPlan skinny_plan(int N16, int K32, bool norm_loader) {
     return p;
 }
 
+static inline PfJob pf_for_gemm(const bf16_t* W, bool fp8, int N16, int K32, bool norm_loader) {
+    const SkinnyPlan p = skinny_plan(N16, K32, norm_loader);
+    const int per_block = p.rt * p.RT, grid = (N16 + per_block - 1) / per_block;
+    const unsigned long long tile = (unsigned long long)K32 * 512 * (fp8 ? 1 : 2);
+    return PfJob{reinterpret_cast<const char*>(W), nullptr, (unsigned)(tile * per_block), (unsigned)grid, tile * N16};
+}
+
 // a weight matrix in the packed layout: bf16 (scale == nullptr) or fp8 e4m3 with one fp32 scale per output row
 struct WRef {
     const bf16_t* w; const float* scale;
@@ -464,9 +497,14 @@ static inline hipError_t launch_skinny_nk_rt(hipStream_t st, WRef W, int N16, in
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, W.w, W.scale, N16, K32, p.ksplit, p.rt, magic, g_skinny_done, ld, ep TL_PASS);
+    const PfJob pf = g_pf_job;
+    g_pf_job = PfJob{nullptr, nullptr, 0u, 0u, 0ull};
+    const int grid_all = pf.n_jobs ? pf_round8(grid) + (int)pf.n_jobs : grid;
+    hipLaunchKernelGGL(kern, dim3(grid_all), dim3(threads), lds, st, W.w, W.scale, N16, K32, p.ksplit, p.rt, magic, g_skinny_done, ld, ep, grid, pf TL_PASS);
     return hipGetLastError();
 }
+// the bytes block j of the skinny GEMM (W, N16, K32, loader kind) reads: one prefetch job per consumer block
+static inline PfJob pf_for_gemm(const bf16_t* W, bool fp8, int N16, int K32, bool norm_loader);
 template <int NK, bool W8, class Ld, class Ep>
 static inline hipError_t launch_skinny_nk(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p, const Ld& ld, const Ep& ep) {
     if constexpr (NK <= 8) {
