@@ -15,6 +15,11 @@ LIB = os.path.join(OUT_DIR, "libwm.so")
 SOURCES = ["wm_engine.hip", "wm_decoder.hip", "wm_encoder.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# gfx950 can hand the first kernel arguments to a wave in SGPRs at launch (kernarg preload): the decode chain's kernels then
+# compute their addresses and issue their first loads without waiting for an s_load round trip.  The code object carries a
+# compatibility prologue for firmware without the feature.  WM_NO_KERNARG_PRELOAD=1 builds without it (A/B runs).
+if not os.environ.get("WM_NO_KERNARG_PRELOAD"):
+    FLAGS += ["-mllvm", "-amdgpu-kernarg-preload-count=16"]
 
 
 def _newest_src():

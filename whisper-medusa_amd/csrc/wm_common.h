@@ -44,6 +44,34 @@ __device__ __host__ __forceinline__ size_t vfrag_index(int key, int dim) {
     return ((size_t)((key >> 5) * 4 + (dim >> 4)) * 64 + (dim & 15) + 16 * (rr >> 2)) * 8 + (r >> 4) * 4 + (rr & 3);
 }
 
+// V^T fragment store for MFMA epilogues.  In the C/D layout a lane (row = lane & 15, g = lane >> 4) holds 4 consecutive
+// features (dims) of ONE row (key position); the V^T layout wants, per dim, 4 consecutive KEYS adjacent (8 bytes).  The 16
+// lanes of a row group hold 16 consecutive rows, so a lane whose position is a multiple of 4 (`lead`) collects the values of
+// the next three lanes (3 DPP row shifts per dim inside the 16-lane group) and writes 8 bytes per dim; a lane not `covered` by such
+// a leader falls back to 2-byte stores.  All 64 lanes must call this convergently.  One 8-B store replaces four 2-B stores:
+// the scattered 2-B stores were what made the launches that write V drain slowly (QKV -> self-attention boundary 3.7 us vs
+// 1.9 us elsewhere) and they are a quarter of the cross-KV projection's epilogue traffic.
+__device__ __forceinline__ void vt_store4(bf16_t* __restrict__ head, int pos, int dim0, float x0, float x1, float x2, float x3,
+                                           bool valid, bool lead, bool covered)
+{
+    const float x[4] = {x0, x1, x2, x3};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        // row_shl:n — lane i of a 16-lane row reads lane i+n (DPP: in the VALU, no LDS round trip like ds_bpermute)
+        const int xi = __float_as_int(x[j]);
+        const float y1 = __int_as_float(__builtin_amdgcn_update_dpp(0, xi, 0x101, 0xf, 0xf, true));
+        const float y2 = __int_as_float(__builtin_amdgcn_update_dpp(0, xi, 0x102, 0xf, 0xf, true));
+        const float y3 = __int_as_float(__builtin_amdgcn_update_dpp(0, xi, 0x103, 0xf, 0xf, true));
+        bf16_t* p = head + vfrag_index(pos, dim0 + j);
+        if (lead) {
+            uint2 o; o.x = pack_bf2(x[j], y1); o.y = pack_bf2(y2, y3);
+            *reinterpret_cast<uint2*>(p) = o;
+        } else if (valid && !covered) {
+            *p = f2bf(x[j]);
+        }
+    }
+}
+
 // Reductions over the four 16-lane rows of a wavefront (lanes c, c+16, c+32, c+48), every lane gets the result:
 // gfx950's v_permlane16_swap / v_permlane32_swap exchange rows in the VALU (a few cycles) where __shfl_xor(.,16|32)
 // goes through the LDS crossbar (ds_bpermute, ~100 cycles of latency on the critical path of every softmax step and

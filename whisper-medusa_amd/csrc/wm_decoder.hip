@@ -175,13 +175,83 @@ __device__ __forceinline__ void attn_step(AttnAcc& st, const KVStep& t, const bf
     }
 }
 
-template <bool CROSS, bool NT>
-__global__ void __launch_bounds__(256)
+// Cross-attention: a wave's two 32-key steps of a split as ONE 64-key block — all 16 score MFMAs first, one max / one sum,
+// no running rescale (a split starts from scratch), then all 16 PV MFMAs: half the dependent softmax rounds of two
+// successive attn_step calls.  `has1`: the second step exists (wave-uniform).
+__device__ __forceinline__ void attn_block64(AttnAcc& st, const KVStep& t0, const KVStep& t1, const bf16x8_t (&qhi)[2], const bf16x8_t (&qlo)[2],
+                                             int kb, int g, int limit, bool has1)
+{
+    f32x4_t s[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    s[0] = mfma16(t0.k00, qhi[0], s[0]); s[0] = mfma16(t0.k01, qhi[1], s[0]); s[0] = mfma16(t0.k00, qlo[0], s[0]); s[0] = mfma16(t0.k01, qlo[1], s[0]);
+    s[1] = mfma16(t0.k10, qhi[0], s[1]); s[1] = mfma16(t0.k11, qhi[1], s[1]); s[1] = mfma16(t0.k10, qlo[0], s[1]); s[1] = mfma16(t0.k11, qlo[1], s[1]);
+    if (has1) {
+        s[2] = mfma16(t1.k00, qhi[0], s[2]); s[2] = mfma16(t1.k01, qhi[1], s[2]); s[2] = mfma16(t1.k00, qlo[0], s[2]); s[2] = mfma16(t1.k01, qlo[1], s[2]);
+        s[3] = mfma16(t1.k10, qhi[0], s[3]); s[3] = mfma16(t1.k11, qhi[1], s[3]); s[3] = mfma16(t1.k10, qlo[0], s[3]); s[3] = mfma16(t1.k11, qlo[1], s[3]);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (kb + 16 * i + 4 * g + r >= limit || (i >= 2 && !has1)) s[i][r] = -INFINITY;
+            mx = fmaxf(mx, s[i][r]);
+        }
+    mx = rows4_max(mx);
+    float p[16], rs = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { p[4 * i + r] = (mx == -INFINITY) ? 0.f : __expf(s[i][r] - mx); rs += p[4 * i + r]; }
+    rs = rows4_sum(rs);
+    st.m_run = mx; st.l_run = rs;
+    bf16x8_t ph0, pl0, ph1, pl1;
+    split_hilo8(p, ph0, pl0);
+    split_hilo8(p + 8, ph1, pl1);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        st.o[dt] = mfma16(t0.v[dt], ph0, st.o[dt]);
+        st.o[dt] = mfma16(t0.v[dt], pl0, st.o[dt]);
+        if (has1) {
+            st.o[dt] = mfma16(t1.v[dt], ph1, st.o[dt]);
+            st.o[dt] = mfma16(t1.v[dt], pl1, st.o[dt]);
+        }
+    }
+}
+
+// LDS of the attention kernels (dynamic, so that the fused variant can put its LayerNorm / projection staging next to it)
+template <int NSP>
+struct AttnLds {
+    float s_m[4][16], s_l[4][16];
+    int s_last; int pad_[3];
+    float s_o[4][16][68];
+    float s_part[NSP][16][68];          // [..][64] = max, [..][65] = sum
+};
+
+// Fused cross-attention query (single-tile passes): the LN2 + cross-q GEMM launch disappears — every cross-attention
+// block computes the 64 query features of ITS head itself: LayerNorm of the token rows (K-slice waves, the LdNorm code and
+// slicing of the stand-alone GEMM), normalised hi/lo fragments through LDS, 4 waves x one 16-feature weight row tile x all
+// K-slices with the stand-alone kernel's accumulation order (slice partials from zero, summed in slice order) -> q is
+// bit-identical to the two-launch path (which the token-tile passes of several streams still use).  The blocks of the 6 key
+// splits of a head repeat the projection (160 KB of weights each, L2 hits after the first): a launch boundary and a
+// dependent weight round trip cost more.
+template <int NK_, int KS_>
+struct FuseQ {
+    static constexpr bool kOn = true;
+    static constexpr int NK = NK_, KS = KS_;
+    LdNorm ln; const bf16_t* Wq; const float* bq;
+};
+struct NoFuseQ { static constexpr bool kOn = false; static constexpr int NK = 1, KS = 1; };
+
+template <bool CROSS, bool NT, class FQ>
+__global__ void __launch_bounds__(FQ::kOn ? (FQ::KS > 4 ? 64 * FQ::KS : 256) : 256)
 k_attn_mfma(const float* __restrict__ q, const bf16_t* __restrict__ kmat, const bf16_t* __restrict__ vtmat,
             const int* __restrict__ base, bf16_t* __restrict__ xout, size_t xplane, float* __restrict__ ml, float* __restrict__ po,
             int* __restrict__ ticket, const int* __restrict__ done, const int* __restrict__ sskip,
-            int Mper, int H, int rows_alloc, int S, int NS, int K32, int nbz, PfJob pf TL_ARG)
+            int Mper, int H, int rows_alloc, int S, int NS, int K32, int nbz, PfJob pf, FQ fq TL_ARG)
 {
+    extern __shared__ __attribute__((aligned(16))) char smem_attn[];
     if ((int)blockIdx.z >= nbz) {          // prefetch-only blocks (extra z slices): wm_skinny_gemm.h, PfJob
         const int main_total = gridDim.x * gridDim.y * nbz;
         pf_block(pf, main_total + (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * (blockIdx.z - nbz))) - pf_round8(main_total));
@@ -190,11 +260,12 @@ k_attn_mfma(const float* __restrict__ q, const bf16_t* __restrict__ kmat, const 
     TL_BEGIN
     // per-stream skip: the stream carried its hidden state, this base-pass row is not used (its K/V reads are saved)
     if (sskip && sskip[blockIdx.z]) return;
-    __shared__ float s_m[4][16], s_l[4][16];
-    __shared__ int s_last;
-    __shared__ __attribute__((aligned(16))) float s_o[4][16][68];
-    __shared__ __attribute__((aligned(16))) float s_part[CROSS ? WM_XATTN_SPB_MAX : 1][16][68];   // [..][64] = max, [..][65] = sum
+    typedef AttnLds<CROSS ? WM_XATTN_SPB_MAX : 1> Lds;
+    Lds& A = *reinterpret_cast<Lds*>(smem_attn);
+    float (&s_m)[4][16] = A.s_m; float (&s_l)[4][16] = A.s_l; int& s_last = A.s_last;
+    float (&s_o)[4][16][68] = A.s_o; auto& s_part = A.s_part;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+    const bool aw = w < 4;                  // the four attention waves (the fused variant may carry more waves for its LayerNorm)
     const int hd = blockIdx.y, s = blockIdx.z, d = H * 64;
     // CROSS: the block walks key splits [sp0, sp1); with gridDim.x == NS that is one split per block (single stream:
     // all CUs busy), with fewer blocks per (stream, head) each walks several (large batches: fewer partial hand-offs).
@@ -212,15 +283,79 @@ k_attn_mfma(const float* __restrict__ q, const bf16_t* __restrict__ kmat, const 
     // 3 blocks per CU): bytes in flight are what the cross-K/V stream needs.  Then q (written by the previous launch).
     KVStep c0 = {}, c1 = {};
     int kb = CROSS ? sp0 * 256 + w * 64 : 32 * w;
-    if (CROSS ? (kb < S) : (kb < rows_alloc)) kv_load<NT>(c0, kp, vp, kb, c, g, lane);
-    if (CROSS && kb + 32 < S) kv_load<NT>(c1, kp, vp, kb + 32, c, g, lane);
+    if (aw && (CROSS ? (kb < S) : (kb < rows_alloc))) kv_load<NT>(c0, kp, vp, kb, c, g, lane);
+    if (aw && CROSS && kb + 32 < S) kv_load<NT>(c1, kp, vp, kb + 32, c, g, lane);
     float4 qraw[2][2];
 #pragma unroll
-    for (int ds = 0; ds < 2; ++ds) {
-        qraw[ds][0] = make_float4(0.f, 0.f, 0.f, 0.f); qraw[ds][1] = qraw[ds][0];
-        if (c < Mper) {
-            const float4* qp = reinterpret_cast<const float4*>(q + (size_t)(s * Mper + c) * d + hd * 64 + ds * 32 + g * 8);
-            qraw[ds][0] = qp[0]; qraw[ds][1] = qp[1];
+    for (int ds = 0; ds < 2; ++ds) { qraw[ds][0] = make_float4(0.f, 0.f, 0.f, 0.f); qraw[ds][1] = qraw[ds][0]; }
+    if constexpr (FQ::kOn) {
+        constexpr int NK = FQ::NK, KS = FQ::KS, KT = NK * KS;          // K32 == KT
+        // LDS: [normalised hi | lo fragments, 2 KT KiB — dead before the attention state A (which aliases it) is first written]
+        //      [gamma | beta | LayerNorm statistics: the LdNorm layout][q tile 16 rows x 64 features fp32]
+        constexpr size_t kFragBytes = (size_t)2 * KT * 1024;
+        constexpr size_t kLnOff = kFragBytes > sizeof(Lds) ? kFragBytes : ((sizeof(Lds) + 15) & ~(size_t)15);
+        char* lnb = smem_attn + kLnOff;
+        float* qt = reinterpret_cast<float*>(lnb + fq.ln.lds_bytes());
+        typename LdNorm::template Regs<NK> xr;
+        fq.ln.template issue<NK>(xr, lnb, w * NK, lane, 0, w < KS);     // K-slice w of the token rows; every wave helps stage gamma / beta
+        // projection weights of this wave's 16-feature row tile: the first slices now, the rest once the LayerNorm registers are free
+        constexpr int KT0 = ((KS + 1) / 2) * NK;
+        const bf16_t* wq = fq.Wq + ((size_t)(hd * 4 + (aw ? w : 0)) * KT * 64 + lane) * 8;
+        u32x4_t a[KT];
+#pragma unroll
+        for (int u = 0; u < KT0; ++u) a[u] = aw ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wq + (size_t)u * 512)) : u32x4_t{0u, 0u, 0u, 0u};
+        const float4 qb = aw ? *reinterpret_cast<const float4*>(fq.bq + hd * 64 + 16 * w + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (done && *done) return;
+        fq.ln.template stats<NK>(xr, lnb, w, KS, w < KS, lane);         // block barrier inside
+        if (w < KS) {
+#pragma unroll
+            for (int u = 0; u < NK; ++u) {
+                bf16x8_t bh, bl;
+                fq.ln.template frag<NK>(xr, lnb, u, w * NK + u, lane, bh, bl);
+                const size_t o = ((size_t)(w * NK + u) * 64 + lane) * 16;
+                *reinterpret_cast<uint4*>(smem_attn + o) = __builtin_bit_cast(uint4, bh);
+                *reinterpret_cast<uint4*>(smem_attn + (size_t)KT * 1024 + o) = __builtin_bit_cast(uint4, bl);
+            }
+        }
+#pragma unroll
+        for (int u = KT0; u < KT; ++u) a[u] = aw ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wq + (size_t)u * 512)) : u32x4_t{0u, 0u, 0u, 0u};
+        __syncthreads();
+        if (aw) {
+            f32x4_t tot = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sl = 0; sl < KS; ++sl) {
+                f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < NK; ++u) {
+                    const int kt = sl * NK + u;
+                    const size_t o = ((size_t)kt * 64 + lane) * 16;
+                    const bf16x8_t bh = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(smem_attn + o));
+                    const bf16x8_t bl = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(smem_attn + (size_t)KT * 1024 + o));
+                    const bf16x8_t av = __builtin_bit_cast(bf16x8_t, a[kt]);
+                    acc = mfma16(av, bh, acc);
+                    acc = mfma16(av, bl, acc);
+                }
+                tot[0] += acc[0]; tot[1] += acc[1]; tot[2] += acc[2]; tot[3] += acc[3];
+            }
+            // (v + bias) * 0.125 exactly like EpF32 of the stand-alone projection; lane holds features 16 w + 4 g .. + 3 of token row c
+            *reinterpret_cast<float4*>(qt + c * 64 + 16 * w + 4 * g) =
+                make_float4((tot[0] + qb.x) * 0.125f, (tot[1] + qb.y) * 0.125f, (tot[2] + qb.z) * 0.125f, (tot[3] + qb.w) * 0.125f);
+        }
+        __syncthreads();                    // q tile complete; the fragment staging is dead: A may be written from here on
+        if (aw && c < Mper) {
+#pragma unroll
+            for (int ds = 0; ds < 2; ++ds) {
+                const float4* qp = reinterpret_cast<const float4*>(qt + (s * Mper + c) * 64 + ds * 32 + g * 8);
+                qraw[ds][0] = qp[0]; qraw[ds][1] = qp[1];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int ds = 0; ds < 2; ++ds) {
+            if (c < Mper) {
+                const float4* qp = reinterpret_cast<const float4*>(q + (size_t)(s * Mper + c) * d + hd * 64 + ds * 32 + g * 8);
+                qraw[ds][0] = qp[0]; qraw[ds][1] = qp[1];
+            }
         }
     }
     const int b0 = CROSS ? 0 : base[s];
@@ -244,10 +379,9 @@ k_attn_mfma(const float* __restrict__ q, const bf16_t* __restrict__ kmat, const 
         if (CROSS) {
             // each step's registers are refilled with the same step of the NEXT split as soon as its math has issued
             const int nkb = (sp + 1) * 256 + w * 64, nkend = (sp + 1 < sp1) ? min(S, nkb + 64) : 0;
-            if (kb < kend) attn_step(st, c0, qhi, qlo, kb, g, limit);
-            if (nkb < nkend) kv_load<NT>(c0, kp, vp, nkb, c, g, lane);
-            if (kb + 32 < kend) attn_step(st, c1, qhi, qlo, kb + 32, g, limit);
-            if (nkb + 32 < nkend) kv_load<NT>(c1, kp, vp, nkb + 32, c, g, lane);
+            if (aw && kb < kend) attn_block64(st, c0, c1, qhi, qlo, kb, g, limit, kb + 32 < kend);
+            if (aw && nkb < nkend) kv_load<NT>(c0, kp, vp, nkb, c, g, lane);
+            if (aw && nkb + 32 < nkend) kv_load<NT>(c1, kp, vp, nkb + 32, c, g, lane);
             kb = nkb; kend = nkend;
         } else {
             for (; kb < kend; kb += 128) {
@@ -259,10 +393,12 @@ k_attn_mfma(const float* __restrict__ q, const bf16_t* __restrict__ kmat, const 
         const float m_run = st.m_run, l_run = st.l_run;
         const f32x4_t (&o)[4] = st.o;
         // merge the 4 waves' partials of this split (fixed order)
-        if (g == 0) { s_m[w][c] = m_run; s_l[w][c] = l_run; }
+        if (aw) {
+            if (g == 0) { s_m[w][c] = m_run; s_l[w][c] = l_run; }
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-            *reinterpret_cast<float4*>(&s_o[w][c][dt * 16 + 4 * g]) = make_float4(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
+            for (int dt = 0; dt < 4; ++dt)
+                *reinterpret_cast<float4*>(&s_o[w][c][dt * 16 + 4 * g]) = make_float4(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
+        }
         __syncthreads();
         M = -INFINITY; L = 0.f; acc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (qr < Mper) {
@@ -634,25 +770,41 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
     WM_HIP(launch_skinny_norm(st, WRef{w.qkv_w, w.qkv_s}, 3 * d / 16, K32, h, w.ln1_w, w.ln1_b, d, R, 1, 0, 1,
                               EpQKVDec{ctx->qbuf, kc, vc, w.qkv_b, base, Mper, d, H, ctx->Tal, R}, ctx->xbuf, xpl));
     if (kv_only) return WM_OK;
-    // 2. causal self-attention over the contiguous cache
-    TL_SET(slot * 16 + 2 + 8192 * Mper);
-    hipLaunchKernelGGL((k_attn_mfma<false, false>), dim3(1, H, nb), dim3(256), 0, st, ctx->qbuf, kc, vc, base, ctx->xbuf, xpl,
-                       nullptr, nullptr, nullptr, g_skinny_done, sskip, Mper, H, ctx->Tal, 0, 1, K32, nb, PfJob{nullptr, nullptr, 0u, 0u, 0ull} TL_PASS);
-    WM_HIP(hipGetLastError());
+    // fused cross-attention query (FuseQ above): single-tile passes with bf16 weights whose projection plan has a compiled instance
+    // OFF by default: measured 14.6 us for the fused launch against 5.6 (LN2 + cross-q) + 2.2 (boundary) + 6.5 (cross-attention)
+    // = 14.3 us for the two it replaces (profiles/r02_timeline_fused_cross_q.md): the 6 key-split blocks of a head each pull the
+    // head's 160 KB of projection weights through one CU (~47 GB/s) and run LayerNorm -> projection -> attention back to back.
+    // Kept (WM_FUSE_CQ=1) because it is bit-identical and the cheapest way to re-measure the trade-off on other shapes.
+    static const bool fuse_env = [] { const char* v = std::getenv("WM_FUSE_CQ"); return v && std::atoi(v) != 0; }();
+    const SkinnyPlan cqp = skinny_plan(d / 16, K32, true);
+    const bool fuse_shape = (cqp.nk == 8 && cqp.ksplit >= 1 && cqp.ksplit <= 5) || (cqp.nk == 4 && (cqp.ksplit == 1 || cqp.ksplit == 3));
+    const bool fuse_cq = fuse_env && R <= 16 && !f8 && fuse_shape && H * 4 == d / 16;
+    const PfJob kvjob = (pf && ctx->NS % xgrid == 0 && ctx->Spad == ctx->NS * 256)
+        ? PfJob{reinterpret_cast<const char*>(kx), reinterpret_cast<const char*>(vx), (unsigned)(ctx->NS / xgrid) * 256 * 128,
+                (unsigned)(xgrid * H * nb), (unsigned long long)H * nb * ctx->Spad * 128}
+        : PfJob{nullptr, nullptr, 0u, 0u, 0ull};
+    // 2. causal self-attention over the contiguous cache (20 blocks: its spare CUs fetch this layer's cross K/V when the
+    //    fused cross-attention follows two launches later; otherwise LN2 + cross-q carries that job)
+    {
+        const PfJob spf = fuse_cq ? kvjob : PfJob{nullptr, nullptr, 0u, 0u, 0ull};
+        const int main_total = H * nb;
+        const int zs = spf.n_jobs ? nb + (pf_round8(main_total) - main_total + (int)spf.n_jobs + H - 1) / H : nb;
+        TL_SET(slot * 16 + 2 + 8192 * Mper);
+        hipLaunchKernelGGL((k_attn_mfma<false, false, NoFuseQ>), dim3(1, H, zs), dim3(256), sizeof(AttnLds<1>), st, ctx->qbuf, kc, vc, base, ctx->xbuf, xpl,
+                           nullptr, nullptr, nullptr, g_skinny_done, sskip, Mper, H, ctx->Tal, 0, 1, K32, nb, spf, NoFuseQ{} TL_PASS);
+        WM_HIP(hipGetLastError());
+    }
     // 3. out_proj + residual
     if (pf) g_pf_job = pf_for_gemm(w.cq_w, f8, d / 16, K32, true);
     TL_SET(slot * 16 + 3 + 8192 * Mper);
     WM_HIP(launch_skinny_rows(st, WRef{w.out_w, w.out_s}, d / 16, K32, R, ctx->xbuf, xpl, EpResidual{h, w.out_b, d, R}));
-    // 4. LN2 + cross-attention q   (carries the cross K/V of this layer: job j = what cross-attention block j reads, K and V
-    //    at the same offsets — the key splits of a (stream, head) are contiguous when every block walks the same number)
-    if (pf && ctx->NS % xgrid == 0 && ctx->Spad == ctx->NS * 256) {
-        const unsigned jb = (unsigned)(ctx->NS / xgrid) * 256 * 128;
-        g_pf_job = PfJob{reinterpret_cast<const char*>(kx), reinterpret_cast<const char*>(vx), jb, (unsigned)(xgrid * H * nb),
-                         (unsigned long long)H * nb * ctx->Spad * 128};
+    // 4. LN2 + cross-attention q (its own launch unless fused into 5.)
+    if (!fuse_cq) {
+        if (pf) g_pf_job = kvjob;
+        TL_SET(slot * 16 + 4 + 8192 * Mper);
+        WM_HIP(launch_skinny_norm(st, WRef{w.cq_w, w.cq_s}, d / 16, K32, h, w.ln2_w, w.ln2_b, d, R, 1, 0, 1, EpF32{ctx->qbuf, w.cq_b, d, R, 0.125f},
+                                  ctx->xbuf, xpl));
     }
-    TL_SET(slot * 16 + 4 + 8192 * Mper);
-    WM_HIP(launch_skinny_norm(st, WRef{w.cq_w, w.cq_s}, d / 16, K32, h, w.ln2_w, w.ln2_b, d, R, 1, 0, 1, EpF32{ctx->qbuf, w.cq_b, d, R, 0.125f},
-                              ctx->xbuf, xpl));
     // 5. cross-attention over the encoder K/V, 256 keys per block
     // a base pass with per-stream carry skips the blocks of carrying streams (about half of them at the measured acceptance
     // mix): the key-split grouping is sized for the blocks that actually run
@@ -666,12 +818,34 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
         }
         TL_SET(slot * 16 + 5 + 8192 * Mper);
         static const bool xattn_nt = [] { const char* v = std::getenv("WM_XATTN_NT"); return v ? std::atoi(v) != 0 : true; }();
-        if (xattn_nt)
-            hipLaunchKernelGGL((k_attn_mfma<true, true>), dim3(xgrid, H, zs), dim3(256), 0, st, ctx->qbuf, kx, vx, base, ctx->xbuf, xpl,
-                               ctx->cml, ctx->co, ctx->ticket, g_skinny_done, sskip, Mper, H, ctx->Spad, ctx->S, ctx->NS, K32, nb, xpf TL_PASS);
+        if (fuse_cq) {
+            const LdNorm ln{h, w.ln2_w, w.ln2_b, d, K32, R, 1, 0};
+#define WM_XFUSE(NKv, KSv)                                                                                                    \
+            do {                                                                                                              \
+                typedef FuseQ<NKv, KSv> FQ;                                                                                   \
+                typedef AttnLds<WM_XATTN_SPB_MAX> LdsT;                                                                       \
+                const size_t fragb = (size_t)2 * NKv * KSv * 1024;                                                            \
+                const size_t lds = (fragb > sizeof(LdsT) ? fragb : ((sizeof(LdsT) + 15) & ~(size_t)15)) + ln.lds_bytes() + 16 * 64 * sizeof(float); \
+                auto kern = k_attn_mfma<true, true, FQ>;                                                                      \
+                WM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                hipLaunchKernelGGL(kern, dim3(xgrid, H, zs), dim3(64 * (KSv > 4 ? KSv : 4)), lds, st, ctx->qbuf, kx, vx, base, ctx->xbuf, xpl, \
+                                   ctx->cml, ctx->co, ctx->ticket, g_skinny_done, sskip, Mper, H, ctx->Spad, ctx->S, ctx->NS, K32, nb, xpf, \
+                                   FQ{ln, w.cq_w, w.cq_b} TL_PASS);                                                         \
+            } while (0)
+            if (cqp.nk == 8 && cqp.ksplit == 5) WM_XFUSE(8, 5);
+            else if (cqp.nk == 8 && cqp.ksplit == 4) WM_XFUSE(8, 4);
+            else if (cqp.nk == 8 && cqp.ksplit == 3) WM_XFUSE(8, 3);
+            else if (cqp.nk == 8 && cqp.ksplit == 2) WM_XFUSE(8, 2);
+            else if (cqp.nk == 8 && cqp.ksplit == 1) WM_XFUSE(8, 1);
+            else if (cqp.nk == 4 && cqp.ksplit == 3) WM_XFUSE(4, 3);
+            else WM_XFUSE(4, 1);
+#undef WM_XFUSE
+        } else if (xattn_nt)
+            hipLaunchKernelGGL((k_attn_mfma<true, true, NoFuseQ>), dim3(xgrid, H, zs), dim3(256), sizeof(AttnLds<WM_XATTN_SPB_MAX>), st, ctx->qbuf, kx, vx, base, ctx->xbuf, xpl,
+                               ctx->cml, ctx->co, ctx->ticket, g_skinny_done, sskip, Mper, H, ctx->Spad, ctx->S, ctx->NS, K32, nb, xpf, NoFuseQ{} TL_PASS);
         else
-            hipLaunchKernelGGL((k_attn_mfma<true, false>), dim3(xgrid, H, zs), dim3(256), 0, st, ctx->qbuf, kx, vx, base, ctx->xbuf, xpl,
-                               ctx->cml, ctx->co, ctx->ticket, g_skinny_done, sskip, Mper, H, ctx->Spad, ctx->S, ctx->NS, K32, nb, xpf TL_PASS);
+            hipLaunchKernelGGL((k_attn_mfma<true, false, NoFuseQ>), dim3(xgrid, H, zs), dim3(256), sizeof(AttnLds<WM_XATTN_SPB_MAX>), st, ctx->qbuf, kx, vx, base, ctx->xbuf, xpl,
+                               ctx->cml, ctx->co, ctx->ticket, g_skinny_done, sskip, Mper, H, ctx->Spad, ctx->S, ctx->NS, K32, nb, xpf, NoFuseQ{} TL_PASS);
         WM_HIP(hipGetLastError());
     }
     // 6. out_proj + residual

@@ -72,23 +72,36 @@ struct EpQKVDec {              // K cache [s][h][pos][64]; V cache [s][h] as V^T
         if (m < M) { p.a = *reinterpret_cast<const float4*>(bias + n); if (n >= d) p.i = base[m / Mper]; }
         return p;
     }
+    // NOTE: must be called by all 64 lanes of a wave together (the V branch exchanges values between lanes)
     __device__ __forceinline__ void fin(int m, int n, f32x4_t v, const EpPre& p) const {
-        if (m >= M) return;
+        const bool valid = m < M;
         const float x0 = v[0] + p.a.x, x1 = v[1] + p.a.y, x2 = v[2] + p.a.z, x3 = v[3] + p.a.w;
-        if (n < d) {
-            *reinterpret_cast<float4*>(q + (size_t)m * d + n) = make_float4(x0 * 0.125f, x1 * 0.125f, x2 * 0.125f, x3 * 0.125f);
+        if (n < d) {                                   // n is wave-uniform up to the 16-feature tile: the branch is uniform
+            if (valid) *reinterpret_cast<float4*>(q + (size_t)m * d + n) = make_float4(x0 * 0.125f, x1 * 0.125f, x2 * 0.125f, x3 * 0.125f);
             return;
         }
-        const int s = m / Mper, r = m - s * Mper;
+        const int mm = valid ? m : 0;
+        const int s = mm / Mper, r = mm - s * Mper;
         int pos = p.i + r; if (pos > Tal - 1) pos = Tal - 1;
         if (n < 2 * d) {
             const int c = n - d;
             uint2 o; o.x = pack_bf2(x0, x1); o.y = pack_bf2(x2, x3);
-            *reinterpret_cast<uint2*>(kc + (((size_t)s * H + (c >> 6)) * Tal + pos) * 64 + (c & 63)) = o;
+            if (valid) *reinterpret_cast<uint2*>(kc + (((size_t)s * H + (c >> 6)) * Tal + pos) * 64 + (c & 63)) = o;
         } else {
             const int c = n - 2 * d;
-            bf16_t* pv = vc + ((size_t)s * H + (c >> 6)) * 64 * Tal + vfrag_index(pos, c & 63);     // dims c..c+3: lanes 8 elements apart
-            pv[0] = f2bf(x0); pv[8] = f2bf(x1); pv[16] = f2bf(x2); pv[24] = f2bf(x3);
+            // leader: position multiple of 4 whose next three rows exist, belong to the same stream and stay inside the cache
+            const bool lead = valid && (pos & 3) == 0 && (m & 15) <= 12 && m + 3 < M && (m + 3) / Mper == s && p.i + r + 3 <= Tal - 1;
+            const int back = pos & 3;                  // my group's leader sits `back` lanes below me (if it is in my row group)
+            const int lane = (int)(threadIdx.x & 63);
+            const int src = lane - back;
+            // lead flag of the lane `back` (1..3) below me inside my 16-lane row: three DPP row shifts (row_shr:n — lane i reads i-n)
+            const int lf = (int)lead;
+            const int l1 = __builtin_amdgcn_update_dpp(0, lf, 0x111, 0xf, 0xf, true);
+            const int l2 = __builtin_amdgcn_update_dpp(0, lf, 0x112, 0xf, 0xf, true);
+            const int l3 = __builtin_amdgcn_update_dpp(0, lf, 0x113, 0xf, 0xf, true);
+            const int lflag = back == 1 ? l1 : (back == 2 ? l2 : l3);
+            const bool covered = valid && back > 0 && src >= (lane & ~15) && lflag != 0;
+            vt_store4(vc + ((size_t)s * H + (c >> 6)) * 64 * Tal, pos, c & 63, x0, x1, x2, x3, valid, lead, covered);
         }
     }
     __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const { fin(m, n, v, pre(m, n)); }
@@ -162,9 +175,9 @@ struct EpQKVEnc {              // q (x 64^-1/2), k as [b][h][s][64]; v as V^T MF
             uint2 o; o.x = pack_bf2(x0, x1); o.y = pack_bf2(x2, x3);
             *reinterpret_cast<uint2*>((isq ? q : k) + (((size_t)b * H + (c >> 6)) * Spad + s) * 64 + (c & 63)) = o;
         } else {
-            const int c = n - 2 * d;
-            bf16_t* p = vt + ((size_t)b * H + (c >> 6)) * 64 * Spad + vfrag_index(s, c & 63);
-            p[0] = f2bf(x0); p[8] = f2bf(x1); p[16] = f2bf(x2); p[24] = f2bf(x3);
+            const int c = n - 2 * d;          // rows of a 16-lane group are 16 consecutive, 16-aligned positions of one clip
+            const bool lead = (s & 3) == 0;
+            vt_store4(vt + ((size_t)b * H + (c >> 6)) * 64 * Spad, s, c & 63, x0, x1, x2, x3, true, lead, !lead);
         }
     }
 };
@@ -183,8 +196,8 @@ struct EpCrossKV {             // K_x [kvl][b][h][s][64], V_x [kvl][b][h] as V^T
             uint2 o; o.x = pack_bf2(v[0] + bb.x, v[1] + bb.y); o.y = pack_bf2(v[2] + bb.z, v[3] + bb.w);
             *reinterpret_cast<uint2*>(kx + slab + (size_t)s * 64 + (c & 63)) = o;
         } else {
-            bf16_t* p = vx + slab + vfrag_index(s, c & 63);
-            p[0] = f2bf(v[0] + bb.x); p[8] = f2bf(v[1] + bb.y); p[16] = f2bf(v[2] + bb.z); p[24] = f2bf(v[3] + bb.w);
+            const bool lead = (s & 3) == 0;
+            vt_store4(vx + slab, s, c & 63, v[0] + bb.x, v[1] + bb.y, v[2] + bb.z, v[3] + bb.w, true, lead, !lead);
         }
     }
 };

@@ -130,12 +130,15 @@ __device__ __forceinline__ void pf_block(const PfJob& pf, int job)
     if (job < 0 || job >= (int)pf.n_jobs) return;
     const unsigned long long lo = (unsigned long long)job * pf.job_bytes;
     const unsigned long long hi = min(lo + pf.job_bytes, pf.total);
-    u32x4_t sink;
+    // The loads are issued from inline asm so that nothing waits for them one by one; their destination is ONE register quad
+    // that stays allocated ("+v" keeps it live) until the final wait — a destination the compiler believed dead would be
+    // reused while loads are still in flight and be overwritten when they land (cdna_hip_programming.md §5.7 item 1).
+    u32x4_t sink = {0u, 0u, 0u, 0u};
     for (unsigned long long i = lo + (unsigned long long)threadIdx.x * 16; i < hi; i += (unsigned long long)blockDim.x * 16) {
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sink) : "v"(pf.p0 + i) : "memory");
-        if (pf.p1) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sink) : "v"(pf.p1 + i) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink) : "v"(pf.p0 + i) : "memory");
+        if (pf.p1) asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink) : "v"(pf.p1 + i) : "memory");
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) :: "memory");
 }
 __host__ __device__ __forceinline__ int pf_round8(int n) { return (n + 7) & ~7; }
 
@@ -177,10 +180,11 @@ struct LdNormT {
     template <int NB> struct Regs { float4 v0[NB], v1[NB]; float mean, rstd; };
     __host__ __device__ int lds_bytes() const { return 2 * d * (int)sizeof(float) + 2048; }   // gamma, beta, statistics
 
+    // `rows`: false for waves that only help staging gamma / beta (the fused cross-attention kernel has more waves than K-slices)
     template <int NB>
-    __device__ __forceinline__ void issue(Regs<NB>& r, char* smem, int kt0, int lane, int row0 = 0) const {
+    __device__ __forceinline__ void issue(Regs<NB>& r, char* smem, int kt0, int lane, int row0 = 0, bool rows = true) const {
         const int rr = lane & 15, g8 = (lane >> 4) * 8;
-        const bool rv = row0 + rr < M;
+        const bool rv = rows && row0 + rr < M;
         const float* hrow = h + (size_t)((row0 + rr) * row_mul + row_off) * d + (size_t)kt0 * 32 + g8;
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
@@ -243,7 +247,7 @@ typedef LdNormT<false> LdIdent;
 template <int NK, int RT, bool W8, class Ld, class Ep>
 __global__ void __launch_bounds__(640)
 k_skinny_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int N16, int K32, int ksplit, int rt_per_wg, int ks_magic,
-              const int* __restrict__ done, Ld ld, Ep ep, int nmain, PfJob pf TL_ARG)
+              int nmain, const int* __restrict__ done, Ld ld, Ep ep, PfJob pf TL_ARG)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if ((int)blockIdx.x >= nmain) { pf_block(pf, (int)blockIdx.x - pf_round8(nmain)); return; }      // prefetch-only blocks
@@ -500,7 +504,7 @@ static inline hipError_t launch_skinny_nk_rt(hipStream_t st, WRef W, int N16, in
     const PfJob pf = g_pf_job;
     g_pf_job = PfJob{nullptr, nullptr, 0u, 0u, 0ull};
     const int grid_all = pf.n_jobs ? pf_round8(grid) + (int)pf.n_jobs : grid;
-    hipLaunchKernelGGL(kern, dim3(grid_all), dim3(threads), lds, st, W.w, W.scale, N16, K32, p.ksplit, p.rt, magic, g_skinny_done, ld, ep, grid, pf TL_PASS);
+    hipLaunchKernelGGL(kern, dim3(grid_all), dim3(threads), lds, st, W.w, W.scale, N16, K32, p.ksplit, p.rt, magic, grid, g_skinny_done, ld, ep, pf TL_PASS);
     return hipGetLastError();
 }
 // the bytes block j of the skinny GEMM (W, N16, K32, loader kind) reads: one prefetch job per consumer block
