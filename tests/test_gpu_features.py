@@ -1,0 +1,138 @@
+"""Features either side of the hot path (SURVEY.md §8f / VERDICT r01 "missing"): prompt_ids conditioning with prompts longer
+than one 16-row pass, long-form chunking, language detection, the data-parallel generate_sharded() entry point."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import MedusaConfig, synth, golden_gen_params, clip_for, check_tokens, ACCEPT_TYPICAL
+from oracle.whisper_medusa_oracle import Oracle
+from whisper_medusa import WhisperMedusaModel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("heads", ["base_head", "medusa_block"])
+@pytest.mark.parametrize("plen", [5, 16, 23, 40])
+def test_long_prompts_match_the_oracle(gpu, heads, plen):
+    """prompt_ids conditioning (reference signature model.py:1431, forwarded to HF at :1519-1529): decoder prompt =
+    prompt_ids + init tokens.  Prompts longer than 16 tokens go through the layers in 16-row chunks (K/V only) before the
+    first iteration; tokens must equal the oracle's, which simply feeds the whole prompt to its first base pass."""
+    cfg = MedusaConfig.micro(K=4, heads_type=heads, n_tgt=96)
+    sd = synth.synth_state_dict(cfg, seed=41)
+    model = WhisperMedusaModel(cfg, sd, device=gpu, max_batch=2)
+    orc = Oracle(cfg, sd, sim="bf16")
+    feats = model.extract_features([clip_for(cfg, 3), clip_for(cfg, 4)[: cfg.n_mel_frames * 80]])
+    pid = torch.tensor([cfg.vocab_size - 5] + [10 + (7 * i) % 900 for i in range(plen - 1)])
+    out = model.generate(feats, prompt_ids=pid, max_new_tokens=20, exponential_decay_length_penalty=(6, 1.3))
+    gp = model._gen_params(None, None, (6, 1.3), 20, None, None, False, None, None, None, None, pid)
+    assert gp.prompt[:plen] == pid.tolist() and out[0, : len(gp.prompt)].tolist() == gp.prompt
+    enc = model.engine.encoder_output(2)
+    for b in range(2):
+        got = out[b].tolist()
+        ref = orc.decode(enc[b], gp)
+        want = ref.ids[: ref.ids.index(gp.eos_token_id) + 1] if gp.eos_token_id in ref.ids[len(gp.prompt):] else ref.ids
+        assert got[: len(want)] == want and all(t == gp.pad_token_id for t in got[len(want):]), (b, got, want)
+    model.engine.close()
+
+
+def test_exponential_decay_start_may_be_a_float(gpu):
+    """eval CLI call shape: --regulation-start is parsed with type=float"""
+    cfg = MedusaConfig.micro(K=4)
+    model = WhisperMedusaModel(cfg, synth.synth_state_dict(cfg, seed=11), device=gpu)
+    feats = model.extract_features(clip_for(cfg, 0))
+    a = model.generate(feats, max_new_tokens=16, exponential_decay_length_penalty=(6.0, 1.3))
+    b = model.generate(feats, max_new_tokens=16, exponential_decay_length_penalty=(6, 1.3))
+    assert torch.equal(a, b)
+    model.engine.close()
+
+
+def test_longform_chunking_equals_per_window_generation(gpu):
+    """chunk_longform=True (the reference raises for > 30 s, model.py:1213-1214): every 30 s window decoded as an independent
+    stream of one batch; a clip's output = prompt + the windows' generated ids in order."""
+    cfg = MedusaConfig.micro(K=4)
+    model = WhisperMedusaModel(cfg, synth.synth_state_dict(cfg, seed=11), device=gpu, max_batch=4)
+    n = cfg.n_mel_frames * 160
+    long_wav = np.concatenate([clip_for(cfg, 5), clip_for(cfg, 6), clip_for(cfg, 7)[: n // 2]])      # 2.5 windows
+    F = cfg.n_mel_frames
+    wins = [long_wav[i * n: (i + 1) * n] for i in range(3)]
+    feats_w = model.extract_features(wins)                                                           # [3, 80, F] (last one padded by the front end)
+    feats_long = torch.cat([feats_w[0], feats_w[1], feats_w[2][:, : F // 2]], dim=1)[None]           # [1, 80, 2.5 F]
+    with pytest.raises(NotImplementedError, match="Longform"):
+        model.generate(feats_long)
+    out = model.generate(feats_long, chunk_longform=True, max_new_tokens=14)
+    P = len(synth.default_prompt(cfg))
+    eos, pad = cfg.eos_token_id, cfg.pad_token_id
+    want = list(synth.default_prompt(cfg))
+    for j in range(3):
+        f = feats_w[j: j + 1].clone()
+        if j == 2:
+            f[..., F // 2:] = feats_long.amin()                      # the chunker pads the last window in the feature domain
+        row = model.generate(f, max_new_tokens=14)[0, P:].tolist()
+        for t in row:
+            if t in (eos, pad):
+                break
+            want.append(t)
+    got = out[0].tolist()
+    assert got[: len(want)] == want and got[len(want)] == eos
+    model.engine.close()
+
+
+def test_language_detection_groups_clips(gpu):
+    """language=None on a multilingual checkpoint: detect per clip from the base logits after <|startoftranscript|> (HF
+    detect_language via _retrieve_init_tokens), then decode each language group with its own prompt."""
+    cfg = MedusaConfig.micro(K=4)
+    cfg.is_multilingual = True
+    cfg.lang_to_id = {"<|en|>": 20, "<|de|>": 21, "<|fr|>": 22}
+    cfg.task_to_id = {"transcribe": 30, "translate": 31}
+    sd = synth.synth_state_dict(cfg, seed=43)
+    model = WhisperMedusaModel(cfg, sd, device=gpu, max_batch=3)
+    orc = Oracle(cfg, sd, sim="bf16")
+    feats = model.extract_features([clip_for(cfg, i) for i in range(3)])
+    langs = model.detect_language(feats)
+    enc = model.engine.encoder_output(3)
+    for b in range(3):
+        z = orc.decoder_pass(orc.new_state(enc[b]), [cfg.decoder_start_token_id], 0, disable_medusa=True)[0, 0]
+        want = max(cfg.lang_to_id, key=lambda k: float(z[cfg.lang_to_id[k]]))
+        top = sorted((float(z[i]) for i in cfg.lang_to_id.values()), reverse=True)
+        assert langs[b] == want or top[0] - top[1] < 1e-3
+    out = model.generate(feats, max_new_tokens=10)
+    assert model.detected_languages == langs
+    for b in range(3):
+        assert out[b, 1].item() == cfg.lang_to_id[langs[b]]
+        alone = model.generate(feats[b: b + 1], language=langs[b], max_new_tokens=10)
+        assert out[b, : alone.shape[1]].tolist() == alone[0].tolist()
+    model.engine.close()
+
+
+def _shard_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as td
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)                               # both ranks share the one GPU of the test box
+    cfg = MedusaConfig.micro(K=4)
+    model = WhisperMedusaModel(cfg, synth.synth_state_dict(cfg, seed=11), device=dev, max_batch=5)
+    feats = model.extract_features([clip_for(cfg, i) for i in range(5)])
+    out = model.generate_sharded(feats, max_new_tokens=12)
+    ref = model.generate(feats, max_new_tokens=12)
+    q.put((rank, torch.equal(out, ref), out.shape))
+    td.destroy_process_group()
+
+
+def test_generate_sharded_two_ranks_share_the_gpu(gpu):
+    """The data-parallel entry point end to end (shard_streams -> generate -> gather_token_lists) with two gloo ranks on the
+    one GPU of the test box: every rank ends with all 5 sequences, identical to a single-process generate()."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 1000
+    ps = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=300) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+    assert sorted(r[0] for r in res) == [0, 1] and all(r[1] for r in res), res

@@ -67,7 +67,7 @@ def test_large_twelve_streams_equal_single_stream_runs(large):
         eng.encode(feats[b: b + 1].contiguous())
         assert eng.decode(gp, 1)[0] == both[b], b
     model.set_micro_batches(2)                                # 2 contexts x 6 streams, concurrently
-    out = model.generate(feats, max_new_tokens=40, exponential_decay_length_penalty=(140, 1.01), suppress_tokens=gp.suppress_tokens)
+    out = model.generate(feats, language="en", max_new_tokens=40, exponential_decay_length_penalty=(140, 1.01), suppress_tokens=gp.suppress_tokens)
     model.set_micro_batches(1)
     for b in range(12):
         got = out[b].tolist()
@@ -241,3 +241,21 @@ def test_large_fp8_decode_loop_matches_the_fp8_oracle(gpu):
     got = eng.decode(gp, 1)[0]
     _check_run(eng, orc, enc, gp, got, "fp8 linear")
     eng.close()
+
+
+def test_large_encoder_big_batch_kernels_match_the_single_clip_path(large):
+    """12 clips take the 256 x 256 GEMM tiles (>= 200 tiles), one clip the 64-row tiles with the in-block K split: same
+    packed operands and rounding points, different fp32 summation order -> encoder outputs agree to bf16 rounding flips."""
+    cfg, sd, model, _ = large
+    eng = model.engine
+    n = cfg.n_mel_frames * 160
+    wav = np.stack([synth.synth_clip(70 + i, n) for i in range(12)])
+    feats = model.extract_features(wav)
+    eng.encode(feats)
+    many = eng.encoder_output(12)
+    for b in (0, 11):
+        eng.encode(feats[b: b + 1].contiguous())
+        one = eng.encoder_output(1)[0]
+        d = (many[b] - one).abs()
+        print(f"clip {b}: encoder 12-batch vs alone max|d| {float(d.max()):.4f} mean|d| {float(d.mean()):.6f}")
+        assert torch.isfinite(many[b]).all() and d.max() <= 0.12 and d.mean() <= 4e-3

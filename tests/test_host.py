@@ -121,28 +121,55 @@ def test_generate_argument_errors_match_reference():
 
 
 def test_skinny_plan_covers_all_whisper_shapes():
-    """The launch plan's invariants (K-slices are whole rounds of U fragments, <= 10 waves per block);
-    mirrors skinny_plan() in csrc/wm_skinny_gemm.h."""
-    def plan(N16, K32, lds):
+    """The launch plan's invariants (K-slices are whole rounds of U fragments, <= 10 waves per block, <= 8 fragments per slice
+    when the token operand is normalised in registers); mirrors skinny_plan() in csrc/wm_skinny_gemm.h."""
+    def plan(N16, K32, norm):
         U = 8 if K32 % 8 == 0 else 4
         q = K32 // U
+        nkmax = 8 if norm else 16
         best = 1
         for s in range(1, min(10, q) + 1):
             if q % s:
                 continue
             best = s
-            if N16 * s >= 1024 and K32 // s <= 16:
+            if N16 * s >= 1024 and K32 // s <= nkmax:
                 break
         rt = 4 if best == 1 else 1
-        if lds and 1 < best <= 5 and N16 > 256:
-            rt = 2
-        return best, rt, U
-    for d in (128, 384, 512, 768, 1024, 1280):
+        nk = K32 // best
+        RT = 2 if (best >= 2 and nk <= 8 and 256 < N16 <= 1024) else 1
+        return best, rt, U, nk, RT
+    for d in (128, 256, 384, 512, 768, 1024, 1280):
         for (N, K) in ((3 * d, d), (d, d), (4 * d, d), (d, 4 * d), (51968, d), (11 * d, d)):
-            for lds in (True, False):
-                ks, rt, U = plan(N // 16, K // 32, lds)
-                assert (K // 32) % (ks * U) == 0 and ks * rt <= 10
-                assert (K // 32) // ks in (4, 8, 12, 16)          # the batched kernel keeps a whole K-slice in registers
+            for norm in (True, False):
+                if norm and K != d:
+                    continue                                      # LayerNorm-fused GEMMs always reduce over d_model
+                ks, rt, U, nk, RT = plan(N // 16, K // 32, norm)
+                assert (K // 32) % (ks * U) == 0 and ks * rt <= 10 and ks >= RT
+                assert nk in (4, 8, 12, 16) and (not norm or nk <= 8)
+                assert all((w * ((256 + ks - 1) // ks)) >> 8 == w // ks for w in range(16))     # the kernel's division-free wave / ksplit
+
+
+def test_language_table_prompt_ids_and_generation_params():
+    from whisper_medusa import WhisperMedusaModel
+    from whisper_medusa.config import default_lang_to_id, language_token
+    table = default_lang_to_id()
+    assert len(table) == 99 and table["<|en|>"] == 50259 and table["<|zh|>"] == 50260 and table["<|su|>"] == 50357
+    assert language_token("English") == "<|en|>" and language_token("de") == "<|de|>" and language_token("<|fr|>") == "<|fr|>"
+    assert language_token("castilian") == "<|es|>"
+    with pytest.raises(ValueError, match="Unsupported language"):
+        language_token("klingon")
+    big = MedusaConfig.large_v2()
+    assert synth.default_prompt(big, "german", "translate") == [50258, 50261, 50358, 50363]
+    m = WhisperMedusaModel(big, {})
+    gp = m._gen_params("en", None, (140.0, 1.01), 32, None, None, False, None, None, None, None, torch.tensor([50361, 11, 12, 13]))
+    assert gp.prompt == [50361, 11, 12, 13, 50258, 50259, 50359, 50363] and gp.max_length == 8 + 32 and gp.begin_index == 8
+    with pytest.raises(ValueError, match="no room"):
+        m._gen_params("en", None, None, None, None, None, False, None, None, None, None, list(range(440)))
+    # the eval CLI parses the regulation start as float: the C struct field is an int32 (ADVICE r01)
+    from whisper_medusa import engine
+    g = engine.WmGenParams()
+    g.exp_decay_start = int(gp.exp_decay[0])
+    assert g.exp_decay_start == 140 and g.force_accept == 0
 
 
 def test_checkpoint_directory_roundtrip_cpu(tmp_path):

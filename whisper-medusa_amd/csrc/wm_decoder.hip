@@ -965,6 +965,32 @@ int wm_dec_pass(wm_ctx* ctx, int b0, int nb, int Mper, int mode, int medusa, int
     return wm_dec_stage_heads(ctx, nb, Mper, Mper - 1, medusa);
 }
 
+__global__ void k_advance_kvlen(int* __restrict__ kvlen, int n, int B)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < B) kvlen[s] += n;
+}
+
+// Long prompts (`prompt_ids` conditioning, model.py:1519-1529 -> HF _prepare_decoder_input_ids): all but the last <= 16 prompt
+// tokens go through the layers in 16-row chunks for their K/V only (Medusa-Block: through the extra layer as well); the
+// first iteration proper then starts from the last chunk.  Returns the number of prompt tokens left for it.
+int wm_dec_prompt_prefix(wm_ctx* ctx, int P)
+{
+    hipStream_t st = ctx->stream;
+    const int B = ctx->Bdec;
+    int left = P;
+    while (left > 16) {
+        const int n = std::min(16, left - 1);                 // keep >= 1 token for the iteration that produces logits
+        int rc = wm_dec_stage_layers(ctx, 0, B, n, 0);
+        if (rc) return -1;
+        if (ctx->block) { rc = wm_dec_stage_final(ctx, 0, B, n, 0, 1); if (rc) return -1; }
+        hipLaunchKernelGGL(k_advance_kvlen, dim3((B + 63) / 64), dim3(64), 0, st, ctx->kvlen, n, B);
+        if (hipGetLastError() != hipSuccess) { ctx->err = "k_advance_kvlen launch failed"; return -1; }
+        left -= n;
+    }
+    return left;
+}
+
 // One full Medusa iteration (or one vanilla step) over all Bdec streams, chunked to <= 16 token rows.
 int wm_dec_iteration(wm_ctx* ctx, int Mper_base)
 {

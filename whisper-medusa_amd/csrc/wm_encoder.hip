@@ -147,12 +147,98 @@ static inline hipError_t launch_gemm_tiled_bm(hipStream_t st, const bf16_t* X, c
     return hipGetLastError();
 }
 
+// =============================================================================================
+// 256 x 256 tile for big batches (>= ~200 tiles): 8 waves as 2 (token halves) x 4 (feature quarters), a wave owns 128 tokens
+// x 64 features = 8 x 4 MFMA tiles (128 accumulator registers).  Per 64-deep k-step a wave reads 24 fragments from LDS for 64
+// MFMAs (the 128 x 128 kernel: 16 for 32) and the block brings 64 KiB in for 4x the math of a 128 x 128 tile, so each
+// operand byte that crosses L2 -> LDS -> registers feeds twice the MFMAs.  Two 64 KiB stages filled by LDS-DMA: the loads of
+// step t+1 go out right after the barrier that opens step t and have its 64 MFMAs per wave (~1 us with two waves per SIMD) to
+// land.  Same packed operands, same k order, one accumulator per output: bit-identical to k_gemm_tiled<128, ., 1>.
+// SQ counters that motivated it (profiles/r02_pmc_sq_bench_b32_before.md): the 128 x 128 kernel's waves sit in s_waitcnt /
+// s_barrier 44-58 % of their cycles, LDS issue stalls 1 %, no bank conflicts — latency, not LDS bandwidth.
+// =============================================================================================
+template <class Ep>
+__global__ void __launch_bounds__(512)
+k_gemm_256(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32, int tiles_m, int tiles_n, Ep ep)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STAGE = 64 * 1024;            // 32 X fragments (16 token tiles x 2 k-tiles) then 32 W fragments
+    const int lane = threadIdx.x & 63;
+    const int wa = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wa >> 2, wn = wa & 3;
+    int bid = blockIdx.x;
+    const int nwg = tiles_m * tiles_n;
+    if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);       // XCD-aware: consecutive tiles of one weight panel share an L2
+    const int tn = bid / tiles_m, tm = bid - tn * tiles_m;
+    const int nkt = K32 >> 1;
+    const bf16_t* xg = X + (size_t)tm * 16 * K32 * 512 + lane * 8;
+    const bf16_t* wg = W + (size_t)tn * 16 * K32 * 512 + lane * 8;
+
+    auto stage_load = [&](int stage, int kt2) {
+        char* sb = smem + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int blk = wa * 8 + i;                // 0..31 X fragments, 32..63 W fragments
+            const bool isx = blk < 32;
+            const int bb = isx ? blk : blk - 32;
+            const int t = bb >> 1, kk = bb & 1;
+            glds16((isx ? xg : wg) + ((size_t)t * K32 + kt2 * 2 + kk) * 512, sb + blk * 1024);
+        }
+    };
+
+    f32x4_t acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    stage_load(0, 0);
+    for (int kt2 = 0; kt2 < nkt; ++kt2) {
+        wait_vmcnt<0>();
+        __syncthreads();                       // stage kt2 landed for everyone; everyone is done reading the other buffer
+        if (kt2 + 1 < nkt) stage_load((kt2 + 1) & 1, kt2 + 1);
+        const bf16_t* xs = reinterpret_cast<const bf16_t*>(smem + (kt2 & 1) * STAGE);
+        const bf16_t* ws = xs + 32 * 512;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t a[4], b[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = ld_frag(ws + (((wn * 4 + i) * 2 + kk) * 64 + lane) * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) b[j] = ld_frag(xs + (((wm * 8 + j) * 2 + kk) * 64 + lane) * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+        }
+    }
+    const int m0 = tm * 256 + wm * 128 + (lane & 15), n0 = tn * 256 + wn * 64 + 4 * (lane >> 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ep.store4(m0 + j * 16, n0 + i * 16, acc[i][j]);
+}
+
+template <class Ep>
+static inline hipError_t launch_gemm_256(hipStream_t st, const bf16_t* X, const bf16_t* W, int Mrows, int N, int K32, const Ep& ep)
+{
+    const int tiles_m = Mrows / 256, tiles_n = N / 256;
+    auto kern = k_gemm_256<Ep>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), 128 * 1024, st, X, W, K32, tiles_m, tiles_n, ep);
+    return hipGetLastError();
+}
+
 template <class Ep>
 static inline hipError_t launch_gemm_tiled(hipStream_t st, const bf16_t* X, const bf16_t* W, int Mrows, int N, int K32, const Ep& ep)
 {
     static const int big_nst = [] { const char* v = std::getenv("WM_ENC_GEMM_STAGES"); return v ? std::atoi(v) : 2; }();
     static const int small_ks = [] { const char* v = std::getenv("WM_ENC_GEMM_KSPLIT"); return v ? std::atoi(v) : 2; }();
     const int blocks128 = (Mrows / 128) * (N / GT_BN);
+    static const int use256 = [] { const char* v = std::getenv("WM_ENC_GEMM_256"); return v ? std::atoi(v) : 1; }();
+    if (use256 && Mrows % 256 == 0 && N % 256 == 0 && K32 % 2 == 0 && (Mrows / 256) * (N / 256) >= 200)
+        return launch_gemm_256(st, X, W, Mrows, N, K32, ep);
     // fewer than ~one block per CU with 128-row tiles: halve the tile to fill the chip and split K inside the block
     if (blocks128 < 200) {
         if (small_ks == 2 && (K32 >> 1) % 2 == 0 && (K32 >> 1) >= 8) return launch_gemm_tiled_bm<64, 3, 2>(st, X, W, Mrows, N, K32, ep);

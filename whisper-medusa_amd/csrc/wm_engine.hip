@@ -201,9 +201,9 @@ extern "C" int wm_decode_begin(wm_ctx* ctx, const wm_gen_params* gp, int B)
     WM_HIP(hipSetDevice(ctx->device));
     if (ctx->Benc < 1 || B != ctx->Benc) { ctx->err = "wm_decode_begin: call wm_encode with the same B first"; return WM_ERR_STATE; }
     const int P = gp->prompt_len, K = ctx->K, Tids = ctx->Tal;
-    if (P < 1 || P > 16 || P >= ctx->Tmax - K - 1) {
+    if (P < 1 || P >= ctx->Tmax - K - 1) {
         // same condition class as the reference's over-long prompt ValueError (model.py:1526-1529)
-        ctx->err = "wm_decode_begin: prompt length must be in [1,16]"; return WM_ERR_ARG; }
+        ctx->err = "wm_decode_begin: prompt length must be in [1, n_tgt - K - 2]"; return WM_ERR_ARG; }
     if (gp->eos_token_id < 0 || gp->eos_token_id >= ctx->V) { ctx->err = "wm_decode_begin: eos out of range"; return WM_ERR_ARG; }
     if (!gp->vanilla && gp->accept_mode == WM_ACCEPT_TYPICAL && !(gp->temperature > 0.f)) {
         ctx->err = "wm_decode_begin: typical acceptance needs temperature > 0"; return WM_ERR_ARG; }
@@ -297,7 +297,9 @@ extern "C" int wm_decode_run(wm_ctx* ctx, int max_iters, int* n_unfinished)
         // launches the base-pass graph only when the hidden state was NOT carried over from the verify pass.
         while (left > 0 && done < max_iters) {
             if (!ctx->first_done) {
-                rc = wm_dec_iteration(ctx, ctx->gp.P);            // iteration 1: the base pass consumes the P prompt tokens
+                const int p_last = wm_dec_prompt_prefix(ctx, ctx->gp.P);      // long prompts: leading chunks for their K/V only
+                if (p_last < 1) return WM_ERR_HIP;
+                rc = wm_dec_iteration(ctx, p_last);               // iteration 1: the base pass consumes the (last <= 16) prompt tokens
                 if (rc) return rc;
                 ctx->first_done = true;
             } else {
@@ -322,7 +324,9 @@ extern "C" int wm_decode_run(wm_ctx* ctx, int max_iters, int* n_unfinished)
             const int burst = std::min(poll, max_iters - done);
             for (int i = 0; i < burst; ++i) {
                 if (!ctx->first_done) {                       // iteration 1: the base pass consumes the P prompt tokens
-                    rc = wm_dec_iteration(ctx, ctx->gp.P);
+                    const int p_last = wm_dec_prompt_prefix(ctx, ctx->gp.P);
+                    if (p_last < 1) return WM_ERR_HIP;
+                    rc = wm_dec_iteration(ctx, p_last);
                     if (rc) return rc;
                     ctx->first_done = true;
                 } else {

@@ -124,6 +124,7 @@ int wm_dec_stage_final(wm_ctx* ctx, int b0, int nb, int Mper, int mode, int medu
 int wm_dec_stage_heads(wm_ctx* ctx, int nsel, int sel_mul, int sel_off, int medusa);
 int wm_dec_pass(wm_ctx* ctx, int b0, int nb, int Mper, int mode, int medusa, int all_rows);
 int wm_dec_iteration(wm_ctx* ctx, int Mper_base);   // one full iteration over all streams
+int wm_dec_prompt_prefix(wm_ctx* ctx, int P);       // K/V of a long prompt's leading chunks; returns the tokens left (<= 16), < 0 on error
 int wm_dec_iter_base(wm_ctx* ctx, int Mper_base);   // base pass layers + final LN
 int wm_dec_iter_rest(wm_ctx* ctx, int Mper_base);   // heads, candidates, verify pass, accept
 int wm_dec_profile(wm_ctx* ctx, int kernel, int rows, int reps, float* ms, double* bytes);

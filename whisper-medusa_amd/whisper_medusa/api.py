@@ -195,7 +195,13 @@ class WhisperMedusaModel:
         cfg = self.config
         prompt = _synth.default_prompt(cfg, language or "en", task or "transcribe")        # G1, model.py:1519-1537
         if prompt_ids is not None:
-            raise NotImplementedError("prompt_ids conditioning is not supported")
+            # short-form conditioning (HF _prepare_decoder_input_ids): decoder_input_ids = cat([prompt_ids, init_tokens]);
+            # `prompt_ids` comes from processor.get_prompt_ids() and already starts with <|startofprev|>
+            pid = [int(t) for t in (prompt_ids.flatten().tolist() if hasattr(prompt_ids, "flatten") else list(prompt_ids))]
+            if len(pid) + len(prompt) + cfg.medusa_num_heads + 2 > cfg.max_target_positions:
+                raise ValueError(f"prompt_ids of length {len(pid)} leave no room to generate "                      # model.py:1526-1529
+                                 f"(max_target_positions {cfg.max_target_positions})")
+            prompt = pid + prompt
         P = len(prompt)
         if max_new_tokens is not None:
             mlen = P + int(max_new_tokens)                                                # G2, model.py:1635-1639
@@ -248,7 +254,15 @@ class WhisperMedusaModel:
         if input_features.dim() != 3:
             raise ValueError("input_features must be [B, n_mels, frames]")
         if input_features.shape[-1] > self.config.n_mel_frames:
-            raise NotImplementedError("Longform generation is not supported yet")                  # model.py:1213-1214
+            if not kwargs.get("chunk_longform"):
+                raise NotImplementedError("Longform generation is not supported yet")              # model.py:1213-1214
+            return self._generate_longform(input_features, dict(kwargs, language=language, task=task, temperature=temperature,
+                                                                prompt_ids=prompt_ids))
+        if language is None and self.config.is_multilingual and kwargs.get("detect_language", True) and input_features.shape[0] >= 1 \
+                and not kwargs.get("_language_resolved"):
+            return self._generate_detecting_language(input_features, dict(kwargs, task=task, temperature=temperature, prompt_ids=prompt_ids,
+                                                                          return_dict_in_generate=return_dict_in_generate,
+                                                                          return_segments=return_segments))
         B = input_features.shape[0]
         if B > self._max_batch:
             self.set_max_batch(B)
@@ -258,6 +272,7 @@ class WhisperMedusaModel:
                               kwargs.get("vanilla", False), kwargs.get("posterior_threshold"),
                               kwargs.get("posterior_alpha"), kwargs.get("suppress_tokens"),
                               kwargs.get("begin_suppress_tokens"), prompt_ids)
+        self._last_prompt = list(gp.prompt)
         feats = input_features.to(self.device, torch.float32).contiguous()
         if return_token_timestamps:
             raise NotImplementedError("token timestamps are not supported with medusa")
@@ -308,6 +323,108 @@ class WhisperMedusaModel:
         for i, s in enumerate(out):
             t[i, : len(s)] = torch.tensor(s, dtype=torch.long)
         return t.to(self.device)
+
+    # ---- beyond the reference's generate(): language detection, long-form chunking, data-parallel sharding -------------
+    @torch.no_grad()
+    def detect_language(self, input_features: torch.Tensor) -> List[str]:
+        """Language token of every clip: argmax over the language ids of the base logits after <|startoftranscript|>
+        (HF WhisperGenerationMixin.detect_language, which the reference reaches through _retrieve_init_tokens when
+        `language` is None, model.py:1519-1537; with the Medusa model the first of the stacked heads is the base head)."""
+        cfg = self.config
+        if not cfg.is_multilingual:
+            raise ValueError("language detection needs a multilingual checkpoint")
+        feats = input_features.to(self.device, torch.float32).contiguous()
+        B = feats.shape[0]
+        if B > self._max_batch:
+            self.set_max_batch(B)
+        self.engine.encode(feats)
+        z = self.engine.forward_logits([[cfg.decoder_start_token_id]] * B, 0, True)[0, :, 0]      # [B, V]
+        toks = sorted(cfg.lang_to_id, key=lambda k: cfg.lang_to_id[k])
+        ids = torch.tensor([cfg.lang_to_id[t] for t in toks])
+        best = z[:, ids].argmax(-1)
+        return [toks[int(i)] for i in best]
+
+    def _generate_detecting_language(self, input_features, kw):
+        langs = self.detect_language(input_features)
+        rdg, rseg = kw.pop("return_dict_in_generate", None), kw.pop("return_segments", False)
+        groups: Dict[str, List[int]] = {}
+        for i, l in enumerate(langs):
+            groups.setdefault(l, []).append(i)
+        rows: List[Optional[torch.Tensor]] = [None] * len(langs)
+        for l, idx in groups.items():
+            out = self.generate(input_features[idx], language=l, _language_resolved=True, **kw)
+            for j, i in enumerate(idx):
+                rows[i] = out[j]
+        T = max(r.numel() for r in rows)
+        t = torch.full((len(rows), T), self.config.pad_token_id, dtype=torch.long, device=self.device)
+        for i, r in enumerate(rows):
+            t[i, : r.numel()] = r
+        self.detected_languages = langs
+        if rdg or rseg:
+            return {"sequences": t}
+        return t
+
+    def _generate_longform(self, input_features, kw):
+        """`chunk_longform=True`: clips longer than 30 s (the reference raises, model.py:1213-1214) are cut into 30 s windows,
+        the windows of all clips are decoded as ONE batch of independent streams (that is what the engine's batch is), and
+        each clip's windows are concatenated: prompt once, then the generated ids of every window without its EOS / padding.
+        No timestamps, no conditioning on the previous window (both unsupported with Medusa in the reference as well)."""
+        cfg = self.config
+        kw.pop("chunk_longform", None)
+        F = cfg.n_mel_frames
+        B, _, T = input_features.shape
+        n = -(-T // F)
+        x = torch.zeros(B, cfg.num_mel_bins, n * F, dtype=torch.float32, device=self.device)
+        x[..., :T] = input_features.to(self.device, torch.float32)
+        # zero-padded log-mel frames are not silence (silence maps to a constant negative level): pad in the feature domain
+        # with the clip's own minimum, which is what the log-mel of digital silence clamps to
+        if n * F > T:
+            x[..., T:] = input_features.to(self.device, torch.float32).amin(dim=(1, 2), keepdim=True)
+        win = x.view(B, cfg.num_mel_bins, n, F).permute(0, 2, 1, 3).reshape(B * n, cfg.num_mel_bins, F).contiguous()
+        kw.setdefault("detect_language", True)
+        out = self.generate(win, **kw)
+        P = len(self._last_prompt)
+        eos, pad = cfg.eos_token_id, cfg.pad_token_id
+        seqs = []
+        for b in range(B):
+            ids = list(self._last_prompt)
+            for j in range(n):
+                row = out[b * n + j, P:].tolist()
+                for t in row:
+                    if t == eos or t == pad:
+                        break
+                    ids.append(t)
+            seqs.append(ids + [eos])
+        Tm = max(len(s_) for s_ in seqs)
+        t = torch.full((B, Tm), pad, dtype=torch.long, device=self.device)
+        for i, s_ in enumerate(seqs):
+            t[i, : len(s_)] = torch.tensor(s_, dtype=torch.long)
+        return t
+
+    @torch.no_grad()
+    def generate_sharded(self, input_features: torch.Tensor, **kw) -> torch.Tensor:
+        """Data-parallel generate() over the ranks of an initialised torch.distributed group (one process per GPU, SURVEY.md
+        §8e): stream s is decoded on rank s mod world (dist.shard_streams), every rank receives all sequences
+        (dist.gather_token_lists: ragged int lists, no device collective on the data path).  Every rank passes the SAME
+        `input_features` (or at least its own shard's rows at the right indices)."""
+        import torch.distributed as td
+        from . import dist as _dist
+        B = input_features.shape[0]
+        if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+            return self.generate(input_features, **kw)
+        rank, world = td.get_rank(), td.get_world_size()
+        mine = _dist.shard_streams(B, rank, world)
+        local = []
+        if mine:
+            out = self.generate(input_features[mine], **kw)
+            local = [(s_, out[j].tolist()) for j, s_ in enumerate(mine)]
+        seqs = _dist.gather_token_lists(local)
+        pad = self.config.pad_token_id
+        T = max(len(s_) for s_ in seqs)
+        t = torch.full((B, T), pad, dtype=torch.long, device=self.device)
+        for i, s_ in enumerate(seqs):
+            t[i, : len(s_)] = torch.tensor(s_, dtype=torch.long)
+        return t
 
     def generate_from_wav(self, wav, **kw) -> torch.Tensor:
         """log-mel on the GPU, then ``generate`` — the whole hot path of SURVEY.md §8a in one call."""

@@ -19,6 +19,48 @@ from typing import List, Optional, Tuple
 
 HEAD_DIM = 64  # every Whisper size uses 64-wide attention heads
 
+# Whisper's multilingual language tokens (<|en|> = 50259 ... in this order: 99 languages for large-v2) and the names HF's
+# `language=` argument accepts besides the codes (HF tokenization_whisper.py LANGUAGES / TO_LANGUAGE_CODE).  Used when a
+# checkpoint ships no generation_config.json with its own `lang_to_id`.
+WHISPER_LANGUAGES = {
+    "en": "english", "zh": "chinese", "de": "german", "es": "spanish", "ru": "russian", "ko": "korean", "fr": "french",
+    "ja": "japanese", "pt": "portuguese", "tr": "turkish", "pl": "polish", "ca": "catalan", "nl": "dutch", "ar": "arabic",
+    "sv": "swedish", "it": "italian", "id": "indonesian", "hi": "hindi", "fi": "finnish", "vi": "vietnamese", "he": "hebrew",
+    "uk": "ukrainian", "el": "greek", "ms": "malay", "cs": "czech", "ro": "romanian", "da": "danish", "hu": "hungarian",
+    "ta": "tamil", "no": "norwegian", "th": "thai", "ur": "urdu", "hr": "croatian", "bg": "bulgarian", "lt": "lithuanian",
+    "la": "latin", "mi": "maori", "ml": "malayalam", "cy": "welsh", "sk": "slovak", "te": "telugu", "fa": "persian",
+    "lv": "latvian", "bn": "bengali", "sr": "serbian", "az": "azerbaijani", "sl": "slovenian", "kn": "kannada", "et": "estonian",
+    "mk": "macedonian", "br": "breton", "eu": "basque", "is": "icelandic", "hy": "armenian", "ne": "nepali", "mn": "mongolian",
+    "bs": "bosnian", "kk": "kazakh", "sq": "albanian", "sw": "swahili", "gl": "galician", "mr": "marathi", "pa": "punjabi",
+    "si": "sinhala", "km": "khmer", "sn": "shona", "yo": "yoruba", "so": "somali", "af": "afrikaans", "oc": "occitan",
+    "ka": "georgian", "be": "belarusian", "tg": "tajik", "sd": "sindhi", "gu": "gujarati", "am": "amharic", "yi": "yiddish",
+    "lo": "lao", "uz": "uzbek", "fo": "faroese", "ht": "haitian creole", "ps": "pashto", "tk": "turkmen", "nn": "nynorsk",
+    "mt": "maltese", "sa": "sanskrit", "lb": "luxembourgish", "my": "myanmar", "bo": "tibetan", "tl": "tagalog", "mg": "malagasy",
+    "as": "assamese", "tt": "tatar", "haw": "hawaiian", "ln": "lingala", "ha": "hausa", "ba": "bashkir", "jw": "javanese",
+    "su": "sundanese",
+}
+LANGUAGE_ALIASES = {"burmese": "my", "valencian": "ca", "flemish": "nl", "haitian": "ht", "letzeburgesch": "lb", "pushto": "ps",
+                    "panjabi": "pa", "moldavian": "ro", "moldovan": "ro", "sinhalese": "si", "castilian": "es", "mandarin": "zh"}
+
+
+def default_lang_to_id(first_id: int = 50259) -> dict:
+    return {f"<|{code}|>": first_id + i for i, code in enumerate(WHISPER_LANGUAGES)}
+
+
+def language_token(language: str) -> str:
+    """'en' | 'english' | '<|en|>' -> '<|en|>' (what HF's _retrieve_init_tokens accepts); ValueError otherwise."""
+    l = language.strip().lower()
+    if l.startswith("<|") and l.endswith("|>"):
+        return l
+    if l in WHISPER_LANGUAGES:
+        return f"<|{l}|>"
+    names = {v: k for k, v in WHISPER_LANGUAGES.items()}
+    names.update(LANGUAGE_ALIASES)
+    if l in names:
+        return f"<|{names[l]}|>"
+    raise ValueError(f"Unsupported language: {language}")
+
+
 HEADS_LINEAR = "base_head"      # reference: model.py:221-230
 HEADS_BLOCK = "medusa_block"
 
@@ -50,7 +92,8 @@ class MedusaConfig:
     pad_token_id: int = 50257
     decoder_start_token_id: int = 50258
     is_multilingual: bool = True
-    lang_to_id: dict = field(default_factory=lambda: {"<|en|>": 50259})
+    lang_to_id: dict = field(default_factory=default_lang_to_id)
+    prev_sot_token_id: int = 50361            # <|startofprev|> (prompt_ids conditioning)
     task_to_id: dict = field(default_factory=lambda: {"transcribe": 50359, "translate": 50358})
     no_timestamps_token_id: int = 50363
     suppress_tokens: Optional[List[int]] = None

@@ -129,7 +129,8 @@ def synth_state_dict(cfg: MedusaConfig, seed: int = 0, device: str = "cpu",
 def default_prompt(cfg: MedusaConfig, language: Optional[str] = "en", task: str = "transcribe") -> List[int]:
     """Decoder prompt ids (G1; reference model.py:1519-1537 via HF ``_retrieve_init_tokens``)."""
     if cfg.is_multilingual:
-        key = f"<|{language}|>" if language and not language.startswith("<|") else language
+        from .config import language_token
+        key = language_token(language or "en")
         if key not in cfg.lang_to_id:
             raise ValueError(f"Unsupported language: {language}")
         return [cfg.decoder_start_token_id, cfg.lang_to_id[key], cfg.task_to_id[task],
