@@ -219,6 +219,120 @@ def golden_medusa_utils(mu):
     return out
 
 
+TREE_CHOICES = ([1, 3, 2], [1, 2, 2, 1], [1, 2, 1, 2, 1], [1, 4, 2], [1, 2, 2, 2], [1, 1, 3, 1])
+
+
+def golden_tree_utils(mu):
+    """Known-answer vectors for candidate trees with top-k > 1: buffers, candidates and the multi-path posterior
+    (medusa_utils.py:305-421, :424-458, :526-588), straight from the reference functions."""
+    out = {}
+    for ch in TREE_CHOICES:
+        tag = "buf" + "".join(str(x) for x in ch)
+        b = mu.generate_medusa_buffers(ch, device="cpu")
+        out[tag + "_tree_indices"] = b["tree_indices"].numpy()
+        out[tag + "_position_ids"] = b["medusa_position_ids"].numpy()
+        out[tag + "_retrieve_indices"] = b["retrieve_indices"].numpy()
+        out[tag + "_attn_mask"] = b["medusa_attn_mask"][0, 0].numpy().astype(np.uint8)
+    g = torch.Generator().manual_seed(4321)
+    V = 193
+    for ci, ch in enumerate(([1, 3, 2], [1, 2, 2, 1], [1, 2, 2, 2])):
+        K = len(ch) - 1
+        b = mu.generate_medusa_buffers(ch, device="cpu")
+        n_paths = b["retrieve_indices"].shape[0]
+        tag = f"tree{ci}"
+        out[tag + "_choices"] = np.array(ch)
+        base = torch.randn(1, 1, V, generator=g) * 3
+        med = torch.randn(K, 1, 1, V, generator=g) * 3
+        c, tc = mu.generate_candidates(med, base, ch[1:], b["tree_indices"])
+        out[tag + "_cand_base"], out[tag + "_cand_med"] = base.numpy(), med.numpy()
+        out[tag + "_cand_out"], out[tag + "_cand_tree_out"] = c.numpy(), tc.numpy()
+        L, C, BT, AT, BG, AG = [], [], [], [], [], []
+        for case in range(32):
+            sharp = [1.0, 3.0, 6.0, 12.0][case % 4]
+            node_logits = torch.randn(b["tree_indices"].shape[0], V, generator=g) * sharp
+            flat = [torch.randint(0, V, (1,), generator=g)] + [torch.randperm(V, generator=g)[: ch[k]] for k in range(1, K + 1)]
+            cand = torch.cartesian_prod(*flat)
+            # make some nodes' tokens the argmax of their parent's row so that accept lengths vary across paths
+            for pth in range(n_paths):
+                for i in range(1, K + 1):
+                    if float(torch.rand(1, generator=g)) < [0.35, 0.55, 0.75][case % 3]:
+                        par, tok = int(b["retrieve_indices"][pth, i - 1]), int(cand[pth, i])
+                        node_logits[par, tok] = node_logits[par].max() + (0.5 + 0.25 * ((case + pth) % 4))
+            logits = node_logits[b["retrieve_indices"]]                      # [n_paths, K+1, V]
+            for temp, bs, as_ in ((1.0, BT, AT), (0.0, BG, AG)):
+                best, a = mu.evaluate_posterior(logits, cand, temp, 0.09, 0.3)
+                bs.append(int(best)); as_.append(int(a))
+            L.append(node_logits.numpy()); C.append(cand.numpy())
+        out[tag + "_post_node_logits"] = np.stack(L).astype(np.float32)
+        out[tag + "_post_cand"] = np.stack(C)
+        out[tag + "_post_best_typical"], out[tag + "_post_accept_typical"] = np.array(BT), np.array(AT)
+        out[tag + "_post_best_greedy"], out[tag + "_post_accept_greedy"] = np.array(BG), np.array(AG)
+        print(f"  {tag} {ch}: typical accepts {AT[:12]} best {BT[:12]} | greedy accepts {AG[:12]}")
+    return out
+
+
+@torch.no_grad()
+def ref_medusa_tree_loop(model, mu, enc, gp: GenParams, choices, use_cache: bool = False):
+    """Semi-live run over a candidate tree with top-k > 1: the reference's buffers / generate_candidates / evaluate_posterior,
+    and for the verify logits the reference forward() along EVERY path (cache-free: cat(ids, path tokens) under the ordinary
+    causal mask) — what tree_decoding (medusa_utils.py:494-521) computes per node when its attention mask is applied: a node
+    attends to the history and to its own ancestors, i.e. exactly the tokens in front of it on its path."""
+    K = len(choices) - 1
+    procs = hf_processors(gp)
+    buffers = mu.generate_medusa_buffers(choices, device="cpu")
+    ids = torch.tensor([gp.prompt], dtype=torch.long)
+    accepts, bests = [], []
+    while True:
+        L = ids.shape[1]
+        out = model(encoder_outputs=(enc[None],), decoder_input_ids=ids, use_cache=use_cache, return_dict=True)
+        logits = out.logits[:, :, -1:, :]
+        orig = procs(ids, logits[0].squeeze(0)).unsqueeze(0)
+        med = procs(ids, logits[1:].reshape(K, -1)).reshape(K, 1, 1, -1)
+        cands, tree_cands = mu.generate_candidates(med, orig, choices[1:], buffers["tree_indices"])
+        assert torch.equal(tree_cands[0][buffers["retrieve_indices"]], cands)
+        rows = []
+        for pth in range(cands.shape[0]):
+            full = torch.cat([ids, cands[pth][None]], dim=1)
+            vout = model(encoder_outputs=(enc[None],), decoder_input_ids=full, use_cache=use_cache, return_dict=True, disable_medusa=True)
+            rows.append(procs(ids, vout.logits[0][0, L:]))
+        proc = torch.stack(rows)                                                # [n_paths, K+1, V]
+        best, a = mu.evaluate_posterior(proc, cands, gp.temperature, gp.posterior_threshold, gp.posterior_alpha)
+        best, a = int(best), int(a)
+        nxt = cands[None, best, : a + 1]
+        if a == 0:
+            nxt = torch.cat([nxt, torch.argmax(proc[None, best, 0], dim=-1).unsqueeze(0)], dim=-1)
+        ids = torch.cat([ids, nxt], dim=-1)
+        accepts.append(a); bests.append(best)
+        L = ids.shape[1]
+        if (nxt == gp.eos_token_id).any() or L >= gp.max_length or L + K >= gp.hard_max_length:
+            break
+    ids = ids[0].tolist()
+    if gp.eos_token_id in ids:
+        j = ids.index(gp.eos_token_id)
+        ids = ids[: j + 1] + [gp.eos_token_id] * (len(ids) - j - 1)
+    return ids, accepts, bests
+
+
+def golden_tree_model(tag, cfg, seed, mu, choices, max_new):
+    sd = synth.synth_state_dict(cfg, seed=seed)
+    model = build_ref(cfg, sd)
+    orc = Oracle(cfg, sd, sim="fp32")
+    wav = synth.synth_clip(0, n_samples=cfg.n_mel_frames * 160)
+    feats = torch.from_numpy(log_mel(wav, cfg.num_mel_bins, cfg.n_mel_frames * 160))
+    with torch.no_grad():
+        enc = model.whisper_model.model.encoder(feats[None]).last_hidden_state[0]
+    out = {f"{tag}_choices": np.array(choices)}
+    for mode, mname in ((ACCEPT_TYPICAL, "typical"), (ACCEPT_GREEDY, "greedy")):
+        gp = gen_params_for(cfg, mode, max_new, suppress_eos=True)
+        ids, accepts, bests = ref_medusa_tree_loop(model, mu, enc, gp, choices, use_cache=cfg.is_block)
+        key = f"{tag}_{mname}"
+        out[key + "_ids"], out[key + "_accepts"], out[key + "_best"] = np.array(ids), np.array(accepts), np.array(bests)
+        r = orc.decode_tree(enc, gp, choices)
+        assert r.ids[: len(ids)] == ids and r.accept_lengths == accepts, (key, r.ids, ids, r.accept_lengths, accepts)
+        print(f"  {key}: {len(ids) - len(gp.prompt)} tokens, accepts {accepts}, best paths {bests}")
+    return out
+
+
 def gen_params_for(cfg, mode, max_new, suppress_eos=True, exp_decay=(6, 1.3)):
     prompt = synth.default_prompt(cfg)
     sup = [cfg.eos_token_id] if suppress_eos else []
@@ -256,8 +370,24 @@ def golden_model(tag, cfg, seed, mu, max_new):
     return out
 
 
+def main_tree():
+    """`python oracle/make_golden.py tree`: the candidate-tree fixtures only (the chain fixtures stay as minted)."""
+    os.makedirs(GOLD, exist_ok=True)
+    mu = load_ref_medusa_utils()
+    np.savez_compressed(os.path.join(GOLD, "medusa_tree_kat.npz"), **golden_tree_utils(mu))
+    print("candidate-tree known-answer vectors written")
+    out = {}
+    out.update(golden_tree_model("micro1221", MedusaConfig.micro(K=3), 21, mu, [1, 2, 2, 1], max_new=36))
+    out.update(golden_tree_model("micro132", MedusaConfig.micro(K=2), 22, mu, [1, 3, 2], max_new=36))
+    out.update(golden_tree_model("micro1222block", MedusaConfig.micro(K=3, heads_type="medusa_block"), 23, mu, [1, 2, 2, 2], max_new=30))
+    np.savez_compressed(os.path.join(GOLD, "reference_tree_runs.npz"), **out)
+    print("reference tree-loop vectors written")
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "tree":
+        return main_tree()
     mu = load_ref_medusa_utils()
     np.savez_compressed(os.path.join(GOLD, "medusa_utils_kat.npz"), **golden_medusa_utils(mu))
     print("medusa_utils known-answer vectors written")

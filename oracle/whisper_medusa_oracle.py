@@ -194,6 +194,81 @@ def evaluate_posterior_chain(v: torch.Tensor, cand: torch.Tensor, gp) -> Tuple[i
     return a, dbg
 
 
+# --------------------------------------------------------------------------------------
+# Candidate trees (medusa_choices with top-k > 1)
+# --------------------------------------------------------------------------------------
+def medusa_buffers(choices: List[int]) -> dict:
+    """Restatement of generate_medusa_buffers (medusa_utils.py:305-421), same steps in numpy: tree_indices (:330-341),
+    attention mask rows (:343-358), position ids (:360-363), retrieve indices (:365-379)."""
+    c = np.asarray(choices, dtype=np.int64)
+    cumprod, cumsum = np.cumprod(c), np.cumsum(c)
+    n = int(cumprod.sum())
+    mask = np.eye(n, dtype=np.float32)
+    tree_indices: List[int] = []
+    prev_sum, prev_prod = 0, 1
+    for i in range(len(c)):
+        tree_indices += list(np.tile(np.arange(prev_sum, cumsum[i]), prev_prod))
+        prev_sum, prev_prod = int(cumsum[i]), int(cumprod[i])
+    prev = -1
+    for i in range(len(c)):
+        cur = int(cumprod[:i].sum())
+        if prev != -1:
+            parent = np.repeat(np.arange(prev, cur), c[i])
+            mask[cur: cur + len(parent)] += mask[parent]
+        prev = cur
+    depth: List[int] = []
+    for i in range(len(c)):
+        depth += [i] * int(cumprod[i])
+    n_paths = int(np.prod(c))
+    retrieve = np.zeros((n_paths, len(c)), dtype=np.int64)
+    prev = 0
+    for i in range(len(c)):
+        cur = int(cumprod[: i + 1].sum())
+        retrieve[:, i] = np.repeat(np.arange(prev, cur), n_paths // (cur - prev))
+        prev = cur
+    anc = [int(sum(1 << j for j in range(n) if mask[m, j] > 0)) for m in range(n)]
+    return dict(tree_indices=[int(x) for x in tree_indices], depth=depth, mask=mask, anc=anc, retrieve=retrieve,
+                n_nodes=n, n_paths=n_paths)
+
+
+def tree_candidates(z: torch.Tensor, choices: List[int]) -> Tuple[torch.Tensor, torch.Tensor]:
+    """generate_candidates (medusa_utils.py:424-458) for processed last-row logits ``z [K+1, V]``: flat list = base argmax +
+    top-c_k of head k; returns (cartesian-product candidates [n_paths, K+1], flat list)."""
+    flat = [torch.argmax(z[0]).unsqueeze(0)]
+    for k in range(1, len(choices)):
+        flat.append(torch.topk(z[k], int(choices[k])).indices)
+    cands = torch.cartesian_prod(*flat)
+    if cands.dim() == 1:
+        cands = cands.unsqueeze(0)
+    return cands, torch.cat(flat)
+
+
+def evaluate_posterior_multi(v: torch.Tensor, cands: torch.Tensor, gp) -> Tuple[int, int, dict]:
+    """evaluate_posterior (medusa_utils.py:526-588) with several candidate paths: ``v [n_paths, K+1, V]`` processed verify
+    logits along each path, ``cands [n_paths, K+1]``.  Returns (best path, accept length, debug)."""
+    if gp.accept_mode == 0 or gp.temperature == 0:                       # :547-560
+        ok = (cands[:, 1:] == torch.argmax(v[:, :-1], dim=-1)).int()
+        al = torch.cumprod(ok, dim=1).sum(dim=1)
+        a = int(al.max())
+        best = 0 if a == 0 else int(torch.argmax(al))
+        return best, a, dict(accept_lengths=al)
+    p = torch.softmax(v[:, :-1] / gp.temperature, dim=-1)                # :562-588
+    p_c = torch.gather(p, -1, cands[:, 1:].unsqueeze(-1)).squeeze(-1)
+    H = -torch.sum(p * torch.log(p + 1e-5), dim=-1)
+    thr = torch.minimum(torch.full_like(H, gp.posterior_threshold), torch.exp(-H) * gp.posterior_alpha)
+    ok = (p_c > thr).int()
+    al = torch.cumprod(ok, dim=1).sum(dim=1)
+    a = int(al.max())
+    lik = None
+    if a == 0:
+        best = 0
+    else:
+        idx = torch.where(al == a)[0]
+        lik = torch.sum(torch.log(p_c[idx, :a]), dim=-1)
+        best = int(idx[torch.argmax(lik)])
+    return best, a, dict(accept_lengths=al, p_c=p_c, thr=thr, H=H, lik=lik)
+
+
 @dataclass
 class DecodeResult:
     ids: List[int]                      # prompt + emitted tokens, post-EOS overwrite applied
@@ -201,6 +276,8 @@ class DecodeResult:
     accept_lengths: List[int] = field(default_factory=list)
     n_iters: int = 0
     trace: List[dict] = field(default_factory=list)
+    verified: int = 0                   # decode_tree(engine_ids=...): ids confirmed identical to the engine's
+    tie: Optional[dict] = None          # ... and the first differing iteration's decision margins
 
 
 class Oracle:
@@ -314,7 +391,13 @@ class Oracle:
         vc = torch.cat([vc[:, :kv_len], self._heads(v)], dim=1)
         st["self_kv"][slot] = (kc, vc)
         mask = torch.full((T, kv_len + T), 0.0)
-        mask[:, kv_len:] = torch.triu(torch.full((T, T), -float("inf")), diagonal=1)
+        if st.get("_anc") is None:
+            mask[:, kv_len:] = torch.triu(torch.full((T, T), -float("inf")), diagonal=1)
+        else:                                                        # candidate tree: node m sees itself and its ancestors
+            for m_, bits in enumerate(st["_anc"]):                   # (the rows of medusa_attn_mask, medusa_utils.py:363-376)
+                for n_ in range(T):
+                    if not (bits >> n_) & 1:
+                        mask[m_, kv_len + n_] = -float("inf")
         a = self._attend(self._heads(q), kc, vc, mask, dec=True)
         h = h + self._lin(a, lp + ".self_attn.out_proj", dec=True)
         xn = self._ln(h, lp + ".encoder_attn_layer_norm")
@@ -339,15 +422,20 @@ class Oracle:
         return self._rd(y) @ self.sd["whisper_model.proj_out.weight"].t()      # tied, no bias (model.py:1277)
 
     def decoder_pass(self, st: dict, tokens: List[int], pos0: int, disable_medusa: bool,
-                     last_only: bool = False) -> torch.Tensor:
+                     last_only: bool = False, depth: Optional[List[int]] = None, anc: Optional[List[int]] = None) -> torch.Tensor:
         """One forward of WhisperMedusaModel (model.py:1223-1347 / 1349-1417) over ``tokens`` at
         positions ``pos0..``; appends T rows to every self-KV slot at ``st['kv_len']``.
         Returns stacked logits [n_heads_out, T, V] (n_heads_out = 1 if disable_medusa else K+1).
-        Does NOT advance ``kv_len`` (the caller applies the F13 keep rule)."""
+        Does NOT advance ``kv_len`` (the caller applies the F13 keep rule).
+        Candidate-tree verify pass: ``depth`` gives every node's position offset (medusa_position_ids, medusa_utils.py:378-384)
+        and ``anc`` its ancestor bitmask (medusa_attn_mask) — what tree_decoding (medusa_utils.py:494-521) would feed the decoder
+        if the reference applied its own mask."""
         sd, cfg, p = self.sd, self.cfg, "whisper_model.model.decoder"
         T = len(tokens)
         ids = torch.tensor(tokens, dtype=torch.long)
-        h = sd[p + ".embed_tokens.weight"][ids] + sd[p + ".embed_positions.weight"][pos0: pos0 + T]
+        pos = torch.arange(pos0, pos0 + T) if depth is None else pos0 + torch.tensor(depth, dtype=torch.long)
+        st["_anc"] = anc
+        h = sd[p + ".embed_tokens.weight"][ids] + sd[p + ".embed_positions.weight"][pos]
         for i in range(cfg.decoder_layers):
             h = self._dec_layer(f"{p}.layers.{i}", h, i, st, T)
         hf = self._ln(h, p + ".layer_norm")                       # post-final-LN state (model.py:1262)
@@ -369,6 +457,8 @@ class Oracle:
         if gp.vanilla:
             return self._decode_vanilla(enc, gp, max_iters)
         cfg = self.cfg
+        if [int(x) for x in cfg.medusa_choices] != [1] * (cfg.medusa_num_heads + 1):
+            return self.decode_tree(enc, gp, max_iters=max_iters)
         K, P, eos = cfg.medusa_num_heads, len(gp.prompt), gp.eos_token_id
         st = self.new_state(enc)
         ids = list(gp.prompt)
@@ -403,6 +493,94 @@ class Oracle:
             if max_iters is not None and res.n_iters >= max_iters:
                 break
         return self._finish(res, ids, P, eos)
+
+    # ---- the decode loop over a candidate tree ----------------------------------------------------------
+    @torch.no_grad()
+    def decode_tree(self, enc: torch.Tensor, gp, choices: Optional[List[int]] = None, engine_ids: Optional[List[int]] = None,
+                    tol_logit: float = 5e-4, tol_rel_p: float = 2e-3, max_iters: Optional[int] = None) -> DecodeResult:
+        """model.py:634-793 with ``medusa_choices = [1, c_1, .., c_K]``: candidates = cartesian product of the base argmax and
+        every head's top-c_k (medusa_utils.py:424-458), ONE verify pass over the tree's nodes at positions L + depth with the
+        ancestor mask (tree_decoding :494-521 — the reference builds that mask and never passes it on; a node's logits are
+        only meaningful with it, so the mask is part of this restatement), accept/reject over all paths (:526-588), keep the
+        K/V rows of the chosen path (model.py:378-402).
+        With ``engine_ids`` the run doubles as a parity check that survives numerical ties: res.trace receives, for the first
+        iteration whose strict outcome differs from the engine's tokens, the smallest decision margin of that iteration
+        (``tie`` entry) — a divergence is a numerical tie iff that margin is below the tolerances — and the walk stops there
+        (``res.verified`` = number of ids confirmed identical)."""
+        cfg = self.cfg
+        choices = [int(x) for x in (choices if choices is not None else cfg.medusa_choices)]
+        K, P, eos = cfg.medusa_num_heads, len(gp.prompt), gp.eos_token_id
+        assert len(choices) == K + 1 and not gp.vanilla
+        tb = medusa_buffers(choices)
+        retrieve = torch.from_numpy(tb["retrieve"])
+        st = self.new_state(enc)
+        ids = list(gp.prompt)
+        res = DecodeResult(ids=[], new_tokens=[])
+        res.verified, res.tie = len(ids), None
+        while True:
+            L, kv = len(ids), st["kv_len"]
+            z = self.decoder_pass(st, ids[kv:L], kv, disable_medusa=False, last_only=True)[:, 0]
+            st["kv_len"] = L
+            z = process_logits(z, L, gp)
+            cands, flat = tree_candidates(z, choices)
+            tree_tok = flat[torch.tensor(tb["tree_indices"])]                      # medusa_utils.py:457
+            vt = self.decoder_pass(st, tree_tok.tolist(), L, disable_medusa=True, depth=tb["depth"], anc=tb["anc"])[0]
+            st["_anc"] = None
+            vt = process_logits(vt, L, gp)                                         # every node sees the same cur_len
+            v = vt[retrieve]                                                       # [n_paths, K+1, V]   (:518-521)
+            best, a, dbg = evaluate_posterior_multi(v, cands, gp)
+            if a == 0:
+                emit = [int(cands[best, 0]), int(torch.argmax(v[best, 0]))]
+                keep = [0]
+            else:
+                emit = [int(t) for t in cands[best, : a + 1]]
+                keep = [int(n) for n in retrieve[best, :a]]
+            if engine_ids is not None:
+                tail = engine_ids[L: L + len(emit)]
+                if tail != emit[: len(tail)] or not tail:
+                    res.tie = dict(L=L, oracle_emit=emit, engine=engine_ids[L: L + K + 2],
+                                   margin=self._tree_margins(z, vt, v, cands, choices, retrieve, best, a, dbg, gp, tol_logit, tol_rel_p))
+                    break
+            # keep the chosen path's K/V rows (select_indices, model.py:378-392)
+            rows = torch.tensor([L + n for n in keep], dtype=torch.long)
+            for slot, (kc, vc) in enumerate(st["self_kv"]):
+                st["self_kv"][slot] = (torch.cat([kc[:, :L], kc[:, rows]], dim=1), torch.cat([vc[:, :L], vc[:, rows]], dim=1))
+            st["kv_len"] = L + len(keep)
+            ids += emit
+            res.verified = len(ids)
+            res.accept_lengths.append(a)
+            res.n_iters += 1
+            L = len(ids)
+            if (eos in emit) or (L >= gp.max_length) or (L + K >= gp.hard_max_length):
+                break
+            if max_iters is not None and res.n_iters >= max_iters:
+                break
+        return self._finish(res, ids, P, eos)
+
+    @staticmethod
+    def _tree_margins(z, vt, v, cands, choices, retrieve, best, a, dbg, gp, tol_logit, tol_rel_p) -> dict:
+        """Smallest margins of one tree iteration's decisions, in units of their tolerance (< 1: a numerical tie is possible)."""
+        m = {}
+        top = torch.topk(z[0], 2).values
+        m["base argmax"] = float(top[0] - top[1]) / tol_logit
+        for k in range(1, len(choices)):
+            t = torch.topk(z[k], int(choices[k]) + 1).values
+            m[f"head {k} top-{choices[k]}"] = float((t[:-1] - t[1:]).min()) / tol_logit
+        if gp.accept_mode == 0 or gp.temperature == 0:
+            t2 = torch.topk(vt, 2, dim=-1).values
+            m["verify argmax"] = float((t2[:, 0] - t2[:, 1]).min()) / tol_logit
+        else:
+            rel = ((dbg["p_c"] - dbg["thr"]).abs() / dbg["thr"])
+            m["p_c vs thr"] = float(rel.min()) / tol_rel_p
+            if dbg.get("lik") is not None and dbg["lik"].numel() > 1:
+                lk = torch.unique(dbg["lik"])
+                if lk.numel() > 1:
+                    lk = torch.sort(lk, descending=True).values
+                    m["path likelihood"] = float(lk[0] - lk[1]) / 1e-4
+            t2 = torch.topk(vt[0], 2).values
+            m["root argmax"] = float(t2[0] - t2[1]) / tol_logit
+        m["min"] = min(m.values())
+        return m
 
     # ---- tie-aware parity ----------------------------------------------------------------------
     @torch.no_grad()

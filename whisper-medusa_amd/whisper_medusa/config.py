@@ -65,6 +65,59 @@ HEADS_LINEAR = "base_head"      # reference: model.py:221-230
 HEADS_BLOCK = "medusa_block"
 
 
+MAX_TREE_NODES = 16      # the verify pass of a stream is one 16-row MFMA token tile
+MAX_TREE_PATHS = 16
+MAX_TREE_TOPK = 4
+
+
+def tree_buffers(medusa_choices) -> dict:
+    """Static index buffers of the candidate tree for ``medusa_choices = [1, c_1, .., c_K]`` (head k contributes its top-c_k
+    tokens, the tree is their cartesian product) — the same objects as the reference's ``generate_medusa_buffers``
+    (medusa_utils.py:305-421; pinned against it in tests/test_oracle_golden.py), derived directly:
+      flat candidate list  [base argmax | top-c_1 of head 1 | top-c_2 of head 2 | ...]
+      node (depth i, index j inside the depth, j in [0, prod_{l<=i} c_l)):  token = flat[cumsum_{i-1} + j % c_i],
+      parent = node (i-1, j // c_i); nodes are numbered depth by depth.
+    Returns tree_indices, depth (= medusa_position_ids), parent, anc_mask (bit n of anc_mask[m]: node n is m or an ancestor of m
+    — the rows of medusa_attn_mask), retrieve_indices [n_paths][K+1] and the per-head top-k."""
+    c = [int(x) for x in medusa_choices]
+    if not c or c[0] != 1 or any(x < 1 for x in c):
+        raise ValueError("medusa_choices must be [1, c_1, ..., c_K] with c_k >= 1")
+    K = len(c) - 1
+    cumprod, cumsum = [], []
+    p = a = 0
+    p = 1
+    for x in c:
+        p *= x; a += x
+        cumprod.append(p); cumsum.append(a)
+    tree_indices, depth, parent = [], [], []
+    start = [0]
+    for i in range(K + 1):
+        start.append(start[-1] + cumprod[i])
+    for i in range(K + 1):
+        off = cumsum[i - 1] if i else 0
+        for j in range(cumprod[i]):
+            tree_indices.append(off + j % c[i])
+            depth.append(i)
+            parent.append(-1 if i == 0 else start[i - 1] + j // c[i])
+    n = len(tree_indices)
+    anc = []
+    for m in range(n):
+        bits, q = 0, m
+        while q >= 0:
+            bits |= 1 << q
+            q = parent[q]
+        anc.append(bits)
+    n_paths = cumprod[-1]
+    retrieve = []
+    for path in range(n_paths):
+        row = []
+        for i in range(K + 1):
+            row.append(start[i] + path // (n_paths // cumprod[i]))
+        retrieve.append(row)
+    return dict(tree_indices=tree_indices, depth=depth, parent=parent, anc_mask=anc, retrieve_indices=retrieve,
+                n_nodes=n, n_paths=n_paths, topk=c[1:], n_flat=cumsum[-1])
+
+
 @dataclass
 class MedusaConfig:
     # --- Whisper dims (HF WhisperConfig names) ---
@@ -118,12 +171,22 @@ class MedusaConfig:
         if self.medusa_hidden_size != self.d_model:
             raise ValueError("medusa_hidden_size must equal d_model (residual head, model.py:210)")
         K = self.medusa_num_heads
-        if list(self.medusa_choices) != [1] * (K + 1):
-            raise ValueError(
-                "only the chain tree medusa_choices=[1]*(K+1) is supported "
-                "(the only form the reference ships; its tree mask is never applied, medusa_utils.py:494-516)")
+        ch = [int(x) for x in self.medusa_choices]
+        if len(ch) != K + 1 or ch[0] != 1:
+            raise ValueError("medusa_choices must have medusa_num_heads + 1 entries and start with 1 (the base head's argmax)")
         if K + 1 > 16:
             raise ValueError("engine supports at most 15 Medusa heads (verify pass is one 16-row MFMA tile)")
+        if ch != [1] * (K + 1):
+            # a real candidate tree (top-k > 1): beyond the reference, which builds the tree mask and never applies it
+            # (medusa_utils.py:494-516).  The verify pass is one 16-row token tile per stream.
+            tb = tree_buffers(ch)
+            if tb["n_nodes"] > MAX_TREE_NODES or tb["n_paths"] > MAX_TREE_PATHS or max(tb["topk"]) > MAX_TREE_TOPK:
+                raise ValueError(f"candidate tree {ch}: {tb['n_nodes']} nodes / {tb['n_paths']} paths / top-{max(tb['topk'])}; the engine "
+                                 f"supports <= {MAX_TREE_NODES} nodes, <= {MAX_TREE_PATHS} paths, top-k <= {MAX_TREE_TOPK}")
+
+    @property
+    def is_tree(self) -> bool:
+        return [int(x) for x in self.medusa_choices] != [1] * (self.medusa_num_heads + 1)
 
     @property
     def is_block(self) -> bool:
@@ -176,8 +239,8 @@ class MedusaConfig:
 
     # named shapes --------------------------------------------------------
     @classmethod
-    def large_v2(cls, heads_type: str = HEADS_LINEAR, K: int = 10) -> "MedusaConfig":
-        return cls(medusa_heads_type=heads_type, medusa_num_heads=K, medusa_choices=[1] * (K + 1))
+    def large_v2(cls, heads_type: str = HEADS_LINEAR, K: int = 10, medusa_choices=None) -> "MedusaConfig":
+        return cls(medusa_heads_type=heads_type, medusa_num_heads=K, medusa_choices=list(medusa_choices or [1] * (K + 1)))
 
     @classmethod
     def tiny_en(cls, heads_type: str = HEADS_LINEAR, K: int = 4) -> "MedusaConfig":
@@ -192,13 +255,13 @@ class MedusaConfig:
 
     @classmethod
     def micro(cls, heads_type: str = HEADS_LINEAR, K: int = 4, d_model: int = 128, layers: int = 2,
-              vocab: int = 1031, n_ctx: int = 96, n_tgt: int = 64) -> "MedusaConfig":
+              vocab: int = 1031, n_ctx: int = 96, n_tgt: int = 64, medusa_choices=None) -> "MedusaConfig":
         """A few-hundred-K-parameter shape for fast parity tests (not a real Whisper size)."""
         return cls(d_model=d_model, encoder_layers=layers, decoder_layers=layers,
                    encoder_attention_heads=d_model // 64, decoder_attention_heads=d_model // 64,
                    encoder_ffn_dim=4 * d_model, decoder_ffn_dim=4 * d_model, vocab_size=vocab,
                    max_source_positions=n_ctx, max_target_positions=n_tgt,
-                   medusa_num_heads=K, medusa_hidden_size=d_model, medusa_choices=[1] * (K + 1),
+                   medusa_num_heads=K, medusa_hidden_size=d_model, medusa_choices=list(medusa_choices or [1] * (K + 1)),
                    medusa_heads_type=heads_type, whisper_model_name="micro",
                    eos_token_id=vocab - 3, pad_token_id=vocab - 3, decoder_start_token_id=vocab - 2,
                    is_multilingual=False, lang_to_id={}, task_to_id={},
