@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define WM_ABI_VERSION 3
+#define WM_ABI_VERSION 4
 
 #define WM_OK 0
 #define WM_ERR_ARG (-1)      /* bad argument / unsupported configuration (reference: ValueError, model.py:225-229) */
@@ -52,11 +52,18 @@ typedef struct wm_config {
     int32_t n_mels;             /* 80 */
     int32_t n_ctx;              /* max_source_positions (1500): encoder frames per clip */
     int32_t n_tgt;              /* max_target_positions (448) */
-    int32_t medusa_heads;       /* K = medusa_num_heads, <= 15; chain tree medusa_choices=[1]*(K+1) */
+    int32_t medusa_heads;       /* K = medusa_num_heads, <= 15 */
     int32_t heads_type;         /* WM_HEADS_* */
     int32_t max_batch;          /* streams the context is sized for */
     int32_t dec_weight_fp8;     /* 1: the six matrices of every decoder layer are fp8 e4m3 (OCP) in the packed layout, with one fp32
                                  * scale per output row appended to the table (BASELINE.json configs[4]); 0: bf16 */
+    int32_t medusa_choices[16]; /* MedusaConfig.medusa_choices = [1, c_1, .., c_K] (utils/config_and_args.py:17-62; consumed by
+                                 * generate_medusa_buffers / generate_candidates, medusa_utils.py:305-458): head k contributes its
+                                 * top-c_k tokens, the candidate tree is their cartesian product.  All zero or all one = the chain
+                                 * [1]*(K+1) every shipped checkpoint uses.  Limits: sum_i prod_{l<=i} c_l <= 16 nodes (the verify
+                                 * pass of a stream is one 16-row token tile), prod c_l <= 16 paths, c_k <= 4.  Each node attends
+                                 * to the history and to its own ancestors and sits at position L + depth — the mask / position
+                                 * ids the reference builds (medusa_utils.py:343-363) and then never hands to its decoder. */
 } wm_config;
 
 /* Packed parameter blob (layout: whisper_medusa/weights.py).  The blob

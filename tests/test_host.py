@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     lib = ctypes.CDLL(built_lib)
     for name in declared:
         assert hasattr(lib, name), f"libwm.so does not export {name}"
-    assert lib.wm_abi_version() == 3
+    assert lib.wm_abi_version() == 4
     from whisper_medusa import engine
     assert sorted(engine.EXPORTS) == declared
     engine.load_library()          # prototypes resolve
@@ -96,7 +96,8 @@ def test_config_roundtrip_and_validation(tmp_path):
     with pytest.raises(ValueError, match="is not supported"):          # reference model.py:225-229
         MedusaConfig(medusa_heads_type="bogus")
     with pytest.raises(ValueError):
-        MedusaConfig(medusa_num_heads=3, medusa_choices=[1, 3, 2, 1])   # non-chain tree
+        MedusaConfig(medusa_num_heads=3, medusa_choices=[1, 3, 3, 1])   # 1 + 3 + 9 + 9 nodes: beyond the 16-row verify tile
+    assert MedusaConfig(medusa_num_heads=3, medusa_choices=[1, 3, 2, 1]).is_tree      # 1 + 3 + 6 + 6 nodes
     assert MedusaConfig.large_v2(HEADS_BLOCK).n_kv_layers == 33
 
 

@@ -13,13 +13,14 @@
 // ---------------------------------------------------------------------------------------------
 __global__ void k_embed(float* __restrict__ h, const bf16_t* __restrict__ tok_emb, const float* __restrict__ pos_emb,
                         const int* __restrict__ base, const int* __restrict__ tok_src, int tok_stride, int use_base_off,
-                        int Mper, int d, int V, int Tmax)
+                        int Mper, int d, int V, int Tmax, const int* __restrict__ depth)
 {
     const int row = blockIdx.x, s = row / Mper, r = row - s * Mper;
     const int b0 = base[s];
     int tok = tok_src[(size_t)s * tok_stride + (use_base_off ? b0 : 0) + r];
     tok = min(max(tok, 0), V - 1);
-    const int pos = min(b0 + r, Tmax - 1);
+    // candidate tree: node r sits at position L + depth(r) (medusa_position_ids, medusa_utils.py:360-363)
+    const int pos = min(b0 + (depth ? depth[r] : r), Tmax - 1);
     const bf16_t* te = tok_emb + (size_t)tok * d;
     const float* pe = pos_emb + (size_t)pos * d;
     for (int j = threadIdx.x * 4; j < d; j += blockDim.x * 4) {
@@ -140,16 +141,20 @@ __device__ __forceinline__ void kv_load(KVStep& t, const bf16_t* kp, const bf16_
 }
 
 // scores of 32 keys x 16 queries, online softmax, O^T += V^T P^T
+// Visibility of key `kidx` for this lane's query: keys below `limit` (chain: history + causal prefix; tree: history only)
+// plus, for a candidate tree, the provisional rows b0 + n of the query node's ancestors (bit n of `anc`; 0 for the chain).
 __device__ __forceinline__ void attn_step(AttnAcc& st, const KVStep& t, const bf16x8_t (&qhi)[2], const bf16x8_t (&qlo)[2],
-                                          int kb, int g, int limit)
+                                          int kb, int g, int limit, int b0 = 0, unsigned anc = 0u)
 {
     f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
     s0 = mfma16(t.k00, qhi[0], s0); s0 = mfma16(t.k01, qhi[1], s0); s0 = mfma16(t.k00, qlo[0], s0); s0 = mfma16(t.k01, qlo[1], s0);
     s1 = mfma16(t.k10, qhi[0], s1); s1 = mfma16(t.k11, qhi[1], s1); s1 = mfma16(t.k10, qlo[0], s1); s1 = mfma16(t.k11, qlo[1], s1);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        if (kb + 4 * g + r >= limit) s0[r] = -INFINITY;
-        if (kb + 16 + 4 * g + r >= limit) s1[r] = -INFINITY;
+        const int k0 = kb + 4 * g + r, k1 = k0 + 16;
+        const unsigned o0 = (unsigned)(k0 - b0), o1 = (unsigned)(k1 - b0);
+        if (k0 >= limit && !(o0 < 16u && ((anc >> o0) & 1u))) s0[r] = -INFINITY;
+        if (k1 >= limit && !(o1 < 16u && ((anc >> o1) & 1u))) s1[r] = -INFINITY;
     }
     float mx = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
     mx = rows4_max(mx);
@@ -249,7 +254,7 @@ __global__ void __launch_bounds__(FQ::kOn ? (FQ::KS > 4 ? 64 * FQ::KS : 256) : 2
 k_attn_mfma(const float* __restrict__ q, const bf16_t* __restrict__ kmat, const bf16_t* __restrict__ vtmat,
             const int* __restrict__ base, bf16_t* __restrict__ xout, size_t xplane, float* __restrict__ ml, float* __restrict__ po,
             int* __restrict__ ticket, const int* __restrict__ done, const int* __restrict__ sskip,
-            int Mper, int H, int rows_alloc, int S, int NS, int K32, int nbz, PfJob pf, FQ fq TL_ARG)
+            int Mper, int H, int rows_alloc, int S, int NS, int K32, int nbz, PfJob pf, FQ fq, const unsigned* __restrict__ anc_tab TL_ARG)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_attn[];
     if ((int)blockIdx.z >= nbz) {          // prefetch-only blocks (extra z slices): wm_skinny_gemm.h, PfJob
@@ -360,7 +365,9 @@ k_attn_mfma(const float* __restrict__ q, const bf16_t* __restrict__ kmat, const 
     }
     const int b0 = CROSS ? 0 : base[s];
     if (done && *done) return;          // all streams finished: checked after the batch went out (off the critical path)
-    const int limit = CROSS ? S : min(b0 + c + 1, rows_alloc);            // keys < limit are visible to query c
+    // keys < limit are visible to query c; a candidate-tree node sees the history and (through `anc`) its ancestors' rows
+    const unsigned anc = (!CROSS && anc_tab) ? anc_tab[c] : 0u;
+    const int limit = CROSS ? S : ((!CROSS && anc_tab) ? min(b0, rows_alloc) : min(b0 + c + 1, rows_alloc));
     int kend = CROSS ? min(S, kb + 64) : min(b0 + Mper, rows_alloc);
     bf16x8_t qhi[2], qlo[2];
 #pragma unroll
@@ -387,7 +394,7 @@ k_attn_mfma(const float* __restrict__ q, const bf16_t* __restrict__ kmat, const 
             for (; kb < kend; kb += 128) {
                 const bool second = CROSS ? false : ((kb >> 7) & 1);        // two register sets alternate: the next step is in flight
                 if (kb + 128 < kend) { if (second) kv_load<NT>(c0, kp, vp, kb + 128, c, g, lane); else kv_load<NT>(c1, kp, vp, kb + 128, c, g, lane); }
-                if (second) attn_step(st, c1, qhi, qlo, kb, g, limit); else attn_step(st, c0, qhi, qlo, kb, g, limit);
+                if (second) attn_step(st, c1, qhi, qlo, kb, g, limit, b0, anc); else attn_step(st, c0, qhi, qlo, kb, g, limit, b0, anc);
             }
         }
         const float m_run = st.m_run, l_run = st.l_run;
@@ -566,7 +573,7 @@ k_select1(const float* __restrict__ logits, GenDev gp, const unsigned char* __re
 __global__ void __launch_bounds__(256)
 k_select2(const float* __restrict__ logits, GenDev gp, const unsigned char* __restrict__ mask, const float* __restrict__ exppen,
           const int* __restrict__ L, const int* __restrict__ cand, int rps, int out_row0, const float* __restrict__ part1,
-          float* __restrict__ part2, int* __restrict__ amax, float* __restrict__ pc)
+          float* __restrict__ part2, int* __restrict__ amax, float* __restrict__ pc, const TreeDev* __restrict__ tree)
 {
     __shared__ float sh[4];
     const int row = blockIdx.y, sp = blockIdx.x, s = row / rps, i = row - s * rps;
@@ -602,13 +609,25 @@ k_select2(const float* __restrict__ logits, GenDev gp, const unsigned char* __re
         part2[(size_t)orow * SEL_SP + sp] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
         if (sp == 0) {
             amax[orow] = mi;
-            float pcv = 0.f;
-            if (i + 1 < rps) {
-                const int c = cand[s * 16 + i + 1];
-                const float vc = proc_logit(x[c], c, cur_len, gp, mask, exppen);
-                pcv = (vc == -INFINITY) ? 0.f : expf((vc - mx) * gp.inv_temp) * invz;
+            if (tree) {
+                // candidate tree: this row is node i's distribution; every child's token is scored under it (pc indexed by child)
+                if (i == 0) pc[out_row0 + s * rps] = 0.f;
+                for (int j = 0; j < 4; ++j) {
+                    const int ch = tree->children[i][j];
+                    if (ch < 0) break;
+                    const int c = cand[s * 16 + ch];
+                    const float vc = proc_logit(x[c], c, cur_len, gp, mask, exppen);
+                    pc[out_row0 + s * rps + ch] = (vc == -INFINITY) ? 0.f : expf((vc - mx) * gp.inv_temp) * invz;
+                }
+            } else {
+                float pcv = 0.f;
+                if (i + 1 < rps) {
+                    const int c = cand[s * 16 + i + 1];
+                    const float vc = proc_logit(x[c], c, cur_len, gp, mask, exppen);
+                    pcv = (vc == -INFINITY) ? 0.f : expf((vc - mx) * gp.inv_temp) * invz;
+                }
+                pc[orow] = pcv;
             }
-            pc[orow] = pcv;
         }
     }
 }
@@ -717,6 +736,182 @@ __global__ void k_accept(GenDev gp, const int* __restrict__ cand, const int* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Candidate trees (medusa_choices with top-k > 1; generate_candidates, medusa_utils.py:424-458).
+// k_tree_cand: one block per (stream, logits row k of the base pass): the top-c_k tokens of the processed row in
+// descending order (ties: lower index first), written as the tokens of every node at depth k:
+// node (k, j) <- top[j % c_k]  (tree_indices).  Row 0 (base head) has c = 1: the argmax.
+// Every thread keeps a sorted top-4 of its strided share; c rounds of block-wide argmax over the threads' heads then pop
+// the winners (the global top-c is inside the union of the per-thread top-c lists).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_tree_cand(const float* __restrict__ logits, GenDev gp, const unsigned char* __restrict__ mask, const float* __restrict__ exppen,
+            const int* __restrict__ L, const TreeDev* __restrict__ tree, int* __restrict__ cand, const int* __restrict__ done)
+{
+    __shared__ float sv[4]; __shared__ int si[4]; __shared__ int s_top[4];
+    if (done && *done) return;
+    const int rps = gp.K + 1, row = blockIdx.x, s = row / rps, k = row - s * rps;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int cur_len = L[s], c = tree->topk[k];
+    const float* x = logits + (size_t)row * gp.Vpad;
+    float t0 = -INFINITY, t1 = -INFINITY, t2 = -INFINITY, t3 = -INFINITY;
+    int i0 = 0x7fffffff, i1 = 0x7fffffff, i2 = 0x7fffffff, i3 = 0x7fffffff;
+    for (int n = tid; n < gp.V; n += 256) {
+        const float v = proc_logit(x[n], n, cur_len, gp, mask, exppen);
+        if (v > t3) {                                   // n ascends inside a thread: an equal value never displaces an earlier index
+            if (v > t0)      { t3 = t2; i3 = i2; t2 = t1; i2 = i1; t1 = t0; i1 = i0; t0 = v; i0 = n; }
+            else if (v > t1) { t3 = t2; i3 = i2; t2 = t1; i2 = i1; t1 = v; i1 = n; }
+            else if (v > t2) { t3 = t2; i3 = i2; t2 = v; i2 = n; }
+            else             { t3 = v; i3 = n; }
+        }
+    }
+    for (int j = 0; j < c; ++j) {
+        float mx = t0; int mi = i0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(mx, o, 64); const int oi = __shfl_xor(mi, o, 64);
+            if (ov > mx || (ov == mx && oi < mi)) { mx = ov; mi = oi; }
+        }
+        if (lane == 0) { sv[w] = mx; si[w] = mi; }
+        __syncthreads();
+        mx = sv[0]; mi = si[0];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) if (sv[q] > mx || (sv[q] == mx && si[q] < mi)) { mx = sv[q]; mi = si[q]; }
+        if (tid == 0) s_top[j] = (mi == 0x7fffffff) ? 0 : mi;
+        if (i0 == mi && mi != 0x7fffffff) { t0 = t1; i0 = i1; t1 = t2; i1 = i2; t2 = t3; i2 = i3; t3 = -INFINITY; i3 = 0x7fffffff; }
+        __syncthreads();
+    }
+    if (tid < tree->cumprod[k]) cand[s * 16 + tree->start[k] + tid] = s_top[tid % c];
+}
+
+// ---------------------------------------------------------------------------------------------
+// accept over a candidate tree: one wavefront per stream, lane p = candidate path p (evaluate_posterior with several
+// candidates, medusa_utils.py:526-588).  Per path the leading run of accepted nodes; the accept length is the maximum over
+// paths; the chosen path is the first of maximal length (greedy) / the one of maximal length with the largest
+// sum log p_c over its accepted nodes, first on ties (typical).  Emits the tokens, records which provisional K/V rows
+// (tree nodes) form the accepted path (k_kv_compact moves them to rows L.., model.py:378-392) and carries the accepted
+// node's post-LN state like k_accept.
+// amax / pc / part2 rows are indexed [stream][node]: node n's logits row is ITS distribution (for its children); pc[n] is
+// p_{parent(n)}(token_n).
+// ---------------------------------------------------------------------------------------------
+__global__ void k_accept_tree(GenDev gp, const TreeDev* __restrict__ tree, const int* __restrict__ cand, const int* __restrict__ amax,
+                              const float* __restrict__ pc, const float* __restrict__ part2, int* __restrict__ ids, int* __restrict__ L,
+                              int* __restrict__ kvlen, int* __restrict__ finished, int* __restrict__ niter, long long* __restrict__ hist,
+                              int* __restrict__ done, int B, int* __restrict__ carry, const float* __restrict__ hf, float* __restrict__ hf_keep,
+                              int d, int* __restrict__ hostflags, const float* __restrict__ hb, float* __restrict__ hb_keep,
+                              int* __restrict__ sel_src, int* __restrict__ sel_n, int* __restrict__ sel_base)
+{
+    const int s = blockIdx.x, lane = threadIdx.x;
+    if (finished[s]) { if (lane == 0) sel_n[s] = 0; return; }
+    const int K = gp.K, tn = tree->n_nodes, tp = tree->n_paths;
+    // threshold of every node's distribution (typical mode): lane n < tn
+    float thr_n = 0.f;
+    if (gp.accept_mode != WM_ACCEPT_GREEDY && lane < tn) {
+        const float* hp = part2 + (size_t)(s * tn + lane) * SEL_SP;
+        float hsum = 0.f;
+#pragma unroll
+        for (int k = 0; k < SEL_SP; ++k) hsum += hp[k];
+        thr_n = fminf(gp.thr, gp.alpha * expf(hsum));
+    }
+    const int p = min(lane, tp - 1);
+    int a_p = 0; float lik = 0.f; bool alive = true;
+    for (int i = 1; i <= K; ++i) {
+        const int node = tree->retrieve[p][i], par = tree->retrieve[p][i - 1];
+        const float thr = __shfl(thr_n, par, 64);
+        bool ok; float pcv = 1.f;
+        if (gp.accept_mode == WM_ACCEPT_GREEDY) ok = cand[s * 16 + node] == amax[s * tn + par];
+        else { pcv = pc[s * tn + node]; ok = pcv > thr; }
+        if (alive && ok) { a_p += 1; lik += logf(pcv); } else alive = false;
+    }
+    if (lane >= tp) { a_p = -1; lik = -INFINITY; }
+    int a = a_p;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a = max(a, __shfl_xor(a, o, 64));
+    int best = 0;
+    if (a > 0) {
+        float bl = (a_p == a) ? lik : -INFINITY; int bi = (a_p == a) ? lane : 64;
+        if (gp.accept_mode == WM_ACCEPT_GREEDY) bl = (a_p == a) ? 0.f : -INFINITY;          // first path of maximal length
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ol = __shfl_xor(bl, o, 64); const int oi = __shfl_xor(bi, o, 64);
+            if (ol > bl || (ol == bl && oi < bi)) { bl = ol; bi = oi; }
+        }
+        best = min(bi, tp - 1);
+    }
+    if (gp.force_accept >= 0) { a = min(gp.force_accept, K); best = 0; }
+    const int Lcur = L[s];
+    const int n_emit = (a == 0) ? 2 : a + 1;
+    int tok = -1;
+    if (lane < n_emit) {
+        tok = (a == 0 && lane == 1) ? amax[s * tn + 0] : cand[s * 16 + tree->retrieve[best][lane]];
+        if (Lcur + lane < gp.Tids) ids[(size_t)s * gp.Tids + Lcur + lane] = tok;
+    }
+    const bool hit_eos = __ballot(lane < n_emit && tok == gp.eos) != 0ull;
+    const bool do_carry = carry != nullptr && a > 0;
+    const int n_keep = (a == 0) ? 1 : (do_carry ? a + 1 : a);           // provisional rows that stay: path nodes 0 .. n_keep-1
+    const int my_src = (lane < n_keep) ? tree->retrieve[best][lane] : lane;
+    if (lane < 16) sel_src[s * 16 + lane] = my_src;
+    const bool moved = __ballot(lane < n_keep && my_src != lane) != 0ull;
+    if (do_carry) {
+        const int nd = tree->retrieve[best][a];
+        const float4* srcp = reinterpret_cast<const float4*>(hf + (size_t)(s * tn + nd) * d);
+        float4* dstp = reinterpret_cast<float4*>(hf_keep + (size_t)s * d);
+        for (int j = lane; j < (d >> 2); j += 64) dstp[j] = srcp[j];
+        if (hb) {
+            const float4* bs = reinterpret_cast<const float4*>(hb + (size_t)(s * tn + nd) * d);
+            float4* bd = reinterpret_cast<float4*>(hb_keep + (size_t)s * d);
+            for (int j = lane; j < (d >> 2); j += 64) bd[j] = bs[j];
+        }
+    }
+    if (lane == 0) {
+        const int Ln = Lcur + n_emit;
+        sel_n[s] = moved ? n_keep : 0; sel_base[s] = Lcur;
+        L[s] = Ln;
+        kvlen[s] = Lcur + n_keep;
+        if (carry) carry[s] = do_carry ? 1 : 0;
+        niter[s] += 1;
+        atomicAdd(reinterpret_cast<unsigned long long*>(hist + a), 1ull);
+        atomicAdd(reinterpret_cast<unsigned long long*>(hist + 16), (unsigned long long)n_emit);
+        const bool fin = hit_eos || Ln >= gp.max_length || Ln + K >= gp.hard_max_length;
+        if (fin) {
+            finished[s] = 1;
+            if (atomicAdd(done + 1, 1) == B - 1) done[0] = 1;
+        }
+        if (hostflags) { hostflags[0] = do_carry ? 1 : 0; hostflags[1] = fin ? 1 : 0; }
+    }
+}
+
+// Moves the K / V^T rows of the accepted path's nodes (provisional rows base + src[i]) to rows base + i of every KV slot:
+// one block per (head, stream, slot); all reads happen before the first write (src[i] >= i, but src[i] may be another
+// destination).  K rows are 128-B lines; V is stored as V^T MFMA fragments (vfrag_index).
+__global__ void __launch_bounds__(256)
+k_kv_compact(bf16_t* __restrict__ kc, bf16_t* __restrict__ vc, const int* __restrict__ sel_src, const int* __restrict__ sel_n,
+             const int* __restrict__ sel_base, int H, int Tal, int maxB)
+{
+    const int hd = blockIdx.x, s = blockIdx.y, slot = blockIdx.z;
+    const int n = sel_n[s];
+    if (n == 0) return;
+    const int base = sel_base[s];
+    const int i = threadIdx.x >> 4, q = threadIdx.x & 15;
+    const size_t off = (((size_t)slot * maxB + s) * H + hd) * (size_t)Tal * 64;
+    bf16_t* kp = kc + off; bf16_t* vp = vc + off;
+    uint2 kv = make_uint2(0u, 0u); bf16_t vv[4] = {0, 0, 0, 0};
+    const bool act = i < n;
+    if (act) {
+        const int src = base + sel_src[s * 16 + i];
+        kv = *reinterpret_cast<const uint2*>(kp + (size_t)src * 64 + q * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vv[j] = vp[vfrag_index(src, q * 4 + j)];
+    }
+    __syncthreads();
+    if (act) {
+        const int dst = base + i;
+        *reinterpret_cast<uint2*>(kp + (size_t)dst * 64 + q * 4) = kv;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vp[vfrag_index(dst, q * 4 + j)] = vv[j];
+    }
+}
+
 __global__ void k_accept_vanilla1(GenDev gp, int B, const int* __restrict__ amax, int* __restrict__ ids, int* __restrict__ L,
                                   int* __restrict__ kvlen, int* __restrict__ finished, int* __restrict__ niter,
                                   long long* __restrict__ hist, int* __restrict__ done)
@@ -791,7 +986,7 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
         const int zs = spf.n_jobs ? nb + (pf_round8(main_total) - main_total + (int)spf.n_jobs + H - 1) / H : nb;
         TL_SET(slot * 16 + 2 + 8192 * Mper);
         hipLaunchKernelGGL((k_attn_mfma<false, false, NoFuseQ>), dim3(1, H, zs), dim3(256), sizeof(AttnLds<1>), st, ctx->qbuf, kc, vc, base, ctx->xbuf, xpl,
-                           nullptr, nullptr, nullptr, g_skinny_done, sskip, Mper, H, ctx->Tal, 0, 1, K32, nb, spf, NoFuseQ{} TL_PASS);
+                           nullptr, nullptr, nullptr, g_skinny_done, sskip, Mper, H, ctx->Tal, 0, 1, K32, nb, spf, NoFuseQ{}, ctx->cur_anc TL_PASS);
         WM_HIP(hipGetLastError());
     }
     // 3. out_proj + residual
@@ -830,7 +1025,7 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
                 WM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
                 hipLaunchKernelGGL(kern, dim3(xgrid, H, zs), dim3(64 * (KSv > 4 ? KSv : 4)), lds, st, ctx->qbuf, kx, vx, base, ctx->xbuf, xpl, \
                                    ctx->cml, ctx->co, ctx->ticket, g_skinny_done, sskip, Mper, H, ctx->Spad, ctx->S, ctx->NS, K32, nb, xpf, \
-                                   FQ{ln, w.cq_w, w.cq_b} TL_PASS);                                                         \
+                                   FQ{ln, w.cq_w, w.cq_b}, nullptr TL_PASS);                                                         \
             } while (0)
             if (cqp.nk == 8 && cqp.ksplit == 5) WM_XFUSE(8, 5);
             else if (cqp.nk == 8 && cqp.ksplit == 4) WM_XFUSE(8, 4);
@@ -842,10 +1037,10 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
 #undef WM_XFUSE
         } else if (xattn_nt)
             hipLaunchKernelGGL((k_attn_mfma<true, true, NoFuseQ>), dim3(xgrid, H, zs), dim3(256), sizeof(AttnLds<WM_XATTN_SPB_MAX>), st, ctx->qbuf, kx, vx, base, ctx->xbuf, xpl,
-                               ctx->cml, ctx->co, ctx->ticket, g_skinny_done, sskip, Mper, H, ctx->Spad, ctx->S, ctx->NS, K32, nb, xpf, NoFuseQ{} TL_PASS);
+                               ctx->cml, ctx->co, ctx->ticket, g_skinny_done, sskip, Mper, H, ctx->Spad, ctx->S, ctx->NS, K32, nb, xpf, NoFuseQ{}, nullptr TL_PASS);
         else
             hipLaunchKernelGGL((k_attn_mfma<true, false, NoFuseQ>), dim3(xgrid, H, zs), dim3(256), sizeof(AttnLds<WM_XATTN_SPB_MAX>), st, ctx->qbuf, kx, vx, base, ctx->xbuf, xpl,
-                               ctx->cml, ctx->co, ctx->ticket, g_skinny_done, sskip, Mper, H, ctx->Spad, ctx->S, ctx->NS, K32, nb, xpf, NoFuseQ{} TL_PASS);
+                               ctx->cml, ctx->co, ctx->ticket, g_skinny_done, sskip, Mper, H, ctx->Spad, ctx->S, ctx->NS, K32, nb, xpf, NoFuseQ{}, nullptr TL_PASS);
         WM_HIP(hipGetLastError());
     }
     // 6. out_proj + residual
@@ -876,11 +1071,12 @@ int wm_dec_stage_layers(wm_ctx* ctx, int b0, int nb, int Mper, int mode)
     if (R > ctx->Rcap || Mper > 16) { ctx->err = "decode pass exceeds the row capacity of the context"; return WM_ERR_ARG; }
     if (mode == 0)
         hipLaunchKernelGGL(k_embed, dim3(R), dim3(256), 0, st, ctx->h, ctx->tok_emb, ctx->dec_pos, base,
-                           ctx->ids + (size_t)b0 * ctx->gp.Tids, ctx->gp.Tids, 1, Mper, d, ctx->V, ctx->Tmax);
+                           ctx->ids + (size_t)b0 * ctx->gp.Tids, ctx->gp.Tids, 1, Mper, d, ctx->V, ctx->Tmax, nullptr);
     else
         hipLaunchKernelGGL(k_embed, dim3(R), dim3(256), 0, st, ctx->h, ctx->tok_emb, ctx->dec_pos, base,
-                           ctx->cand + (size_t)b0 * 16, 16, 0, Mper, d, ctx->V, ctx->Tmax);
+                           ctx->cand + (size_t)b0 * 16, 16, 0, Mper, d, ctx->V, ctx->Tmax, ctx->tn ? ctx->tree->depth : nullptr);
     WM_HIP(hipGetLastError());
+    ctx->cur_anc = (mode == 1 && ctx->tn) ? ctx->tree->anc : nullptr;
     // batched hidden-state carry: a stream whose previous verify pass accepted a > 0 candidates already has the state
     // of its base token (k_accept saved it, k_rows_norm below picks it up); its rows still ride through the GEMMs
     // (the weights are streamed once for everybody) but its attention blocks exit, saving their K/V reads
@@ -1038,26 +1234,45 @@ int wm_dec_iter_rest(wm_ctx* ctx, int Mper_base)
     g_skinny_done = ctx->use_done ? ctx->done : nullptr;
     int rc = wm_dec_stage_heads(ctx, nb, Mper_base, Mper_base - 1, 1);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_select1, dim3(SEL_SP, nb * rps), dim3(256), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen, ctx->L, rps, ctx->part1);
-    WM_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_select_argmax, dim3((nb * rps + 63) / 64), dim3(64), 0, st, ctx->part1, nb * rps, 0, ctx->amax);
-    WM_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_set_cand, dim3((nb * rps + 63) / 64), dim3(64), 0, st, ctx->amax, ctx->cand, rps, nb * rps);
-    WM_HIP(hipGetLastError());
-    // (d) verify pass over the candidates at positions L..L+K, then posterior statistics
-    rc = wm_dec_pass(ctx, 0, nb, rps, 1, 0, 1);
+    const int vr = ctx->tn ? ctx->tn : rps;                  // rows per stream of the verify pass: tree nodes / chain candidates
+    if (ctx->tn) {
+        hipLaunchKernelGGL(k_tree_cand, dim3(nb * rps), dim3(256), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen, ctx->L, ctx->tree,
+                           ctx->cand, g_skinny_done);
+        WM_HIP(hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(k_select1, dim3(SEL_SP, nb * rps), dim3(256), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen, ctx->L, rps, ctx->part1);
+        WM_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_select_argmax, dim3((nb * rps + 63) / 64), dim3(64), 0, st, ctx->part1, nb * rps, 0, ctx->amax);
+        WM_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_set_cand, dim3((nb * rps + 63) / 64), dim3(64), 0, st, ctx->amax, ctx->cand, rps, nb * rps);
+        WM_HIP(hipGetLastError());
+    }
+    // (d) verify pass over the candidates (chain: positions L..L+K; tree: node n at L + depth(n), ancestor-masked), then
+    //     posterior statistics of every row
+    rc = wm_dec_pass(ctx, 0, nb, vr, 1, 0, 1);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_select1, dim3(SEL_SP, nb * rps), dim3(256), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen, ctx->L, rps, ctx->part1);
+    hipLaunchKernelGGL(k_select1, dim3(SEL_SP, nb * vr), dim3(256), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen, ctx->L, vr, ctx->part1);
     WM_HIP(hipGetLastError());
     if (gp.accept_mode == WM_ACCEPT_TYPICAL)
-        hipLaunchKernelGGL(k_select2, dim3(SEL_SP, nb * rps), dim3(256), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen, ctx->L,
-                           ctx->cand, rps, 0, ctx->part1, ctx->part2, ctx->amax, ctx->pc);
+        hipLaunchKernelGGL(k_select2, dim3(SEL_SP, nb * vr), dim3(256), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen, ctx->L,
+                           ctx->cand, vr, 0, ctx->part1, ctx->part2, ctx->amax, ctx->pc, ctx->tn ? ctx->tree : nullptr);
     else
-        hipLaunchKernelGGL(k_select_argmax, dim3((nb * rps + 63) / 64), dim3(64), 0, st, ctx->part1, nb * rps, 0, ctx->amax);
+        hipLaunchKernelGGL(k_select_argmax, dim3((nb * vr + 63) / 64), dim3(64), 0, st, ctx->part1, nb * vr, 0, ctx->amax);
     WM_HIP(hipGetLastError());
     // (f)-(j) accept / emit / compact / stop.  With host_carry the carried post-LN row goes straight to hf row 0
     // (where the skipped base pass would have put it) and the carry / finished flags to host-mapped memory; with
     // dev_carry (several streams) it goes to hf_keep[stream] and the next base pass's final LayerNorm selects it.
+    if (ctx->tn) {
+        hipLaunchKernelGGL(k_accept_tree, dim3(B), dim3(64), 0, st, gp, ctx->tree, ctx->cand, ctx->amax, ctx->pc, ctx->part2, ctx->ids, ctx->L,
+                           ctx->kvlen, ctx->finished, ctx->niter, ctx->hist, ctx->done, B, (carry || ctx->dev_carry) ? ctx->carry : nullptr, ctx->hf,
+                           carry ? ctx->hf : ctx->hf_keep, ctx->d, carry ? ctx->hostflags_dev : nullptr,
+                           ctx->block ? ctx->hblk : nullptr, carry ? ctx->hblk : ctx->hb_keep, ctx->sel_src, ctx->sel_n, ctx->sel_base);
+        WM_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_kv_compact, dim3(ctx->H, B, ctx->nkv), dim3(256), 0, st, ctx->kc, ctx->vc, ctx->sel_src, ctx->sel_n, ctx->sel_base,
+                           ctx->H, ctx->Tal, ctx->maxB);
+        WM_HIP(hipGetLastError());
+        return WM_OK;
+    }
     hipLaunchKernelGGL(k_accept, dim3(B), dim3(64), 0, st, gp, ctx->cand, ctx->amax, ctx->pc, ctx->part2, ctx->ids, ctx->L,
                        ctx->kvlen, ctx->finished, ctx->niter, ctx->hist, ctx->done, B, (carry || ctx->dev_carry) ? ctx->carry : nullptr, ctx->hf,
                        carry ? ctx->hf : ctx->hf_keep, ctx->d, carry ? ctx->hostflags_dev : nullptr,

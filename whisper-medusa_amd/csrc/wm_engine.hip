@@ -34,7 +34,7 @@ extern "C" void wm_destroy(wm_ctx* ctx)
                     ctx->enc_out, ctx->kx, ctx->vx, ctx->kc, ctx->vc, ctx->h, ctx->hblk, ctx->hf, ctx->qbuf, ctx->xbuf, ctx->fbuf,
                     ctx->ybuf, ctx->cml, ctx->co, ctx->ticket, ctx->logits, ctx->amax, ctx->pc, ctx->part1, ctx->part2, ctx->ids, ctx->L, ctx->kvlen,
                     ctx->finished, ctx->cand, ctx->niter, ctx->hist, ctx->supmask, ctx->exppen, ctx->tap_tok, ctx->done,
-                    ctx->hf_keep, ctx->hb_keep, ctx->carry, ctx->rs_table};
+                    ctx->hf_keep, ctx->hb_keep, ctx->carry, ctx->rs_table, ctx->tree, ctx->sel_src, ctx->sel_n, ctx->sel_base};
     for (void* b : bufs) if (b) hipFree(b);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
@@ -52,8 +52,48 @@ extern "C" int wm_create(const wm_config* cfg, const wm_weights* w, int device, 
     if (cfg->ffn_dim % 128 || cfg->medusa_heads < 1 || cfg->medusa_heads > 15 || cfg->max_batch < 1 || cfg->n_mels * 3 > 256 ||
         (cfg->heads_type != WM_HEADS_LINEAR && cfg->heads_type != WM_HEADS_BLOCK) || cfg->n_tgt < 8 || cfg->n_ctx < 8) {
         g_create_err = "wm_create: unsupported configuration"; return WM_ERR_ARG; }
+    // candidate tree (medusa_choices): zero / all-one entries = the chain
+    TreeDev tree{};
+    int tn = 0, tp = 0;
+    {
+        const int K = cfg->medusa_heads;
+        bool chain = true, zero = true;
+        for (int i = 0; i < 16; ++i) { zero = zero && cfg->medusa_choices[i] == 0; }
+        for (int i = 0; i <= K; ++i) chain = chain && cfg->medusa_choices[i] == 1;
+        if (!zero && !chain) {
+            const int32_t* c = cfg->medusa_choices;
+            bool ok = c[0] == 1;
+            for (int i = 0; i <= K; ++i) ok = ok && c[i] >= 1 && c[i] <= 4;
+            for (int i = K + 1; i < 16; ++i) ok = ok && c[i] == 0;
+            long nodes = 0, prod = 1;
+            for (int i = 0; ok && i <= K; ++i) { prod *= c[i]; nodes += prod; if (prod > 16 || nodes > 16) ok = false; }
+            if (!ok) { g_create_err = "wm_create: medusa_choices must be [1, c_1..c_K] with c_k in 1..4, <= 16 tree nodes and <= 16 paths"; return WM_ERR_ARG; }
+            // generate_medusa_buffers (medusa_utils.py:305-421): node (depth i, index j) has parent (i-1, j / c_i) and takes
+            // the (j % c_i)-th of head i's top-c_i tokens; path p visits node (i, p / (n_paths / cumprod_i)) at depth i
+            tree.K = K; tree.n_paths = (int)prod; tree.n_nodes = (int)nodes;
+            int cp = 1;
+            tree.start[0] = 0;
+            for (int i = 0; i <= K; ++i) { cp *= c[i]; tree.cumprod[i] = cp; tree.topk[i] = c[i]; tree.start[i + 1] = tree.start[i] + cp; }
+            for (int n = 0; n < 16; ++n) { tree.parent[n] = -1; for (int j = 0; j < 4; ++j) tree.children[n][j] = -1; }
+            for (int i = 0; i <= K; ++i)
+                for (int j = 0; j < tree.cumprod[i]; ++j) {
+                    const int n = tree.start[i] + j;
+                    tree.depth[n] = i;
+                    if (i > 0) {
+                        const int par = tree.start[i - 1] + j / c[i];
+                        tree.parent[n] = par;
+                        tree.children[par][j % c[i]] = n;
+                    }
+                    tree.anc[n] = (1u << n) | (i > 0 ? tree.anc[tree.parent[n]] : 0u);
+                }
+            for (int p = 0; p < tree.n_paths; ++p)
+                for (int i = 0; i <= K; ++i) tree.retrieve[p][i] = tree.start[i] + p / (tree.n_paths / tree.cumprod[i]);
+            tn = tree.n_nodes; tp = tree.n_paths;
+        }
+    }
     wm_ctx* ctx = new wm_ctx();
     ctx->cfg = *cfg; ctx->device = device;
+    ctx->tn = tn; ctx->tp = tp; ctx->tree_host = tree;
 #define CREATE_HIP(expr)                                                                       \
     do { hipError_t _e = (expr); if (_e != hipSuccess) {                                       \
         g_create_err = std::string(#expr) + ": " + hipGetErrorString(_e); wm_destroy(ctx); return WM_ERR_HIP; } } while (0)
@@ -136,6 +176,13 @@ extern "C" int wm_create(const wm_config* cfg, const wm_weights* w, int device, 
     CREATE_HIP(dev_alloc(&ctx->hf_keep, B * d, st));
     CREATE_HIP(dev_alloc(&ctx->hb_keep, B * d, st));
     CREATE_HIP(dev_alloc(&ctx->carry, B, st));
+    CREATE_HIP(dev_alloc(&ctx->sel_src, B * 16, st));
+    CREATE_HIP(dev_alloc(&ctx->sel_n, B, st));
+    CREATE_HIP(dev_alloc(&ctx->sel_base, B, st));
+    if (ctx->tn) {
+        CREATE_HIP(dev_alloc(&ctx->tree, 1, st));
+        CREATE_HIP(hipMemcpyAsync(ctx->tree, &ctx->tree_host, sizeof(TreeDev), hipMemcpyHostToDevice, st));
+    }
     CREATE_HIP(dev_alloc(&ctx->qbuf, RW * d, st));
     CREATE_HIP(dev_alloc(&ctx->xbuf, 2 * RW * d, st));          // hi + lo planes
     CREATE_HIP(dev_alloc(&ctx->fbuf, 2 * RW * ctx->ffn, st));

@@ -32,6 +32,19 @@ struct GenDev {
     int accept_mode, vanilla, K, V, Vpad, Tids, fuse, force_accept;
 };
 
+// Static tables of the candidate tree (device memory; medusa_utils.py:305-421).  Nodes are numbered depth by depth.
+struct TreeDev {
+    int n_nodes, n_paths, K, pad_;
+    int topk[16];           // c_k of logits row k (row 0 = base head: 1)
+    int start[17];          // first node of depth i
+    int cumprod[16];        // nodes at depth i
+    int depth[16];          // medusa_position_ids
+    unsigned anc[16];       // bit n of anc[m]: node n is m or one of its ancestors (rows of medusa_attn_mask)
+    int parent[16];
+    int children[16][4];    // -1 padded
+    int retrieve[16][16];   // [path][depth] -> node (retrieve_indices)
+};
+
 struct wm_ctx {
     wm_config cfg{};
     int device = 0;
@@ -78,6 +91,12 @@ struct wm_ctx {
     float *hb_keep = nullptr;                                               // Medusa-Block: carried block-layer output row per stream
     float *hf_cur = nullptr, *hf_keep = nullptr;                            // current chunk's rows; carried row per stream
     int* carry = nullptr;                                                   // [maxB] next base pass is redundant
+    // candidate tree (medusa_choices with top-k > 1); tn == 0: the chain
+    int tn = 0, tp = 0;
+    TreeDev tree_host{};
+    TreeDev* tree = nullptr;
+    const unsigned* cur_anc = nullptr;                                      // ancestor masks of the pass being enqueued (verify pass of a tree)
+    int *sel_src = nullptr, *sel_n = nullptr, *sel_base = nullptr;          // K/V rows of the chosen path to move: [maxB*16], [maxB], [maxB]
     bool fuse = true;
     bool host_carry = false;                                                // single-stream runs: the host skips the base pass
     float* rs_table = nullptr; int rs_og = 0, rs_nw = 0, rs_width = 0;     // cached resampling filter bank [taps][phases]
