@@ -83,7 +83,7 @@ def cpu_baseline_leg(cfg, sd, eng, gp, wav0, engine_ids, n_iters, fp8, full_budg
     ncore = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(ncore)
     sd_cpu = {k: v.float().cpu() for k, v in sd.items()}
-    orc = Oracle(cfg, sd_cpu, sim="fp32", dec_fp8=fp8)             # the reference's default dtype
+    orc = Oracle(cfg, sd_cpu, sim="fp32", dec_fp8=fp8, enc_fp8=fp8)             # the reference's default dtype
     n = cfg.n_mel_frames * 160
     wav = wav0.cpu().numpy()
 
@@ -100,7 +100,7 @@ def cpu_baseline_leg(cfg, sd, eng, gp, wav0, engine_ids, n_iters, fp8, full_budg
     t_dec, r = timed(lambda: orc.decode(enc, gp, max_iters=iters))
     ntok = len(r.ids) - len(gp.prompt)
     # parity on the same iterations, engine contract
-    orc16 = Oracle(cfg, sd_cpu, sim="bf16", dec_fp8=fp8)
+    orc16 = Oracle(cfg, sd_cpu, sim="bf16", dec_fp8=fp8, enc_fp8=fp8)
     r16 = orc16.decode(enc, gp, max_iters=iters)
     ok = engine_ids[: len(r16.ids)] == r16.ids
     first = next((i for i, (a, b) in enumerate(zip(engine_ids, r16.ids)) if a != b), min(len(engine_ids), len(r16.ids)))
@@ -139,9 +139,9 @@ def extra_config(name, heads, B, fp8, dev, logit_std, max_new, steps=2):
     from whisper_medusa import MedusaConfig, WhisperMedusaModel, ACCEPT_TYPICAL, synth, weights
     cfg = MedusaConfig.large_v2(heads, K=10)
     sd = synth.synth_state_dict(cfg, seed=0, device=str(dev), logit_std=logit_std)
-    blob, offs = weights.build_blob(cfg, sd, device=dev, dec_fp8=fp8)
+    blob, offs = weights.build_blob(cfg, sd, device=dev, dec_fp8=fp8, enc_fp8=fp8)
     del sd
-    model = WhisperMedusaModel.from_blob(cfg, blob, offs, max_batch=B, dec_weight_fp8=fp8)
+    model = WhisperMedusaModel.from_blob(cfg, blob, offs, max_batch=B, dec_weight_fp8=fp8, enc_fp8=fp8)
     eng = model.engine
     n_samp = cfg.n_mel_frames * 160
     wav = torch.from_numpy(np.stack([synth.synth_clip(500 + j, n_samp) for j in range(B)])).to(dev)
@@ -191,7 +191,8 @@ def main():
     ap.add_argument("--micro-batches", type=int, default=1,
                     help="decode the per-GPU batch as this many concurrent micro-batches (whisper_medusa/pool.py); 1 = one context")
     ap.add_argument("--fp8-weights", action="store_true",
-                    help="BASELINE configs[4]: decoder-layer matrices as fp8 e4m3 + per-row scale (bf16 hi/lo MFMA on the widened fragments)")
+                    help="BASELINE configs[4]: encoder QKV / FC1 / cross-K/V projection on the fp8 MFMA (e4m3 x e4m3, per-row scales) and the "
+                         "decoder-layer matrices stored as fp8 e4m3 + per-row scale (widened to bf16 in registers: the decode step is HBM-bound)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vanilla", action="store_true",
                     help="skip the vanilla-greedy anchor (PMC passes: only Medusa iterations in the counter totals)")
@@ -224,12 +225,12 @@ def main():
     blob = offs = sd = None
     if rank == 0:
         sd = synth.synth_state_dict(cfg, seed=0, device=str(dev), logit_std=args.logit_std)
-        blob, offs = weights.build_blob(cfg, sd, device=dev, dec_fp8=args.fp8_weights)
+        blob, offs = weights.build_blob(cfg, sd, device=dev, dec_fp8=args.fp8_weights, enc_fp8=args.fp8_weights)
     t0 = time.time()
     blob, offs = wd.broadcast_blob(blob, offs, device=dev)
     torch.cuda.synchronize()
     t_bcast = time.time() - t0
-    model = WhisperMedusaModel.from_blob(cfg, blob, offs, max_batch=B, dec_weight_fp8=args.fp8_weights)
+    model = WhisperMedusaModel.from_blob(cfg, blob, offs, max_batch=B, dec_weight_fp8=args.fp8_weights, enc_fp8=args.fp8_weights)
     eng = model.engine
 
     # ---- inputs resident in HBM ----
@@ -243,7 +244,7 @@ def main():
     pool = None
     if args.micro_batches > 1:
         from whisper_medusa.pool import ContextPool
-        pool = ContextPool(cfg, blob, offs, args.micro_batches, B, dec_weight_fp8=args.fp8_weights)
+        pool = ContextPool(cfg, blob, offs, args.micro_batches, B, dec_weight_fp8=args.fp8_weights, enc_fp8=args.fp8_weights)
 
     def step():
         wav = wavs[step_no[0] % n_sets]
@@ -316,7 +317,7 @@ def main():
         "metric": "decoded_tokens_per_sec", "value": round(tokens_all / elapsed, 2), "unit": "tokens/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16" if not args.fp8_weights else "bf16 (fp8 e4m3 decoder-layer weights)", "data": "synthetic",
+        "vs_baseline": None, "dtype": "bf16" if not args.fp8_weights else "bf16 + fp8 e4m3 (fp8 MFMA in the encoder's LayerNorm-fed GEMMs and the cross-K/V projection, fp8-stored decoder-layer weights)", "data": "synthetic",
         "config": {"workload": f"whisper-{args.model} + medusa-{args.heads} K={cfg.medusa_num_heads}, "
                                f"{B} x 30 s clip(s) per GPU, log-mel+encoder+decode, max_new_tokens={args.max_new}, "
                                f"typical acceptance (T=1.0), hipGraph decode loop, random-init weights (logit_std={args.logit_std})",
@@ -354,7 +355,7 @@ def main():
             extra = []
             for name, heads_x, Bx, fp8x in (("configs[2] large-v2 + Medusa-Block K=10, 32 streams", "medusa_block", 32, False),
                                             ("configs[1] shape at 32 streams (Medusa-Linear)", "base_head", 32, False),
-                                            ("configs[4] fp8 decoder weights + Medusa-Linear, 32 streams", "base_head", 32, True)):
+                                            ("configs[4] fp8 (encoder fp8 MFMA + fp8 decoder weights) + Medusa-Linear, 32 streams", "base_head", 32, True)):
                 try:
                     extra.append(extra_config(name, heads_x, Bx, fp8x, dev, args.logit_std, args.max_new))
                 except Exception as e:  # noqa: BLE001

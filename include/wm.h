@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define WM_ABI_VERSION 4
+#define WM_ABI_VERSION 5
 
 #define WM_OK 0
 #define WM_ERR_ARG (-1)      /* bad argument / unsupported configuration (reference: ValueError, model.py:225-229) */
@@ -64,6 +64,11 @@ typedef struct wm_config {
                                  * pass of a stream is one 16-row token tile), prod c_l <= 16 paths, c_k <= 4.  Each node attends
                                  * to the history and to its own ancestors and sits at position L + depth — the mask / position
                                  * ids the reference builds (medusa_utils.py:343-363) and then never hands to its decoder. */
+    int32_t enc_fp8;            /* 1: the encoder GEMMs fed by a LayerNorm (QKV, FC1) and the cross-K/V projection run on the CDNA4
+                                 * fp8 MFMA (BASELINE.json configs[4]): e4m3 weights with one fp32 scale per output row — 4 table
+                                 * entries per encoder layer (qkv, qkv scales, fc1, fc1 scales) + 2 (cross-K/V) appended after the
+                                 * decoder scales, the bf16 entries of those matrices may then be 16-byte placeholders — and the
+                                 * LayerNorm output quantised to e4m3 with one scale per token row; 0: bf16 */
 } wm_config;
 
 /* Packed parameter blob (layout: whisper_medusa/weights.py).  The blob

@@ -283,9 +283,15 @@ class DecodeResult:
 class Oracle:
     """Functional Whisper-Medusa over a plain state dict (reference key layout)."""
 
-    def __init__(self, cfg, sd: Dict[str, torch.Tensor], sim: str = "fp32", dec_fp8: bool = False):
+    def __init__(self, cfg, sd: Dict[str, torch.Tensor], sim: str = "fp32", dec_fp8: bool = False, enc_fp8: bool = False):
         assert sim in ("fp32", "bf16")
         self.cfg, self.sim = cfg, sim
+        # BASELINE.json configs[4] "fp8 MFMA" (not a reference feature): the encoder GEMMs whose operand is a LayerNorm output
+        # (q/k/v, fc1) and the cross-K/V projection multiply e4m3 by e4m3: the LayerNorm output row x is quantised as
+        # q_x = rne_e4m3(x / s_x), s_x = max|x| / 448 (1 for a zero row), the weight row likewise, and the product is
+        # ((q_x . q_w) * s_x) * s_w in fp32.  The cross-K/V projection quantises the STORED (bf16) encoder output.
+        self.enc_fp8 = enc_fp8
+        self.w8: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
         self.sd = {k: v.detach().to(torch.float32).cpu() for k, v in sd.items()}
         self.H = cfg.d_model // HEAD_DIM
         if "whisper_model.proj_out.weight" not in self.sd:
@@ -324,6 +330,24 @@ class Oracle:
             y = y + self.sd[prefix + ".bias"]
         return y
 
+    @staticmethod
+    def _q8_rows(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        amax = x.abs().amax(dim=1)
+        scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+        q = (x / scale[:, None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32)
+        return q, scale
+
+    def _lin8(self, x, prefix, bias=True):
+        """fp8-MFMA linear: e4m3 activations (row scale) x e4m3 weights (row scale), fp32 accumulation."""
+        if prefix not in self.w8:
+            self.w8[prefix] = self._q8_rows(self.sd[prefix + ".weight"])
+        wq, ws = self.w8[prefix]
+        xq, xs = self._q8_rows(x)
+        y = ((xq @ wq.t()) * xs[:, None]) * ws[None, :]
+        if bias and (prefix + ".bias") in self.sd:
+            y = y + self.sd[prefix + ".bias"]
+        return y
+
     def _ln(self, x, prefix):
         return F.layer_norm(x, (x.shape[-1],), self.sd[prefix + ".weight"], self.sd[prefix + ".bias"], 1e-5)
 
@@ -355,13 +379,14 @@ class Oracle:
         for i in range(self.cfg.encoder_layers):
             lp = f"{p}.layers.{i}"
             xn = self._ln(h, lp + ".self_attn_layer_norm")
-            q = self._r(self._lin(xn, lp + ".self_attn.q_proj") * HEAD_DIM ** -0.5)
-            k = self._r(self._lin(xn, lp + ".self_attn.k_proj", bias=False))
-            v = self._r(self._lin(xn, lp + ".self_attn.v_proj"))
+            lin = self._lin8 if self.enc_fp8 else self._lin
+            q = self._r(lin(xn, lp + ".self_attn.q_proj") * HEAD_DIM ** -0.5)
+            k = self._r(lin(xn, lp + ".self_attn.k_proj", bias=False))
+            v = self._r(lin(xn, lp + ".self_attn.v_proj"))
             a = self._attend(self._heads(q), self._heads(k), self._heads(v), round_p=True)
             h = h + self._lin(a, lp + ".self_attn.out_proj")
             xn = self._ln(h, lp + ".final_layer_norm")
-            h = h + self._lin(F.gelu(self._lin(xn, lp + ".fc1")), lp + ".fc2")
+            h = h + self._lin(F.gelu(lin(xn, lp + ".fc1")), lp + ".fc2")
         return self._r(self._ln(h, p + ".layer_norm"))
 
     # ---- F2 cross-KV projection (HF:modeling_whisper.py:322-335; Block: model.py:1382-1393) -----
@@ -373,9 +398,10 @@ class Oracle:
 
     def cross_kv(self, enc: torch.Tensor):
         out = []
+        lin = self._lin8 if self.enc_fp8 else self._lin
         for lp in self._kv_layer_prefixes():
-            k = self._r(self._lin(enc, lp + ".encoder_attn.k_proj", bias=False))
-            v = self._r(self._lin(enc, lp + ".encoder_attn.v_proj"))
+            k = self._r(lin(enc, lp + ".encoder_attn.k_proj", bias=False))
+            v = self._r(lin(enc, lp + ".encoder_attn.v_proj"))
             out.append((self._heads(k), self._heads(v)))
         return out
 

@@ -243,6 +243,39 @@ def test_large_fp8_decode_loop_matches_the_fp8_oracle(gpu):
     eng.close()
 
 
+def test_large_fp8_mfma_encoder_and_decode_loop(gpu):
+    """configs[4] at the real shape with the fp8 MFMA encoder path on top of the fp8 decoder weights: encoder output within the
+    fp8 tolerance of the oracle's fp8 mode (stated in tests/test_gpu_parity.py::test_fp8_mfma_encoder_matches_the_fp8_oracle),
+    decode loop token-exact against the oracle on the engine's encoder output; 12 clips take the 256 x 256 fp8 tile kernel."""
+    from oracle.whisper_medusa_oracle import Oracle, log_mel
+    cfg = MedusaConfig.large_v2("base_head", K=10)
+    sd = synth.synth_state_dict(cfg, seed=5, device=str(gpu), logit_std=4.5)
+    model = WhisperMedusaModel(cfg, sd, device=gpu, max_batch=12, dec_weight_fp8=True, enc_fp8=True)
+    eng = model.engine
+    orc = Oracle(cfg, _cpu_sd(sd), sim="bf16", dec_fp8=True, enc_fp8=True)
+    n = cfg.n_mel_frames * 160
+    wav = synth.synth_clip(61, n)
+    f_np = log_mel(wav, cfg.num_mel_bins, n)
+    feats = torch.from_numpy(f_np[None]).to(gpu)
+    eng.encode(feats)
+    enc = eng.encoder_output(1)[0]
+    ref = orc.encode(torch.from_numpy(f_np))
+    d = (enc - ref).abs()
+    print(f"large fp8 encoder: max|d| {float(d.max()):.4f} mean|d| {float(d.mean()):.5f} (|ref| mean {float(ref.abs().mean()):.3f})")
+    assert torch.isfinite(enc).all() and d.max() <= 0.5 and d.mean() <= 2.5e-2
+    gp = synth.bench_gen_params(cfg, max_new_tokens=NEW_TOKENS, accept_mode=ACCEPT_TYPICAL)
+    got = eng.decode(gp, 1)[0]
+    _check_run(eng, orc, enc, gp, got, "fp8 mfma linear")
+    wavs = np.stack([synth.synth_clip(80 + i, n) for i in range(12)])
+    wavs[0] = wav
+    eng.encode(model.extract_features(wavs))
+    many = eng.encoder_output(12)[0]
+    dm = (many - enc).abs()
+    print(f"large fp8 encoder 12-batch (256-tile kernel) vs alone: max|d| {float(dm.max()):.4f} mean|d| {float(dm.mean()):.6f}")
+    assert dm.max() <= 0.5 and dm.mean() <= 1.5e-2
+    eng.close()
+
+
 def test_large_encoder_big_batch_kernels_match_the_single_clip_path(large):
     """12 clips take the 256 x 256 GEMM tiles (>= 200 tiles), one clip the 64-row tiles with the in-block K split: same
     packed operands and rounding points, different fp32 summation order -> encoder outputs agree to bf16 rounding flips."""

@@ -333,6 +333,55 @@ def test_fp8_decoder_weights_match_the_fp8_oracle(gpu, heads):
     eng.close(); ref16.engine.close()
 
 
+@pytest.mark.parametrize("tag", ["micro", "tiny", "microblock"])
+def test_fp8_mfma_encoder_matches_the_fp8_oracle(gpu, tag):
+    """BASELINE configs[4] "CDNA4 fp8 MFMA": the encoder GEMMs fed by a LayerNorm (QKV, FC1) and the cross-K/V projection run
+    e4m3 x e4m3 on v_mfma_f32_16x16x32_fp8_fp8 (weights: per-row scale, LayerNorm output: per-token-row scale).
+    Tolerances (oracle: sim="bf16", enc_fp8=True — the same quantisation points):
+      encoder output   max |d| <= 0.35, mean |d| <= 2e-2 on O(1) values: a value landing on the other side of an e4m3
+                       rounding boundary moves by 6 %, where a bf16 flip moved it by 0.4 % (bf16 path: 0.12 / 6e-3)
+      cross K/V        given the ENGINE's stored encoder output both sides quantise identical values to identical e4m3
+                       codes, so the projection differs by fp32 summation order only: the bf16-path tolerance
+      token ids        bit-exact (tie-aware) against the oracle run on the engine's encoder output, fp8 decoder weights too."""
+    mk, seed = SHAPES[tag]
+    cfg = mk()
+    sd = synth.synth_state_dict(cfg, seed=seed)
+    B = 3
+    model = WhisperMedusaModel(cfg, sd, device=gpu, max_batch=B, dec_weight_fp8=True, enc_fp8=True)
+    ref16 = WhisperMedusaModel(cfg, sd, device=gpu, max_batch=1)
+    eng = model.engine
+    orc = Oracle(cfg, sd, sim="bf16", dec_fp8=True, enc_fp8=True)
+    n = cfg.n_mel_frames * 160
+    wavs = [clip_for(cfg, i) for i in range(B)]
+    wavs[-1] = wavs[-1][: n // 3]
+    feats_np = np.stack([log_mel(w, cfg.num_mel_bins, n) for w in wavs])
+    feats = torch.from_numpy(feats_np).to(gpu)
+    eng.encode(feats)
+    enc = eng.encoder_output(B)
+    for b in range(B):
+        ref = orc.encode(torch.from_numpy(feats_np[b]))
+        d = (enc[b] - ref).abs()
+        print(f"fp8 encoder [{tag}] clip {b}: max|d| {float(d.max()):.4f} mean|d| {float(d.mean()):.5f} (|ref| mean {float(ref.abs().mean()):.3f})")
+        assert torch.isfinite(enc[b]).all() and d.max() <= 0.35 and d.mean() <= 2e-2
+    ref16.engine.encode(feats[:1].contiguous())
+    d16 = (ref16.engine.encoder_output(1)[0] - enc[0]).abs()
+    assert d16.mean() > 2e-3                                     # it really is a different (quantised) encoder
+    # cross K/V from the engine's stored encoder output
+    kv = orc.cross_kv(enc[0])
+    for layer in (0, cfg.n_kv_layers - 1):
+        k, v = eng.cross_kv(layer, 0, 1)
+        rk, rv = kv[layer][0][1], kv[layer][1][1]
+        assert (k - rk).abs().max() <= 0.07 and (v - rv).abs().max() <= 0.07, (layer, float((k - rk).abs().max()), float((v - rv).abs().max()))
+        assert (k - rk).abs().mean() <= 2e-3 and (v - rv).abs().mean() <= 2e-3
+    for mode in (ACCEPT_TYPICAL, ACCEPT_GREEDY):
+        gp = golden_gen_params(cfg, mode, 32)
+        eng.encode(feats)
+        both = eng.decode(gp, B)
+        for b in range(B):
+            check_tokens(orc, enc[b], gp, both[b], ("fp8 mfma", tag, mode, b))
+    eng.close(); ref16.engine.close()
+
+
 def test_generate_api_end_to_end(rig):
     """from wav: log-mel -> encoder -> decode through the drop-in generate() (README.md:101-142 call shape)."""
     feats = rig.model.extract_features(rig.wavs[:1])

@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     lib = ctypes.CDLL(built_lib)
     for name in declared:
         assert hasattr(lib, name), f"libwm.so does not export {name}"
-    assert lib.wm_abi_version() == 4
+    assert lib.wm_abi_version() == 5
     from whisper_medusa import engine
     assert sorted(engine.EXPORTS) == declared
     engine.load_library()          # prototypes resolve

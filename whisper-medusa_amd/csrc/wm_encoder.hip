@@ -256,6 +256,202 @@ static inline hipError_t launch_gemm_tiled(hipStream_t st, const bf16_t* X, cons
 }
 
 // =============================================================================================
+// fp8 (OCP e4m3) MFMA GEMMs of the encoder (BASELINE configs[4]): out[m][n] = xs[m] * ws[n] * sum_k X8[m][k] W8[n][k] on
+// v_mfma_f32_16x16x32_fp8_fp8 (twice the bf16 rate, half the operand bytes through L2 -> LDS -> registers).
+//   X8: the LayerNorm output of a token row, quantised to e4m3 with ONE fp32 scale per row (xs[m] = max|row| / 448): the
+//       LayerNorm kernel has the whole row in one wave, so the scale costs one wave reduction.  Only the GEMMs whose operand
+//       IS a LayerNorm output take this path (QKV, FC1, cross-K/V projection: 7/12 of the encoder's GEMM flops + the
+//       projection); out-proj and FC2 read attention / GELU outputs whose row maximum is spread over blocks and stay bf16.
+//   W8: e4m3 with one fp32 scale per output row (weights.quantize_rows_e4m3).
+// Packed fp8 layout (both operands): [R/16][K/64][64 lanes][16 B] — lane l holds row l & 15, and for the two 32-wide k-tiles
+// of the 64-k unit the 8 values k = 8 (l >> 4) .. +8 (bytes 0..7: first k-tile, 8..15: second).  One unit = 1 KiB = one
+// LDS-DMA instruction; one 16-B ds_read feeds two MFMAs.  The kernels are the bf16 ones with half the fragments per k-step
+// and deeper rings in the same LDS.
+// =============================================================================================
+__device__ __forceinline__ f32x4_t mfma16_f8(long a, long b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a, b, c, 0, 0, 0); }
+
+__device__ __host__ __forceinline__ size_t f8_index(int row, int k, int K64) {       // byte index of (row, k) in the packed fp8 layout
+    return ((size_t)(row >> 4) * K64 + (k >> 6)) * 1024 + (size_t)(((row & 15) + 16 * ((k & 31) >> 3)) * 16 + ((k >> 5) & 1) * 8 + (k & 7));
+}
+
+template <class Ep>
+struct EpScaled {              // fp8 GEMM: dequantise the accumulator (token-row scale, then weight-row scale) in front of the epilogue
+    Ep ep; const float* xs; const float* ws;
+    __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const {
+        const float s = xs[m];
+        const float4 w = *reinterpret_cast<const float4*>(ws + n);
+        ep.store4(m, n, f32x4_t{(v[0] * s) * w.x, (v[1] * s) * w.y, (v[2] * s) * w.z, (v[3] * s) * w.w});
+    }
+};
+
+struct F8Frag { long lo, hi; };
+__device__ __forceinline__ F8Frag ld_f8(const unsigned char* p) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p);
+    F8Frag f;
+    f.lo = (long)(((unsigned long long)v.y << 32) | v.x);
+    f.hi = (long)(((unsigned long long)v.w << 32) | v.z);
+    return f;
+}
+
+template <int BM, int NST, class Ep>
+__global__ void __launch_bounds__(256)
+k_gemm_f8(const unsigned char* __restrict__ X, const unsigned char* __restrict__ W, int K64, int tiles_m, int tiles_n, Ep ep)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int XB = BM / 16;                // X units per stage (one 64-k unit per token tile)
+    constexpr int NB = XB + 8;                 // + 8 W units (128 features)
+    constexpr int STAGE = NB * 1024;
+    constexpr int LPW = NB / 4;
+    constexpr int MJ = BM / 32;
+    static_assert(NB % 4 == 0, "stage must split evenly over 4 waves");
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wn = w >> 1, wm = w & 1;
+    int bid = blockIdx.x;
+    const int nwg = tiles_m * tiles_n;
+    if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+    const int tn = bid / tiles_m, tm = bid - tn * tiles_m;
+    const unsigned char* xg = X + (size_t)tm * XB * K64 * 1024 + lane * 16;
+    const unsigned char* wg = W + (size_t)tn * 8 * K64 * 1024 + lane * 16;
+
+    auto stage_load = [&](int stage, int kt) {
+        char* sb = smem + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < LPW; ++i) {
+            const int blk = w * LPW + i;
+            const bool isx = blk < XB;
+            const int t = isx ? blk : blk - XB;
+            const unsigned char* src = (isx ? xg : wg) + ((size_t)t * K64 + kt) * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(sb + blk * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4_t acc[4][MJ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st)
+        if (st < K64) stage_load(st, st);
+
+    for (int kt = 0; kt < K64; ++kt) {
+        const int younger = min(K64 - 1, kt + NST - 2) - kt;
+        if (NST >= 4 && younger >= 2) wait_vmcnt<2 * LPW>();
+        else if (NST >= 3 && younger >= 1) wait_vmcnt<LPW>();
+        else wait_vmcnt<0>();
+        __syncthreads();
+        if (kt + NST - 1 < K64) stage_load((kt + NST - 1) % NST, kt + NST - 1);
+        const unsigned char* xs = reinterpret_cast<const unsigned char*>(smem + (kt % NST) * STAGE);
+        const unsigned char* ws = xs + XB * 1024;
+        F8Frag a[4], b[MJ];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = ld_f8(ws + ((wn * 4 + i) * 64 + lane) * 16);
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) b[j] = ld_f8(xs + ((wm * MJ + j) * 64 + lane) * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < MJ; ++j) { acc[i][j] = mfma16_f8(a[i].lo, b[j].lo, acc[i][j]); acc[i][j] = mfma16_f8(a[i].hi, b[j].hi, acc[i][j]); }
+    }
+    const int m0 = tm * BM + wm * (BM / 2) + (lane & 15), n0 = tn * GT_BN + wn * 64 + 4 * (lane >> 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) ep.store4(m0 + j * 16, n0 + i * 16, acc[i][j]);
+}
+
+// 256 x 256 tile, 8 waves (2 x 4), wave = 128 tokens x 64 features; a 64-k step is 32 KiB (16 X + 16 W units): three stages
+template <class Ep>
+__global__ void __launch_bounds__(512)
+k_gemm_f8_256(const unsigned char* __restrict__ X, const unsigned char* __restrict__ W, int K64, int tiles_m, int tiles_n, Ep ep)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STAGE = 32 * 1024, NST = 3, LPW = 4;
+    const int lane = threadIdx.x & 63;
+    const int wa = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wa >> 2, wn = wa & 3;
+    int bid = blockIdx.x;
+    const int nwg = tiles_m * tiles_n;
+    if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+    const int tn = bid / tiles_m, tm = bid - tn * tiles_m;
+    const unsigned char* xg = X + (size_t)tm * 16 * K64 * 1024 + lane * 16;
+    const unsigned char* wg = W + (size_t)tn * 16 * K64 * 1024 + lane * 16;
+
+    auto stage_load = [&](int stage, int kt) {
+        char* sb = smem + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < LPW; ++i) {
+            const int blk = wa * LPW + i;              // 0..15 X units, 16..31 W units
+            const bool isx = blk < 16;
+            const int t = isx ? blk : blk - 16;
+            const unsigned char* src = (isx ? xg : wg) + ((size_t)t * K64 + kt) * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(sb + blk * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4_t acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    stage_load(0, 0);
+    if (K64 > 1) stage_load(1, 1);
+    for (int kt = 0; kt < K64; ++kt) {
+        if (kt + 1 < K64) wait_vmcnt<LPW>(); else wait_vmcnt<0>();
+        __syncthreads();
+        if (kt + 2 < K64) stage_load((kt + 2) % NST, kt + 2);
+        const unsigned char* xs = reinterpret_cast<const unsigned char*>(smem + (kt % NST) * STAGE);
+        const unsigned char* ws = xs + 16 * 1024;
+        F8Frag a[4], b[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = ld_f8(ws + ((wn * 4 + i) * 64 + lane) * 16);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b[j] = ld_f8(xs + ((wm * 8 + j) * 64 + lane) * 16);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { acc[i][j] = mfma16_f8(a[i].lo, b[j].lo, acc[i][j]); acc[i][j] = mfma16_f8(a[i].hi, b[j].hi, acc[i][j]); }
+    }
+    const int m0 = tm * 256 + wm * 128 + (lane & 15), n0 = tn * 256 + wn * 64 + 4 * (lane >> 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ep.store4(m0 + j * 16, n0 + i * 16, acc[i][j]);
+}
+
+template <int BM, int NST, class Ep>
+static inline hipError_t launch_gemm_f8_bm(hipStream_t st, const unsigned char* X, const unsigned char* W, int Mrows, int N, int K64, const Ep& ep)
+{
+    const int tiles_m = Mrows / BM, tiles_n = N / GT_BN;
+    constexpr int lds = NST * (BM / 16 + 8) * 1024;
+    auto kern = k_gemm_f8<BM, NST, Ep>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), lds, st, X, W, K64, tiles_m, tiles_n, ep);
+    return hipGetLastError();
+}
+
+template <class Ep>
+static inline hipError_t launch_gemm_f8(hipStream_t st, const unsigned char* X, const unsigned char* W, int Mrows, int N, int K64, const Ep& ep)
+{
+    static const int use256 = [] { const char* v = std::getenv("WM_ENC_GEMM_256"); return v ? std::atoi(v) : 1; }();
+    if (use256 && Mrows % 256 == 0 && N % 256 == 0 && (Mrows / 256) * (N / 256) >= 200) {
+        auto kern = k_gemm_f8_256<Ep>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3((Mrows / 256) * (N / 256)), dim3(512), 96 * 1024, st, X, W, K64, Mrows / 256, N / 256, ep);
+        return hipGetLastError();
+    }
+    if ((Mrows / 128) * (N / GT_BN) < 200) return launch_gemm_f8_bm<64, 4>(st, X, W, Mrows, N, K64, ep);
+    return launch_gemm_f8_bm<128, 4>(st, X, W, Mrows, N, K64, ep);
+}
+
+// =============================================================================================
 // Encoder self-attention (non-causal, S keys): flash-style, one wave = 16 queries, 32 keys per step.
 //   S^T = K Q^T   (A = K rows, B = Q^T; a lane then owns 8 scores of ONE query -> softmax reduces over
 //                  2 xor-shuffles), P stays in registers and feeds O^T = V^T P^T directly: the MFMA
@@ -420,6 +616,72 @@ k_enc_ln(const float* __restrict__ src, const float* __restrict__ gamma, const f
             o.x = pack_bf2((v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y);
             o.y = pack_bf2((v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w);
             *reinterpret_cast<uint2*>(out_p + packed_index(m, j * 4, K32)) = o;
+        }
+    }
+}
+
+// LayerNorm -> fp8 e4m3 operand + one fp32 scale per row (fp8 MFMA GEMMs above).  RB: the LayerNorm output is first rounded to
+// bf16 and also stored packed (the encoder output: stored bf16 by contract, and the cross-K/V projection quantises exactly
+// those stored values, so that an oracle given the stored encoder output reproduces the fp8 codes bit for bit).
+// scale = max|row| / 448 (1 for an all-zero row); q = y / scale, round-to-nearest-even e4m3 (v_cvt_pk_fp8_f32; |q| <= 448).
+template <bool RB>
+__global__ void __launch_bounds__(256)
+k_enc_ln_f8(const float* __restrict__ src, const float* __restrict__ gamma, const float* __restrict__ beta,
+            unsigned char* __restrict__ out8, float* __restrict__ xs, bf16_t* __restrict__ out_p, int K32, int d, int M)
+{
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int nv = d >> 2;
+    const float4* sp = reinterpret_cast<const float4*>(src + (size_t)m * d);
+    float4 v[8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int j = lane + 64 * i;
+        v[i] = (j < nv) ? sp[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (lane + 64 * i < nv) {
+            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, e = v[i].w - mean;
+            q += a * a + b * b + c * c + e * e;
+        }
+    const float rstd = rsqrtf(wave_sum(q) / (float)d + 1e-5f);
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int j = lane + 64 * i;
+        if (j < nv) {
+            const float4 g = reinterpret_cast<const float4*>(gamma)[j];
+            const float4 b = reinterpret_cast<const float4*>(beta)[j];
+            float4 y = make_float4((v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y,
+                                   (v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w);
+            if (RB) {
+                uint2 o; o.x = pack_bf2(y.x, y.y); o.y = pack_bf2(y.z, y.w);
+                *reinterpret_cast<uint2*>(out_p + packed_index(m, j * 4, K32)) = o;
+                y = make_float4(__uint_as_float(o.x << 16), __uint_as_float(o.x & 0xffff0000u), __uint_as_float(o.y << 16), __uint_as_float(o.y & 0xffff0000u));
+            }
+            v[i] = y;
+            amax = fmaxf(fmaxf(amax, fmaxf(fabsf(y.x), fabsf(y.y))), fmaxf(fabsf(y.z), fabsf(y.w)));
+        }
+    }
+    amax = wave_max(amax);
+    const float scale = amax > 0.f ? amax / 448.0f : 1.0f;
+    if (lane == 0) xs[m] = scale;
+    const int K64 = K32 >> 1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int j = lane + 64 * i;
+        if (j < nv) {
+            const float q0 = fminf(fmaxf(v[i].x / scale, -448.f), 448.f), q1 = fminf(fmaxf(v[i].y / scale, -448.f), 448.f);
+            const float q2 = fminf(fmaxf(v[i].z / scale, -448.f), 448.f), q3 = fminf(fmaxf(v[i].w / scale, -448.f), 448.f);
+            int pk = __builtin_amdgcn_cvt_pk_fp8_f32(q0, q1, 0, false);
+            pk = __builtin_amdgcn_cvt_pk_fp8_f32(q2, q3, pk, true);
+            *reinterpret_cast<int*>(out8 + f8_index(m, j * 4, K64)) = pk;
         }
     }
 }
@@ -666,6 +928,7 @@ int wm_enc_encode(wm_ctx* ctx, const float* feats, int B)
     if (B < 1 || B > ctx->maxB) { ctx->err = "wm_encode: B out of range"; return WM_ERR_ARG; }
     const int d = ctx->d, H = ctx->H, ffn = ctx->ffn, S = ctx->S, Spad = ctx->Spad, Tm = ctx->Tm, Tmpad = ctx->Tmpad;
     const int K32 = d / 32, M = B * Spad;
+    const bool f8 = ctx->enc_f8;               // fp8 MFMA for the LayerNorm-fed GEMMs (QKV, FC1, cross-K/V projection)
     WM_HIP(hipEventRecord(ctx->ev0, st));
     // conv1 + GELU
     {
@@ -685,25 +948,47 @@ int wm_enc_encode(wm_ctx* ctx, const float* feats, int B)
     }
     for (int l = 0; l < ctx->cfg.enc_layers; ++l) {
         const EncLayerW& w = ctx->enc[l];
-        hipLaunchKernelGGL(k_enc_ln, dim3((M + 3) / 4), dim3(256), 0, st, ctx->eh, w.ln1_w, w.ln1_b, ctx->exn, K32, d, M);
-        WM_HIP(hipGetLastError());
-        WM_HIP(launch_gemm_tiled(st, ctx->exn, w.qkv_w, M, 3 * d, K32, EpQKVEnc{ctx->eq, ctx->ek, ctx->evt, w.qkv_b, Spad, H, d}));
+        if (f8) {
+            hipLaunchKernelGGL(k_enc_ln_f8<false>, dim3((M + 3) / 4), dim3(256), 0, st, ctx->eh, w.ln1_w, w.ln1_b, ctx->exn8, ctx->exs, nullptr, K32, d, M);
+            WM_HIP(hipGetLastError());
+            WM_HIP(launch_gemm_f8(st, ctx->exn8, w.qkv_w8, M, 3 * d, K32 / 2,
+                                  EpScaled<EpQKVEnc>{EpQKVEnc{ctx->eq, ctx->ek, ctx->evt, w.qkv_b, Spad, H, d}, ctx->exs, w.qkv_ws}));
+        } else {
+            hipLaunchKernelGGL(k_enc_ln, dim3((M + 3) / 4), dim3(256), 0, st, ctx->eh, w.ln1_w, w.ln1_b, ctx->exn, K32, d, M);
+            WM_HIP(hipGetLastError());
+            WM_HIP(launch_gemm_tiled(st, ctx->exn, w.qkv_w, M, 3 * d, K32, EpQKVEnc{ctx->eq, ctx->ek, ctx->evt, w.qkv_b, Spad, H, d}));
+        }
         if (B * (Spad / 128) * H >= 256 && Spad % 256 == 0)
             hipLaunchKernelGGL(k_flash_enc<4>, dim3(Spad / 256, H, B), dim3(256), 3 * 16 * 1024, st, ctx->eq, ctx->ek, ctx->evt, ctx->exn, S, Spad, H, K32);
         else
             hipLaunchKernelGGL(k_flash_enc<2>, dim3(Spad / 128, H, B), dim3(256), 3 * 16 * 1024, st, ctx->eq, ctx->ek, ctx->evt, ctx->exn, S, Spad, H, K32);
         WM_HIP(hipGetLastError());
         WM_HIP(launch_gemm_tiled(st, ctx->exn, w.out_w, M, d, K32, EpResidual{ctx->eh, w.out_b, d, M}));
-        hipLaunchKernelGGL(k_enc_ln, dim3((M + 3) / 4), dim3(256), 0, st, ctx->eh, w.ln2_w, w.ln2_b, ctx->exn, K32, d, M);
-        WM_HIP(hipGetLastError());
-        WM_HIP(launch_gemm_tiled(st, ctx->exn, w.fc1_w, M, ffn, K32, EpPackedAct<1>{ctx->eff, nullptr, w.fc1_b, ffn / 32, M}));
+        if (f8) {
+            hipLaunchKernelGGL(k_enc_ln_f8<false>, dim3((M + 3) / 4), dim3(256), 0, st, ctx->eh, w.ln2_w, w.ln2_b, ctx->exn8, ctx->exs, nullptr, K32, d, M);
+            WM_HIP(hipGetLastError());
+            WM_HIP(launch_gemm_f8(st, ctx->exn8, w.fc1_w8, M, ffn, K32 / 2,
+                                  EpScaled<EpPackedAct<1>>{EpPackedAct<1>{ctx->eff, nullptr, w.fc1_b, ffn / 32, M}, ctx->exs, w.fc1_ws}));
+        } else {
+            hipLaunchKernelGGL(k_enc_ln, dim3((M + 3) / 4), dim3(256), 0, st, ctx->eh, w.ln2_w, w.ln2_b, ctx->exn, K32, d, M);
+            WM_HIP(hipGetLastError());
+            WM_HIP(launch_gemm_tiled(st, ctx->exn, w.fc1_w, M, ffn, K32, EpPackedAct<1>{ctx->eff, nullptr, w.fc1_b, ffn / 32, M}));
+        }
         WM_HIP(launch_gemm_tiled(st, ctx->eff, w.fc2_w, M, d, ffn / 32, EpResidual{ctx->eh, w.fc2_b, d, M}));
     }
-    hipLaunchKernelGGL(k_enc_ln, dim3((M + 3) / 4), dim3(256), 0, st, ctx->eh, ctx->enc_lnf_w, ctx->enc_lnf_b, ctx->enc_out, K32, d, M);
-    WM_HIP(hipGetLastError());
     // cross K/V of every decoder layer (+ the Medusa block) in one GEMM
-    WM_HIP(launch_gemm_tiled(st, ctx->enc_out, ctx->ckv_w, M, ctx->nkv * 2 * d, K32,
-                             EpCrossKV{ctx->kx, ctx->vx, ctx->ckv_b, Spad, H, d, B}));
+    if (f8) {
+        hipLaunchKernelGGL(k_enc_ln_f8<true>, dim3((M + 3) / 4), dim3(256), 0, st, ctx->eh, ctx->enc_lnf_w, ctx->enc_lnf_b, ctx->exn8, ctx->exs,
+                           ctx->enc_out, K32, d, M);
+        WM_HIP(hipGetLastError());
+        WM_HIP(launch_gemm_f8(st, ctx->exn8, ctx->ckv_w8, M, ctx->nkv * 2 * d, K32 / 2,
+                              EpScaled<EpCrossKV>{EpCrossKV{ctx->kx, ctx->vx, ctx->ckv_b, Spad, H, d, B}, ctx->exs, ctx->ckv_ws}));
+    } else {
+        hipLaunchKernelGGL(k_enc_ln, dim3((M + 3) / 4), dim3(256), 0, st, ctx->eh, ctx->enc_lnf_w, ctx->enc_lnf_b, ctx->enc_out, K32, d, M);
+        WM_HIP(hipGetLastError());
+        WM_HIP(launch_gemm_tiled(st, ctx->enc_out, ctx->ckv_w, M, ctx->nkv * 2 * d, K32,
+                                 EpCrossKV{ctx->kx, ctx->vx, ctx->ckv_b, Spad, H, d, B}));
+    }
     ctx->Benc = B;
     WM_HIP(hipEventRecord(ctx->ev1, st));
     WM_HIP(hipEventSynchronize(ctx->ev1));

@@ -34,7 +34,7 @@ extern "C" void wm_destroy(wm_ctx* ctx)
                     ctx->enc_out, ctx->kx, ctx->vx, ctx->kc, ctx->vc, ctx->h, ctx->hblk, ctx->hf, ctx->qbuf, ctx->xbuf, ctx->fbuf,
                     ctx->ybuf, ctx->cml, ctx->co, ctx->ticket, ctx->logits, ctx->amax, ctx->pc, ctx->part1, ctx->part2, ctx->ids, ctx->L, ctx->kvlen,
                     ctx->finished, ctx->cand, ctx->niter, ctx->hist, ctx->supmask, ctx->exppen, ctx->tap_tok, ctx->done,
-                    ctx->hf_keep, ctx->hb_keep, ctx->carry, ctx->rs_table, ctx->tree, ctx->sel_src, ctx->sel_n, ctx->sel_base};
+                    ctx->hf_keep, ctx->hb_keep, ctx->carry, ctx->rs_table, ctx->tree, ctx->sel_src, ctx->sel_n, ctx->sel_base, ctx->exn8, ctx->exs};
     for (void* b : bufs) if (b) hipFree(b);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
@@ -118,7 +118,10 @@ extern "C" int wm_create(const wm_config* cfg, const wm_weights* w, int device, 
 
     // ---- parameter table ----
     const bool w8 = cfg->dec_weight_fp8 != 0;
-    const int n_expected = 19 + 12 * cfg->enc_layers + 18 * ctx->nkv + (w8 ? 6 * ctx->nkv : 0);
+    const bool e8 = cfg->enc_fp8 != 0;
+    ctx->enc_f8 = e8;
+    if (e8 && (cfg->d_model % 64 || cfg->ffn_dim % 128)) { g_create_err = "wm_create: enc_fp8 needs d_model % 64 == 0"; wm_destroy(ctx); return WM_ERR_ARG; }
+    const int n_expected = 19 + 12 * cfg->enc_layers + 18 * ctx->nkv + (w8 ? 6 * ctx->nkv : 0) + (e8 ? 4 * cfg->enc_layers + 2 : 0);
     if (w->n_offsets != n_expected || !w->blob || !w->offsets) {
         g_create_err = "wm_create: weight table has " + std::to_string(w->n_offsets) + " entries, expected " + std::to_string(n_expected);
         wm_destroy(ctx); return WM_ERR_ARG;
@@ -147,6 +150,11 @@ extern "C" int wm_create(const wm_config* cfg, const wm_weights* w, int device, 
     }
     if (w8)                                    // fp8 e4m3 decoder-layer matrices: one fp32 scale per output row, appended to the table
         for (auto& e : ctx->dec) { e.qkv_s = F(); e.out_s = F(); e.cq_s = F(); e.cout_s = F(); e.fc1_s = F(); e.fc2_s = F(); }
+    if (e8) {                                  // fp8 MFMA encoder: e4m3 matrices (64-k unit layout) + per-row scales, appended last
+        auto U8 = [&]() { return reinterpret_cast<const unsigned char*>(base + w->offsets[t++]); };
+        for (auto& e : ctx->enc) { e.qkv_w8 = U8(); e.qkv_ws = F(); e.fc1_w8 = U8(); e.fc1_ws = F(); }
+        ctx->ckv_w8 = U8(); ctx->ckv_ws = F();
+    }
 
     // ---- HBM allocation ----
     hipStream_t st = ctx->stream;
@@ -159,6 +167,7 @@ extern "C" int wm_create(const wm_config* cfg, const wm_weights* w, int device, 
     CREATE_HIP(dev_alloc(&ctx->A2, Menc * 3 * d, st));
     CREATE_HIP(dev_alloc(&ctx->eh, Menc * d, st));
     CREATE_HIP(dev_alloc(&ctx->exn, Menc * d, st));
+    if (e8) { CREATE_HIP(dev_alloc(&ctx->exn8, Menc * d, st)); CREATE_HIP(dev_alloc(&ctx->exs, Menc, st)); }
     CREATE_HIP(dev_alloc(&ctx->eq, Menc * d, st));
     CREATE_HIP(dev_alloc(&ctx->ek, Menc * d, st));
     CREATE_HIP(dev_alloc(&ctx->evt, Menc * d, st));

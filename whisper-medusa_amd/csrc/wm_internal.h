@@ -18,6 +18,9 @@
 struct EncLayerW {
     const float *ln1_w, *ln1_b, *qkv_b, *out_b, *ln2_w, *ln2_b, *fc1_b, *fc2_b;
     const bf16_t *qkv_w, *out_w, *fc1_w, *fc2_w;
+    // fp8 MFMA encoder (wm_config.enc_fp8): e4m3 copies of the LayerNorm-fed matrices in the 64-k unit layout + per-row scales
+    const unsigned char *qkv_w8 = nullptr, *fc1_w8 = nullptr;
+    const float *qkv_ws = nullptr, *fc1_ws = nullptr;
 };
 struct DecLayerW {
     const float *ln1_w, *ln1_b, *qkv_b, *out_b, *ln2_w, *ln2_b, *cq_b, *cout_b, *ln3_w, *ln3_b, *fc1_b, *fc2_b;
@@ -80,6 +83,10 @@ struct wm_ctx {
     bf16_t* eff = nullptr;            // packed [B*Spad][ffn]
     bf16_t* enc_out = nullptr;        // packed [B*Spad][d]
     int K1pad = 0;
+    bool enc_f8 = false;              // fp8 MFMA encoder path
+    unsigned char* exn8 = nullptr;    // packed fp8 [B*Spad][d] (LayerNorm output as e4m3)
+    float* exs = nullptr;             // [B*Spad] row scales of exn8
+    const unsigned char* ckv_w8 = nullptr; const float* ckv_ws = nullptr;
 
     // ---- caches ----
     bf16_t *kx = nullptr, *vx = nullptr;   // cross K/V [nkv][Benc][H][Spad][64]

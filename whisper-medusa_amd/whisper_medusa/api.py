@@ -34,12 +34,13 @@ class MedusaForwardOutput:
 
 class WhisperMedusaModel:
     def __init__(self, config: MedusaConfig, state_dict: Dict[str, torch.Tensor], device: Union[str, torch.device, None] = None,
-                 max_batch: int = 1, dec_weight_fp8: bool = False):
+                 max_batch: int = 1, dec_weight_fp8: bool = False, enc_fp8: bool = False):
         self.config = config
         self.generation_config = config          # posterior_threshold / alpha / token ids live on the config here
         self._sd = state_dict
         self._max_batch = max_batch
         self._fp8 = bool(dec_weight_fp8)         # decoder-layer matrices stored as fp8 e4m3 + per-row scale (BASELINE configs[4])
+        self._enc_fp8 = bool(enc_fp8)            # encoder QKV / FC1 / cross-K/V projection on the fp8 MFMA (BASELINE configs[4])
         self._micro_batches = 1
         self._pool = None
         self._engine: Optional[Engine] = None
@@ -50,12 +51,13 @@ class WhisperMedusaModel:
 
     # ---- construction ---------------------------------------------------------------------
     @classmethod
-    def from_pretrained(cls, pretrained_model_name_or_path, *args, device=None, max_batch: int = 1, dec_weight_fp8: bool = False, **kwargs):
+    def from_pretrained(cls, pretrained_model_name_or_path, *args, device=None, max_batch: int = 1, dec_weight_fp8: bool = False,
+                        enc_fp8: bool = False, **kwargs):
         """Load ``config.json`` + ``model.safetensors`` from a local checkpoint directory
         (reference model.py:265-291; there is no hub access in this environment)."""
         config = MedusaConfig.from_pretrained(pretrained_model_name_or_path)
         sd = _weights.load_state_dict_from_dir(pretrained_model_name_or_path)
-        return cls(config, sd, device=device, max_batch=max_batch, dec_weight_fp8=dec_weight_fp8)
+        return cls(config, sd, device=device, max_batch=max_batch, dec_weight_fp8=dec_weight_fp8, enc_fp8=enc_fp8)
 
     def save_pretrained(self, save_directory: str, safe_serialization: bool = True) -> None:
         """``config.json`` + ``model.safetensors`` with the reference's parameter names (what its Trainer writes,
@@ -74,13 +76,14 @@ class WhisperMedusaModel:
             torch.save(sd, os.path.join(save_directory, "pytorch_model.bin"))
 
     @classmethod
-    def from_blob(cls, config: MedusaConfig, blob: torch.Tensor, offsets: np.ndarray, max_batch: int = 1, dec_weight_fp8: bool = False):
+    def from_blob(cls, config: MedusaConfig, blob: torch.Tensor, offsets: np.ndarray, max_batch: int = 1, dec_weight_fp8: bool = False,
+                  enc_fp8: bool = False):
         """Build directly from a packed parameter blob already resident on a GPU (the path the
         8-GPU data-parallel launcher uses after the RCCL broadcast, ``dist.py``)."""
-        self = cls(config, {}, device=None, max_batch=max_batch, dec_weight_fp8=dec_weight_fp8)
+        self = cls(config, {}, device=None, max_batch=max_batch, dec_weight_fp8=dec_weight_fp8, enc_fp8=enc_fp8)
         self._blob, self._offsets = blob, offsets
         self.device = blob.device
-        self._engine = Engine(config, blob, offsets, max_batch=max_batch, device=blob.device, dec_weight_fp8=dec_weight_fp8)
+        self._engine = Engine(config, blob, offsets, max_batch=max_batch, device=blob.device, dec_weight_fp8=dec_weight_fp8, enc_fp8=enc_fp8)
         return self
 
     def to(self, device):
@@ -100,12 +103,12 @@ class WhisperMedusaModel:
             self._engine = None
         with torch.cuda.device(device):
             if self._sd:
-                self._blob, self._offsets = _weights.build_blob(self.config, self._sd, device=device, dec_fp8=self._fp8)
+                self._blob, self._offsets = _weights.build_blob(self.config, self._sd, device=device, dec_fp8=self._fp8, enc_fp8=self._enc_fp8)
             elif self._blob is not None:
                 self._blob = self._blob.to(device)                 # built with from_blob: move the packed blob itself
             else:
                 raise RuntimeError("model has neither a state dict nor a packed blob to place on the device")
-            self._engine = Engine(self.config, self._blob, self._offsets, max_batch=self._max_batch, device=device, dec_weight_fp8=self._fp8)
+            self._engine = Engine(self.config, self._blob, self._offsets, max_batch=self._max_batch, device=device, dec_weight_fp8=self._fp8, enc_fp8=self._enc_fp8)
         self._drop_pool()
         self.device = device
         return self
@@ -121,7 +124,7 @@ class WhisperMedusaModel:
             self._max_batch = max_batch
             if self._engine is not None:
                 self._engine.close()
-                self._engine = Engine(self.config, self._blob, self._offsets, max_batch=max_batch, device=self.device, dec_weight_fp8=self._fp8)
+                self._engine = Engine(self.config, self._blob, self._offsets, max_batch=max_batch, device=self.device, dec_weight_fp8=self._fp8, enc_fp8=self._enc_fp8)
             self._drop_pool()
         return self
 
@@ -144,7 +147,7 @@ class WhisperMedusaModel:
         if self._pool is None:
             from .pool import ContextPool
             _ = self.engine                                         # raises when not on a HIP device
-            self._pool = ContextPool(self.config, self._blob, self._offsets, self._micro_batches, self._max_batch, self._fp8)
+            self._pool = ContextPool(self.config, self._blob, self._offsets, self._micro_batches, self._max_batch, self._fp8, self._enc_fp8)
         return self._pool
 
     @property

@@ -16,13 +16,13 @@ from .config import MedusaConfig, GenParams, HEADS_BLOCK
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwm.so")      # the product library; tests/microbench scripts may point WM_LIB at a debug build
-WM_ABI_VERSION = 4
+WM_ABI_VERSION = 5
 
 
 class WmConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "abi_version", "d_model", "enc_layers", "dec_layers", "n_heads", "ffn_dim", "vocab", "n_mels",
-        "n_ctx", "n_tgt", "medusa_heads", "heads_type", "max_batch", "dec_weight_fp8")] + [("medusa_choices", C.c_int32 * 16)]
+        "n_ctx", "n_tgt", "medusa_heads", "heads_type", "max_batch", "dec_weight_fp8")] + [("medusa_choices", C.c_int32 * 16), ("enc_fp8", C.c_int32)]
 
 
 class WmWeights(C.Structure):
@@ -102,7 +102,7 @@ class Engine:
     """One context = one GPU.  ``blob`` is the packed parameter tensor (uint8, on that GPU)."""
 
     def __init__(self, cfg: MedusaConfig, blob: torch.Tensor, offsets: np.ndarray, max_batch: int = 1,
-                 device: Optional[torch.device] = None, dec_weight_fp8: bool = False):
+                 device: Optional[torch.device] = None, dec_weight_fp8: bool = False, enc_fp8: bool = False):
         if not torch.cuda.is_available():
             raise RuntimeError("no HIP device visible: the Whisper-Medusa engine has no CPU path")
         self.lib = load_library()
@@ -117,7 +117,7 @@ class Engine:
                      cfg.decoder_ffn_dim, cfg.vocab_size, cfg.num_mel_bins, cfg.max_source_positions,
                      cfg.max_target_positions, cfg.medusa_num_heads,
                      1 if cfg.medusa_heads_type == HEADS_BLOCK else 0, self.max_batch, 1 if dec_weight_fp8 else 0,
-                     (C.c_int32 * 16)(*[int(x) for x in cfg.medusa_choices]))
+                     (C.c_int32 * 16)(*[int(x) for x in cfg.medusa_choices]), 1 if enc_fp8 else 0)
         w = WmWeights(C.c_void_p(blob.data_ptr()), blob.numel(),
                       self._offsets.ctypes.data_as(C.POINTER(C.c_uint64)), len(self._offsets))
         # every context owns a private non-blocking HIP stream (NULL -> wm_create makes one): several contexts built under

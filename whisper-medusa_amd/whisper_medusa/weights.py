@@ -60,6 +60,16 @@ def pack_matrix_fp8(q: torch.Tensor) -> torch.Tensor:
     return t.permute(0, 2, 3, 1, 4).contiguous().view(-1)
 
 
+def pack_matrix_fp8_k64(q: torch.Tensor) -> torch.Tensor:
+    """float8_e4m3fn [N, K] -> uint8 in the fp8-MFMA operand layout [N/16][K/64][64 lanes][16]: lane (r = row & 15, g) holds, for the
+    two 32-wide k-tiles of a 64-k unit, the 8 values k = 8 g .. 8 g + 7 (bytes 0..7 first tile, 8..15 second)  (csrc/wm_encoder.hip,
+    f8_index).  N % 16 == 0, K % 64 == 0."""
+    n, k = q.shape
+    assert n % 16 == 0 and k % 64 == 0, (n, k)
+    t = q.view(torch.uint8).view(n // 16, 16, k // 64, 2, 4, 8)        # (nt, r, u, kt, g, e)
+    return t.permute(0, 2, 4, 1, 3, 5).contiguous().view(-1)            # (nt, u, g, r, kt, e): lane = g*16 + r, byte = kt*8 + e
+
+
 def _pad2(w: torch.Tensor, n: int, k: int) -> torch.Tensor:
     if w.shape == (n, k):
         return w
@@ -68,9 +78,12 @@ def _pad2(w: torch.Tensor, n: int, k: int) -> torch.Tensor:
     return out
 
 
-def canonical_tensors(cfg: MedusaConfig, sd: Dict[str, torch.Tensor], device, dec_fp8: bool = False) -> List[torch.Tensor]:
+def canonical_tensors(cfg: MedusaConfig, sd: Dict[str, torch.Tensor], device, dec_fp8: bool = False, enc_fp8: bool = False) -> List[torch.Tensor]:
     """The parameter list in the engine's canonical order; each entry is a flat fp32 / bf16 (/ uint8 fp8) tensor.
-    ``dec_fp8``: the six matrices of every decoder layer are stored as fp8 e4m3 and their per-row scales are appended."""
+    ``dec_fp8``: the six matrices of every decoder layer are stored as fp8 e4m3 and their per-row scales are appended.
+    ``enc_fp8``: the encoder matrices that multiply a LayerNorm output (q/k/v, fc1) and the fused cross-K/V projection are
+    ALSO given as e4m3 in the fp8-MFMA layout with per-row scales (appended last: 4 entries per encoder layer + 2); their
+    bf16 entries shrink to 16-byte placeholders (the engine does not read them in that mode)."""
     d, dev = cfg.d_model, device
     f32 = lambda t: t.detach().to(dev, torch.float32).contiguous().view(-1)
     mat = lambda t: pack_matrix(t.detach().to(dev, torch.float32))
@@ -95,8 +108,23 @@ def canonical_tensors(cfg: MedusaConfig, sd: Dict[str, torch.Tensor], device, de
     out += [mat(torch.cat([sd[f"medusa_heads.{k}.0.linear.weight"].to(dev, torch.float32) for k in range(n_res)], 0)),
             f32(torch.cat([sd[f"medusa_heads.{k}.0.linear.bias"].to(dev, torch.float32) for k in range(n_res)], 0))]
     kv_prefixes = [f"{dec}.layers.{i}" for i in range(cfg.decoder_layers)] + (["medusa_block"] if cfg.is_block else [])
-    out += [mat(torch.cat([torch.cat([sd[p + ".encoder_attn.k_proj.weight"].to(dev, torch.float32),
-                                       sd[p + ".encoder_attn.v_proj.weight"].to(dev, torch.float32)], 0) for p in kv_prefixes], 0)),
+    enc8: List[torch.Tensor] = []
+    placeholder = lambda: torch.zeros(8, dtype=torch.bfloat16, device=dev)
+
+    def emat(w):                 # encoder matrix with a LayerNorm-output operand
+        if not enc_fp8:
+            return mat(w)
+        q, sc = quantize_rows_e4m3(w)
+        enc8.extend([pack_matrix_fp8_k64(q).to(dev), sc.to(dev).contiguous()])
+        return placeholder()
+
+    ckv = torch.cat([torch.cat([sd[p + ".encoder_attn.k_proj.weight"].to(dev, torch.float32),
+                                sd[p + ".encoder_attn.v_proj.weight"].to(dev, torch.float32)], 0) for p in kv_prefixes], 0)
+    ckv8: List[torch.Tensor] = []
+    if enc_fp8:
+        q, sc = quantize_rows_e4m3(ckv)
+        ckv8 = [pack_matrix_fp8_k64(q).to(dev), sc.to(dev).contiguous()]
+    out += [placeholder() if enc_fp8 else mat(ckv),
             torch.cat([torch.cat([zeros(d), f32(sd[p + ".encoder_attn.v_proj.bias"])]) for p in kv_prefixes])]
 
     scales: List[torch.Tensor] = []
@@ -121,23 +149,27 @@ def canonical_tensors(cfg: MedusaConfig, sd: Dict[str, torch.Tensor], device, de
 
     for i in range(cfg.encoder_layers):
         p = f"{enc}.layers.{i}"
-        out += ln(p + ".self_attn_layer_norm") + qkv(p + ".self_attn") + lin(p + ".self_attn.out_proj")
-        out += ln(p + ".final_layer_norm") + lin(p + ".fc1") + lin(p + ".fc2")
+        wq = torch.cat([sd[p + ".self_attn.q_proj.weight"], sd[p + ".self_attn.k_proj.weight"], sd[p + ".self_attn.v_proj.weight"]], 0)
+        bq = torch.cat([f32(sd[p + ".self_attn.q_proj.bias"]), zeros(d), f32(sd[p + ".self_attn.v_proj.bias"])])
+        out += ln(p + ".self_attn_layer_norm") + [emat(wq), bq] + lin(p + ".self_attn.out_proj")
+        out += ln(p + ".final_layer_norm") + [emat(sd[p + ".fc1.weight"]), f32(sd[p + ".fc1.bias"])] + lin(p + ".fc2")
     for p in kv_prefixes:
         out += ln(p + ".self_attn_layer_norm") + qkv(p + ".self_attn", dec_fp8) + lin(p + ".self_attn.out_proj", dec_fp8)
         out += ln(p + ".encoder_attn_layer_norm") + lin(p + ".encoder_attn.q_proj", dec_fp8) + lin(p + ".encoder_attn.out_proj", dec_fp8)
         out += ln(p + ".final_layer_norm") + lin(p + ".fc1", dec_fp8) + lin(p + ".fc2", dec_fp8)
-    return out + scales          # fp8: 6 scale vectors per decoder layer, in launch order (qkv, out, cq, cout, fc1, fc2)
+    # fp8: 6 scale vectors per decoder layer, in launch order (qkv, out, cq, cout, fc1, fc2); then the fp8-MFMA encoder entries
+    return out + scales + enc8 + ckv8
 
 
-def n_table_entries(cfg: MedusaConfig, dec_fp8: bool = False) -> int:
-    return 19 + 12 * cfg.encoder_layers + 18 * cfg.n_kv_layers + (6 * cfg.n_kv_layers if dec_fp8 else 0)
+def n_table_entries(cfg: MedusaConfig, dec_fp8: bool = False, enc_fp8: bool = False) -> int:
+    return (19 + 12 * cfg.encoder_layers + 18 * cfg.n_kv_layers + (6 * cfg.n_kv_layers if dec_fp8 else 0)
+            + (4 * cfg.encoder_layers + 2 if enc_fp8 else 0))
 
 
-def build_blob(cfg: MedusaConfig, sd: Dict[str, torch.Tensor], device="cpu", dec_fp8: bool = False) -> Tuple[torch.Tensor, np.ndarray]:
+def build_blob(cfg: MedusaConfig, sd: Dict[str, torch.Tensor], device="cpu", dec_fp8: bool = False, enc_fp8: bool = False) -> Tuple[torch.Tensor, np.ndarray]:
     """-> (uint8 blob on ``device``, uint64 offsets[n_table_entries])."""
-    tensors = canonical_tensors(cfg, sd, device, dec_fp8)
-    assert len(tensors) == n_table_entries(cfg, dec_fp8), (len(tensors), n_table_entries(cfg, dec_fp8))
+    tensors = canonical_tensors(cfg, sd, device, dec_fp8, enc_fp8)
+    assert len(tensors) == n_table_entries(cfg, dec_fp8, enc_fp8), (len(tensors), n_table_entries(cfg, dec_fp8, enc_fp8))
     offsets, total = [], 0
     for t in tensors:
         offsets.append(total)
