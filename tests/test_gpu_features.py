@@ -136,3 +136,19 @@ def test_generate_sharded_two_ranks_share_the_gpu(gpu):
     for p in ps:
         p.join(timeout=60)
     assert sorted(r[0] for r in res) == [0, 1] and all(r[1] for r in res), res
+
+
+def test_packed_fp8_export_loads_and_decodes_identically(gpu, tmp_path):
+    """save_packed -> from_packed (fp8 decoder weights + fp8 MFMA encoder): the re-loaded engine-ready blob gives the same tokens
+    as the model it was exported from."""
+    cfg = MedusaConfig.micro(K=4)
+    sd = synth.synth_state_dict(cfg, seed=31)
+    a = WhisperMedusaModel(cfg, sd, device=gpu, max_batch=2, dec_weight_fp8=True, enc_fp8=True)
+    a.save_packed(str(tmp_path / "packed"))
+    b = WhisperMedusaModel.from_packed(str(tmp_path / "packed"), device=gpu, max_batch=2)
+    n = cfg.n_mel_frames * 160
+    feats = a.extract_features([synth.synth_clip(i, n) for i in range(2)])
+    ia = a.generate(feats, max_new_tokens=24)
+    ib = b.generate(feats, max_new_tokens=24)
+    assert torch.equal(ia, ib) and ia.shape[1] > 8
+    a.engine.close(); b.engine.close()

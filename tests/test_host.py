@@ -259,3 +259,32 @@ def test_fp8_row_quantiser_and_blob_layout():
     b8, o8 = build_blob(cfg, sd, dec_fp8=True)
     assert len(o8) == n_table_entries(cfg, True) == len(o16) + 6 * cfg.n_kv_layers
     assert b8.numel() < b16.numel()
+
+
+def test_packed_export_roundtrip_and_checks(tmp_path):
+    """save_packed / from_packed (the engine-ready export, incl. the fp8 variants): same bytes back, refuses corruption and a
+    blob written for another table layout.  CPU only: no engine is created."""
+    import json
+    from whisper_medusa import WhisperMedusaModel, weights
+    cfg = MedusaConfig.micro(K=3)
+    sd = synth.synth_state_dict(cfg, seed=4)
+    for dec8, enc8 in ((False, False), (True, True)):
+        d = tmp_path / f"p{int(dec8)}{int(enc8)}"
+        m = WhisperMedusaModel(cfg, sd, dec_weight_fp8=dec8, enc_fp8=enc8)
+        m.save_packed(str(d))
+        blob, offs = weights.build_blob(cfg, sd, dec_fp8=dec8, enc_fp8=enc8)
+        m2 = WhisperMedusaModel.from_packed(str(d))
+        assert torch.equal(m2._blob, blob) and m2._offsets.tolist() == offs.tolist()
+        assert (m2._fp8, m2._enc_fp8) == (dec8, enc8) and m2.config.to_dict() == cfg.to_dict()
+    small, big = (tmp_path / "p00" / "wm_packed.bin").stat().st_size, (tmp_path / "p11" / "wm_packed.bin").stat().st_size
+    assert big < small                                     # e4m3 matrices: fewer bytes despite the scale vectors
+    meta_path = tmp_path / "p11" / "wm_packed.json"
+    meta = json.loads(meta_path.read_text())
+    meta["abi_layout"] -= 1
+    meta_path.write_text(json.dumps(meta))
+    with pytest.raises(ValueError, match="re-export"):
+        WhisperMedusaModel.from_packed(str(tmp_path / "p11"))
+    with open(tmp_path / "p00" / "wm_packed.bin", "r+b") as f:
+        f.seek(1000); f.write(b"\x55\xaa")
+    with pytest.raises(ValueError, match="corrupt"):
+        WhisperMedusaModel.from_packed(str(tmp_path / "p00"))

@@ -75,6 +75,50 @@ class WhisperMedusaModel:
         else:
             torch.save(sd, os.path.join(save_directory, "pytorch_model.bin"))
 
+    # ---- packed export (checkpoint tooling; the fp8 export format) -----------------------------------------
+    PACKED_FORMAT = 1
+
+    def save_packed(self, save_directory: str) -> None:
+        """Write the engine-ready parameter blob: ``wm_packed.bin`` (the bytes ``wm_create`` consumes: bf16 MFMA-fragment
+        matrices, fp32 vectors and — for models built with ``dec_weight_fp8`` / ``enc_fp8`` — the e4m3 matrices with their
+        per-row scales, quantised once, on the CPU) and ``wm_packed.json`` (format + ABI layout version, the fp8 flags, the
+        offset table, sha256 of the blob) next to ``config.json``.  ``from_packed`` loads it without touching the fp32 checkpoint."""
+        import hashlib, json, os
+        from .engine import WM_ABI_VERSION
+        if self._blob is None:
+            if not self._sd:
+                raise RuntimeError("nothing to export: the model holds neither a state dict nor a packed blob")
+            self._blob, self._offsets = _weights.build_blob(self.config, self._sd, device="cpu", dec_fp8=self._fp8, enc_fp8=self._enc_fp8)
+        os.makedirs(save_directory, exist_ok=True)
+        self.config.save_pretrained(save_directory)
+        raw = self._blob.detach().cpu().contiguous().numpy().tobytes()
+        with open(os.path.join(save_directory, "wm_packed.bin"), "wb") as f:
+            f.write(raw)
+        meta = dict(packed_format=self.PACKED_FORMAT, abi_layout=WM_ABI_VERSION, dec_weight_fp8=self._fp8, enc_fp8=self._enc_fp8,
+                    n_bytes=len(raw), sha256=hashlib.sha256(raw).hexdigest(), offsets=[int(o) for o in self._offsets])
+        with open(os.path.join(save_directory, "wm_packed.json"), "w") as f:
+            json.dump(meta, f)
+
+    @classmethod
+    def from_packed(cls, directory: str, device=None, max_batch: int = 1):
+        """Load a ``save_packed`` export.  Refuses a blob written for another parameter-table layout or with a wrong checksum."""
+        import hashlib, json, os
+        from .engine import WM_ABI_VERSION
+        with open(os.path.join(directory, "wm_packed.json")) as f:
+            meta = json.load(f)
+        if meta.get("packed_format") != cls.PACKED_FORMAT or meta.get("abi_layout") != WM_ABI_VERSION:
+            raise ValueError(f"packed export has format {meta.get('packed_format')} / table layout {meta.get('abi_layout')}; this build "
+                             f"reads format {cls.PACKED_FORMAT} / layout {WM_ABI_VERSION}: re-export from the checkpoint")
+        raw = np.fromfile(os.path.join(directory, "wm_packed.bin"), dtype=np.uint8)
+        if raw.size != meta["n_bytes"] or hashlib.sha256(raw.tobytes()).hexdigest() != meta["sha256"]:
+            raise ValueError("packed export is truncated or corrupt (size / sha256 mismatch)")
+        config = MedusaConfig.from_pretrained(directory)
+        if len(meta["offsets"]) != _weights.n_table_entries(config, meta["dec_weight_fp8"], meta["enc_fp8"]):
+            raise ValueError("packed export's offset table does not match its config")
+        self = cls(config, {}, device=None, max_batch=max_batch, dec_weight_fp8=meta["dec_weight_fp8"], enc_fp8=meta["enc_fp8"])
+        self._blob, self._offsets = torch.from_numpy(raw), np.asarray(meta["offsets"], dtype=np.uint64)
+        return self.to(device) if device is not None else self
+
     @classmethod
     def from_blob(cls, config: MedusaConfig, blob: torch.Tensor, offsets: np.ndarray, max_batch: int = 1, dec_weight_fp8: bool = False,
                   enc_fp8: bool = False):
