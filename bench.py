@@ -58,14 +58,17 @@ def prefill_flops(cfg):
     return L * per_layer + conv + cross
 
 
+DECODE_SOURCES = ("wm_common.h", "wm_decoder.hip", "wm_engine.hip", "wm_epilogues.h", "wm_internal.h", "wm_skinny_gemm.h")
+
+
 def kernels_sha():
-    """sha1 over the HIP sources: a PMC traffic file measured on other kernels is refused as stale."""
+    """sha1 over the HIP sources of the DECODE path (the traffic figure is the decode iteration's): a PMC traffic file measured
+    on other kernels is refused as stale.  tests/pmc_summary.py stamps the same hash into the file it writes."""
     import hashlib
     h = hashlib.sha1()
     d = os.path.join(ROOT, "whisper-medusa_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
-            h.update(open(os.path.join(d, f), "rb").read())
+    for f in DECODE_SOURCES:
+        h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -302,7 +305,8 @@ def main():
         tj = json.load(open(tpath))
         if tj.get("kernels_sha") == kernels_sha():
             traffic = tj["medusa_iteration_bytes"]      # PMC FETCH_SIZE x2, see profiles/
-            traffic_src = {"file": "profiles/r02_pmc_traffic.json", "command": tj.get("command"), "kernels_sha": tj.get("kernels_sha")}
+            traffic_src = {"file": "profiles/r02_pmc_traffic.json", "command": tj.get("command"), "kernels_sha": tj.get("kernels_sha"),
+                           "counts": tj.get("counts"), "without_prefetch_blocks": tj.get("without_prefetch_blocks")}
         else:
             traffic_src = {"file": "profiles/r02_pmc_traffic.json", "stale": True, "file_kernels_sha": tj.get("kernels_sha"), "kernels_sha": kernels_sha()}
     t_iter_ms = ms_dec / max(iters, 1)

@@ -27,7 +27,11 @@ print(out)
 if len(sys.argv) > 2:
     open(sys.argv[2], "w").write(out + "\n")
 if len(sys.argv) > 3 and n_iter and not n_van:
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vanilla (MI355X)",
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from bench import kernels_sha
+    cmd = "rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vanilla --no-extra-configs (MI355X)"
+    json.dump({"source": cmd, "command": cmd, "kernels_sha": kernels_sha(),
                "correction": "FETCH_SIZE x 2 (gfx950 counts 64 B per 128-B request on wide coalesced streams, MI355X_MICROARCH.md HBM section)",
                "medusa_iterations": n_iter, "medusa_iteration_bytes": round(2 * tot * 1024 * 1024 / n_iter),
                "note": "host-driven hidden-state carry: an iteration is a verify pass plus a base pass only when the previous accept length was 0",
