@@ -144,30 +144,24 @@ __host__ __device__ __forceinline__ int pf_round8(int n) { return (n + 7) & ~7; 
 
 // ---- token operand: packed hi/lo planes in global memory (written by the previous kernel's epilogue) ------------
 struct LdPacked {
-    const bf16_t* X; int K32; size_t plane; int M;           // lo plane at X + plane; rows >= M count as zero
+    const bf16_t* X; int K32; size_t plane; int M;           // lo plane at X + plane; rows >= M are not read
     static constexpr bool kNorm = false;
-    template <int NB> struct Regs { bf16x8_t h[NB], l[NB]; bool rv; };
+    template <int NB> struct Regs { bf16x8_t h[NB], l[NB]; };
     __host__ __device__ int lds_bytes() const { return 0; }
-    // The loads are unconditional (a 16-row tile is always allocated; rows >= M of it hold stale bytes) and the row mask is
-    // applied when a fragment is consumed.  Loading under `if (row < M)` into zero-initialised registers made the register
-    // allocator place a copy of a freshly loaded register in the middle of the batch — an `s_waitcnt vmcnt` there, which
-    // split every launch's memory batch into two dependent rounds (found in the ISA: `L16 W2 L10` instead of `L26`).
     template <int NB>
     __device__ __forceinline__ void issue(Regs<NB>& r, char*, int kt0, int lane, int = 0) const {
-        r.rv = (lane & 15) < M;
+        const bool rv = (lane & 15) < M;
+        const bf16x8_t z = __builtin_bit_cast(bf16x8_t, make_uint4(0u, 0u, 0u, 0u));
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
             const bf16_t* p = X + ((size_t)(kt0 + u) * 64 + lane) * 8;
-            r.h[u] = ld_frag(p); r.l[u] = ld_frag(p + plane);
+            r.h[u] = z; r.l[u] = z;
+            if (rv) { r.h[u] = ld_frag(p); r.l[u] = ld_frag(p + plane); }
         }
     }
     template <int NB> __device__ __forceinline__ void stats(Regs<NB>&, char*, int, int, bool, int) const {}
     template <int NB>
-    __device__ __forceinline__ void frag(const Regs<NB>& r, const char*, int u, int, int, bf16x8_t& bh, bf16x8_t& bl) const {
-        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-        bh = r.rv ? r.h[u] : __builtin_bit_cast(bf16x8_t, z);
-        bl = r.rv ? r.l[u] : __builtin_bit_cast(bf16x8_t, z);
-    }
+    __device__ __forceinline__ void frag(const Regs<NB>& r, const char*, int u, int, int, bf16x8_t& bh, bf16x8_t& bl) const { bh = r.h[u]; bl = r.l[u]; }
 };
 
 // ---- token operand: fp32 residual rows -> LayerNorm (or identity) -> hi/lo fragments, in registers -------------------
@@ -183,24 +177,19 @@ struct LdNormT {
     int d, K32, M, row_mul, row_off;
     static constexpr bool kNorm = true;
     static constexpr bool do_norm = NORM;
-    template <int NB> struct Regs { float4 v0[NB], v1[NB]; float mean, rstd; bool rv; };
+    template <int NB> struct Regs { float4 v0[NB], v1[NB]; float mean, rstd; };
     __host__ __device__ int lds_bytes() const { return 2 * d * (int)sizeof(float) + 2048; }   // gamma, beta, statistics
 
     // `rows`: false for waves that only help staging gamma / beta (the fused cross-attention kernel has more waves than K-slices)
     template <int NB>
     __device__ __forceinline__ void issue(Regs<NB>& r, char* smem, int kt0, int lane, int row0 = 0, bool rows = true) const {
         const int rr = lane & 15, g8 = (lane >> 4) * 8;
-        r.rv = rows && row0 + rr < M;
-        // unconditional loads (rows >= M read the last valid row again and are zeroed in stats(), the first consumer): a load
-        // under `if (row < M)` into zero-initialised registers cost a mid-batch s_waitcnt, see LdPacked::issue
-        const int rc = max(min(row0 + rr, M - 1), 0);
-        const float* hrow = h + (size_t)(rc * row_mul + row_off) * d + (size_t)kt0 * 32 + g8;
-        if (rows) {                    // wave-uniform
+        const bool rv = rows && row0 + rr < M;
+        const float* hrow = h + (size_t)((row0 + rr) * row_mul + row_off) * d + (size_t)kt0 * 32 + g8;
 #pragma unroll
-            for (int u = 0; u < NB; ++u) { const float4* src = reinterpret_cast<const float4*>(hrow + u * 32); r.v0[u] = src[0]; r.v1[u] = src[1]; }
-        } else {
-#pragma unroll
-            for (int u = 0; u < NB; ++u) { r.v0[u] = make_float4(0.f, 0.f, 0.f, 0.f); r.v1[u] = r.v0[u]; }
+        for (int u = 0; u < NB; ++u) {
+            r.v0[u] = make_float4(0.f, 0.f, 0.f, 0.f); r.v1[u] = r.v0[u];
+            if (rv) { const float4* src = reinterpret_cast<const float4*>(hrow + u * 32); r.v0[u] = src[0]; r.v1[u] = src[1]; }
         }
         if constexpr (NORM) {       // gamma | beta -> LDS, 1 KiB pieces (256 floats) spread over the block's waves
             const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6, np = (2 * d + 255) >> 8;
@@ -215,10 +204,6 @@ struct LdNormT {
     template <int NB>
     __device__ __forceinline__ void stats(Regs<NB>& r, char* smem, int ks, int ksplit, bool leader, int lane) const {
         r.mean = 0.f; r.rstd = 1.f;
-        if (!r.rv) {
-#pragma unroll
-            for (int u = 0; u < NB; ++u) { r.v0[u] = make_float4(0.f, 0.f, 0.f, 0.f); r.v1[u] = r.v0[u]; }
-        }
         if constexpr (!NORM) return;
         float2* part = reinterpret_cast<float2*>(smem + (size_t)2 * d * sizeof(float));      // [ksplit <= 16][16 rows]
         float s = 0.f, q2 = 0.f;
@@ -259,11 +244,8 @@ typedef LdNormT<false> LdIdent;
 // when the slice is long: the second half is issued as soon as the first has been consumed).  RT = weight row tiles per
 // wave (register blocking: the token fragment — and, for LdNorm, its normalisation — is shared by RT tiles; used where one
 // tile per block would put more blocks than CUs on the chip).  RT > 1 needs ksplit >= RT.
-// Launch bound: LayerNorm-fused instances hold the fp32 token rows AND the raw weights of the whole K-slice in registers
-// (128 VGPRs before anything else) and run with at most 8 waves (nk <= 8 => ksplit * rt <= 8): 512 threads leave them 256
-// VGPRs — at 640 they spilled once the whole memory batch was kept in flight.
 template <int NK, int RT, bool W8, class Ld, class Ep>
-__global__ void __launch_bounds__(Ld::kNorm ? 512 : 640)
+__global__ void __launch_bounds__(640)
 k_skinny_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int N16, int K32, int ksplit, int rt_per_wg, int ks_magic,
               int nmain, const int* __restrict__ done, Ld ld, Ep ep, PfJob pf TL_ARG)
 {
@@ -539,7 +521,7 @@ static inline hipError_t launch_skinny_nk(hipStream_t st, WRef W, int N16, int K
 
 template <bool W8, class Ld, class Ep>
 static inline hipError_t launch_skinny_w(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p, const Ld& ld, const Ep& ep) {
-    if (p.ksplit * p.rt > (Ld::kNorm ? 8 : 10) || p.ksplit * p.nk != K32 || (Ld::kNorm && p.nk > 8)) return hipErrorInvalidConfiguration;
+    if (p.ksplit * p.rt > 10 || p.ksplit * p.nk != K32 || (Ld::kNorm && p.nk > 8)) return hipErrorInvalidConfiguration;
     switch (p.nk) {
         case 4: return launch_skinny_nk<4, W8>(st, W, N16, K32, p, ld, ep);
         case 8: return launch_skinny_nk<8, W8>(st, W, N16, K32, p, ld, ep);
