@@ -240,7 +240,9 @@ static inline hipError_t launch_gemm_tiled(hipStream_t st, const bf16_t* X, cons
     if (use256 && Mrows % 256 == 0 && N % 256 == 0 && K32 % 2 == 0 && (Mrows / 256) * (N / 256) >= 200)
         return launch_gemm_256(st, X, W, Mrows, N, K32, ep);
     // fewer than ~one block per CU with 128-row tiles: halve the tile to fill the chip and split K inside the block
-    if (blocks128 < 200) {
+    // tuning knob; 600 / 1000 (64-row tiles for the one-clip QKV / FC1 GEMMs too) measured 7.9 ms per encoder pass against 6.4
+    static const int bm64_below = [] { const char* v = std::getenv("WM_ENC_BM64_BELOW"); return v ? std::atoi(v) : 200; }();
+    if (blocks128 < bm64_below) {
         if (small_ks == 2 && (K32 >> 1) % 2 == 0 && (K32 >> 1) >= 8) return launch_gemm_tiled_bm<64, 3, 2>(st, X, W, Mrows, N, K32, ep);
         return launch_gemm_tiled_bm<64, 4, 1>(st, X, W, Mrows, N, K32, ep);
     }
@@ -555,11 +557,14 @@ k_flash_enc(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kt, const b
                 pw.x = pack_bf2(p0[0], p0[1]); pw.y = pack_bf2(p0[2], p0[3]);
                 pw.z = pack_bf2(p1[0], p1[1]); pw.w = pack_bf2(p1[2], p1[3]);
                 const bf16x8_t pb = __builtin_bit_cast(bf16x8_t, pw);
+                // lazy rescale: once the running maxima have settled alpha is exactly 1 for every query of the wave and the 16
+                // multiplies per tile are skipped (wave-uniform branch; x * 1.0f == x, results unchanged)
+                if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0ull) {
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    o[t][dt][0] *= alpha; o[t][dt][1] *= alpha; o[t][dt][2] *= alpha; o[t][dt][3] *= alpha;
-                    o[t][dt] = mfma16(va[dt], pb, o[t][dt]);
+                    for (int dt = 0; dt < 4; ++dt) { o[t][dt][0] *= alpha; o[t][dt][1] *= alpha; o[t][dt][2] *= alpha; o[t][dt][3] *= alpha; }
                 }
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) o[t][dt] = mfma16(va[dt], pb, o[t][dt]);
             }
         }
     }
@@ -958,8 +963,14 @@ int wm_enc_encode(wm_ctx* ctx, const float* feats, int B)
             WM_HIP(hipGetLastError());
             WM_HIP(launch_gemm_tiled(st, ctx->exn, w.qkv_w, M, 3 * d, K32, EpQKVEnc{ctx->eq, ctx->ek, ctx->evt, w.qkv_b, Spad, H, d}));
         }
+        // queries per block: 256 (QT = 4: every K / V fragment read from LDS serves 4 query tiles) once that still gives >= 256
+        // blocks; with one or two clips 64 (QT = 1): twice the blocks of the 128-query form, two or three resident per CU, so
+        // one block's softmax (VALU) overlaps another's MFMAs — at one wave per SIMD nothing did
+        static const int qt1_below = [] { const char* v = std::getenv("WM_FLASH_QT1_BELOW"); return v ? std::atoi(v) : 256; }();     // one clip: 6.63 -> 6.42 ms per encoder pass
         if (B * (Spad / 128) * H >= 256 && Spad % 256 == 0)
             hipLaunchKernelGGL(k_flash_enc<4>, dim3(Spad / 256, H, B), dim3(256), 3 * 16 * 1024, st, ctx->eq, ctx->ek, ctx->evt, ctx->exn, S, Spad, H, K32);
+        else if (B * (Spad / 128) * H < qt1_below)
+            hipLaunchKernelGGL(k_flash_enc<1>, dim3(Spad / 64, H, B), dim3(256), 3 * 16 * 1024, st, ctx->eq, ctx->ek, ctx->evt, ctx->exn, S, Spad, H, K32);
         else
             hipLaunchKernelGGL(k_flash_enc<2>, dim3(Spad / 128, H, B), dim3(256), 3 * 16 * 1024, st, ctx->eq, ctx->ek, ctx->evt, ctx->exn, S, Spad, H, K32);
         WM_HIP(hipGetLastError());
