@@ -1,7 +1,8 @@
 """MFMA utilisation per kernel from a `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace` run.
 SQ_VALU_MFMA_BUSY_CYCLES summed over all counter instances of a dispatch = 16 cycles x number of
 v_mfma_f32_16x16x32_bf16 wave-instructions (calibrated on the FC1 GEMM: M/16 x N/16 x K/32 MFMAs), so
-utilisation = busy cycles / (kernel duration x 2.4 GHz x 1024 SIMDs).   python tests/mfma_summary.py <db> [out.md]"""
+utilisation = busy cycles / (kernel duration x 2.4 GHz x 1024 SIMDs).  The fp8 kernels' v_mfma_f32_16x16x32_fp8_fp8 occupies the
+pipe for the same 16 cycles (non-scaled fp8 runs at the bf16 rate on gfx950).   python tests/mfma_summary.py <db> [out.md]"""
 import re
 import sqlite3
 import sys
@@ -19,7 +20,7 @@ for n, d, v, t in c.execute(q):
     a[0] += 1; a[1] += v; a[2] += t * 1e-9
 lines = ["| kernel | dispatches | avg us | MFMA wave-instructions / dispatch | MFMA utilisation |", "|---|---|---|---|---|"]
 for n, (k, busy, sec) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
-    if not re.search(r"k_gemm_tiled|k_flash_enc|k_rows_gemm|k_skinny|k_attn", n) or sec <= 0:
+    if not re.search(r"k_gemm_tiled|k_gemm_256|k_gemm_f8|k_flash_enc|k_rows_gemm|k_skinny|k_attn", n) or sec <= 0:
         continue
     lines.append(f"| `{n}` | {k} | {sec / k * 1e6:.1f} | {busy / 16 / k:.4g} | {busy / (sec * CLK * SIMDS):.3f} |")
 out = "\n".join(lines)

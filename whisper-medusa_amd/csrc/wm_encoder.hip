@@ -90,18 +90,21 @@ k_gemm_tiled(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32
         if (kt2 + NST - 1 < nkt) stage_load((kt2 + NST - 1) % NST, kt2 + NST - 1);
         const bf16_t* xs = reinterpret_cast<const bf16_t*>(smem + (kt2 % NST) * STAGE);
         const bf16_t* ws = xs + XB * 512;
+        bf16x8_t a[2][4], b[2][MJ];          // both halves' fragment reads first (see k_gemm_256)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8_t a[4], b[MJ];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = ld_frag(ws + (((wn * 4 + i) * 2 + kk) * 64 + lane) * 8);
+            for (int i = 0; i < 4; ++i) a[kk][i] = ld_frag(ws + (((wn * 4 + i) * 2 + kk) * 64 + lane) * 8);
 #pragma unroll
-            for (int j = 0; j < MJ; ++j) b[j] = ld_frag(xs + (((wm * MJ + j) * 2 + kk) * 64 + lane) * 8);
+            for (int j = 0; j < MJ; ++j) b[kk][j] = ld_frag(xs + (((wm * MJ + j) * 2 + kk) * 64 + lane) * 8);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < MJ; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
-        }
+                for (int j = 0; j < MJ; ++j) acc[i][j] = mfma16(a[kk][i], b[kk][j], acc[i][j]);
     }
 
     if (KS > 1) {                              // partial tiles of groups 1.. go through LDS, group 0 adds them in order
@@ -199,18 +202,25 @@ k_gemm_256(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32, 
         if (kt2 + 1 < nkt) stage_load((kt2 + 1) & 1, kt2 + 1);
         const bf16_t* xs = reinterpret_cast<const bf16_t*>(smem + (kt2 & 1) * STAGE);
         const bf16_t* ws = xs + 32 * 512;
+        // both 32-deep halves of the step are requested from LDS before the first MFMA: the second half's reads land under
+        // the first half's 32 MFMAs (PMC: the pipes were 30 % busy — with one wave pair per SIMD every fragment read was
+        // an exposed LDS round trip in front of the MFMAs that needed it)
+        bf16x8_t a[2][4], b[2][8];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8_t a[4], b[8];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = ld_frag(ws + (((wn * 4 + i) * 2 + kk) * 64 + lane) * 8);
+            for (int i = 0; i < 4; ++i) a[kk][i] = ld_frag(ws + (((wn * 4 + i) * 2 + kk) * 64 + lane) * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) b[j] = ld_frag(xs + (((wm * 8 + j) * 2 + kk) * 64 + lane) * 8);
+            for (int j = 0; j < 8; ++j) b[kk][j] = ld_frag(xs + (((wm * 8 + j) * 2 + kk) * 64 + lane) * 8);
+        }
+        __builtin_amdgcn_sched_barrier(0);     // keep the reads above the MFMAs: left alone, the scheduler sinks each ds_read to just in
+                                               // front of its first use and waits lgkmcnt(0) there (ISA: R1 w0 M4 R1 w0 M4 ...)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int j = 0; j < 8; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
-        }
+                for (int i = 0; i < 4; ++i) acc[i][j] = mfma16(a[kk][i], b[kk][j], acc[i][j]);
     }
     const int m0 = tm * 256 + wm * 128 + (lane & 15), n0 = tn * 256 + wn * 64 + 4 * (lane >> 4);
 #pragma unroll
