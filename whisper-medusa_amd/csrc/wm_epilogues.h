@@ -132,6 +132,7 @@ struct EpHead {
 
 // ---- encoder -----------------------------------------------------------------------------
 struct EpConv1 {               // a1[b][t][n] = gelu(conv1) as row-major bf16 (input of the conv2 im2col)
+    static constexpr bool kPre = false;
     bf16_t* a1; const float* bias; int T, Tpad, d;
     __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const {
         const int b = m / Tpad, t = m - b * Tpad;
@@ -145,6 +146,7 @@ struct EpConv1 {               // a1[b][t][n] = gelu(conv1) as row-major bf16 (i
 };
 
 struct EpConv2 {               // h = gelu(conv2) + embed_positions   (HF:modeling_whisper.py:626-632)
+    static constexpr bool kPre = false;
     float* h; const float* bias; const float* pos; int S, Spad, d;
     __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const {
         const int s = m % Spad;
@@ -160,6 +162,7 @@ struct EpConv2 {               // h = gelu(conv2) + embed_positions   (HF:modeli
 };
 
 struct EpQKVEnc {              // q (x 64^-1/2), k as [b][h][s][64]; v as V^T MFMA fragments per [b][h] (vfrag_index)
+    static constexpr bool kPre = false;
     bf16_t* q; bf16_t* k; bf16_t* vt; const float* bias; int Spad, H, d;
     __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const {
         const int b = m / Spad, s = m - b * Spad;
@@ -180,6 +183,7 @@ struct EpQKVEnc {              // q (x 64^-1/2), k as [b][h][s][64]; v as V^T MF
 };
 
 struct EpCrossKV {             // K_x [kvl][b][h][s][64], V_x [kvl][b][h] as V^T MFMA fragments (vfrag_index)   (HF:modeling_whisper.py:322-335)
+    static constexpr bool kPre = false;
     bf16_t* kx; bf16_t* vx; const float* bias; int Spad, H, d, B;
     __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const {
         const int b = m / Spad, s = m - b * Spad;
