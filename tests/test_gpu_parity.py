@@ -219,6 +219,14 @@ def test_micro_batches_match_single_context(gpu):
         assert model.last_stats["micro_batches"] == mb
         assert model.last_stats["tokens_emitted"] == st1["tokens_emitted"]
         assert model.last_stats["accept_hist"] == st1["accept_hist"]
+    # automatic policy: two or three clips -> one context per clip, more -> one batched context; same tokens
+    model.set_micro_batches(None)
+    for nclips in (2, 3):
+        out = model.generate(feats[:nclips], max_new_tokens=28)
+        w = out.shape[1]                      # padded to the longest of these clips only
+        assert torch.equal(out, one[:nclips, :w]) and bool((one[:nclips, w:] == cfg.pad_token_id).all())
+        assert model.last_stats["micro_batches"] == nclips
+    assert torch.equal(model.generate(feats, max_new_tokens=28), one)
     model.set_micro_batches(1)
     orc = Oracle(cfg, sd, sim="bf16")
     gp = model._gen_params(None, None, None, 28, None, None, False, None, None, None, None, None)

@@ -288,3 +288,17 @@ def test_packed_export_roundtrip_and_checks(tmp_path):
         f.seek(1000); f.write(b"\x55\xaa")
     with pytest.raises(ValueError, match="corrupt"):
         WhisperMedusaModel.from_packed(str(tmp_path / "p00"))
+
+
+def test_automatic_micro_batch_policy():
+    from whisper_medusa import WhisperMedusaModel
+    m = WhisperMedusaModel(MedusaConfig.micro(), {})
+    assert [m._micro_batches_for(b) for b in (1, 2, 3, 32)] == [1, 1, 1, 1]          # default: one context
+    m.set_micro_batches(None)
+    assert [m._micro_batches_for(b) for b in (1, 2, 3, 4, 8, 32)] == [1, 2, 3, 1, 1, 1]
+    m.set_micro_batches(2)
+    assert [m._micro_batches_for(b) for b in (1, 2, 3, 32)] == [2, 2, 2, 2]
+    m.set_micro_batches(None)
+    assert m._micro_batches_for(2) == 2 and m._micro_batches_for(5) == 1
+    with pytest.raises(ValueError):
+        m.set_micro_batches(0)

@@ -41,7 +41,7 @@ class WhisperMedusaModel:
         self._max_batch = max_batch
         self._fp8 = bool(dec_weight_fp8)         # decoder-layer matrices stored as fp8 e4m3 + per-row scale (BASELINE configs[4])
         self._enc_fp8 = bool(enc_fp8)            # encoder QKV / FC1 / cross-K/V projection on the fp8 MFMA (BASELINE configs[4])
-        self._micro_batches = 1
+        self._micro_batches = 1                  # contexts a batch is decoded with; None = automatic (set_micro_batches(None))
         self._pool = None
         self._engine: Optional[Engine] = None
         self._blob = None
@@ -172,26 +172,39 @@ class WhisperMedusaModel:
             self._drop_pool()
         return self
 
-    def set_micro_batches(self, n: int):
+    def set_micro_batches(self, n: Optional[int]):
         """Decode batches as ``n`` concurrent micro-batches (own engine context + HIP stream each, shared weights):
-        see ``pool.py``.  n = 1 (default) is the single-context path; tokens do not depend on n."""
-        if n < 1:
+        see ``pool.py``.  n = 1 (default) is the single-context path — the model's own engine then holds the state of the
+        last call (encoder output, statistics); ``None`` picks per call (``_micro_batches_for``).  Tokens do not depend on n."""
+        if n is not None and n < 1:
             raise ValueError("micro_batches must be >= 1")
         if n != self._micro_batches:
             self._micro_batches = n
             self._drop_pool()
         return self
 
+    def _micro_batches_for(self, B: int) -> int:
+        """Contexts a batch of B clips is decoded with.  Automatic policy, measured on MI355X with large-v2 (tests/microbench/
+        r02_call25.sh): two or three streams decode faster as single-stream contexts running side by side (2: 2135 vs 1455
+        tokens/s, 3: 2335 vs 2187 — the single-stream kernels are the fused 16-row ones and two chains of short launches fill
+        each other's gaps), from four streams on one batched context wins (4: 2822 vs 2517 / 2477; 8: 4177 vs 3834 / 2326)."""
+        if self._micro_batches is not None:
+            return self._micro_batches
+        return B if B in (2, 3) else 1
+
     def _drop_pool(self):
         if self._pool is not None:
             self._pool.close()
             self._pool = None
 
-    def _get_pool(self):
+    def _get_pool(self, n: int):
+        if self._pool is not None and getattr(self, "_pool_n", None) != n:
+            self._drop_pool()
         if self._pool is None:
             from .pool import ContextPool
             _ = self.engine                                         # raises when not on a HIP device
-            self._pool = ContextPool(self.config, self._blob, self._offsets, self._micro_batches, self._max_batch, self._fp8, self._enc_fp8)
+            self._pool = ContextPool(self.config, self._blob, self._offsets, n, max(self._max_batch, n), self._fp8, self._enc_fp8)
+            self._pool_n = n
         return self._pool
 
     @property
@@ -323,8 +336,9 @@ class WhisperMedusaModel:
         feats = input_features.to(self.device, torch.float32).contiguous()
         if return_token_timestamps:
             raise NotImplementedError("token timestamps are not supported with medusa")
-        if self._micro_batches > 1 and B >= 2:
-            pool = self._get_pool()
+        n_ctx = self._micro_batches_for(B) if kwargs.get("streamer") is None else 1
+        if n_ctx > 1 and B >= 2:
+            pool = self._get_pool(n_ctx)
             seqs = pool.run(feats, gp)                                      # F1..F14 per micro-batch, concurrently
             self.last_stats = pool.last_stats
             return self._outputs(seqs, gp, return_dict_in_generate, return_segments)
