@@ -477,6 +477,18 @@ class Oracle:
             out += [self._vocab(self._res_head(k, g_rows)) for k in range(K)]
         return torch.stack(out)
 
+    @torch.no_grad()
+    def detect_language(self, enc: torch.Tensor, lang_ids: List[int], start_token: Optional[int] = None) -> int:
+        """HF WhisperGenerationMixin.detect_language (generation_whisper.py: one decoder step on <|startoftranscript|>, every
+        non-language logit masked to -inf, argmax) — what the reference's generate() reaches through _retrieve_init_tokens
+        when `language` is None (model.py:1519-1537).  With the Medusa model the first of the stacked heads is the base head.
+        Returns the winning language TOKEN ID."""
+        tok = self.cfg.decoder_start_token_id if start_token is None else start_token
+        z = self.decoder_pass(self.new_state(enc), [tok], 0, disable_medusa=True)[0, 0]
+        mask = torch.full_like(z, -float("inf"))
+        mask[list(lang_ids)] = 0.0
+        return int(torch.argmax(z + mask))
+
     # ---- the decode loop (model.py:634-810; SURVEY.md Appendix A) --------------------------
     @torch.no_grad()
     def decode(self, enc: torch.Tensor, gp, trace: bool = False, max_iters: Optional[int] = None) -> DecodeResult:

@@ -161,3 +161,25 @@ def test_processors_match_hf():
         assert torch.equal(torch.isinf(got), torch.isinf(ref))
         fin = ~torch.isinf(ref)
         assert torch.equal(got[fin], ref[fin])
+
+
+def test_language_detection_matches_hf(hf_tiny):
+    """Oracle.detect_language == HF detect_language on the same weights (the product's detect_language is checked against the
+    oracle on the GPU, tests/test_gpu_features.py)."""
+    from transformers import GenerationConfig
+    from transformers.modeling_outputs import BaseModelOutput
+    cfg, sd, m = hf_tiny
+    orc = Oracle(MedusaConfig.tiny_en("medusa_block", K=4), {**sd, **{k.replace("whisper_model.model.decoder.layers.3", "medusa_block"): v
+                                                                      for k, v in sd.items() if "decoder.layers.3." in k}})
+    lang_to_id = {f"<|l{i}|>": 50259 + i for i in range(12)}
+    gc = GenerationConfig(decoder_start_token_id=50257, lang_to_id=lang_to_id, is_multilingual=True, task_to_id={"transcribe": 50359})
+    picks = set()
+    for clip in range(4):
+        feats = torch.from_numpy(log_mel(synth.synth_clip(clip)))
+        with torch.no_grad():
+            e_ref = m.model.encoder(feats[None]).last_hidden_state
+            want = int(m.detect_language(encoder_outputs=BaseModelOutput(last_hidden_state=e_ref), generation_config=gc)[0])
+        got = orc.detect_language(e_ref[0], list(lang_to_id.values()), start_token=50257)
+        assert got == want and got in lang_to_id.values()
+        picks.add(got)
+    assert len(picks) >= 1
