@@ -384,10 +384,43 @@ def main_tree():
     print("reference tree-loop vectors written")
 
 
+def main_prompt():
+    """`python oracle/make_golden.py prompt`: decode runs conditioned on a long decoder prompt (`prompt_ids`, model.py:1519-1529:
+    <|startofprev|> + previous text + the forced init tokens) through the reference forward() + candidates / posterior."""
+    os.makedirs(GOLD, exist_ok=True)
+    mu = load_ref_medusa_utils()
+    out = {}
+    for tag, cfg, seed in (("microprompt", MedusaConfig.micro(K=4, n_tgt=96), 41),
+                           ("microblockprompt", MedusaConfig.micro(K=4, heads_type="medusa_block", n_tgt=96), 42)):
+        sd = synth.synth_state_dict(cfg, seed=seed)
+        model = build_ref(cfg, sd)
+        orc = Oracle(cfg, sd, sim="fp32")
+        wav = synth.synth_clip(2, n_samples=cfg.n_mel_frames * 160)
+        feats = torch.from_numpy(log_mel(wav, cfg.num_mel_bins, cfg.n_mel_frames * 160))
+        with torch.no_grad():
+            enc = model.whisper_model.model.encoder(feats[None]).last_hidden_state[0]
+        for plen in (5, 23, 40):
+            gp = gen_params_for(cfg, ACCEPT_TYPICAL, 24)
+            prev = [cfg.vocab_size - 5] + [10 + (7 * i) % 900 for i in range(plen - 1)]
+            gp.prompt = prev + list(gp.prompt)
+            gp.max_length = min(len(gp.prompt) + 24, cfg.max_target_positions)
+            ids, accepts, _ = ref_medusa_loop(model, mu, enc, gp, cfg.medusa_num_heads, use_cache=cfg.is_block)
+            r = orc.decode(enc, gp)
+            assert r.ids[: len(ids)] == ids and r.accept_lengths == accepts, (tag, plen)
+            out[f"{tag}_{plen}_prompt"] = np.array(gp.prompt)
+            out[f"{tag}_{plen}_ids"] = np.array(ids)
+            out[f"{tag}_{plen}_accepts"] = np.array(accepts)
+            print(f"  {tag} prompt {len(gp.prompt)}: {len(ids) - len(gp.prompt)} new tokens, accepts {accepts}")
+    np.savez_compressed(os.path.join(GOLD, "reference_prompt_runs.npz"), **out)
+    print("reference long-prompt vectors written")
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "tree":
         return main_tree()
+    if len(sys.argv) > 1 and sys.argv[1] == "prompt":
+        return main_prompt()
     mu = load_ref_medusa_utils()
     np.savez_compressed(os.path.join(GOLD, "medusa_utils_kat.npz"), **golden_medusa_utils(mu))
     print("medusa_utils known-answer vectors written")

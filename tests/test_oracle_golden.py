@@ -183,3 +183,21 @@ def test_language_detection_matches_hf(hf_tiny):
         assert got == want and got in lang_to_id.values()
         picks.add(got)
     assert len(picks) >= 1
+
+
+@pytest.mark.parametrize("tag,heads,seed", [("microprompt", "base_head", 41), ("microblockprompt", "medusa_block", 42)])
+def test_long_prompt_runs_match_reference(tag, heads, seed):
+    """`prompt_ids` conditioning: decode runs started from decoder prompts of 7 / 25 / 42 tokens (previous-text token + text +
+    init tokens), minted from the reference forward() (oracle/make_golden.py prompt) — the oracle reproduces tokens and accept
+    lengths; the engine's chunked prompt pass is compared with the oracle on the GPU (tests/test_gpu_features.py)."""
+    runs = np.load(f"{GOLD}/reference_prompt_runs.npz")
+    cfg = MedusaConfig.micro(K=4, heads_type=heads, n_tgt=96)
+    sd = synth.synth_state_dict(cfg, seed=seed)
+    orc = Oracle(cfg, sd, sim="fp32")
+    enc = orc.encode(torch.from_numpy(log_mel(clip_for(cfg, 2), cfg.num_mel_bins, cfg.n_mel_frames * 160)))
+    for plen in (5, 23, 40):
+        gp = golden_gen_params(cfg, ACCEPT_TYPICAL, 24)
+        gp.prompt = runs[f"{tag}_{plen}_prompt"].tolist()
+        gp.max_length = min(len(gp.prompt) + 24, cfg.max_target_positions)
+        r = orc.decode(enc, gp)
+        assert r.ids == runs[f"{tag}_{plen}_ids"].tolist() and r.accept_lengths == runs[f"{tag}_{plen}_accepts"].tolist(), (tag, plen)
