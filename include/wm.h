@@ -163,8 +163,10 @@ int wm_forward_logits(wm_ctx* ctx, int B, const int32_t* tokens /* HOST [B][T] *
 /* cross K/V of one kv-layer/stream/head: HOST float32 [n_ctx][64] each */
 int wm_get_cross_kv(wm_ctx* ctx, int kv_layer, int stream, int head, float* k_out, float* v_out);
 /* Times `reps` launches of one decode-path kernel class in its current shape with hipEvents on
- * the context stream (bench.py roofline leg).  kernel: 0 = weight-streaming GEMM of one decoder
- * layer pass (all 6 GEMMs), returns avg ms per rep in *ms and the algorithmic bytes in *bytes. */
+ * the context stream (bench.py roofline leg).  kernel: 0 = the weight-streaming GEMMs of one decoder
+ * layer pass (all 6), 1..6 = one of them (LN1+QKV, out-proj, LN2+cross-q, cross-out, LN3+FC1+GELU, FC2),
+ * 7 = the shared vocabulary projection; rows = token rows (<= 16 x max_batch).  Returns avg ms per rep
+ * in *ms and the weight bytes those launches stream in *bytes.  No reference counterpart (measurement). */
 int wm_profile_kernel(wm_ctx* ctx, int kernel, int rows, int reps, float* ms, double* bytes);
 
 #ifdef __cplusplus

@@ -1,0 +1,111 @@
+"""Round 3 micro-benchmark: the decode GEMMs of one decoder layer at B-stream row counts (old register-blocked kernel vs the
+LDS-ring tile kernel in every tile shape), and the encoder pass at 1 / 32 clips (round-2 two-stage 256 x 256 kernel vs the
+pipelined one, ring depths).  One process, one model: the knobs are environment variables read per launch.
+
+    python tests/microbench/r03_sweep.py [--dec] [--enc] [--out gpurun_out/r03_sweep.json]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+for p in (os.path.join(ROOT, "whisper-medusa_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+NAMES = {0: "layer(6)", 1: "LN1+QKV", 2: "out-proj", 3: "LN2+cross-q", 4: "cross-out", 5: "LN3+FC1", 6: "FC2", 7: "vocab"}
+
+
+def setenv(**kw):
+    for k, v in kw.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = str(v)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dec", action="store_true")
+    ap.add_argument("--enc", action="store_true")
+    ap.add_argument("--streams", type=int, default=32)
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r03_sweep.json"))
+    args = ap.parse_args()
+    if not (args.dec or args.enc):
+        args.dec = args.enc = True
+    from whisper_medusa import MedusaConfig, WhisperMedusaModel, synth, weights
+    dev = torch.device("cuda", 0)
+    cfg = MedusaConfig.large_v2("base_head", K=10)
+    sd = synth.synth_state_dict(cfg, seed=0, device=str(dev), logit_std=4.5)
+    blob, offs = weights.build_blob(cfg, sd, device=dev)
+    del sd
+    B = args.streams
+    model = WhisperMedusaModel.from_blob(cfg, blob, offs, max_batch=B)
+    eng = model.engine
+    res = {"decode_gemms_us": {}, "encoder_ms": {}}
+
+    if args.dec:
+        for rows in (B * 11, 176, 88, 48):
+            if rows > 16 * B:
+                continue
+            table = {}
+            for kern in (1, 2, 3, 4, 5, 6, 7, 0):
+                row = {}
+                setenv(WM_TILE_GEMM_MIN_MT=0, WM_TILE_F=None, WM_TILE_TT=None, WM_LN_PREFETCH=None)
+                row["old"] = round(eng.profile_layer_gemms(rows, 30, kern)[0] * 1e3, 2)
+                setenv(WM_TILE_GEMM_MIN_MT=None)
+                row["tile"] = round(eng.profile_layer_gemms(rows, 30, kern)[0] * 1e3, 2)
+                if kern in (1, 3, 5, 0):
+                    setenv(WM_LN_PREFETCH=0)
+                    row["tile_nopf"] = round(eng.profile_layer_gemms(rows, 30, kern)[0] * 1e3, 2)
+                    setenv(WM_LN_PREFETCH=None)
+                if rows == B * 11 and kern != 0:
+                    for F in (1, 2):
+                        for TT in (2, 4, 6, 8):
+                            setenv(WM_TILE_F=F, WM_TILE_TT=TT)
+                            try:
+                                row[f"F{F}TT{TT}"] = round(eng.profile_layer_gemms(rows, 20, kern)[0] * 1e3, 2)
+                            except Exception as e:  # noqa: BLE001
+                                row[f"F{F}TT{TT}"] = repr(e)
+                    setenv(WM_TILE_F=None, WM_TILE_TT=None)
+                table[NAMES[kern]] = row
+                print(f"rows={rows} {NAMES[kern]:12s} {row}", flush=True)
+            res["decode_gemms_us"][str(rows)] = table
+
+    if args.enc:
+        n_samp = cfg.n_mel_frames * 160
+        for nb in (B, 1):
+            wav = torch.from_numpy(np.stack([synth.synth_clip(900 + j, n_samp) for j in range(nb)])).to(dev)
+            feats = eng.logmel(wav)
+            variants = [("r02_256", dict(WM_ENC_GEMM_256P=0)), ("p_ring4", dict(WM_ENC_GEMM_256P=1, WM_ENC_GEMM_RING=4)),
+                        ("p_ring5", dict(WM_ENC_GEMM_256P=1, WM_ENC_GEMM_RING=5)), ("p_ring3", dict(WM_ENC_GEMM_256P=1, WM_ENC_GEMM_RING=3))] if nb > 1 else \
+                       [("stages2", dict(WM_ENC_GEMM_STAGES=2)), ("stages3", dict(WM_ENC_GEMM_STAGES=3))]
+            row = {}
+            for name, env in variants:
+                setenv(**env)
+                eng.encode(feats)
+                ts = []
+                for _ in range(3):
+                    eng.encode(feats)
+                    ts.append(eng.stats()["ms_encode"])
+                row[name] = round(min(ts), 3)
+                for k in env:
+                    setenv(**{k: None})
+            flops = 2.587e12 * nb
+            row["tflops"] = {k: round(flops / (v * 1e-3) / 1e12, 1) for k, v in row.items()}
+            print(f"encoder {nb} clip(s): {row}", flush=True)
+            res["encoder_ms"][str(nb)] = row
+
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    with open(args.out, "w") as f:
+        json.dump(res, f, indent=1)
+    print("wrote", args.out)
+
+
+if __name__ == "__main__":
+    main()

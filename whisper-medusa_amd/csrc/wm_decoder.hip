@@ -1287,27 +1287,39 @@ int wm_dec_iter_rest(wm_ctx* ctx, int Mper_base)
     return WM_OK;
 }
 
-// Times the six weight-streaming GEMMs of one decoder layer for `rows` token rows (bench.py roofline leg).
+// Times decode-path GEMMs of decoder layer 0 for `rows` token rows (bench.py roofline leg; tests/microbench).
+// kernel 0: the six weight-streaming GEMMs of a layer back to back (LayerNorm-fused / LN launch + token-tile GEMM as the pass
+// would run them); 1..6: one of them alone (1 LN1+QKV, 2 out-proj, 3 LN2+cross-q, 4 cross-out, 5 LN3+FC1+GELU, 6 FC2);
+// 7: the shared vocabulary projection.  *bytes = the weight bytes the timed launches stream.
 int wm_dec_profile(wm_ctx* ctx, int kernel, int rows, int reps, float* ms, double* bytes)
 {
-    if (kernel != 0 || rows < 1 || rows > 16) { ctx->err = "wm_profile_kernel: bad arguments"; return WM_ERR_ARG; }
+    if (kernel < 0 || kernel > 7 || rows < 1 || rows > ctx->Rcap) { ctx->err = "wm_profile_kernel: bad arguments"; return WM_ERR_ARG; }
     g_skinny_done = nullptr;
     hipStream_t st = ctx->stream;
     const int d = ctx->d, K32 = d / 32, R = rows, H = ctx->H, F32 = ctx->ffn / 32;
     const size_t xpl = (size_t)ctx->Rcap * d, fpl = (size_t)ctx->Rcap * ctx->ffn;
     const DecLayerW& w = ctx->dec[0];
-    WM_HIP(hipMemsetAsync(ctx->h, 0, (size_t)16 * d * sizeof(float), st));
+    WM_HIP(hipMemsetAsync(ctx->h, 0, (size_t)ctx->Rcap * d * sizeof(float), st));
     WM_HIP(hipMemsetAsync(ctx->kvlen, 0, sizeof(int) * ctx->maxB, st));
+    const bool all = kernel == 0;
     auto body = [&]() -> int {
-        WM_HIP(launch_skinny_norm(st, WRef{w.qkv_w, w.qkv_s}, 3 * d / 16, K32, ctx->h, w.ln1_w, w.ln1_b, d, R, 1, 0, 1,
-                                  EpQKVDec{ctx->qbuf, ctx->kc, ctx->vc, w.qkv_b, ctx->kvlen, R, d, H, ctx->Tal, R}, ctx->xbuf, xpl));
-        WM_HIP(launch_skinny_rows(st, WRef{w.out_w, w.out_s}, d / 16, K32, R, ctx->xbuf, xpl, EpResidual{ctx->h, w.out_b, d, R}));
-        WM_HIP(launch_skinny_norm(st, WRef{w.cq_w, w.cq_s}, d / 16, K32, ctx->h, w.ln2_w, w.ln2_b, d, R, 1, 0, 1, EpF32{ctx->qbuf, w.cq_b, d, R, 0.125f},
-                                  ctx->xbuf, xpl));
-        WM_HIP(launch_skinny_rows(st, WRef{w.cout_w, w.cout_s}, d / 16, K32, R, ctx->xbuf, xpl, EpResidual{ctx->h, w.cout_b, d, R}));
-        WM_HIP(launch_skinny_norm(st, WRef{w.fc1_w, w.fc1_s}, ctx->ffn / 16, K32, ctx->h, w.ln3_w, w.ln3_b, d, R, 1, 0, 1,
-                                  EpPackedAct<1>{ctx->fbuf, ctx->fbuf + fpl, w.fc1_b, F32, R}, ctx->xbuf, xpl));
-        WM_HIP(launch_skinny_rows(st, WRef{w.fc2_w, w.fc2_s}, d / 16, F32, R, ctx->fbuf, fpl, EpResidual{ctx->h, w.fc2_b, d, R}));
+        if (all || kernel == 1)
+            WM_HIP(launch_skinny_norm(st, WRef{w.qkv_w, w.qkv_s}, 3 * d / 16, K32, ctx->h, w.ln1_w, w.ln1_b, d, R, 1, 0, 1,
+                                      EpQKVDec{ctx->qbuf, ctx->kc, ctx->vc, w.qkv_b, ctx->kvlen, R, d, H, ctx->Tal, R}, ctx->xbuf, xpl));
+        if (all || kernel == 2)
+            WM_HIP(launch_skinny_rows(st, WRef{w.out_w, w.out_s}, d / 16, K32, R, ctx->xbuf, xpl, EpResidual{ctx->h, w.out_b, d, R}));
+        if (all || kernel == 3)
+            WM_HIP(launch_skinny_norm(st, WRef{w.cq_w, w.cq_s}, d / 16, K32, ctx->h, w.ln2_w, w.ln2_b, d, R, 1, 0, 1, EpF32{ctx->qbuf, w.cq_b, d, R, 0.125f},
+                                      ctx->xbuf, xpl));
+        if (all || kernel == 4)
+            WM_HIP(launch_skinny_rows(st, WRef{w.cout_w, w.cout_s}, d / 16, K32, R, ctx->xbuf, xpl, EpResidual{ctx->h, w.cout_b, d, R}));
+        if (all || kernel == 5)
+            WM_HIP(launch_skinny_norm(st, WRef{w.fc1_w, w.fc1_s}, ctx->ffn / 16, K32, ctx->h, w.ln3_w, w.ln3_b, d, R, 1, 0, 1,
+                                      EpPackedAct<1>{ctx->fbuf, ctx->fbuf + fpl, w.fc1_b, F32, R}, ctx->xbuf, xpl));
+        if (all || kernel == 6)
+            WM_HIP(launch_skinny_rows(st, WRef{w.fc2_w, w.fc2_s}, d / 16, F32, R, ctx->fbuf, fpl, EpResidual{ctx->h, w.fc2_b, d, R}));
+        if (kernel == 7)
+            WM_HIP(launch_skinny_rows(st, ctx->vocab_w, ctx->Vpad / 16, K32, R, ctx->ybuf, xpl, EpF32{ctx->logits, nullptr, ctx->Vpad, R, 1.0f}));
         return WM_OK;
     };
     int rc = body();
@@ -1319,7 +1331,9 @@ int wm_dec_profile(wm_ctx* ctx, int kernel, int rows, int reps, float* ms, doubl
     float t = 0.f;
     WM_HIP(hipEventElapsedTime(&t, ctx->ev0, ctx->ev1));
     *ms = t / reps;
-    *bytes = 2.0 * ((double)(3 + 1 + 1 + 1) * d * d + 2.0 * (double)d * ctx->ffn);
+    const double dd = (double)d * d, df = (double)d * ctx->ffn;
+    const double wb[8] = {2.0 * (6 * dd + 2 * df), 6 * dd, 2 * dd, 2 * dd, 2 * dd, 2 * df, 2 * df, 2.0 * ctx->Vpad * d};
+    *bytes = wb[kernel];
     return WM_OK;
 }
 

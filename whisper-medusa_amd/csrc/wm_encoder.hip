@@ -23,6 +23,21 @@ __device__ __forceinline__ void glds16(const bf16_t* gsrc, char* lds_wave_base)
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// Block barrier of the LDS-DMA ring kernels.  NOT __syncthreads(): an LDS-DMA in flight is a pending LDS write on the vector
+// memory counter, so the fence inside __syncthreads() emits s_waitcnt vmcnt(0) and drains the whole ring at every step (the
+// round-2 ISA of every ring kernel here had exactly that in front of its s_barrier: the "partial" waits never took effect).
+// The wave's own fragment reads of the stage about to be refilled are retired first (lgkmcnt), the DMA pieces it needs were
+// waited for with a counted vmcnt by the caller.
+// The lgkmcnt wait is the BUILTIN, not inline asm: the compiler's wait-count pass then knows that every LDS read and scalar
+// load issued so far is complete.  With an opaque asm wait it kept the kernel-argument s_loads of the epilogue "pending" through
+// the whole K loop and, SMEM returning out of order, turned every counted LDS wait of the loop into lgkmcnt(0) — i.e. the MFMAs of
+// a step waited for the fragment reads of the NEXT step that had just been issued.
+__device__ __forceinline__ void ring_barrier()
+{
+    __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0); vmcnt / expcnt fields left at their maxima (no wait)
+    __builtin_amdgcn_s_barrier();
+}
+
 // BM = token rows per tile: 128 (default) or 64 (doubles the block count of the N=d GEMMs).
 // NST = LDS ring stages: a stage (64 k of the X tile and of the 128-feature W tile) is filled by LDS-DMA; NST-1 stages
 // are in flight while one is consumed, and the consumer waits with a partial vmcnt for ITS stage only.
@@ -86,7 +101,7 @@ k_gemm_tiled(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32
         if (NST >= 4 && younger >= 2) wait_vmcnt<2 * LPW>();
         else if (NST >= 3 && younger >= 1) wait_vmcnt<LPW>();
         else wait_vmcnt<0>();
-        __syncthreads();                       // every wave's part of stage kt2 landed; everyone is done with stage kt2-1
+        ring_barrier();                        // every wave's part of stage kt2 landed; everyone is done with stage kt2-1
         if (kt2 + NST - 1 < nkt) stage_load((kt2 + NST - 1) % NST, kt2 + NST - 1);
         const bf16_t* xs = reinterpret_cast<const bf16_t*>(smem + (kt2 % NST) * STAGE);
         const bf16_t* ws = xs + XB * 512;
@@ -198,7 +213,7 @@ k_gemm_256(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32, 
     stage_load(0, 0);
     for (int kt2 = 0; kt2 < nkt; ++kt2) {
         wait_vmcnt<0>();
-        __syncthreads();                       // stage kt2 landed for everyone; everyone is done reading the other buffer
+        ring_barrier();                        // stage kt2 landed for everyone; everyone is done reading the other buffer
         if (kt2 + 1 < nkt) stage_load((kt2 + 1) & 1, kt2 + 1);
         const bf16_t* xs = reinterpret_cast<const bf16_t*>(smem + (kt2 & 1) * STAGE);
         const bf16_t* ws = xs + 32 * 512;
@@ -229,6 +244,146 @@ k_gemm_256(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32, 
         for (int j = 0; j < 8; ++j) ep.store4(m0 + j * 16, n0 + i * 16, acc[i][j]);
 }
 
+// =============================================================================================
+// 256 x 256 tile, software-pipelined (round 3).  Same tile, wave layout, operands, k order and accumulators as k_gemm_256
+// (bit-identical results); what changes is WHEN things happen:
+//   * stages are 32 k deep (32 KiB: 16 X + 16 W fragments), NST of them in a ring; a stage is refilled as soon as its
+//     fragments sit in registers and only a counted `s_waitcnt vmcnt` + raw s_barrier stands between steps, so NST-1 stages
+//     (96 KiB) stay in flight across the barrier (k_gemm_256 drained the queue, vmcnt(0), at every step);
+//   * fragments are double-buffered in registers: right after the barrier a wave requests the 12 fragments of step t+1
+//     and then issues the 32 MFMAs of step t from the registers filled one step earlier — LDS latency and the LDS pipe's
+//     transfer time (8 waves x 12 KiB per step) sit under the matrix pipe instead of in front of it.  PMC of the round-2
+//     kernel: matrix pipes 29-33 % busy, waves parked in s_waitcnt / s_barrier half of their cycles.
+//   * blockIdx -> tile: an XCD (32 CUs, one private L2) walks PM x PN patches of tiles, so the ~32 blocks resident on it
+//     share PM token panels and PN weight panels through its L2 (PM + PN panels enter the L2 per patch instead of PM*PN + 1:
+//     with the panel-major order every resident block streamed its own token panel from the Infinity Cache).
+// =============================================================================================
+template <int NST, class Ep>
+__global__ void __launch_bounds__(512)
+k_gemm_256p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32, int tiles_m, int tiles_n, int PM, int PN, Ep ep)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STAGE = 32 * 1024;            // 16 X fragments (token tiles) then 16 W fragments (row tiles), one k-tile
+    constexpr int LPW = 4;                      // LDS-DMA pieces per wave per stage
+    const int lane = threadIdx.x & 63;
+    const int wa = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wa >> 2, wn = wa & 3;
+    // tile of this block: XCD x (= blockIdx % 8, observed placement) owns the contiguous range [x * per, (x+1) * per) of the
+    // patch-major tile order; inside a patch tiles run token-fastest.  Bijective for any grid (r extra tiles go to XCDs 0..r-1).
+    const int nwg = tiles_m * tiles_n;
+    int id;
+    {
+        const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
+    const int per_patch = PM * PN, patches_m = tiles_m / PM;        // the launcher picks PM | tiles_m, PN | tiles_n
+    const int patch = id / per_patch, within = id - patch * per_patch;
+    const int pn = patch / patches_m, pm = patch - pn * patches_m;
+    const int tn = pn * PN + within / PM, tm = pm * PM + within % PM;
+    const int NT = K32;                         // stages (even; the launcher checks)
+    const bf16_t* xg = X + (size_t)tm * 16 * K32 * 512 + lane * 8;
+    const bf16_t* wg = W + (size_t)tn * 16 * K32 * 512 + lane * 8;
+
+    auto stage_load = [&](int kt) {
+        char* sb = smem + (kt % NST) * STAGE;
+#pragma unroll
+        for (int i = 0; i < LPW; ++i) {
+            const int blk = wa * LPW + i;              // 0..15 X fragments, 16..31 W fragments
+            const bool isx = blk < 16;
+            const int t = isx ? blk : blk - 16;
+            glds16((isx ? xg : wg) + ((size_t)t * K32 + kt) * 512, sb + blk * 1024);
+        }
+    };
+    auto frag_load = [&](int kt, bf16x8_t (&a)[4], bf16x8_t (&b)[8]) {
+        const bf16_t* xs = reinterpret_cast<const bf16_t*>(smem + (kt % NST) * STAGE);
+        const bf16_t* ws = xs + 16 * 512;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = ld_frag(ws + ((wn * 4 + i) * 64 + lane) * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b[j] = ld_frag(xs + ((wm * 8 + j) * 64 + lane) * 8);
+    };
+
+    f32x4_t acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int s = 0; s < NST; ++s)
+        if (s < NT) stage_load(s);
+    // stage 0 -> registers
+    if (NT >= NST) wait_vmcnt<(NST - 1) * LPW>(); else wait_vmcnt<0>();
+    ring_barrier();
+    bf16x8_t a0[4], b0[8], a1[4], b1[8];
+    frag_load(0, a0, b0);
+
+    // one step: stage t is in (ac, bc); request stage t+1 into (an, bn), then the MFMAs of stage t
+    auto step = [&](int t, bf16x8_t (&ac)[4], bf16x8_t (&bc)[8], bf16x8_t (&an)[4], bf16x8_t (&bn)[8]) {
+        // stages issued so far: 0 .. min(NT-1, t+NST-1); stage t+1 must have landed: only the stages after it may be outstanding
+        const int younger = min(NT - 1, t + NST - 1) - (t + 1);
+        if (younger >= 3) wait_vmcnt<3 * LPW>();
+        else if (younger == 2) wait_vmcnt<2 * LPW>();
+        else if (younger == 1) wait_vmcnt<LPW>();
+        else wait_vmcnt<0>();
+        ring_barrier();                        // everyone's pieces of stage t+1 landed; everyone's reads of stage t (and older) are complete
+        if (t + NST < NT) stage_load(t + NST);                  // into the buffer of stage t: it lives in registers now
+        frag_load(t + 1, an, bn);              // unconditional (after the last step it re-reads a stale buffer, unused): a branch here makes
+                                               // the compiler wait lgkmcnt(0) at the join, i.e. for THESE reads, in front of the MFMAs below
+        __builtin_amdgcn_sched_barrier(0);     // keep the requests above the MFMAs
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = mfma16(ac[i], bc[j], acc[i][j]);
+    };
+    static_assert(NST >= 3 && NST <= 5, "ring depth");
+    for (int t = 0; t < NT; t += 2) {
+        step(t, a0, b0, a1, b1);
+        step(t + 1, a1, b1, a0, b0);
+    }
+    const int m0 = tm * 256 + wm * 128 + (lane & 15), n0 = tn * 256 + wn * 64 + 4 * (lane >> 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ep.store4(m0 + j * 16, n0 + i * 16, acc[i][j]);
+}
+
+// patch of the XCD-aware tile order: PN = the largest divisor of tiles_n that is <= 6, PM = the largest divisor of tiles_m
+// with PM * PN <= 32 (the blocks resident on one XCD)
+static inline void gemm256_patch(int tiles_m, int tiles_n, int& PM, int& PN)
+{
+    PN = 1;
+    for (int c = 6; c >= 1; --c) if (tiles_n % c == 0) { PN = c; break; }
+    PM = 1;
+    for (int c = 32 / PN; c >= 1; --c) if (tiles_m % c == 0) { PM = c; break; }
+}
+
+template <class Ep>
+static inline hipError_t launch_gemm_256p(hipStream_t st, const bf16_t* X, const bf16_t* W, int Mrows, int N, int K32, const Ep& ep)
+{
+    const int tiles_m = Mrows / 256, tiles_n = N / 256;
+    int PM, PN;
+    gemm256_patch(tiles_m, tiles_n, PM, PN);
+    const int nst = [] { const char* v = std::getenv("WM_ENC_GEMM_RING"); return v ? std::atoi(v) : 4; }();      // read per launch (sweeps)
+    if (nst == 5) {
+        auto kern = k_gemm_256p<5, Ep>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), 160 * 1024, st, X, W, K32, tiles_m, tiles_n, PM, PN, ep);
+    } else if (nst == 3) {
+        auto kern = k_gemm_256p<3, Ep>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), 96 * 1024, st, X, W, K32, tiles_m, tiles_n, PM, PN, ep);
+    } else {
+        auto kern = k_gemm_256p<4, Ep>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), 128 * 1024, st, X, W, K32, tiles_m, tiles_n, PM, PN, ep);
+    }
+    return hipGetLastError();
+}
+
 template <class Ep>
 static inline hipError_t launch_gemm_256(hipStream_t st, const bf16_t* X, const bf16_t* W, int Mrows, int N, int K32, const Ep& ep)
 {
@@ -243,12 +398,13 @@ static inline hipError_t launch_gemm_256(hipStream_t st, const bf16_t* X, const 
 template <class Ep>
 static inline hipError_t launch_gemm_tiled(hipStream_t st, const bf16_t* X, const bf16_t* W, int Mrows, int N, int K32, const Ep& ep)
 {
-    static const int big_nst = [] { const char* v = std::getenv("WM_ENC_GEMM_STAGES"); return v ? std::atoi(v) : 2; }();
+    const int big_nst = [] { const char* v = std::getenv("WM_ENC_GEMM_STAGES"); return v ? std::atoi(v) : 2; }();          // read per launch (sweeps)
     static const int small_ks = [] { const char* v = std::getenv("WM_ENC_GEMM_KSPLIT"); return v ? std::atoi(v) : 2; }();
     const int blocks128 = (Mrows / 128) * (N / GT_BN);
     static const int use256 = [] { const char* v = std::getenv("WM_ENC_GEMM_256"); return v ? std::atoi(v) : 1; }();
+    const int use256p = [] { const char* v = std::getenv("WM_ENC_GEMM_256P"); return v ? std::atoi(v) : 1; }();   // 0: the round-2 two-stage kernel (read per launch: A/B inside one process)
     if (use256 && Mrows % 256 == 0 && N % 256 == 0 && K32 % 2 == 0 && (Mrows / 256) * (N / 256) >= 200)
-        return launch_gemm_256(st, X, W, Mrows, N, K32, ep);
+        return use256p ? launch_gemm_256p(st, X, W, Mrows, N, K32, ep) : launch_gemm_256(st, X, W, Mrows, N, K32, ep);
     // fewer than ~one block per CU with 128-row tiles: halve the tile to fill the chip and split K inside the block
     // tuning knob; 600 / 1000 (64-row tiles for the one-clip QKV / FC1 GEMMs too) measured 7.9 ms per encoder pass against 6.4
     static const int bm64_below = [] { const char* v = std::getenv("WM_ENC_BM64_BELOW"); return v ? std::atoi(v) : 200; }();
@@ -353,7 +509,7 @@ k_gemm_f8(const unsigned char* __restrict__ X, const unsigned char* __restrict__
         if (NST >= 4 && younger >= 2) wait_vmcnt<2 * LPW>();
         else if (NST >= 3 && younger >= 1) wait_vmcnt<LPW>();
         else wait_vmcnt<0>();
-        __syncthreads();
+        ring_barrier();
         if (kt + NST - 1 < K64) stage_load((kt + NST - 1) % NST, kt + NST - 1);
         const unsigned char* xs = reinterpret_cast<const unsigned char*>(smem + (kt % NST) * STAGE);
         const unsigned char* ws = xs + XB * 1024;
@@ -413,7 +569,7 @@ k_gemm_f8_256(const unsigned char* __restrict__ X, const unsigned char* __restri
     if (K64 > 1) stage_load(1, 1);
     for (int kt = 0; kt < K64; ++kt) {
         if (kt + 1 < K64) wait_vmcnt<LPW>(); else wait_vmcnt<0>();
-        __syncthreads();
+        ring_barrier();
         if (kt + 2 < K64) stage_load((kt + 2) % NST, kt + 2);
         const unsigned char* xs = reinterpret_cast<const unsigned char*>(smem + (kt % NST) * STAGE);
         const unsigned char* ws = xs + 16 * 1024;
@@ -525,7 +681,7 @@ k_flash_enc(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kt, const b
         // stage i has landed when at most the 4 loads of stage i+1 are still outstanding (vmcnt counts in order)
         if (i + 1 < nsteps) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                               // everyone's part landed; everyone is done with stage i-1
+        ring_barrier();                                                // everyone's part landed; everyone is done with stage i-1
         if (i + 2 < nsteps) stage_load((i + 2) % NST, i + 2);
         const bf16_t* sb = reinterpret_cast<const bf16_t*>(smem + (i % NST) * STAGE);
 #pragma unroll

@@ -142,6 +142,21 @@ __device__ __forceinline__ void pf_block(const PfJob& pf, int job)
 }
 __host__ __device__ __forceinline__ int pf_round8(int n) { return (n + 7) & ~7; }
 
+// XCD-sliced variant for the token-tile GEMM (k_tile_gemm): that kernel gives XCD x the x-th eighth of the weight row tiles, so job j
+// (run by a block on XCD j % 8) fetches piece j / 8 of the x-th eighth of the matrix: n_jobs = 8 * pieces per slice.
+__device__ __forceinline__ void pf_block_sliced(const PfJob& pf, int job)
+{
+    if (job < 0 || job >= (int)pf.n_jobs) return;
+    const unsigned long long slice = ((pf.total + 7) / 8 + 1023) & ~1023ull;
+    const unsigned long long base = (unsigned long long)(job & 7) * slice;
+    const unsigned long long lo = base + (unsigned long long)(job >> 3) * pf.job_bytes;
+    const unsigned long long hi = min(min(lo + pf.job_bytes, base + slice), pf.total);
+    u32x4_t sink = {0u, 0u, 0u, 0u};
+    for (unsigned long long i = lo + (unsigned long long)threadIdx.x * 16; i < hi; i += (unsigned long long)blockDim.x * 16)
+        asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink) : "v"(pf.p0 + i) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) :: "memory");
+}
+
 // ---- token operand: packed hi/lo planes in global memory (written by the previous kernel's epilogue) ------------
 struct LdPacked {
     const bf16_t* X; int K32; size_t plane; int M;           // lo plane at X + plane; rows >= M are not read
@@ -344,10 +359,13 @@ k_skinny_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, in
 // (one wave per slice), so the operand bits equal those of a 16-row launch.
 template <int NK, class Ld>
 __global__ void __launch_bounds__(640)
-k_ln_tiles(Ld ld, int ksplit, bf16_t* __restrict__ xg, size_t plane, const int* __restrict__ done)
+k_ln_tiles(Ld ld, int ksplit, bf16_t* __restrict__ xg, size_t plane, const int* __restrict__ done, int nmain, PfJob pf)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (done && *done) return;
+    // blocks beyond the token tiles: the launch has 22 blocks of work at 32 streams — the rest of the chip pulls the weight matrix of
+    // the GEMM that follows into the L2 of the XCD that will read it
+    if ((int)blockIdx.x >= nmain) { pf_block_sliced(pf, (int)blockIdx.x - pf_round8(nmain)); return; }
     const int lane = threadIdx.x & 63;
     const int ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int kt0 = ks * NK;
@@ -439,6 +457,188 @@ k_rows_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int 
                     ep.store4((mt0 + j) * 16 + (lane & 15), (rt0 + i) * 16 + 4 * (lane >> 4), acc[i][j]);
                 }
     }
+}
+
+// ---- token-tile GEMM through an LDS ring (R >= 48 token rows: the verify pass of several streams) -----------------
+// At 352 rows (32 streams x 11 candidates) a decoder GEMM is ~20 output tiles per CU: neither weight-streaming (the
+// register-blocked kernel above re-reads every operand from L2 once per wave: 8 KB per 16 MFMAs, L2 -> CU bound) nor big
+// enough for the encoder's 256 x 256 tiles (22 token tiles).  Here a block of 8 waves owns 4F weight row tiles x TT token
+// tiles and walks ALL of K: every operand byte crosses L2 -> CU once per block, through a ring of LDS stages filled by
+// LDS-DMA (global_load_lds, 1 KiB packed fragments, lane-linear: conflict-free ds_read_b128), R - 1 stages in flight.
+//   wave (w = wave & 3, hh = wave >> 2): row tiles w*F .. +F of the block, token tiles hh*TH .. +TH (TH = TT / 2): two
+//   waves per SIMD, so one wave's fragment reads hide under the other's MFMAs (no register double buffering needed);
+//   stage = 2 k-tiles (64 k): [W 4F x 2 KiB][X hi TT x 2 KiB][X lo TT x 2 KiB], pieces dealt round-robin to the 8 waves;
+//   sync per stage: counted s_waitcnt vmcnt (the wave's own pieces of the NEXT stage; younger stages stay in flight) ->
+//   s_barrier (raw: __syncthreads() would drain vmcnt(0), LDS-DMA counts as a pending LDS write) -> refill of the stage that
+//   just moved to registers -> fragment requests of the next stage -> MFMAs of this one (fragments double-buffered in registers).
+// Accumulation order per output = the 16-row kernel's: a fresh accumulator per K-slice of nk k-tiles (k ascending, hi then
+// lo), slice partials added in slice order to a running total that starts from +0 => bit-identical to single-stream runs.
+// blockIdx -> tile: XCD-aware (block b runs on XCD b % 8): an XCD owns a contiguous range of weight row tiles and walks
+// the token groups inside it, so each weight byte enters ONE L2 (not eight) and is re-read there by the token groups.
+template <int N> __device__ __forceinline__ void wm_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int LPW>
+__device__ __forceinline__ void wm_wait_younger(int younger)          // block-uniform: `younger` stages issued after the one needed
+{
+    static_assert(8 * LPW <= 63, "vmcnt is a 6-bit counter");
+    switch (younger) {
+        case 0: wm_wait_vmcnt<0>(); break;
+        case 1: wm_wait_vmcnt<LPW>(); break;
+        case 2: wm_wait_vmcnt<2 * LPW>(); break;
+        case 3: wm_wait_vmcnt<3 * LPW>(); break;
+        case 4: wm_wait_vmcnt<4 * LPW>(); break;
+        case 5: wm_wait_vmcnt<5 * LPW>(); break;
+        case 6: wm_wait_vmcnt<6 * LPW>(); break;
+        case 7: wm_wait_vmcnt<7 * LPW>(); break;
+        default: wm_wait_vmcnt<8 * LPW>(); break;
+    }
+}
+
+template <int F, int TT>
+struct TileGemmCfg {
+    static constexpr int TH = TT / 2;
+    static constexpr int NPW = 8 * F, NPX = 4 * TT, NP = NPW + NPX;   // 1 KiB pieces of a stage (2 k-tiles)
+    static constexpr int LPW = NP / 8;                                // pieces per wave per stage
+    static constexpr int STAGE = NP * 1024;
+    static constexpr int R_FIT = (160 * 1024) / STAGE;
+    static constexpr int R = R_FIT > 9 ? 9 : R_FIT;                   // ring stages (<= 8 younger stages in flight)
+    static_assert(TT % 2 == 0 && NP % 8 == 0 && R >= 3, "tile shape");
+};
+
+template <int F, int TT, class Ep>
+__global__ void __launch_bounds__(512)
+k_tile_gemm(const bf16_t* __restrict__ W, int N16, int K32, int nk, const bf16_t* __restrict__ X, size_t plane, int MT,
+            int n_fb, int n_tg, const int* __restrict__ done, Ep ep)
+{
+    typedef TileGemmCfg<F, TT> C;
+    constexpr int TH = C::TH, LPW = C::LPW, R = C::R, STAGE = C::STAGE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int w = wave & 3, hh = wave >> 2;
+    // XCD-aware tile order (bijective for any grid size, cdna_hip_programming.md §5 template)
+    const int nwg = n_fb * n_tg;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int fb = bid / n_tg, tg = bid - fb * n_tg;
+    const int rt0 = fb * 4 * F, mt0 = tg * TT;
+    const int NS = K32 >> 1;                   // stages
+
+    // per-piece source pointers of this wave (stage 0); a stage advances every piece by 2 KiB
+    const char* src[LPW];
+#pragma unroll
+    for (int i = 0; i < LPW; ++i) {
+        const int p = i * 8 + wave;            // piece index inside the stage = LDS position
+        if (p < C::NPW) {
+            const int t = min(rt0 + (p >> 1), N16 - 1), kk = p & 1;
+            src[i] = reinterpret_cast<const char*>(W) + ((size_t)t * K32 + kk) * 1024 + lane * 16;
+        } else {
+            const int q = p - C::NPW, pl = q / (2 * TT), rr = q - pl * 2 * TT;
+            const int t = min(mt0 + (rr >> 1), MT - 1), kk = rr & 1;
+            src[i] = reinterpret_cast<const char*>(X + (pl ? plane : 0)) + ((size_t)t * K32 + kk) * 1024 + lane * 16;
+        }
+    }
+    auto issue = [&](int s) {
+        char* sb = smem + (s % R) * STAGE + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < LPW; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)s * 2048),
+                                             (__attribute__((address_space(3))) void*)(sb + i * 8192), 16, 0, 0);
+    };
+    // fragments of one stage (both k-tiles): a[kk][i], token hi / lo [kk][j]
+    struct Frags { bf16x8_t a[2][F], xh[2][TH], xl[2][TH]; };
+    auto frag_load = [&](int s, Frags& f) {
+        const char* sb = smem + (s % R) * STAGE + lane * 16;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int i = 0; i < F; ++i) f.a[kk][i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb + ((w * F + i) * 2 + kk) * 1024));
+#pragma unroll
+            for (int j = 0; j < TH; ++j) {
+                f.xh[kk][j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb + C::NPW * 1024 + ((hh * TH + j) * 2 + kk) * 1024));
+                f.xl[kk][j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb + (C::NPW + 2 * TT) * 1024 + ((hh * TH + j) * 2 + kk) * 1024));
+            }
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < R; ++s)
+        if (s < NS) issue(s);
+    if (done && *done) {                       // every stream finished: nothing may stay in flight into a released LDS allocation
+        wm_wait_vmcnt<0>();
+        return;
+    }
+
+    f32x4_t acc[F][TH], tot[F][TH];
+#pragma unroll
+    for (int i = 0; i < F; ++i)
+#pragma unroll
+        for (int j = 0; j < TH; ++j) { acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f}; tot[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+    int left = nk;                             // k-tiles until the current slice is complete (nk is even)
+
+    // stage 0 -> registers
+    wm_wait_younger<LPW>(min(NS, R) - 1);
+    __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0) as the builtin: the compiler's wait-count pass sees it (wm_encoder.hip ring_barrier)
+    __builtin_amdgcn_s_barrier();
+    Frags f0, f1;
+    frag_load(0, f0);
+
+    // One step: stage s sits in `cur`; wait for stage s+1, barrier, refill the buffer of stage s (it lives in registers now), request
+    // the fragments of stage s+1 into `nxt`, then issue the MFMAs of stage s — the LDS round trip of a stage hides under the MFMAs of
+    // the stage before it.  The request is unconditional (after the last stage it re-reads a stale buffer, unused): a branch there
+    // makes the compiler wait for those very reads in front of the MFMAs.
+    auto step = [&](int s, const Frags& cur, Frags& nxt) {
+        wm_wait_younger<LPW>(max(min(NS - 1, s + R - 1) - (s + 1), 0));
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
+        if (s + R < NS) issue(s + R);
+        frag_load(s + 1, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int i = 0; i < F; ++i)
+#pragma unroll
+                for (int j = 0; j < TH; ++j) acc[i][j] = mfma16(cur.a[kk][i], cur.xh[kk][j], acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < F; ++i)
+#pragma unroll
+                for (int j = 0; j < TH; ++j) acc[i][j] = mfma16(cur.a[kk][i], cur.xl[kk][j], acc[i][j]);
+        }
+        left -= 2;
+        if (left == 0) {                       // slice complete: add its partial to the running total, start a fresh accumulator
+            left = nk;
+#pragma unroll
+            for (int i = 0; i < F; ++i)
+#pragma unroll
+                for (int j = 0; j < TH; ++j) {
+                    tot[i][j][0] += acc[i][j][0]; tot[i][j][1] += acc[i][j][1]; tot[i][j][2] += acc[i][j][2]; tot[i][j][3] += acc[i][j][3];
+                    acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                }
+        }
+    };
+    for (int s = 0; s < NS; s += 2) {          // NS is even (d_model and ffn_dim are multiples of 128)
+        step(s, f0, f1);
+        step(s + 1, f1, f0);
+    }
+    // epilogue: the operands of every tile (bias, residual, cache position) are requested in one batch, then the stores go out
+    EpPre pre[F][TH];
+#pragma unroll
+    for (int i = 0; i < F; ++i)
+#pragma unroll
+        for (int j = 0; j < TH; ++j) {
+            const int rt = rt0 + w * F + i, mt = mt0 + hh * TH + j;
+            pre[i][j].i = 0; pre[i][j].a = make_float4(0.f, 0.f, 0.f, 0.f); pre[i][j].b = pre[i][j].a;
+            if (rt < N16 && mt < MT) pre[i][j] = ep.pre(mt * 16 + (lane & 15), rt * 16 + 4 * (lane >> 4));
+        }
+#pragma unroll
+    for (int i = 0; i < F; ++i)
+#pragma unroll
+        for (int j = 0; j < TH; ++j) {
+            const int rt = rt0 + w * F + i, mt = mt0 + hh * TH + j;
+            if (rt < N16 && mt < MT) ep.fin(mt * 16 + (lane & 15), rt * 16 + 4 * (lane >> 4), tot[i][j], pre[i][j]);
+        }
 }
 
 // ---- host-side launch plan -------------------------------------------------------------------
@@ -572,9 +772,59 @@ static inline hipError_t launch_skinny_mt_nk(hipStream_t st, WRef W, int N16, in
     return launch_rows_gemm<NKR, 1>(st, W, N16, K32, p, X, plane, MT, ep);
 }
 
+// ---- LDS-ring token-tile GEMM: tile shape and launch ----
+// One round of blocks (<= 256, one per CU) costs what ONE block costs, and a block's time is its L2 -> LDS bytes,
+// K x (128 F + 64 TT) [weight rows 2 B, token rows 4 B as a hi/lo pair]: pick the shape that minimises rounds x bytes; ties go
+// to two row tiles per wave (each token fragment read from LDS then feeds two MFMAs).  WM_TILE_F / WM_TILE_TT pin it (sweeps).
+struct TilePlan { int F, TT; };
+static inline TilePlan tile_plan(int N16, int MT) {
+    const int envF = skinny_env("WM_TILE_F", 0), envTT = skinny_env("WM_TILE_TT", 0);       // read per launch: sweeps flip them inside one process
+    TilePlan best{1, 2};
+    double bc = 1e30;
+    for (int F = 2; F >= 1; --F)
+        for (int TT = 2; TT <= 8; TT += 2) {
+            if ((envF && F != envF) || (envTT && TT != envTT)) continue;
+            const int blocks = ((N16 + 4 * F - 1) / (4 * F)) * ((MT + TT - 1) / TT);
+            const double rounds = blocks <= 256 ? 1.0 : blocks / 256.0;
+            const double cost = rounds * (128.0 * F + 64.0 * TT);
+            if (cost < bc - 1e-9) { bc = cost; best = TilePlan{F, TT}; }
+        }
+    return best;
+}
+
+template <int F, int TT, class Ep>
+static inline hipError_t launch_tile_gemm_ft(hipStream_t st, const bf16_t* W, int N16, int K32, int nk, const bf16_t* X, size_t plane, int MT, const Ep& ep) {
+    typedef TileGemmCfg<F, TT> C;
+    const int n_fb = (N16 + 4 * F - 1) / (4 * F), n_tg = (MT + TT - 1) / TT;
+    constexpr int lds = C::R * C::STAGE;
+    auto kern = k_tile_gemm<F, TT, Ep>;
+    static thread_local bool attr_done = false;        // per instantiation and host thread
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(n_fb * n_tg), dim3(512), lds, st, W, N16, K32, nk, X, plane, MT, n_fb, n_tg, g_skinny_done, ep);
+    return hipGetLastError();
+}
+
+template <class Ep>
+static inline hipError_t launch_tile_gemm(hipStream_t st, const bf16_t* W, int N16, int K32, int nk, const bf16_t* X, size_t plane, int MT, const Ep& ep) {
+    const TilePlan t = tile_plan(N16, MT);
+#define WM_TG(Fv, TTv) if (t.F == Fv && t.TT == TTv) return launch_tile_gemm_ft<Fv, TTv>(st, W, N16, K32, nk, X, plane, MT, ep)
+    WM_TG(1, 2); WM_TG(1, 4); WM_TG(1, 6); WM_TG(1, 8);
+    WM_TG(2, 2); WM_TG(2, 4); WM_TG(2, 6); WM_TG(2, 8);
+#undef WM_TG
+    return hipErrorInvalidConfiguration;
+}
+
 template <class Ep>
 static inline hipError_t launch_skinny_mt(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p,
                                           const bf16_t* X, size_t plane, int MT, const Ep& ep) {
+    // >= 3 token tiles, bf16 weights: the LDS-ring tile kernel (same accumulation order, bit-identical results)
+    const int tile_min_mt = skinny_env("WM_TILE_GEMM_MIN_MT", 3);            // 0 = off (register-blocked kernel everywhere)
+    if (tile_min_mt > 0 && MT >= tile_min_mt && !W.scale && (p.nk & 1) == 0 && (K32 & 1) == 0)
+        return launch_tile_gemm(st, W.w, N16, K32, p.nk, X, plane, MT, ep);
     if (p.nk == 16) return launch_skinny_mt_nk<16>(st, W, N16, K32, p, X, plane, MT, ep);
     if (p.nk == 12) return launch_skinny_mt_nk<12>(st, W, N16, K32, p, X, plane, MT, ep);
     if (p.nk == 8) return launch_skinny_mt_nk<8>(st, W, N16, K32, p, X, plane, MT, ep);
@@ -598,8 +848,19 @@ static inline hipError_t launch_skinny_norm_t(hipStream_t st, WRef W, int N16, i
     if (p.nk > 8 || K32 * 32 != ld.d) return hipErrorInvalidConfiguration;
     if (R <= 16) return launch_skinny(st, W, N16, K32, p, ld, ep);
     const int MT = (R + 15) / 16;
-    if (p.nk == 8) hipLaunchKernelGGL((k_ln_tiles<8, Ld>), dim3(MT), dim3(64 * p.ksplit), ld.lds_bytes(), st, ld, p.ksplit, xscr, plane, g_skinny_done);
-    else if (p.nk == 4) hipLaunchKernelGGL((k_ln_tiles<4, Ld>), dim3(MT), dim3(64 * p.ksplit), ld.lds_bytes(), st, ld, p.ksplit, xscr, plane, g_skinny_done);
+    // weight prefetch riding on the LayerNorm launch (token-tile path with bf16 weights only; WM_LN_PREFETCH=0 turns it off)
+    const int ln_pf = skinny_env("WM_LN_PREFETCH", 1);
+    const int tile_min_mt = skinny_env("WM_TILE_GEMM_MIN_MT", 3);
+    PfJob pf{nullptr, nullptr, 0u, 0u, 0ull};
+    int grid = MT;
+    if (ln_pf && tile_min_mt > 0 && MT >= tile_min_mt && !W.scale) {
+        const unsigned long long total = (unsigned long long)N16 * K32 * 1024, slice = ((total + 7) / 8 + 1023) & ~1023ull;
+        const unsigned job_bytes = 64 * 1024;
+        pf = PfJob{reinterpret_cast<const char*>(W.w), nullptr, job_bytes, (unsigned)(8 * ((slice + job_bytes - 1) / job_bytes)), total};
+        grid = pf_round8(MT) + (int)pf.n_jobs;
+    }
+    if (p.nk == 8) hipLaunchKernelGGL((k_ln_tiles<8, Ld>), dim3(grid), dim3(64 * p.ksplit), ld.lds_bytes(), st, ld, p.ksplit, xscr, plane, g_skinny_done, MT, pf);
+    else if (p.nk == 4) hipLaunchKernelGGL((k_ln_tiles<4, Ld>), dim3(grid), dim3(64 * p.ksplit), ld.lds_bytes(), st, ld, p.ksplit, xscr, plane, g_skinny_done, MT, pf);
     else return hipErrorInvalidConfiguration;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

@@ -257,7 +257,9 @@ class Engine:
                                                out.ctypes.data_as(C.POINTER(C.c_float))), "wm_forward_logits")
         return torch.from_numpy(out)
 
-    def profile_layer_gemms(self, rows: int, reps: int = 50):
+    def profile_layer_gemms(self, rows: int, reps: int = 50, kernel: int = 0):
+        """hipEvent-timed decode GEMMs of decoder layer 0 at `rows` token rows: kernel 0 = all six of a layer, 1..6 = one of them
+        (LN1+QKV, out-proj, LN2+cross-q, cross-out, LN3+FC1, FC2), 7 = vocabulary projection.  Returns (ms per repetition, weight bytes)."""
         ms, nbytes = C.c_float(0), C.c_double(0)
-        self._check(self.lib.wm_profile_kernel(self.h, 0, rows, reps, C.byref(ms), C.byref(nbytes)), "wm_profile_kernel")
+        self._check(self.lib.wm_profile_kernel(self.h, kernel, rows, reps, C.byref(ms), C.byref(nbytes)), "wm_profile_kernel")
         return ms.value, nbytes.value
