@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define WM_ABI_VERSION 5
+#define WM_ABI_VERSION 6
 
 #define WM_OK 0
 #define WM_ERR_ARG (-1)      /* bad argument / unsupported configuration (reference: ValueError, model.py:225-229) */
@@ -100,6 +100,10 @@ typedef struct wm_gen_params {
     float temperature;              /* divides verify logits in typical mode (1.0 via generate()) */
     int32_t accept_mode;            /* WM_ACCEPT_* */
     int32_t vanilla;                /* 1 = plain greedy decoding on the base head (anchor measurement) */
+    int32_t begin_index;            /* sequence length at which the begin-suppress list applies (SuppressTokensAtBeginLogitsProcessor
+                                     * begin_index).  < 0: prompt_len.  With `prompt_ids` the reference hands HF the number of init tokens
+                                     * only (model.py:1537 `begin_index = init_tokens.shape[1]`, :1640-1644 set_begin_index), not the
+                                     * length of the whole decoder prompt — the caller passes that number here */
     int32_t force_accept;           /* measurement knob (bench.py acceptance-sensitivity rows): >= 0 forces every iteration's accept
                                      * length to min(force_accept, K) whatever the posterior says — the tokens are then meaningless,
                                      * the cost of an iteration at that acceptance is not; < 0 = off (always, outside benchmarks) */

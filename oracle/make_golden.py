@@ -134,7 +134,7 @@ def hf_processors(gp: GenParams):
     if gp.exp_decay is not None:                     # HF default list first (model.py:1106-1116)
         procs.append(ExponentialDecayLengthPenalty(gp.exp_decay, gp.eos_token_id, len(gp.prompt)))
     if gp.begin_suppress_tokens:                     # model.py:1188-1199 prepends begin-suppress ...
-        procs.append(SuppressTokensAtBeginLogitsProcessor(gp.begin_suppress_tokens, begin_index=len(gp.prompt)))
+        procs.append(SuppressTokensAtBeginLogitsProcessor(gp.begin_suppress_tokens, begin_index=gp.begin_index))
     if gp.suppress_tokens:                           # ... in front of suppress (model.py:1177-1186)
         procs.append(SuppressTokensLogitsProcessor(gp.suppress_tokens))
     return LogitsProcessorList(procs)
@@ -402,6 +402,10 @@ def main_prompt():
         for plen in (5, 23, 40):
             gp = gen_params_for(cfg, ACCEPT_TYPICAL, 24)
             prev = [cfg.vocab_size - 5] + [10 + (7 * i) % 900 for i in range(plen - 1)]
+            # the reference's generate() builds the processors with begin_index = init_tokens.shape[1] (model.py:1537, 1551) — the
+            # init tokens WITHOUT the prepended prompt_ids — and set_begin_index() repeats it (:1640-1644): the begin suppression
+            # therefore never fires under prompt conditioning.  The processors of this run are built the same way.
+            gp.begin_suppress_index = len(gp.prompt)
             gp.prompt = prev + list(gp.prompt)
             gp.max_length = min(len(gp.prompt) + 24, cfg.max_target_positions)
             ids, accepts, _ = ref_medusa_loop(model, mu, enc, gp, cfg.medusa_num_heads, use_cache=cfg.is_block)
@@ -410,6 +414,7 @@ def main_prompt():
             out[f"{tag}_{plen}_prompt"] = np.array(gp.prompt)
             out[f"{tag}_{plen}_ids"] = np.array(ids)
             out[f"{tag}_{plen}_accepts"] = np.array(accepts)
+            out[f"{tag}_{plen}_begin_index"] = np.array(gp.begin_index)
             print(f"  {tag} prompt {len(gp.prompt)}: {len(ids) - len(gp.prompt)} new tokens, accepts {accepts}")
     np.savez_compressed(os.path.join(GOLD, "reference_prompt_runs.npz"), **out)
     print("reference long-prompt vectors written")

@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--dec", action="store_true")
     ap.add_argument("--enc", action="store_true")
     ap.add_argument("--streams", type=int, default=32)
+    ap.add_argument("--tile-shapes", action="store_true", help="sweep every (F, TT) shape of the tile kernel at the full row count")
+    ap.add_argument("--enc-only-batch", action="store_true", help="encoder legs at the full batch only")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r03_sweep.json"))
     args = ap.parse_args()
     if not (args.dec or args.enc):
@@ -50,21 +52,33 @@ def main():
     res = {"decode_gemms_us": {}, "encoder_ms": {}}
 
     if args.dec:
-        for rows in (B * 11, 176, 88, 48):
+        for rows in (B * 11, 88, 32, 22):
             if rows > 16 * B:
+                continue
+            if rows <= 32:                       # two token tiles: register-blocked kernel vs the weight-streaming kernel with a second tile
+                table = {}
+                for kern in (1, 2, 3, 4, 5, 6, 7, 0):
+                    row = {}
+                    setenv(WM_SKINNY2=0)
+                    row["rows_gemm"] = round(eng.profile_layer_gemms(rows, 30, kern)[0] * 1e3, 2)
+                    setenv(WM_SKINNY2=None)
+                    row["skinny2"] = round(eng.profile_layer_gemms(rows, 30, kern)[0] * 1e3, 2)
+                    table[NAMES[kern]] = row
+                    print(f"rows={rows} {NAMES[kern]:12s} {row}", flush=True)
+                res["decode_gemms_us"][str(rows)] = table
                 continue
             table = {}
             for kern in (1, 2, 3, 4, 5, 6, 7, 0):
                 row = {}
                 setenv(WM_TILE_GEMM_MIN_MT=0, WM_TILE_F=None, WM_TILE_TT=None, WM_LN_PREFETCH=None)
                 row["old"] = round(eng.profile_layer_gemms(rows, 30, kern)[0] * 1e3, 2)
-                setenv(WM_TILE_GEMM_MIN_MT=None)
+                setenv(WM_TILE_GEMM_MIN_MT=None, WM_TILE_GEMM_MIN_N16=0)
                 row["tile"] = round(eng.profile_layer_gemms(rows, 30, kern)[0] * 1e3, 2)
                 if kern in (1, 3, 5, 0):
                     setenv(WM_LN_PREFETCH=0)
                     row["tile_nopf"] = round(eng.profile_layer_gemms(rows, 30, kern)[0] * 1e3, 2)
                     setenv(WM_LN_PREFETCH=None)
-                if rows == B * 11 and kern != 0:
+                if args.tile_shapes and rows == B * 11 and kern != 0:
                     for F in (1, 2):
                         for TT in (2, 4, 6, 8):
                             setenv(WM_TILE_F=F, WM_TILE_TT=TT)
@@ -73,6 +87,7 @@ def main():
                             except Exception as e:  # noqa: BLE001
                                 row[f"F{F}TT{TT}"] = repr(e)
                     setenv(WM_TILE_F=None, WM_TILE_TT=None)
+                setenv(WM_TILE_GEMM_MIN_N16=None)
                 table[NAMES[kern]] = row
                 print(f"rows={rows} {NAMES[kern]:12s} {row}", flush=True)
             res["decode_gemms_us"][str(rows)] = table
@@ -82,8 +97,11 @@ def main():
         for nb in (B, 1):
             wav = torch.from_numpy(np.stack([synth.synth_clip(900 + j, n_samp) for j in range(nb)])).to(dev)
             feats = eng.logmel(wav)
-            variants = [("r02_256", dict(WM_ENC_GEMM_256P=0)), ("p_ring4", dict(WM_ENC_GEMM_256P=1, WM_ENC_GEMM_RING=4)),
-                        ("p_ring5", dict(WM_ENC_GEMM_256P=1, WM_ENC_GEMM_RING=5)), ("p_ring3", dict(WM_ENC_GEMM_256P=1, WM_ENC_GEMM_RING=3))] if nb > 1 else \
+            if nb == 1 and args.enc_only_batch:
+                continue
+            variants = [("r02_256", dict(WM_ENC_GEMM_256P=0)), ("p_tile_per_block", dict(WM_ENC_GEMM_256P=1, WM_ENC_GEMM_PERSIST=0)),
+                        ("p_persist_ring4", dict(WM_ENC_GEMM_256P=1, WM_ENC_GEMM_PERSIST=1, WM_ENC_GEMM_RING=4)),
+                        ("p_persist_ring5", dict(WM_ENC_GEMM_256P=1, WM_ENC_GEMM_PERSIST=1, WM_ENC_GEMM_RING=5))] if nb > 1 else \
                        [("stages2", dict(WM_ENC_GEMM_STAGES=2)), ("stages3", dict(WM_ENC_GEMM_STAGES=3))]
             row = {}
             for name, env in variants:

@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     lib = ctypes.CDLL(built_lib)
     for name in declared:
         assert hasattr(lib, name), f"libwm.so does not export {name}"
-    assert lib.wm_abi_version() == 5
+    assert lib.wm_abi_version() == 6
     from whisper_medusa import engine
     assert sorted(engine.EXPORTS) == declared
     engine.load_library()          # prototypes resolve
@@ -163,14 +163,14 @@ def test_language_table_prompt_ids_and_generation_params():
     assert synth.default_prompt(big, "german", "translate") == [50258, 50261, 50358, 50363]
     m = WhisperMedusaModel(big, {})
     gp = m._gen_params("en", None, (140.0, 1.01), 32, None, None, False, None, None, None, None, torch.tensor([50361, 11, 12, 13]))
-    assert gp.prompt == [50361, 11, 12, 13, 50258, 50259, 50359, 50363] and gp.max_length == 8 + 32 and gp.begin_index == 8
+    assert gp.prompt == [50361, 11, 12, 13, 50258, 50259, 50359, 50363] and gp.max_length == 8 + 32 and gp.begin_index == 4   # begin suppression: init tokens only (reference model.py:1537)
     with pytest.raises(ValueError, match="no room"):
         m._gen_params("en", None, None, None, None, None, False, None, None, None, None, list(range(440)))
     # the eval CLI parses the regulation start as float: the C struct field is an int32
     from whisper_medusa import engine
     g = engine.WmGenParams()
     g.exp_decay_start = int(gp.exp_decay[0])
-    assert g.exp_decay_start == 140 and g.force_accept == 0
+    assert g.exp_decay_start == 140 and g.force_accept == 0 and g.begin_index == 0
 
 
 def test_checkpoint_directory_roundtrip_cpu(tmp_path):
@@ -302,3 +302,44 @@ def test_automatic_micro_batch_policy():
     assert m._micro_batches_for(2) == 2 and m._micro_batches_for(5) == 1
     with pytest.raises(ValueError):
         m.set_micro_batches(0)
+
+
+def test_hf_processors_and_criteria_are_lowered_into_generation_params():
+    """generate(logits_processor=..., stopping_criteria=...) (reference model.py:1106-1124 hands them to HF): the static ones are
+    folded into wm_gen_params, built here with the REAL transformers classes; anything dynamic is refused."""
+    from transformers.generation.logits_process import (LogitsProcessorList, SuppressTokensLogitsProcessor, TemperatureLogitsWarper,
+                                                        SuppressTokensAtBeginLogitsProcessor, ExponentialDecayLengthPenalty)
+    from transformers.generation.stopping_criteria import StoppingCriteriaList, MaxLengthCriteria, MaxTimeCriteria
+    from whisper_medusa import WhisperMedusaModel
+    from whisper_medusa.api import lower_processors
+    big = MedusaConfig.large_v2()
+    m = WhisperMedusaModel(big, {})
+    gp = m._gen_params("en", None, None, 64, None, None, False, None, None, None, None, None)
+    P = len(gp.prompt)
+    procs = LogitsProcessorList([SuppressTokensLogitsProcessor([5, 7, 9]), SuppressTokensAtBeginLogitsProcessor([220, 50257], begin_index=P),
+                                 ExponentialDecayLengthPenalty((10, 1.25), big.eos_token_id, P)])
+    gp = lower_processors(gp, procs, StoppingCriteriaList([MaxLengthCriteria(P + 20)]))
+    assert gp.suppress_tokens == [5, 7, 9] and gp.begin_suppress_tokens == [220, 50257] and gp.begin_index == P
+    assert gp.exp_decay == (10, 1.25) and gp.max_length == P + 20
+    with pytest.raises(NotImplementedError, match="TemperatureLogitsWarper"):
+        lower_processors(gp, [TemperatureLogitsWarper(0.7)], None)
+    with pytest.raises(NotImplementedError, match="MaxTimeCriteria"):
+        lower_processors(gp, None, [MaxTimeCriteria(1.0)])
+
+
+def test_generate_output_object_mirrors_the_reference_model_output():
+    from whisper_medusa.api import GenerateEncoderDecoderOutput
+    t = torch.arange(6).view(2, 3)
+    o = GenerateEncoderDecoderOutput(t, segments=[["x"], ["y"]])
+    assert o.sequences is t and o["sequences"] is t and o[0] is t and o.scores is None and o.past_key_values is None
+    assert o["segments"] == [["x"], ["y"]] and "sequences" in o
+    with pytest.raises(AttributeError):
+        _ = o.nope
+    m_cfg = MedusaConfig.micro(K=4)
+    from whisper_medusa import WhisperMedusaModel
+    m = WhisperMedusaModel(m_cfg, {})
+    out = m._wrap_outputs(t, [1, 1], m_cfg.pad_token_id, m_cfg.eos_token_id, True, True)
+    assert isinstance(out, GenerateEncoderDecoderOutput) and len(out.segments) == 2 and out.segments[0][0]["result"].tolist() == [0, 1, 2]
+    assert m._wrap_outputs(t, [1, 1], m_cfg.pad_token_id, m_cfg.eos_token_id, False, False) is t
+    d = m._wrap_outputs(t, [1, 1], m_cfg.pad_token_id, m_cfg.eos_token_id, False, True)
+    assert set(d) == {"sequences", "segments"}

@@ -197,6 +197,8 @@ def test_long_prompt_runs_match_reference(tag, heads, seed):
     enc = orc.encode(torch.from_numpy(log_mel(clip_for(cfg, 2), cfg.num_mel_bins, cfg.n_mel_frames * 160)))
     for plen in (5, 23, 40):
         gp = golden_gen_params(cfg, ACCEPT_TYPICAL, 24)
+        gp.begin_suppress_index = int(runs[f"{tag}_{plen}_begin_index"])       # = number of init tokens (reference model.py:1537)
+        assert gp.begin_suppress_index == len(gp.prompt)
         gp.prompt = runs[f"{tag}_{plen}_prompt"].tolist()
         gp.max_length = min(len(gp.prompt) + 24, cfg.max_target_positions)
         r = orc.decode(enc, gp)

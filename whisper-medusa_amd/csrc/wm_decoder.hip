@@ -532,7 +532,7 @@ __device__ __forceinline__ float proc_logit(float x, int n, int cur_len, const G
 {
     if (n == gp.eos && gp.exp_start >= 0 && cur_len > gp.exp_start) x += fabsf(x) * exppen[cur_len];
     const unsigned char mk = mask[n];
-    if ((mk & 1) || ((mk & 2) && cur_len == gp.P)) x = -INFINITY;
+    if ((mk & 1) || ((mk & 2) && cur_len == gp.begin)) x = -INFINITY;
     return x;
 }
 

@@ -260,7 +260,7 @@ k_gemm_256(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32, 
 // =============================================================================================
 template <int NST, class Ep>
 __global__ void __launch_bounds__(512)
-k_gemm_256p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32, int tiles_m, int tiles_n, int PM, int PN, Ep ep)
+k_gemm_256p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32, int tiles_m, int tiles_n, int PM, int PN, int persistent, Ep ep)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int STAGE = 32 * 1024;            // 16 X fragments (token tiles) then 16 W fragments (row tiles), one k-tile
@@ -268,120 +268,141 @@ k_gemm_256p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32,
     const int lane = threadIdx.x & 63;
     const int wa = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wa >> 2, wn = wa & 3;
-    // tile of this block: XCD x (= blockIdx % 8, observed placement) owns the contiguous range [x * per, (x+1) * per) of the
-    // patch-major tile order; inside a patch tiles run token-fastest.  Bijective for any grid (r extra tiles go to XCDs 0..r-1).
-    const int nwg = tiles_m * tiles_n;
-    int id;
-    {
-        const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
-        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-    }
     const int per_patch = PM * PN, patches_m = tiles_m / PM;        // the launcher picks PM | tiles_m, PN | tiles_n
-    const int patch = id / per_patch, within = id - patch * per_patch;
-    const int pn = patch / patches_m, pm = patch - pn * patches_m;
-    const int tn = pn * PN + within / PM, tm = pm * PM + within % PM;
+    const int n_patches = patches_m * (tiles_n / PN);
     const int NT = K32;                         // stages (even; the launcher checks)
-    const bf16_t* xg = X + (size_t)tm * 16 * K32 * 512 + lane * 8;
-    const bf16_t* wg = W + (size_t)tn * 16 * K32 * 512 + lane * 8;
-
-    auto stage_load = [&](int kt) {
-        char* sb = smem + (kt % NST) * STAGE;
-#pragma unroll
-        for (int i = 0; i < LPW; ++i) {
-            const int blk = wa * LPW + i;              // 0..15 X fragments, 16..31 W fragments
-            const bool isx = blk < 16;
-            const int t = isx ? blk : blk - 16;
-            glds16((isx ? xg : wg) + ((size_t)t * K32 + kt) * 512, sb + blk * 1024);
-        }
-    };
-    auto frag_load = [&](int kt, bf16x8_t (&a)[4], bf16x8_t (&b)[8]) {
-        const bf16_t* xs = reinterpret_cast<const bf16_t*>(smem + (kt % NST) * STAGE);
-        const bf16_t* ws = xs + 16 * 512;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = ld_frag(ws + ((wn * 4 + i) * 64 + lane) * 8);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) b[j] = ld_frag(xs + ((wm * 8 + j) * 64 + lane) * 8);
-    };
-
-    f32x4_t acc[4][8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll
-    for (int s = 0; s < NST; ++s)
-        if (s < NT) stage_load(s);
-    // stage 0 -> registers
-    if (NT >= NST) wait_vmcnt<(NST - 1) * LPW>(); else wait_vmcnt<0>();
-    ring_barrier();
-    bf16x8_t a0[4], b0[8], a1[4], b1[8];
-    frag_load(0, a0, b0);
-
-    // one step: stage t is in (ac, bc); request stage t+1 into (an, bn), then the MFMAs of stage t
-    auto step = [&](int t, bf16x8_t (&ac)[4], bf16x8_t (&bc)[8], bf16x8_t (&an)[4], bf16x8_t (&bn)[8]) {
-        // stages issued so far: 0 .. min(NT-1, t+NST-1); stage t+1 must have landed: only the stages after it may be outstanding
-        const int younger = min(NT - 1, t + NST - 1) - (t + 1);
-        if (younger >= 3) wait_vmcnt<3 * LPW>();
-        else if (younger == 2) wait_vmcnt<2 * LPW>();
-        else if (younger == 1) wait_vmcnt<LPW>();
-        else wait_vmcnt<0>();
-        ring_barrier();                        // everyone's pieces of stage t+1 landed; everyone's reads of stage t (and older) are complete
-        if (t + NST < NT) stage_load(t + NST);                  // into the buffer of stage t: it lives in registers now
-        frag_load(t + 1, an, bn);              // unconditional (after the last step it re-reads a stale buffer, unused): a branch here makes
-                                               // the compiler wait lgkmcnt(0) at the join, i.e. for THESE reads, in front of the MFMAs below
-        __builtin_amdgcn_sched_barrier(0);     // keep the requests above the MFMAs
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i][j] = mfma16(ac[i], bc[j], acc[i][j]);
-    };
-    static_assert(NST >= 3 && NST <= 5, "ring depth");
-    for (int t = 0; t < NT; t += 2) {
-        step(t, a0, b0, a1, b1);
-        step(t + 1, a1, b1, a0, b0);
+    // Tile(s) of this block.  XCD x = blockIdx % 8 (observed placement; only speed depends on it).
+    //  persistent (grid = 8 XCDs x 32 slots, one block per CU): the 32 blocks of an XCD walk the patches x, x+8, ... TOGETHER, slot c
+    //   taking tile c of the patch: equal work, so they stay in step along K and the XCD's L2 only has to hold the current K-window
+    //   of the patch's PM + PN operand panels.  With independently scheduled blocks the residents of an XCD drift apart along K and
+    //   each needs its WHOLE panels (PM + PN panels x 655 KB > 4 MB of L2 at large-v2) — the operands then stream from the Infinity
+    //   Cache at ~11 B/clk per CU, which is what bounded the round-2 kernel (and the first, non-persistent, form of this one).
+    //  otherwise: one tile per block, patch-major order, XCD x owns a contiguous range of it (bijective for any grid).
+    int patch, within, patch_step;
+    if (persistent) {
+        patch = blockIdx.x & 7; within = blockIdx.x >> 3; patch_step = 8;
+    } else {
+        const int nwg = tiles_m * tiles_n;
+        const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+        const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+        patch = id / per_patch; within = id - patch * per_patch; patch_step = n_patches;
     }
-    const int m0 = tm * 256 + wm * 128 + (lane & 15), n0 = tn * 256 + wn * 64 + 4 * (lane >> 4);
+    if (within >= per_patch) return;            // spare slots of a persistent grid (patches of fewer than 32 tiles)
+
+    for (; patch < n_patches; patch += patch_step) {
+        const int pn = patch / patches_m, pm = patch - pn * patches_m;
+        const int tn = pn * PN + within / PM, tm = pm * PM + within % PM;
+        const bf16_t* xg = X + (size_t)tm * 16 * K32 * 512 + lane * 8;
+        const bf16_t* wg = W + (size_t)tn * 16 * K32 * 512 + lane * 8;
+
+        auto stage_load = [&](int kt) {
+            char* sb = smem + (kt % NST) * STAGE;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < LPW; ++i) {
+                const int blk = wa * LPW + i;              // 0..15 X fragments, 16..31 W fragments
+                const bool isx = blk < 16;
+                const int t = isx ? blk : blk - 16;
+                glds16((isx ? xg : wg) + ((size_t)t * K32 + kt) * 512, sb + blk * 1024);
+            }
+        };
+        auto frag_load = [&](int kt, bf16x8_t (&a)[4], bf16x8_t (&b)[8]) {
+            const bf16_t* xs = reinterpret_cast<const bf16_t*>(smem + (kt % NST) * STAGE);
+            const bf16_t* ws = xs + 16 * 512;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ep.store4(m0 + j * 16, n0 + i * 16, acc[i][j]);
+            for (int i = 0; i < 4; ++i) a[i] = ld_frag(ws + ((wn * 4 + i) * 64 + lane) * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) b[j] = ld_frag(xs + ((wm * 8 + j) * 64 + lane) * 8);
+        };
+
+        f32x4_t acc[4][8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+        // (a later tile of a persistent block: every wave has passed the last barrier of the previous tile, after which no wave
+        //  reads the ring again except for the unused trailing request — the buffers may be refilled)
+#pragma unroll
+        for (int s = 0; s < NST; ++s)
+            if (s < NT) stage_load(s);
+        // stage 0 -> registers
+        if (NT >= NST) wait_vmcnt<(NST - 1) * LPW>(); else wait_vmcnt<0>();
+        ring_barrier();
+        bf16x8_t a0[4], b0[8], a1[4], b1[8];
+        frag_load(0, a0, b0);
+
+        // one step: stage t is in (ac, bc); request stage t+1 into (an, bn), then the MFMAs of stage t
+        auto step = [&](int t, bf16x8_t (&ac)[4], bf16x8_t (&bc)[8], bf16x8_t (&an)[4], bf16x8_t (&bn)[8]) {
+            // stages issued so far: 0 .. min(NT-1, t+NST-1); stage t+1 must have landed: only the stages after it may be outstanding
+            const int younger = min(NT - 1, t + NST - 1) - (t + 1);
+            if (younger >= 3) wait_vmcnt<3 * LPW>();
+            else if (younger == 2) wait_vmcnt<2 * LPW>();
+            else if (younger == 1) wait_vmcnt<LPW>();
+            else wait_vmcnt<0>();
+            ring_barrier();                        // everyone's pieces of stage t+1 landed; everyone's reads of stage t (and older) are complete
+            if (t + NST < NT) stage_load(t + NST);                  // into the buffer of stage t: it lives in registers now
+            frag_load(t + 1, an, bn);              // unconditional (after the last step it re-reads a stale buffer, unused): a branch here makes
+                                                   // the compiler wait lgkmcnt(0) at the join, i.e. for THESE reads, in front of the MFMAs below
+            __builtin_amdgcn_sched_barrier(0);     // keep the requests above the MFMAs
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][j] = mfma16(ac[i], bc[j], acc[i][j]);
+        };
+        static_assert(NST >= 3 && NST <= 5, "ring depth");
+        for (int t = 0; t < NT; t += 2) {
+            step(t, a0, b0, a1, b1);
+            step(t + 1, a1, b1, a0, b0);
+        }
+        const int m0 = tm * 256 + wm * 128 + (lane & 15), n0 = tn * 256 + wn * 64 + 4 * (lane >> 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ep.store4(m0 + j * 16, n0 + i * 16, acc[i][j]);
+        // the trailing (unused) fragment request of the last step must not be in flight when the next tile refills the ring
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+    }
 }
 
-// patch of the XCD-aware tile order: PN = the largest divisor of tiles_n that is <= 6, PM = the largest divisor of tiles_m
-// with PM * PN <= 32 (the blocks resident on one XCD)
+// patch of the XCD-aware tile order: PM | tiles_m, PN | tiles_n, PM * PN <= 32 (the blocks resident on one XCD) as large as possible;
+// among equals the most square one (PM + PN operand panels enter the L2 per patch)
 static inline void gemm256_patch(int tiles_m, int tiles_n, int& PM, int& PN)
 {
-    PN = 1;
-    for (int c = 6; c >= 1; --c) if (tiles_n % c == 0) { PN = c; break; }
-    PM = 1;
-    for (int c = 32 / PN; c >= 1; --c) if (tiles_m % c == 0) { PM = c; break; }
+    PM = 1; PN = 1;
+    int best = 0, best_sum = 1 << 30;
+    for (int pn = 1; pn <= 32 && pn <= tiles_n; ++pn) {
+        if (tiles_n % pn) continue;
+        for (int pm = 1; pm * pn <= 32 && pm <= tiles_m; ++pm) {
+            if (tiles_m % pm) continue;
+            const int prod = pm * pn, sum = pm + pn;
+            if (prod > best || (prod == best && sum < best_sum)) { best = prod; best_sum = sum; PM = pm; PN = pn; }
+        }
+    }
+}
+
+template <int NST, class Ep>
+static inline hipError_t launch_gemm_256p_nst(hipStream_t st, const bf16_t* X, const bf16_t* W, int K32, int tiles_m, int tiles_n, const Ep& ep)
+{
+    int PM, PN;
+    gemm256_patch(tiles_m, tiles_n, PM, PN);
+    // persistent patch-lockstep grid (one block per CU) once there are more tiles than CUs; WM_ENC_GEMM_PERSIST=0: one tile per block
+    const int persist_env = [] { const char* v = std::getenv("WM_ENC_GEMM_PERSIST"); return v ? std::atoi(v) : 1; }();
+    const int persistent = (persist_env && tiles_m * tiles_n > 256) ? 1 : 0;
+    auto kern = k_gemm_256p<NST, Ep>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, NST * 32 * 1024);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(persistent ? 256 : tiles_m * tiles_n), dim3(512), NST * 32 * 1024, st, X, W, K32, tiles_m, tiles_n, PM, PN, persistent, ep);
+    return hipGetLastError();
 }
 
 template <class Ep>
 static inline hipError_t launch_gemm_256p(hipStream_t st, const bf16_t* X, const bf16_t* W, int Mrows, int N, int K32, const Ep& ep)
 {
     const int tiles_m = Mrows / 256, tiles_n = N / 256;
-    int PM, PN;
-    gemm256_patch(tiles_m, tiles_n, PM, PN);
     const int nst = [] { const char* v = std::getenv("WM_ENC_GEMM_RING"); return v ? std::atoi(v) : 4; }();      // read per launch (sweeps)
-    if (nst == 5) {
-        auto kern = k_gemm_256p<5, Ep>;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), 160 * 1024, st, X, W, K32, tiles_m, tiles_n, PM, PN, ep);
-    } else if (nst == 3) {
-        auto kern = k_gemm_256p<3, Ep>;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), 96 * 1024, st, X, W, K32, tiles_m, tiles_n, PM, PN, ep);
-    } else {
-        auto kern = k_gemm_256p<4, Ep>;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), 128 * 1024, st, X, W, K32, tiles_m, tiles_n, PM, PN, ep);
-    }
-    return hipGetLastError();
+    if (nst == 5) return launch_gemm_256p_nst<5>(st, X, W, K32, tiles_m, tiles_n, ep);
+    if (nst == 3) return launch_gemm_256p_nst<3>(st, X, W, K32, tiles_m, tiles_n, ep);
+    return launch_gemm_256p_nst<4>(st, X, W, K32, tiles_m, tiles_n, ep);
 }
 
 template <class Ep>

@@ -272,6 +272,7 @@ extern "C" int wm_decode_begin(wm_ctx* ctx, const wm_gen_params* gp, int B)
     g.thr = gp->posterior_threshold; g.alpha = gp->posterior_alpha;
     g.inv_temp = (gp->accept_mode == WM_ACCEPT_TYPICAL && gp->temperature > 0.f) ? 1.0f / gp->temperature : 1.0f;
     g.force_accept = gp->force_accept;
+    g.begin = gp->begin_index >= 0 ? gp->begin_index : P;
     g.accept_mode = gp->accept_mode; g.vanilla = gp->vanilla; g.K = K; g.V = ctx->V; g.Vpad = ctx->Vpad; g.Tids = Tids;
     ctx->fuse = std::getenv("WM_NO_CARRY") == nullptr;
     ctx->host_carry = ctx->fuse && B == 1 && !gp->vanilla;

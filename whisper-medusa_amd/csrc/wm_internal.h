@@ -33,6 +33,7 @@ struct GenDev {
     int P, eos, pad, max_length, hard_max_length, exp_start /* absolute: start + P, or -1 */;
     float thr, alpha, inv_temp;
     int accept_mode, vanilla, K, V, Vpad, Tids, fuse, force_accept;
+    int begin;      // sequence length at which the begin-suppress list applies (wm_gen_params.begin_index; P when that is < 0)
 };
 
 // Static tables of the candidate tree (device memory; medusa_utils.py:305-421).  Nodes are numbered depth by depth.

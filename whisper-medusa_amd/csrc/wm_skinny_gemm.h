@@ -459,6 +459,96 @@ k_rows_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int 
     }
 }
 
+// ---- 17..32 token rows (two token tiles): the weight-streaming kernel with a second token tile ---------------------
+// The base pass of up to 32 streams (and every vanilla step) is still a weight-streaming problem: 3-13 MB of weights against
+// <= 64 KB of token operand.  Same organisation as k_skinny_gemm — the wave's whole K-slice of the weight stream, both token
+// tiles' hi/lo fragments and the epilogue operands are requested in one batch at entry — with every weight fragment feeding
+// four MFMAs.  (The register-blocked kernel walked its K-slice in dependent groups of 4 fragments: FC2 at 32 rows took 15 us
+// against 7 us for the single-tile launch.)  Same plan, same accumulation order: bit-identical to single-stream runs.
+template <int NK, bool W8, class Ep>
+__global__ void __launch_bounds__(640)
+k_skinny2_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int N16, int K32, int ksplit, int rt_per_wg, int ks_magic,
+               const int* __restrict__ done, const bf16_t* __restrict__ X, size_t plane, int M, Ep ep)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // token fragments held at a time: 4 k-tiles x 2 token tiles x hi/lo = 64 registers next to the wave's NK weight fragments (a block
+    // of 10 waves leaves 168 registers per lane); the next round is requested as soon as the MFMAs of this one have issued
+    constexpr int XB = 4;
+    static_assert(NK % XB == 0, "K-slice is a multiple of 4 k-tiles");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rtl = (wave * ks_magic) >> 8, ks = wave - rtl * ksplit;
+    const int tile0 = blockIdx.x * rt_per_wg + rtl;
+    const int kt0 = ks * NK;
+    typename WRaw<W8>::type a[NK];
+    {
+        const size_t wp = ((size_t)min(tile0, N16 - 1) * K32 + kt0) * 512 + lane * 8;
+#pragma unroll
+        for (int u = 0; u < NK; ++u) a[u] = ld_wraw<W8, true>(W, wp + (size_t)u * 512);
+    }
+    const bool rv0 = (lane & 15) < M, rv1 = 16 + (lane & 15) < M;
+    const bf16x8_t z = __builtin_bit_cast(bf16x8_t, make_uint4(0u, 0u, 0u, 0u));
+    bf16x8_t h0[XB], l0[XB], h1[XB], l1[XB];
+    auto issue = [&](int kt) {
+#pragma unroll
+        for (int u = 0; u < XB; ++u) {
+            const bf16_t* p0 = X + ((size_t)(kt + u) * 64 + lane) * 8;
+            const bf16_t* p1 = p0 + (size_t)K32 * 512;
+            h0[u] = z; l0[u] = z; h1[u] = z; l1[u] = z;
+            if (rv0) { h0[u] = ld_frag(p0); l0[u] = ld_frag(p0 + plane); }
+            if (rv1) { h1[u] = ld_frag(p1); l1[u] = ld_frag(p1 + plane); }
+        }
+    };
+    issue(kt0);
+    // the element this thread finishes: with K-slices, wave f < 2 * rt_per_wg finishes (row tile f >> 1, token tile f & 1) of the block
+    const int nfin = 2 * rt_per_wg;
+    const int tf = (ksplit > 1) ? blockIdx.x * rt_per_wg + (wave >> 1) : tile0;
+    const int en = tf * 16 + 4 * (lane >> 4);
+    const bool edo = ((ksplit > 1) ? (wave < nfin) : true) && tf < N16;
+    EpPre pre0, pre1; pre0.i = 0; pre0.a = make_float4(0.f, 0.f, 0.f, 0.f); pre0.b = pre0.a; pre1 = pre0;
+    float4 wsc = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (edo) {
+        if (ksplit > 1) pre0 = ep.pre((wave & 1) * 16 + (lane & 15), en);
+        else { pre0 = ep.pre(lane & 15, en); pre1 = ep.pre(16 + (lane & 15), en); }
+        if constexpr (W8) wsc = *reinterpret_cast<const float4*>(wscale + en);
+    }
+    if (done && *done) return;
+
+    f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < NK / XB; ++r) {
+        if (r > 0) issue(kt0 + r * XB);
+#pragma unroll
+        for (int u = 0; u < XB; ++u) {
+            const bf16x8_t av = w_expand<W8>(a[r * XB + u]);
+            acc0 = mfma16(av, h0[u], acc0); acc0 = mfma16(av, l0[u], acc0);
+            acc1 = mfma16(av, h1[u], acc1); acc1 = mfma16(av, l1[u], acc1);
+        }
+    }
+    if (ksplit > 1) {
+        float4* red = reinterpret_cast<float4*>(smem);
+        red[((rtl * 2 + 0) * ksplit + ks) * 64 + lane] = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
+        red[((rtl * 2 + 1) * ksplit + ks) * 64 + lane] = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);
+        __syncthreads();
+        if (edo) {
+            f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+            for (int k2 = 0; k2 < ksplit; ++k2) {
+                const float4 p = red[(wave * ksplit + k2) * 64 + lane];
+                s[0] += p.x; s[1] += p.y; s[2] += p.z; s[3] += p.w;
+            }
+            if constexpr (W8) s = f32x4_t{s[0] * wsc.x, s[1] * wsc.y, s[2] * wsc.z, s[3] * wsc.w};
+            ep.fin((wave & 1) * 16 + (lane & 15), en, s, pre0);
+        }
+    } else if (edo) {
+        if constexpr (W8) {
+            acc0 = f32x4_t{acc0[0] * wsc.x, acc0[1] * wsc.y, acc0[2] * wsc.z, acc0[3] * wsc.w};
+            acc1 = f32x4_t{acc1[0] * wsc.x, acc1[1] * wsc.y, acc1[2] * wsc.z, acc1[3] * wsc.w};
+        }
+        ep.fin(lane & 15, en, acc0, pre0);
+        ep.fin(16 + (lane & 15), en, acc1, pre1);
+    }
+}
+
 // ---- token-tile GEMM through an LDS ring (R >= 48 token rows: the verify pass of several streams) -----------------
 // At 352 rows (32 streams x 11 candidates) a decoder GEMM is ~20 output tiles per CU: neither weight-streaming (the
 // register-blocked kernel above re-reads every operand from L2 once per wave: 8 KB per 16 MFMAs, L2 -> CU bound) nor big
@@ -818,13 +908,50 @@ static inline hipError_t launch_tile_gemm(hipStream_t st, const bf16_t* W, int N
     return hipErrorInvalidConfiguration;
 }
 
+// Which kernel takes a GEMM of MT >= 2 token tiles.  Measured on MI355X, large-v2, 352 rows (tests/microbench/r03_sweep.py,
+// profiles/r03_tile_gemm_sweep.md): both kernels are bound by the L2 -> CU fill rate (~31 B/clk per CU on L2 hits): the LDS-ring
+// tile kernel moves fewer bytes but pays ~4.5 us of ring fill / drain per launch, so it wins where the grid is many rounds of blocks
+// deep (vocabulary projection: 211 -> 116 us at 352 rows, 63 -> 39 us at 88) and loses on the one-round layer GEMMs (out-proj
+// 6.6 -> 9.4 us, QKV 19 -> 18 us, FC2 23 -> 29 us).  WM_TILE_GEMM_MIN_N16 / _MIN_MT move the boundary (sweeps; 0 = tile kernel off).
+static inline bool use_tile_gemm(int N16, int K32, int MT, bool w8, int nk) {
+    const int min_mt = skinny_env("WM_TILE_GEMM_MIN_MT", 3), min_n16 = skinny_env("WM_TILE_GEMM_MIN_N16", 1024);
+    return min_mt > 0 && MT >= min_mt && N16 >= min_n16 && !w8 && (nk & 1) == 0 && (K32 & 1) == 0;
+}
+
+template <int NK, bool W8, class Ep>
+static inline hipError_t launch_skinny2_nk(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p, const bf16_t* X, size_t plane, int R, const Ep& ep) {
+    const int grid = (N16 + p.rt - 1) / p.rt, threads = 64 * p.ksplit * p.rt;
+    const size_t lds = p.ksplit > 1 ? (size_t)p.rt * 2 * p.ksplit * 1024 : 0;
+    const int magic = (256 + p.ksplit - 1) / p.ksplit;
+    hipLaunchKernelGGL((k_skinny2_gemm<NK, W8, Ep>), dim3(grid), dim3(threads), lds, st, W.w, W.scale, N16, K32, p.ksplit, p.rt, magic, g_skinny_done,
+                       X, plane, R, ep);
+    return hipGetLastError();
+}
+template <bool W8, class Ep>
+static inline hipError_t launch_skinny2_w(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p, const bf16_t* X, size_t plane, int R, const Ep& ep) {
+    switch (p.nk) {
+        case 4: return launch_skinny2_nk<4, W8>(st, W, N16, K32, p, X, plane, R, ep);
+        case 8: return launch_skinny2_nk<8, W8>(st, W, N16, K32, p, X, plane, R, ep);
+        case 12: return launch_skinny2_nk<12, W8>(st, W, N16, K32, p, X, plane, R, ep);
+        case 16: return launch_skinny2_nk<16, W8>(st, W, N16, K32, p, X, plane, R, ep);
+        default: return hipErrorInvalidConfiguration;
+    }
+}
+template <class Ep>
+static inline hipError_t launch_skinny2(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p, const bf16_t* X, size_t plane, int R, const Ep& ep) {
+    if (W.scale) return launch_skinny2_w<true>(st, W, N16, K32, p, X, plane, R, ep);
+    return launch_skinny2_w<false>(st, W, N16, K32, p, X, plane, R, ep);
+}
+
 template <class Ep>
 static inline hipError_t launch_skinny_mt(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p,
-                                          const bf16_t* X, size_t plane, int MT, const Ep& ep) {
-    // >= 3 token tiles, bf16 weights: the LDS-ring tile kernel (same accumulation order, bit-identical results)
-    const int tile_min_mt = skinny_env("WM_TILE_GEMM_MIN_MT", 3);            // 0 = off (register-blocked kernel everywhere)
-    if (tile_min_mt > 0 && MT >= tile_min_mt && !W.scale && (p.nk & 1) == 0 && (K32 & 1) == 0)
+                                          const bf16_t* X, size_t plane, int MT, int R, const Ep& ep) {
+    // the LDS-ring tile kernel (same accumulation order, bit-identical results)
+    if (use_tile_gemm(N16, K32, MT, W.scale != nullptr, p.nk))
         return launch_tile_gemm(st, W.w, N16, K32, p.nk, X, plane, MT, ep);
+    // two token tiles: the weight-streaming kernel with a second token tile (WM_SKINNY2=0: the register-blocked kernel)
+    if (MT == 2 && skinny_env("WM_SKINNY2", 1) && p.ksplit * p.rt <= 10 && p.ksplit * p.nk == K32)
+        return launch_skinny2(st, W, N16, K32, p, X, plane, R, ep);
     if (p.nk == 16) return launch_skinny_mt_nk<16>(st, W, N16, K32, p, X, plane, MT, ep);
     if (p.nk == 12) return launch_skinny_mt_nk<12>(st, W, N16, K32, p, X, plane, MT, ep);
     if (p.nk == 8) return launch_skinny_mt_nk<8>(st, W, N16, K32, p, X, plane, MT, ep);
@@ -838,7 +965,7 @@ static inline hipError_t launch_skinny_rows(hipStream_t st, WRef W, int N16, int
                                             const Ep& ep) {
     const SkinnyPlan p = skinny_plan(N16, K32, false);
     if (R <= 16) return launch_skinny(st, W, N16, K32, p, LdPacked{X, K32, plane, R}, ep);
-    return launch_skinny_mt(st, W, N16, K32, p, X, plane, (R + 15) / 16, ep);
+    return launch_skinny_mt(st, W, N16, K32, p, X, plane, (R + 15) / 16, R, ep);
 }
 
 template <class Ld, class Ep>
@@ -850,10 +977,9 @@ static inline hipError_t launch_skinny_norm_t(hipStream_t st, WRef W, int N16, i
     const int MT = (R + 15) / 16;
     // weight prefetch riding on the LayerNorm launch (token-tile path with bf16 weights only; WM_LN_PREFETCH=0 turns it off)
     const int ln_pf = skinny_env("WM_LN_PREFETCH", 1);
-    const int tile_min_mt = skinny_env("WM_TILE_GEMM_MIN_MT", 3);
     PfJob pf{nullptr, nullptr, 0u, 0u, 0ull};
     int grid = MT;
-    if (ln_pf && tile_min_mt > 0 && MT >= tile_min_mt && !W.scale) {
+    if (ln_pf && use_tile_gemm(N16, K32, MT, W.scale != nullptr, p.nk)) {
         const unsigned long long total = (unsigned long long)N16 * K32 * 1024, slice = ((total + 7) / 8 + 1023) & ~1023ull;
         const unsigned job_bytes = 64 * 1024;
         pf = PfJob{reinterpret_cast<const char*>(W.w), nullptr, job_bytes, (unsigned)(8 * ((slice + job_bytes - 1) / job_bytes)), total};
@@ -864,7 +990,7 @@ static inline hipError_t launch_skinny_norm_t(hipStream_t st, WRef W, int N16, i
     else return hipErrorInvalidConfiguration;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    return launch_skinny_mt(st, W, N16, K32, p, xscr, plane, MT, ep);
+    return launch_skinny_mt(st, W, N16, K32, p, xscr, plane, MT, R, ep);
 }
 
 // LayerNorm-fused GEMM over R token rows.  R <= 16: one fused launch.  R > 16: the same LayerNorm code writes

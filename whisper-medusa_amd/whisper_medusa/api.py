@@ -32,6 +32,80 @@ class MedusaForwardOutput:
     logits: torch.Tensor                 # [K+1 (or 1), B, T, V]  (model.py:1301)
 
 
+class GenerateEncoderDecoderOutput(dict):
+    """What ``generate(return_dict_in_generate=True)`` returns in the reference (model.py:812-823: HF's ModelOutput of the same
+    name): fields by attribute, by key and by position.  The engine keeps scores / attentions / hidden states on the device and
+    never materialises them, so — as in the reference when ``output_scores`` etc. are not requested — they are ``None``; the KV
+    cache is engine state, not a Python object (``past_key_values`` is ``None``)."""
+    _fields = ("sequences", "scores", "logits", "encoder_attentions", "encoder_hidden_states", "decoder_attentions",
+               "cross_attentions", "decoder_hidden_states", "past_key_values")
+
+    def __init__(self, sequences, **extra):
+        super().__init__({k: None for k in self._fields})
+        self["sequences"] = sequences
+        self.update(extra)
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def to_tuple(self):
+        return tuple(self[k] for k in self.keys() if self[k] is not None)
+
+    def __getitem__(self, k):
+        if isinstance(k, int):
+            return self.to_tuple()[k]
+        return super().__getitem__(k)
+
+
+# HF logits processors / stopping criteria that are STATIC functions of (token id, current length) are lowered into wm_gen_params
+# (reference: generate() hands `logits_processor` / `stopping_criteria` to HF's _get_logits_processor / _get_stopping_criteria,
+# model.py:1106-1124; the engine fuses exactly these into its select kernels).  Matched by class name: no transformers import.
+_LOWERABLE_PROCESSORS = ("SuppressTokensLogitsProcessor", "SuppressTokensAtBeginLogitsProcessor", "ExponentialDecayLengthPenalty")
+_LOWERABLE_CRITERIA = ("MaxLengthCriteria", "EosTokenCriteria")
+
+
+def _as_int_list(x) -> List[int]:
+    if x is None:
+        return []
+    if hasattr(x, "flatten"):
+        return [int(v) for v in x.flatten().tolist()]
+    if isinstance(x, (list, tuple, set)):
+        return [int(v) for v in x]
+    return [int(x)]
+
+
+def lower_processors(gp: GenParams, logits_processor, stopping_criteria) -> GenParams:
+    """Fold caller-supplied HF processors / criteria into the generation parameters.  A custom processor replaces the default of
+    its type (HF's merge rule); anything that is not a static mask / penalty / length rule raises NotImplementedError."""
+    P = len(gp.prompt)
+    for proc in (logits_processor or []):
+        name = type(proc).__name__
+        if name == "SuppressTokensLogitsProcessor":
+            gp.suppress_tokens = _as_int_list(proc.suppress_tokens)
+        elif name == "SuppressTokensAtBeginLogitsProcessor":
+            gp.begin_suppress_tokens = _as_int_list(proc.begin_suppress_tokens)
+            gp.begin_suppress_index = int(proc.begin_index)
+        elif name == "ExponentialDecayLengthPenalty":
+            if _as_int_list(proc.eos_token_id) != [gp.eos_token_id]:
+                raise NotImplementedError("ExponentialDecayLengthPenalty on a token other than eos_token_id is not supported by the HIP engine")
+            gp.exp_decay = (int(proc.regulation_start) - P, float(proc.regulation_factor))     # regulation_start is absolute in HF
+        else:
+            raise NotImplementedError(f"logits processor {name} is not supported by the HIP engine (supported: {', '.join(_LOWERABLE_PROCESSORS)})")
+    for crit in (stopping_criteria or []):
+        name = type(crit).__name__
+        if name == "MaxLengthCriteria":
+            gp.max_length = min(gp.max_length, int(crit.max_length))
+        elif name == "EosTokenCriteria":
+            if _as_int_list(crit.eos_token_id) != [gp.eos_token_id]:
+                raise NotImplementedError("EosTokenCriteria with other ids than eos_token_id is not supported by the HIP engine")
+        else:
+            raise NotImplementedError(f"stopping criterion {name} is not supported by the HIP engine (supported: {', '.join(_LOWERABLE_CRITERIA)})")
+    return gp
+
+
 class WhisperMedusaModel:
     def __init__(self, config: MedusaConfig, state_dict: Dict[str, torch.Tensor], device: Union[str, torch.device, None] = None,
                  max_batch: int = 1, dec_weight_fp8: bool = False, enc_fp8: bool = False):
@@ -254,6 +328,7 @@ class WhisperMedusaModel:
                     begin_suppress_tokens, prompt_ids) -> GenParams:
         cfg = self.config
         prompt = _synth.default_prompt(cfg, language or "en", task or "transcribe")        # G1, model.py:1519-1537
+        begin_suppress_index = None
         if prompt_ids is not None:
             # short-form conditioning (HF _prepare_decoder_input_ids): decoder_input_ids = cat([prompt_ids, init_tokens]);
             # `prompt_ids` comes from processor.get_prompt_ids() and already starts with <|startofprev|>
@@ -261,6 +336,7 @@ class WhisperMedusaModel:
             if len(pid) + len(prompt) + cfg.medusa_num_heads + 2 > cfg.max_target_positions:
                 raise ValueError(f"prompt_ids of length {len(pid)} leave no room to generate "                      # model.py:1526-1529
                                  f"(max_target_positions {cfg.max_target_positions})")
+            begin_suppress_index = len(prompt)      # reference model.py:1537: begin_index = init_tokens.shape[1] (without prompt_ids)
             prompt = pid + prompt
         P = len(prompt)
         if max_new_tokens is not None:
@@ -284,7 +360,8 @@ class WhisperMedusaModel:
                          exp_decay=tuple(exponential_decay_length_penalty) if exponential_decay_length_penalty else None,
                          posterior_threshold=cfg.posterior_threshold if posterior_threshold is None else posterior_threshold,
                          posterior_alpha=cfg.posterior_alpha if posterior_alpha is None else posterior_alpha,
-                         accept_mode=mode, temperature=1.0 if mode == ACCEPT_TYPICAL else 0.0, vanilla=bool(vanilla))
+                         accept_mode=mode, temperature=1.0 if mode == ACCEPT_TYPICAL else 0.0, vanilla=bool(vanilla),
+                         begin_suppress_index=begin_suppress_index)
 
     @torch.no_grad()
     def generate(self, input_features: Optional[torch.Tensor] = None, generation_config=None, logits_processor=None,
@@ -307,8 +384,10 @@ class WhisperMedusaModel:
             raise NotImplementedError("no_speech_detection is not supported with medusa for now")  # model.py:1201-1205
         if kwargs.get("num_beams", 1) not in (None, 1):
             raise Exception("Beam search is not supported with medusa for now")                     # model.py:1153-1156
-        if logits_processor or stopping_criteria or prefix_allowed_tokens_fn:
-            raise NotImplementedError("custom logits processors / stopping criteria are not supported by the HIP engine")
+        if prefix_allowed_tokens_fn:
+            raise NotImplementedError("prefix_allowed_tokens_fn is not supported by the HIP engine")
+        if return_token_timestamps:
+            raise NotImplementedError("token timestamps are not supported with medusa")
         if input_features is None:
             raise ValueError("input_features is required")
         if input_features.dim() != 3:
@@ -317,12 +396,14 @@ class WhisperMedusaModel:
             if not kwargs.get("chunk_longform"):
                 raise NotImplementedError("Longform generation is not supported yet")              # model.py:1213-1214
             return self._generate_longform(input_features, dict(kwargs, language=language, task=task, temperature=temperature,
-                                                                prompt_ids=prompt_ids))
+                                                                prompt_ids=prompt_ids, logits_processor=logits_processor,
+                                                                stopping_criteria=stopping_criteria))
         if language is None and self.config.is_multilingual and kwargs.get("detect_language", True) and input_features.shape[0] >= 1 \
                 and not kwargs.get("_language_resolved"):
             return self._generate_detecting_language(input_features, dict(kwargs, task=task, temperature=temperature, prompt_ids=prompt_ids,
                                                                           return_dict_in_generate=return_dict_in_generate,
-                                                                          return_segments=return_segments))
+                                                                          return_segments=return_segments, logits_processor=logits_processor,
+                                                                          stopping_criteria=stopping_criteria))
         B = input_features.shape[0]
         if B > self._max_batch:
             self.set_max_batch(B)
@@ -332,10 +413,10 @@ class WhisperMedusaModel:
                               kwargs.get("vanilla", False), kwargs.get("posterior_threshold"),
                               kwargs.get("posterior_alpha"), kwargs.get("suppress_tokens"),
                               kwargs.get("begin_suppress_tokens"), prompt_ids)
+        if logits_processor or stopping_criteria:
+            gp = lower_processors(gp, logits_processor, stopping_criteria)
         self._last_prompt = list(gp.prompt)
         feats = input_features.to(self.device, torch.float32).contiguous()
-        if return_token_timestamps:
-            raise NotImplementedError("token timestamps are not supported with medusa")
         n_ctx = self._micro_batches_for(B) if kwargs.get("streamer") is None else 1
         if n_ctx > 1 and B >= 2:
             pool = self._get_pool(n_ctx)
@@ -360,16 +441,22 @@ class WhisperMedusaModel:
     def _outputs(self, seqs, gp, return_dict_in_generate, return_segments):
         """Default: the padded LongTensor.  ``return_dict_in_generate`` / ``return_segments``: the reference's dict form
         ``{"sequences": ..., ["segments": ...]}`` (model.py:1747-1779; one segment per clip, short-form only)."""
-        t = self._pad(seqs, gp)
+        return self._wrap_outputs(self._pad(seqs, gp), [len(gp.prompt)] * len(seqs), gp.pad_token_id, gp.eos_token_id,
+                                  return_dict_in_generate, return_segments)
+
+    def _wrap_outputs(self, t, prompt_lens, pad, eos, return_dict_in_generate, return_segments):
+        """``return_dict_in_generate``: a GenerateEncoderDecoderOutput (model.py:812-823, :1715-1742); ``return_segments`` alone:
+        the dict {"sequences", "segments"} of model.py:1764-1779 (one segment per clip, short-form only)."""
         if not return_dict_in_generate and not return_segments:
             return t
-        out = {"sequences": t}
+        segs = None
         if return_segments:
-            P = len(gp.prompt)
-            out["segments"] = [[{"start": torch.tensor(0.0), "end": torch.tensor(30.0 * self.config.max_source_positions / 1500.0),
-                                 "tokens": t[i, P:][t[i, P:] != gp.pad_token_id] if gp.pad_token_id != gp.eos_token_id else t[i, P:],
-                                 "result": t[i]}] for i in range(t.shape[0])]
-        return out
+            segs = [[{"start": torch.tensor(0.0), "end": torch.tensor(30.0 * self.config.max_source_positions / 1500.0),
+                      "tokens": t[i, P:][t[i, P:] != pad] if pad != eos else t[i, P:],
+                      "result": t[i]}] for i, P in enumerate(prompt_lens)]
+        if return_dict_in_generate:
+            return GenerateEncoderDecoderOutput(t, **({"segments": segs} if segs is not None else {}))
+        return {"sequences": t, "segments": segs}
 
     def _pad(self, seqs: List[List[int]], gp: GenParams) -> torch.Tensor:
         """G3: strip trailing pad/eos beyond the first EOS, right-pad to a tensor (model.py:1929-1973,1747-1762)."""
@@ -400,7 +487,9 @@ class WhisperMedusaModel:
             self.set_max_batch(B)
         self.engine.encode(feats)
         z = self.engine.forward_logits([[cfg.decoder_start_token_id]] * B, 0, True)[0, :, 0]      # [B, V]
-        toks = sorted(cfg.lang_to_id, key=lambda k: cfg.lang_to_id[k])
+        toks = [k for k in sorted(cfg.lang_to_id, key=lambda k: cfg.lang_to_id[k]) if 0 <= cfg.lang_to_id[k] < cfg.vocab_size]
+        if not toks:
+            raise ValueError("language detection: no language token of lang_to_id lies inside the vocabulary")
         ids = torch.tensor([cfg.lang_to_id[t] for t in toks])
         best = z[:, ids].argmax(-1)
         return [toks[int(i)] for i in best]
@@ -412,18 +501,18 @@ class WhisperMedusaModel:
         for i, l in enumerate(langs):
             groups.setdefault(l, []).append(i)
         rows: List[Optional[torch.Tensor]] = [None] * len(langs)
+        plens = [0] * len(langs)
         for l, idx in groups.items():
             out = self.generate(input_features[idx], language=l, _language_resolved=True, **kw)
             for j, i in enumerate(idx):
                 rows[i] = out[j]
+                plens[i] = len(self._last_prompt)
         T = max(r.numel() for r in rows)
         t = torch.full((len(rows), T), self.config.pad_token_id, dtype=torch.long, device=self.device)
         for i, r in enumerate(rows):
             t[i, : r.numel()] = r
         self.detected_languages = langs
-        if rdg or rseg:
-            return {"sequences": t}
-        return t
+        return self._wrap_outputs(t, plens, self.config.pad_token_id, self.config.eos_token_id, rdg, rseg)
 
     def _generate_longform(self, input_features, kw):
         """`chunk_longform=True`: clips longer than 30 s (the reference raises, model.py:1213-1214) are cut into 30 s windows,
@@ -442,15 +531,31 @@ class WhisperMedusaModel:
         if n * F > T:
             x[..., T:] = input_features.to(self.device, torch.float32).amin(dim=(1, 2), keepdim=True)
         win = x.view(B, cfg.num_mel_bins, n, F).permute(0, 2, 1, 3).reshape(B * n, cfg.num_mel_bins, F).contiguous()
-        kw.setdefault("detect_language", True)
-        out = self.generate(win, **kw)
-        P = len(self._last_prompt)
+        # the language is detected ONCE per clip, on its first window, and every window of the clip is decoded in that language
+        # (clips of different languages go through generate() as separate groups, each with its own prompt)
+        if kw.get("language") is None and cfg.is_multilingual and kw.get("detect_language", True):
+            first = self.detect_language(win[::n])
+            kw["detect_language"] = False
+            langs = first
+        else:
+            langs = [kw.get("language")] * B
+        kw.pop("language", None)
+        rows, prompts = [None] * (B * n), [None] * B
+        for l in sorted(set(langs), key=lambda v: (v is None, v or "")):
+            clips = [b for b in range(B) if langs[b] == l]
+            widx = [b * n + j for b in clips for j in range(n)]
+            o = self.generate(win[widx], language=l, **kw)
+            for q, wi in enumerate(widx):
+                rows[wi] = o[q]
+            for b in clips:
+                prompts[b] = list(self._last_prompt)
         eos, pad = cfg.eos_token_id, cfg.pad_token_id
         seqs = []
         for b in range(B):
-            ids = list(self._last_prompt)
+            ids = list(prompts[b])
+            P = len(ids)
             for j in range(n):
-                row = out[b * n + j, P:].tolist()
+                row = rows[b * n + j][P:].tolist()
                 for t in row:
                     if t == eos or t == pad:
                         break

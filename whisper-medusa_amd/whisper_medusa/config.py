@@ -290,7 +290,11 @@ class GenParams:
     temperature: float = 1.0
     vanilla: bool = False            # anchor: plain greedy decoding with head 0 / base logits
     force_accept: int = -1           # benchmark knob (wm.h): >= 0 forces the accept length of every iteration; -1 = off
+    begin_suppress_index: Optional[int] = None
+    # ^ sequence length at which SuppressTokensAtBeginLogitsProcessor fires.  None = len(prompt) (no prompt_ids: the prompt IS the
+    #   init tokens).  With `prompt_ids` the reference passes begin_index = init_tokens.shape[1] (model.py:1537, 1551, 1640-1644),
+    #   i.e. the number of init tokens WITHOUT the prepended previous-text ids, so the begin suppression never fires there.
 
     @property
     def begin_index(self) -> int:
-        return len(self.prompt)
+        return len(self.prompt) if self.begin_suppress_index is None else int(self.begin_suppress_index)

@@ -16,7 +16,7 @@ from .config import MedusaConfig, GenParams, HEADS_BLOCK
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwm.so")      # the product library; tests/microbench scripts may point WM_LIB at a debug build
-WM_ABI_VERSION = 5
+WM_ABI_VERSION = 6
 
 
 class WmConfig(C.Structure):
@@ -38,7 +38,8 @@ class WmGenParams(C.Structure):
                 ("max_length", C.c_int32), ("hard_max_length", C.c_int32),
                 ("exp_decay_start", C.c_int32), ("exp_decay_factor", C.c_float),
                 ("posterior_threshold", C.c_float), ("posterior_alpha", C.c_float),
-                ("temperature", C.c_float), ("accept_mode", C.c_int32), ("vanilla", C.c_int32), ("force_accept", C.c_int32)]
+                ("temperature", C.c_float), ("accept_mode", C.c_int32), ("vanilla", C.c_int32), ("begin_index", C.c_int32),
+                ("force_accept", C.c_int32)]
 
 
 class WmStats(C.Structure):
@@ -198,7 +199,7 @@ class Engine:
                         int(gp.exp_decay[0]) if gp.exp_decay is not None else -1,      # the eval CLI parses the start as float
                         float(gp.exp_decay[1]) if gp.exp_decay is not None else 1.0,
                         gp.posterior_threshold, gp.posterior_alpha, gp.temperature if gp.temperature else 0.0,
-                        gp.accept_mode, 1 if gp.vanilla else 0, int(getattr(gp, "force_accept", -1)))
+                        gp.accept_mode, 1 if gp.vanilla else 0, int(gp.begin_index), int(getattr(gp, "force_accept", -1)))
         self._check(self.lib.wm_decode_begin(self.h, C.byref(g), B), "wm_decode_begin")
         left = C.c_int32(0)
         if on_iteration is None:
