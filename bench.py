@@ -136,13 +136,27 @@ def acceptance_sensitivity(eng, cfg, gp_base, B, max_new):
     return out
 
 
+def leg_parity(cfg, sd, eng, gp, fp8, iters=2):
+    """Stream 0 of the leg's LAST decoded batch against the oracle in the engine's numeric contract, fed with the engine's encoder
+    output, for the first `iters` Medusa iterations (the checker, never the thing measured)."""
+    from oracle.whisper_medusa_oracle import Oracle
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    orc = Oracle(cfg, {k: v.float().cpu() for k, v in sd.items()}, sim="bf16", dec_fp8=fp8, enc_fp8=fp8)
+    enc = eng.encoder_output(1)[0]
+    ref = orc.decode(enc, gp, max_iters=iters)
+    got = eng.tokens(0)
+    n = len(ref.ids)
+    return {"parity_checked": bool(got[:n] == ref.ids), "parity_tokens_compared": n - len(gp.prompt), "parity_iterations": ref.n_iters}
+
+
 def extra_config(name, heads, B, fp8, dev, logit_std, max_new, steps=2):
     """One more BASELINE.json config measured in the same process (B streams, one context): whole-step tokens/s, decode
-    iteration time, vanilla anchor, roofline fractions."""
+    iteration time, vanilla anchor, roofline fractions, and a parity check of stream 0 against the oracle."""
     from whisper_medusa import MedusaConfig, WhisperMedusaModel, ACCEPT_TYPICAL, synth, weights
     cfg = MedusaConfig.large_v2(heads, K=10)
     sd = synth.synth_state_dict(cfg, seed=0, device=str(dev), logit_std=logit_std)
     blob, offs = weights.build_blob(cfg, sd, device=dev, dec_fp8=fp8, enc_fp8=fp8)
+    sd_cpu = {k: v.cpu() for k, v in sd.items()}
     del sd
     model = WhisperMedusaModel.from_blob(cfg, blob, offs, max_batch=B, dec_weight_fp8=fp8, enc_fp8=fp8)
     eng = model.engine
@@ -160,6 +174,11 @@ def extra_config(name, heads, B, fp8, dev, logit_std, max_new, steps=2):
     for _ in range(steps):
         n, st = step(); tok += n; it += st["iterations"]; ms_dec += st["ms_decode"]; ms_enc += st["ms_encode"]
     torch.cuda.synchronize(); el = time.perf_counter() - t0
+    try:
+        parity = leg_parity(cfg, sd_cpu, eng, gp, fp8)
+    except Exception as e:  # noqa: BLE001
+        parity = {"parity_checked": False, "parity_error": repr(e)}
+    del sd_cpu
     gpv = synth.bench_gen_params(cfg, max_new_tokens=max_new, vanilla=True)
     eng.decode(gpv, B); eng.decode(gpv, B)
     stv = eng.stats()
@@ -170,9 +189,13 @@ def extra_config(name, heads, B, fp8, dev, logit_std, max_new, steps=2):
            "tokens_per_sec": round(tok / el, 1), "decode_tokens_per_sec": round(tok / (ms_dec * 1e-3), 1),
            "ms_per_iteration": round(t_iter, 4), "tokens_per_iteration": round(tok / max(it, 1) / B, 3),
            "vanilla_tokens_per_sec": round(van, 1), "medusa_over_vanilla": round(tok / (ms_dec * 1e-3) / van, 3),
+           "roofline": {"bound": "hbm", "bytes_per_launch": round(bytes_iter), "ms_per_launch": round(t_iter, 4),
+                        "achieved": round(bytes_iter / (t_iter * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                        "frac": round(bytes_iter / (t_iter * 1e-3) / 8e12, 4)},
            "roofline_frac_hbm": round(bytes_iter / (t_iter * 1e-3) / 8e12, 4),
            "prefill_tflops": round(prefill_flops(cfg) * B / (ms_enc / steps * 1e-3) / 1e12, 1),
            "prefill_frac_mfma": round(prefill_flops(cfg) * B / (ms_enc / steps * 1e-3) / 2.5e15, 4)}
+    out.update(parity)
     eng.close()
     del model, blob
     torch.cuda.empty_cache()
@@ -282,6 +305,7 @@ def main():
     wd.barrier()
     elapsed = wd.max_over_ranks(time.perf_counter() - t0, dev)
     tokens_all = wd.sum_over_ranks(float(tokens), dev)
+    per_rank_tokens = wd.gather_floats(float(tokens), dev)          # one entry per rank: every rank of the launch really decoded
 
     # ---- anchor: vanilla greedy decoding on the same engine / clips / budget (one untimed-region step) ----
     vanilla_tps = vanilla_ms_step = None
@@ -328,6 +352,7 @@ def main():
                    "streams_per_gpu": B, "micro_batches": args.micro_batches, "fp8_decoder_weights": bool(args.fp8_weights), "parallelism": f"dp{world}",
                    "max_new_tokens": args.max_new},
         "tokens_per_sec_per_gpu": round(tokens_all / elapsed / world, 2),
+        "ranks_seen": len(per_rank_tokens), "tokens_per_rank": [int(t) for t in per_rank_tokens],
         "rtf": round(elapsed / audio_s, 6), "x_realtime": round(audio_s / elapsed, 2),
         "decode_tokens_per_sec_per_gpu": round(tokens / (ms_dec * 1e-3), 2),
         "iters_per_sec": round(iters / (ms_dec * 1e-3), 2), "tokens_per_iter": round(tok_per_iter, 3),
@@ -357,7 +382,8 @@ def main():
             out["acceptance_sensitivity"] = {"failed": repr(e)}
         if args.model == "large-v2" and B == 1 and args.heads == "linear" and not args.fp8_weights:
             extra = []
-            for name, heads_x, Bx, fp8x in (("configs[2] large-v2 + Medusa-Block K=10, 32 streams", "medusa_block", 32, False),
+            for name, heads_x, Bx, fp8x in (("large-v2 + Medusa-Block K=10, 1 stream (the batch the reference's x1.37 is quoted on)", "medusa_block", 1, False),
+                                            ("configs[2] large-v2 + Medusa-Block K=10, 32 streams", "medusa_block", 32, False),
                                             ("configs[1] shape at 32 streams (Medusa-Linear)", "base_head", 32, False),
                                             ("configs[4] fp8 (encoder fp8 MFMA + fp8 decoder weights) + Medusa-Linear, 32 streams", "base_head", 32, True)):
                 try:

@@ -32,3 +32,27 @@ def gpu(built_lib):
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")
     return torch.device("cuda", 0)
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """One line of parity evidence per session + tests/parity_report.json (ties followed must be counted,
+    agreement numbers asserted AND visible in the driver's log)."""
+    try:
+        import json
+        import helpers
+        P = helpers.PARITY
+    except Exception:  # noqa: BLE001
+        return
+    if not P["runs"] and not P["tables"]:
+        return
+    line = (f"parity ties: {len(P['ties'])} over {P['runs']} oracle-compared runs ({P['strict_equal']} strictly identical); "
+            + "; ".join(f"{k}: {v}" for k, v in P["tables"].items()))
+    terminalreporter.write_line(line)
+    rep = dict(P, summary=line)
+    for d in (os.path.join(ROOT, "tests"), os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "parity_report.json"), "w") as f:
+                    json.dump(rep, f, indent=1)
+            except OSError:
+                pass

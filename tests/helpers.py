@@ -44,16 +44,30 @@ def clip_for(cfg, i=0):
     return synth.synth_clip(i, n_samples=cfg.n_mel_frames * 160)
 
 
+# Parity evidence of one pytest session: every oracle comparison is counted, every followed numerical tie recorded, and the
+# agreement tables of the cross-mode tests kept; tests/conftest.py prints ONE summary line at the end of the run (visible in the
+# driver's -q log) and writes tests/parity_report.json (+ gpurun_out/ when that exists).
+PARITY = {"runs": 0, "strict_equal": 0, "ties": [], "tables": {}}
+
+
+def record_table(name, **numbers):
+    PARITY["tables"][name] = numbers
+
+
 def check_tokens(orc, enc_b, gp, got, label="", max_ties=2, tol_logit=5e-4):
     """Token parity of one engine run against the oracle: strictly identical ids, or — when the first difference sits at a
     decision whose margin in the ORACLE is below the numerical difference of two correct implementations (an argmax between
     logits < tol_logit apart, p_c within 2e-3 relative of the threshold) — identical along the engine's admissible branch
     (oracle.decode_following).  Returns (accept lengths, ties); ties are printed: they are part of the evidence."""
     ref = orc.decode(enc_b, gp)
+    PARITY["runs"] += 1
     if got == ref.ids:
+        PARITY["strict_equal"] += 1
         return ref.accept_lengths, []
     ok, ties, ids = orc.decode_following(enc_b, gp, got, tol_logit=tol_logit)
     first = next((i for i, (a, b) in enumerate(zip(got, ref.ids)) if a != b), min(len(got), len(ref.ids)))
     print(f"parity[{label}]: strict comparison differs at index {first}; numerical ties followed: {ties}")
     assert ok and 0 < len(ties) <= max_ties and all("kind" in t for t in ties), (label, first, got, ref.ids, ties)
+    for t in ties:
+        PARITY["ties"].append({"run": str(label), **{k: (float(v) if isinstance(v, (int, float)) else str(v)) for k, v in t.items()}})
     return list(orc.last_follow_accepts), ties

@@ -15,7 +15,7 @@ for r in rows[:45]:
     lines.append(f"| {r[2] / tot * 100:.1f} | {r[1]} | {r[3]:.2f} | {r[4]:.2f} | {r[5]:.2f} | `{name}` |")
 # reconciliation with bench.py's hipEvent timing: decode-path kernel time per Medusa iteration (run bench.py --no-vanilla)
 dec = c.execute("select sum(end-start)/1e3, count(*) from kernels where name like '%k_skinny%' or name like '%k_attn%' or name like '%k_rows_gemm%' "
-                "or name like '%k_ln_tiles%' or name like '%k_select%' or name like '%k_embed%' or name like '%k_rows_norm%' "
+                "or name like '%k_ln_tiles%' or name like '%k_tile_gemm%' or name like '%k_select%' or name like '%k_embed%' or name like '%k_rows_norm%' "
                 "or name like '%k_accept%' or name like '%k_set_cand%'").fetchone()
 n_iter = c.execute("select count(*) from kernels where name like '%k_accept%' and name not like '%vanilla%'").fetchone()[0]
 n_van = c.execute("select count(*) from kernels where name like '%k_accept_vanilla%'").fetchone()[0]

@@ -1,0 +1,33 @@
+"""The exact command the driver uses for the multi-GPU scaling runs — `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` — exercised every round with two ranks sharing the ONE available
+GPU (WM_DIST_BACKEND=gloo: RCCL needs one device per rank; everything else — weight broadcast, barriers, rank reductions, the
+rank-0 report — is the code the 8-GPU launch runs).  Micro shape, so the whole thing takes seconds."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from helpers import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_two_ranks_under_torch_distributed_run(gpu):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, WM_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--model", "micro",
+           "--batch", "3", "--max-new", "24", "--no-cpu-baseline", "--no-extra-configs"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                     # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and len(d["tokens_per_rank"]) == 2 and all(t > 0 for t in d["tokens_per_rank"])
+    assert d["scaling"] == "weak" and d["value"] > 0 and d["config"]["parallelism"] == "dp2"
+    assert abs(sum(d["tokens_per_rank"]) / (d["ms_per_step"] * 1e-3 * d["steps"]) - d["value"]) <= 0.02 * d["value"]

@@ -27,8 +27,9 @@ def _worker(rank, world, port, q):
     allv = wd.gather_token_lists(local)
     tmax = wd.max_over_ranks(1.0 + r)
     tot = wd.sum_over_ranks(len(mine))
+    per_rank = wd.gather_floats(float(len(mine)))
     wd.barrier()
-    q.put((r, int(blob.to(torch.int64).sum()), offs.tolist(), allv, tmax, tot))
+    q.put((r, int(blob.to(torch.int64).sum()), offs.tolist(), allv, tmax, tot, per_rank))
 
 
 def test_two_rank_shard_broadcast_gather():
@@ -47,7 +48,8 @@ def test_two_rank_shard_broadcast_gather():
     cfg = MedusaConfig.micro(K=4)
     from whisper_medusa import weights
     blob, offs = weights.build_blob(cfg, synth.synth_state_dict(cfg, seed=7))
-    for r, bsum, o, allv, tmax, tot in res:
+    for r, bsum, o, allv, tmax, tot, per_rank in res:
+        assert per_rank == [4.0, 3.0]                                                  # rank order, on every rank
         assert bsum == int(blob.to(torch.int64).sum()) and o == offs.tolist()       # identical weights everywhere
         assert allv == [[s] * (s + 1) for s in range(7)]                               # ordered, ragged, complete
         assert tmax == 2.0 and tot == 7

@@ -178,18 +178,69 @@ def test_large_end_to_end_audio_to_tokens(large, large_oracle):
     first = next((i for i, (a, b) in enumerate(zip(got, ref.ids)) if a != b), min(len(got), len(ref.ids)))
     print(f"large end-to-end: encoder max|d| {float(d.max()):.4f} mean|d| {float(d.mean()):.5f}; tokens agree on the first "
           f"{first - len(gp.prompt)} of {len(ref.ids) - len(gp.prompt)} generated ids")
+    from helpers import record_table
+    record_table("large-v2 end-to-end (bf16-contract oracle, own log-mel + encoder)", agree=first - len(gp.prompt),
+                 total=len(ref.ids) - len(gp.prompt), enc_max_abs_diff=round(float(d.max()), 4), enc_mean_abs_diff=round(float(d.mean()), 5))
     assert d.max() <= 0.25 and d.mean() <= 8e-3
-    assert first >= len(gp.prompt) + 2                      # the first iteration (base token + its successor) agrees
+    # floor on the ids reproduced before the first divergence (two encoders that round to bf16 at the same points but sum in
+    # different orders): half of the budget; the measured value is recorded in tests/parity_report.json
+    assert first - len(gp.prompt) >= 16, (first - len(gp.prompt), len(ref.ids) - len(gp.prompt))
     # given the oracle's encoder output bit for bit, the decode loop agrees completely
     # (encoder_output round-trips through the bf16 cache, so feed the oracle what the engine holds)
     assert large_oracle.decode(enc_e, gp).ids == got
+
+
+@pytest.mark.parametrize("mode", [ACCEPT_GREEDY, ACCEPT_TYPICAL])
+def test_large_token_agreement_with_the_pinned_fp32_oracle(large, mode, capsys):
+    """The cross-mode table of tests/test_gpu_parity.py at large-v2: engine (bf16 contract) against the oracle
+    in the mode PINNED to the reference (sim="fp32"), audio -> tokens with nothing shared but checkpoint and waveform: 4 clips,
+    16 new tokens, first-divergence index and the oracle's top-2 margin there.  The fp32 oracle runs its own log-mel and its own
+    fp32 encoder on the host cores (~7 s per clip)."""
+    from oracle.whisper_medusa_oracle import Oracle
+    from helpers import record_table
+    cfg, sd, model, _ = large
+    eng = model.engine
+    orc32 = Oracle(cfg, _cpu_sd(sd), sim="fp32")
+    n = cfg.n_mel_frames * 160
+    N, NEW = 4, 16
+    wavs = [synth.synth_clip(300 + i, n) for i in range(N)]
+    gp = synth.bench_gen_params(cfg, max_new_tokens=NEW, accept_mode=mode)
+    eng.encode(model.extract_features(np.stack(wavs)))
+    got = eng.decode(gp, N)
+    P = len(gp.prompt)
+    rows, agree, total = [], 0, 0
+    for i in range(N):
+        ref = orc32.transcribe(wavs[i], gp, trace=True)
+        f = next((j for j, (a, b) in enumerate(zip(got[i], ref.ids)) if a != b), min(len(got[i]), len(ref.ids)))
+        ngen = len(ref.ids) - P
+        agree += f - P; total += ngen
+        margin = float("nan")
+        if f < len(ref.ids):
+            pos = P
+            for t in ref.trace:
+                if pos + len(t["emit"]) > f:
+                    top2 = torch.topk(t["v"][0], 2).values
+                    margin = float(top2[0] - top2[1])
+                    break
+                pos += len(t["emit"])
+        rows.append((i, f - P, ngen, margin))
+    name = f"fp32-pinned end-to-end large-v2 {'typical' if mode == ACCEPT_TYPICAL else 'exact-match'}"
+    with capsys.disabled():
+        print(f"\n{name}:")
+        for i, f, ngen, margin in rows:
+            print(f"  clip {i}: {f:2d} / {ngen} generated ids agree before the first divergence; top-2 logit margin there {margin:.4f}")
+        print(f"  total {agree} / {total} = {agree / max(total, 1):.3f}")
+    record_table(name, agree=agree, total=total, frac=round(agree / max(total, 1), 3),
+                 first_divergence=[r[1] for r in rows], top2_margin=[None if r[3] != r[3] else round(r[3], 4) for r in rows])
+    assert all(f >= 1 for _, f, _, _ in rows)                # never on the first token
+    assert agree >= 0.5 * total, (agree, total)              # floor until a measured value is on record (then: measured - 5 %)
 
 
 @pytest.fixture(scope="module")
 def large_block(gpu):
     cfg = MedusaConfig.large_v2("medusa_block", K=10)
     sd = synth.synth_state_dict(cfg, seed=3, device=str(gpu), logit_std=4.5)
-    model = WhisperMedusaModel(cfg, sd, device=gpu, max_batch=6)
+    model = WhisperMedusaModel(cfg, sd, device=gpu, max_batch=32)
     yield cfg, sd, model
     model.engine.close()
 
@@ -225,6 +276,27 @@ def test_large_block_decode_loop_matches_the_oracle(large_block):
     scale = float(r.abs().max())
     print("large block prompt pass: max|d|", float((z - r).abs().max()), "mean|d|", float((z - r).abs().mean()), "scale", scale)
     assert (z - r).abs().max() <= 2e-3 * scale and (z - r).abs().mean() <= 2e-4 * scale
+
+
+def test_large_block_thirty_two_streams_match_the_oracle(large_block):
+    """configs[2] at ITS OWN shape: large-v2 + Medusa-Block K=10, 32 streams in one context (352 verify rows through the
+    token-tile GEMMs, per-stream carry with the block-output row, 32-row base passes through the two-tile weight-streaming
+    kernel): streams 0, 13 and 31 against the oracle fed with the engine's encoder output, typical acceptance, 24 new tokens."""
+    from oracle.whisper_medusa_oracle import Oracle
+    cfg, sd, model = large_block
+    eng = model.engine
+    orc = Oracle(cfg, _cpu_sd(sd), sim="bf16")
+    n = cfg.n_mel_frames * 160
+    B = 32
+    wav = np.stack([synth.synth_clip(400 + i, n) for i in range(B)])
+    eng.encode(model.extract_features(wav))
+    enc = eng.encoder_output(B)
+    gp = synth.bench_gen_params(cfg, max_new_tokens=24, accept_mode=ACCEPT_TYPICAL)
+    got = eng.decode(gp, B)
+    for s_ in (0, 13, 31):
+        accepts, ties = check_tokens(orc, enc[s_], gp, got[s_], f"block B=32 stream {s_}", tol_logit=2e-3)
+        assert len(got[s_]) >= len(gp.prompt) + 24 - 11
+        print(f"large block B=32 stream {s_}: accept lengths {accepts}")
 
 
 def test_large_fp8_decode_loop_matches_the_fp8_oracle(gpu):

@@ -538,6 +538,10 @@ def test_token_agreement_with_the_pinned_fp32_oracle_end_to_end(gpu, mode, capsy
     full = sum(1 for _, f, ngen, _ in rows if f == ngen)
     # floors (measured values are printed above and recorded in DESIGN.md §2): the two sides never disagree on the first token,
     # and a clear majority of the generated ids is reproduced although no rounding point is shared
+    from helpers import record_table
+    record_table(f"fp32-pinned end-to-end tiny.en {'typical' if mode == ACCEPT_TYPICAL else 'exact-match'}",
+                 agree=agree, total=total, frac=round(agree / max(total, 1), 3), clips_fully_equal=full, clips=N)
     assert all(f >= 1 for _, f, _, _ in rows)
-    assert agree >= 0.5 * total, (agree, total, full)
+    # measured in round 2 on MI355X: 491 / 512 (exact-match) and 496 / 516 (typical) = 0.96; floor = measured - 5 %
+    assert agree >= 0.91 * total, (agree, total, full)
     model.engine.close()

@@ -260,8 +260,10 @@ k_gemm_256(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32, 
 // =============================================================================================
 template <int NST, class Ep>
 __global__ void __launch_bounds__(512)
-k_gemm_256p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32, int tiles_m, int tiles_n, int PM, int PN, int persistent, Ep ep)
+k_gemm_256p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32, int tiles_m, int tiles_n, int PM, int PN, int persistent, int dbg, Ep ep)
 {
+    // dbg (WM_ENC_GEMM_DBG, measurement only, results are then wrong): bit 0 skips the MFMAs, bit 1 the ring refills inside the K loop,
+    // bit 2 the epilogue, bit 3 the fragment reads of the K loop — what is left shows which part bounds the kernel
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int STAGE = 32 * 1024;            // 16 X fragments (token tiles) then 16 W fragments (row tiles), one k-tile
     constexpr int LPW = 4;                      // LDS-DMA pieces per wave per stage
@@ -340,14 +342,16 @@ k_gemm_256p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32,
             else if (younger == 1) wait_vmcnt<LPW>();
             else wait_vmcnt<0>();
             ring_barrier();                        // everyone's pieces of stage t+1 landed; everyone's reads of stage t (and older) are complete
-            if (t + NST < NT) stage_load(t + NST);                  // into the buffer of stage t: it lives in registers now
-            frag_load(t + 1, an, bn);              // unconditional (after the last step it re-reads a stale buffer, unused): a branch here makes
+            if (t + NST < NT && !(dbg & 2)) stage_load(t + NST);    // into the buffer of stage t: it lives in registers now
+            if (!(dbg & 8)) frag_load(t + 1, an, bn);   // unconditional (after the last step it re-reads a stale buffer, unused): a branch here makes
                                                    // the compiler wait lgkmcnt(0) at the join, i.e. for THESE reads, in front of the MFMAs below
             __builtin_amdgcn_sched_barrier(0);     // keep the requests above the MFMAs
+            if (!(dbg & 1)) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+                for (int j = 0; j < 8; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i][j] = mfma16(ac[i], bc[j], acc[i][j]);
+                    for (int i = 0; i < 4; ++i) acc[i][j] = mfma16(ac[i], bc[j], acc[i][j]);
+            }
         };
         static_assert(NST >= 3 && NST <= 5, "ring depth");
         for (int t = 0; t < NT; t += 2) {
@@ -355,10 +359,12 @@ k_gemm_256p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32,
             step(t + 1, a1, b1, a0, b0);
         }
         const int m0 = tm * 256 + wm * 128 + (lane & 15), n0 = tn * 256 + wn * 64 + 4 * (lane >> 4);
+        if (!(dbg & 4)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) ep.store4(m0 + j * 16, n0 + i * 16, acc[i][j]);
+                for (int j = 0; j < 8; ++j) ep.store4(m0 + j * 16, n0 + i * 16, acc[i][j]);
+        } else if (acc[0][0][0] == 12345.678f) ep.store4(m0, n0, acc[1][1]);      // keeps the accumulators alive
         // the trailing (unused) fragment request of the last step must not be in flight when the next tile refills the ring
         __builtin_amdgcn_s_waitcnt(0xC07F);
     }
@@ -388,10 +394,11 @@ static inline hipError_t launch_gemm_256p_nst(hipStream_t st, const bf16_t* X, c
     // persistent patch-lockstep grid (one block per CU) once there are more tiles than CUs; WM_ENC_GEMM_PERSIST=0: one tile per block
     const int persist_env = [] { const char* v = std::getenv("WM_ENC_GEMM_PERSIST"); return v ? std::atoi(v) : 1; }();
     const int persistent = (persist_env && tiles_m * tiles_n > 256) ? 1 : 0;
+    const int dbg = [] { const char* v = std::getenv("WM_ENC_GEMM_DBG"); return v ? std::atoi(v) : 0; }();
     auto kern = k_gemm_256p<NST, Ep>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, NST * 32 * 1024);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(persistent ? 256 : tiles_m * tiles_n), dim3(512), NST * 32 * 1024, st, X, W, K32, tiles_m, tiles_n, PM, PN, persistent, ep);
+    hipLaunchKernelGGL(kern, dim3(persistent ? 256 : tiles_m * tiles_n), dim3(512), NST * 32 * 1024, st, X, W, K32, tiles_m, tiles_n, PM, PN, persistent, dbg, ep);
     return hipGetLastError();
 }
 

@@ -90,6 +90,17 @@ def sum_over_ranks(value: float, device=None) -> float:
     return float(t.item())
 
 
+def gather_floats(value: float, device=None) -> List[float]:
+    """One scalar per rank, in rank order, on every rank (bench.py: tokens decoded per rank = which ranks really ran)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(value)]
+    dev = device if dist.get_backend() == "nccl" else "cpu"
+    mine = torch.tensor([value], dtype=torch.float64, device=dev)
+    parts = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, mine)
+    return [float(p.item()) for p in parts]
+
+
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
