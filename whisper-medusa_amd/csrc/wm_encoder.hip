@@ -145,10 +145,7 @@ k_gemm_tiled(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32
     }
 
     const int m0 = tm * BM + wm * (BM / 2) + (lane & 15), n0 = tn * GT_BN + wn * 64 + 4 * (lane >> 4);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < MJ; ++j) ep.store4(m0 + j * 16, n0 + i * 16, acc[i][j]);
+    ep_tiles<4, MJ>(ep, m0, n0, acc);
 }
 
 template <int BM, int NST, int KS, class Ep>
@@ -238,10 +235,7 @@ k_gemm_256(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32, 
                 for (int i = 0; i < 4; ++i) acc[i][j] = mfma16(a[kk][i], b[kk][j], acc[i][j]);
     }
     const int m0 = tm * 256 + wm * 128 + (lane & 15), n0 = tn * 256 + wn * 64 + 4 * (lane >> 4);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) ep.store4(m0 + j * 16, n0 + i * 16, acc[i][j]);
+    ep_tiles<4, 8>(ep, m0, n0, acc);
 }
 
 // =============================================================================================
@@ -359,12 +353,8 @@ k_gemm_256p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32,
             step(t + 1, a1, b1, a0, b0);
         }
         const int m0 = tm * 256 + wm * 128 + (lane & 15), n0 = tn * 256 + wn * 64 + 4 * (lane >> 4);
-        if (!(dbg & 4)) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) ep.store4(m0 + j * 16, n0 + i * 16, acc[i][j]);
-        } else if (acc[0][0][0] == 12345.678f) ep.store4(m0, n0, acc[1][1]);      // keeps the accumulators alive
+        if (!(dbg & 4)) ep_tiles<4, 8>(ep, m0, n0, acc);
+        else if (acc[0][0][0] == 12345.678f) ep.store4(m0, n0, acc[1][1]);      // keeps the accumulators alive
         // the trailing (unused) fragment request of the last step must not be in flight when the next tile refills the ring
         __builtin_amdgcn_s_waitcnt(0xC07F);
     }
@@ -473,11 +463,18 @@ __device__ __host__ __forceinline__ size_t f8_index(int row, int k, int K64) {  
 template <class Ep>
 struct EpScaled {              // fp8 GEMM: dequantise the accumulator (token-row scale, then weight-row scale) in front of the epilogue
     Ep ep; const float* xs; const float* ws;
-    __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const {
-        const float s = xs[m];
-        const float4 w = *reinterpret_cast<const float4*>(ws + n);
-        ep.store4(m, n, f32x4_t{(v[0] * s) * w.x, (v[1] * s) * w.y, (v[2] * s) * w.z, (v[3] * s) * w.w});
+    // the wrapped epilogues (EpQKVEnc, EpPackedAct, EpCrossKV) only use pre.a: the weight scales ride in pre.b, the token scale in pre.i
+    __device__ __forceinline__ EpPre pre(int m, int n) const {
+        EpPre p = ep.pre(m, n);
+        p.b = *reinterpret_cast<const float4*>(ws + n);
+        p.i = __float_as_int(xs[m]);
+        return p;
     }
+    __device__ __forceinline__ void fin(int m, int n, f32x4_t v, const EpPre& p) const {
+        const float s = __int_as_float(p.i);
+        ep.fin(m, n, f32x4_t{(v[0] * s) * p.b.x, (v[1] * s) * p.b.y, (v[2] * s) * p.b.z, (v[3] * s) * p.b.w}, p);
+    }
+    __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const { fin(m, n, v, pre(m, n)); }
 };
 
 struct F8Frag { long lo, hi; };
@@ -552,10 +549,7 @@ k_gemm_f8(const unsigned char* __restrict__ X, const unsigned char* __restrict__
             for (int j = 0; j < MJ; ++j) { acc[i][j] = mfma16_f8(a[i].lo, b[j].lo, acc[i][j]); acc[i][j] = mfma16_f8(a[i].hi, b[j].hi, acc[i][j]); }
     }
     const int m0 = tm * BM + wm * (BM / 2) + (lane & 15), n0 = tn * GT_BN + wn * 64 + 4 * (lane >> 4);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < MJ; ++j) ep.store4(m0 + j * 16, n0 + i * 16, acc[i][j]);
+    ep_tiles<4, MJ>(ep, m0, n0, acc);
 }
 
 // 256 x 256 tile, 8 waves (2 x 4), wave = 128 tokens x 64 features; a 64-k step is 32 KiB (16 X + 16 W units): three stages
@@ -612,10 +606,7 @@ k_gemm_f8_256(const unsigned char* __restrict__ X, const unsigned char* __restri
             for (int i = 0; i < 4; ++i) { acc[i][j] = mfma16_f8(a[i].lo, b[j].lo, acc[i][j]); acc[i][j] = mfma16_f8(a[i].hi, b[j].hi, acc[i][j]); }
     }
     const int m0 = tm * 256 + wm * 128 + (lane & 15), n0 = tn * 256 + wn * 64 + 4 * (lane >> 4);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) ep.store4(m0 + j * 16, n0 + i * 16, acc[i][j]);
+    ep_tiles<4, 8>(ep, m0, n0, acc);
 }
 
 template <int BM, int NST, class Ep>

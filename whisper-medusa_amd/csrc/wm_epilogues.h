@@ -132,12 +132,16 @@ struct EpHead {
 
 // ---- encoder -----------------------------------------------------------------------------
 struct EpConv1 {               // a1[b][t][n] = gelu(conv1) as row-major bf16 (input of the conv2 im2col)
-    static constexpr bool kPre = false;
     bf16_t* a1; const float* bias; int T, Tpad, d;
-    __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const {
+    __device__ __forceinline__ EpPre pre(int, int n) const {
+        EpPre p; p.i = 0; p.b = make_float4(0.f, 0.f, 0.f, 0.f); p.a = *reinterpret_cast<const float4*>(bias + n);
+        return p;
+    }
+    __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const { fin(m, n, v, pre(m, n)); }
+    __device__ __forceinline__ void fin(int m, int n, f32x4_t v, const EpPre& p) const {
         const int b = m / Tpad, t = m - b * Tpad;
         if (t >= T) return;
-        const float4 bb = *reinterpret_cast<const float4*>(bias + n);
+        const float4 bb = p.a;
         uint2 o;
         o.x = pack_bf2(gelu_erf(v[0] + bb.x), gelu_erf(v[1] + bb.y));
         o.y = pack_bf2(gelu_erf(v[2] + bb.z), gelu_erf(v[3] + bb.w));
@@ -146,14 +150,20 @@ struct EpConv1 {               // a1[b][t][n] = gelu(conv1) as row-major bf16 (i
 };
 
 struct EpConv2 {               // h = gelu(conv2) + embed_positions   (HF:modeling_whisper.py:626-632)
-    static constexpr bool kPre = false;
     float* h; const float* bias; const float* pos; int S, Spad, d;
-    __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const {
+    __device__ __forceinline__ EpPre pre(int m, int n) const {
+        EpPre p; p.i = 0; p.a = make_float4(0.f, 0.f, 0.f, 0.f); p.b = p.a;
+        const int s = m % Spad;
+        if (s < S) { p.a = *reinterpret_cast<const float4*>(bias + n); p.b = *reinterpret_cast<const float4*>(pos + (size_t)s * d + n); }
+        return p;
+    }
+    __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const { fin(m, n, v, pre(m, n)); }
+    __device__ __forceinline__ void fin(int m, int n, f32x4_t v, const EpPre& p) const {
         const int s = m % Spad;
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
         if (s < S) {
-            const float4 bb = *reinterpret_cast<const float4*>(bias + n);
-            const float4 pp = *reinterpret_cast<const float4*>(pos + (size_t)s * d + n);
+            const float4 bb = p.a;
+            const float4 pp = p.b;
             o = make_float4(gelu_erf(v[0] + bb.x) + pp.x, gelu_erf(v[1] + bb.y) + pp.y,
                             gelu_erf(v[2] + bb.z) + pp.z, gelu_erf(v[3] + bb.w) + pp.w);
         }
@@ -162,11 +172,15 @@ struct EpConv2 {               // h = gelu(conv2) + embed_positions   (HF:modeli
 };
 
 struct EpQKVEnc {              // q (x 64^-1/2), k as [b][h][s][64]; v as V^T MFMA fragments per [b][h] (vfrag_index)
-    static constexpr bool kPre = false;
     bf16_t* q; bf16_t* k; bf16_t* vt; const float* bias; int Spad, H, d;
-    __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const {
+    __device__ __forceinline__ EpPre pre(int, int n) const {
+        EpPre p; p.i = 0; p.b = make_float4(0.f, 0.f, 0.f, 0.f); p.a = *reinterpret_cast<const float4*>(bias + n);
+        return p;
+    }
+    __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const { fin(m, n, v, pre(m, n)); }
+    __device__ __forceinline__ void fin(int m, int n, f32x4_t v, const EpPre& p) const {
         const int b = m / Spad, s = m - b * Spad;
-        const float4 bb = *reinterpret_cast<const float4*>(bias + n);
+        const float4 bb = p.a;
         float x0 = v[0] + bb.x, x1 = v[1] + bb.y, x2 = v[2] + bb.z, x3 = v[3] + bb.w;
         if (n < 2 * d) {
             const bool isq = n < d;
@@ -183,14 +197,18 @@ struct EpQKVEnc {              // q (x 64^-1/2), k as [b][h][s][64]; v as V^T MF
 };
 
 struct EpCrossKV {             // K_x [kvl][b][h][s][64], V_x [kvl][b][h] as V^T MFMA fragments (vfrag_index)   (HF:modeling_whisper.py:322-335)
-    static constexpr bool kPre = false;
     bf16_t* kx; bf16_t* vx; const float* bias; int Spad, H, d, B;
-    __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const {
+    __device__ __forceinline__ EpPre pre(int, int n) const {
+        EpPre p; p.i = 0; p.b = make_float4(0.f, 0.f, 0.f, 0.f); p.a = *reinterpret_cast<const float4*>(bias + n);
+        return p;
+    }
+    __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const { fin(m, n, v, pre(m, n)); }
+    __device__ __forceinline__ void fin(int m, int n, f32x4_t v, const EpPre& p) const {
         const int b = m / Spad, s = m - b * Spad;
         const int kvl = n / (2 * d), rem = n - kvl * 2 * d;
         const bool isv = rem >= d;
         const int c = isv ? rem - d : rem;
-        const float4 bb = *reinterpret_cast<const float4*>(bias + n);
+        const float4 bb = p.a;
         const size_t slab = (((size_t)kvl * B + b) * H + (c >> 6)) * Spad * 64;
         if (!isv) {
             uint2 o; o.x = pack_bf2(v[0] + bb.x, v[1] + bb.y); o.y = pack_bf2(v[2] + bb.z, v[3] + bb.w);
@@ -201,3 +219,26 @@ struct EpCrossKV {             // K_x [kvl][b][h][s][64], V_x [kvl][b][h] as V^T
         }
     }
 };
+
+// Epilogue of a wave's NI x NJ output tiles (encoder GEMMs): per feature tile the operands of all NJ token tiles (bias, residual,
+// positions) are requested in ONE batch, then the arithmetic and the stores run.  Calling store4 tile by tile made every tile a
+// dependent memory round trip — the compiler cannot hoist loads over the stores of the previous tile (possible aliasing) — and
+// 32 round trips per wave were a third of the big-batch GEMM time (tests/microbench/r03_call3.sh: 117 -> 89 ms per 32-clip encoder
+// pass with the epilogue switched off).
+template <int NI, int NJ, class Ep>
+__device__ __forceinline__ void ep_tiles(const Ep& ep, int m0, int n0, f32x4_t (&acc)[NI][NJ])
+{
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        EpPre pre[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) pre[j] = ep.pre(m0 + j * 16, n0 + i * 16);
+        // loads of the NEXT group must not be hoisted above this group's stores: loads and stores share one counter (vmcnt) and
+        // complete out of order with respect to each other, so a load consumed after a store has been issued costs s_waitcnt vmcnt(0),
+        // i.e. the completion of that store — per tile
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) ep.fin(m0 + j * 16, n0 + i * 16, acc[i][j], pre[j]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}

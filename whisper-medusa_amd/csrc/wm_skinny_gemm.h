@@ -174,7 +174,7 @@ struct LdPacked {
             if (rv) { r.h[u] = ld_frag(p); r.l[u] = ld_frag(p + plane); }
         }
     }
-    template <int NB> __device__ __forceinline__ void stats(Regs<NB>&, char*, int, int, bool, int) const {}
+    template <int NB> __device__ __forceinline__ void stats(Regs<NB>&, char*, int, int, bool, int, int = 0) const {}
     template <int NB>
     __device__ __forceinline__ void frag(const Regs<NB>& r, const char*, int u, int, int, bf16x8_t& bh, bf16x8_t& bl) const { bh = r.h[u]; bl = r.l[u]; }
 };
@@ -197,7 +197,7 @@ struct LdNormT {
 
     // `rows`: false for waves that only help staging gamma / beta (the fused cross-attention kernel has more waves than K-slices)
     template <int NB>
-    __device__ __forceinline__ void issue(Regs<NB>& r, char* smem, int kt0, int lane, int row0 = 0, bool rows = true) const {
+    __device__ __forceinline__ void issue(Regs<NB>& r, char* smem, int kt0, int lane, int row0 = 0, bool rows = true, bool dma = true) const {
         const int rr = lane & 15, g8 = (lane >> 4) * 8;
         const bool rv = rows && row0 + rr < M;
         const float* hrow = h + (size_t)((row0 + rr) * row_mul + row_off) * d + (size_t)kt0 * 32 + g8;
@@ -207,7 +207,7 @@ struct LdNormT {
             if (rv) { const float4* src = reinterpret_cast<const float4*>(hrow + u * 32); r.v0[u] = src[0]; r.v1[u] = src[1]; }
         }
         if constexpr (NORM) {       // gamma | beta -> LDS, 1 KiB pieces (256 floats) spread over the block's waves
-            const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6, np = (2 * d + 255) >> 8;
+            const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6, np = dma ? (2 * d + 255) >> 8 : 0;
             for (int p = wave; p < np; p += nw) {
                 const int idx = p * 256 + lane * 4;
                 if (idx < 2 * d) glds16_f(idx < d ? gamma + idx : beta + (idx - d), smem + (size_t)p * 1024);
@@ -216,11 +216,13 @@ struct LdNormT {
     }
     // per-row statistics over the whole row: needs every K-slice -> LDS exchange (contains the block barrier, which also
     // makes the LDS-DMA'd gamma / beta visible).  `leader`: this wave publishes its slice's partial (one wave per slice).
+    // `slot`: which half of the 2 KiB statistics area is used (the two-tile kernel normalises its tiles one after the other: the
+    // second tile's partials must not overwrite the first's while a slower wave still reads them; slots hold <= 8 K-slices)
     template <int NB>
-    __device__ __forceinline__ void stats(Regs<NB>& r, char* smem, int ks, int ksplit, bool leader, int lane) const {
+    __device__ __forceinline__ void stats(Regs<NB>& r, char* smem, int ks, int ksplit, bool leader, int lane, int slot = 0) const {
         r.mean = 0.f; r.rstd = 1.f;
         if constexpr (!NORM) return;
-        float2* part = reinterpret_cast<float2*>(smem + (size_t)2 * d * sizeof(float));      // [ksplit <= 16][16 rows]
+        float2* part = reinterpret_cast<float2*>(smem + (size_t)2 * d * sizeof(float)) + slot * 128;      // [ksplit <= 16][16 rows]
         float s = 0.f, q2 = 0.f;
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
@@ -297,7 +299,10 @@ k_skinny_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, in
     }
     // done: every stream finished (the rest of this replay is a no-op).  Checked after the batch went out: the flag's
     // latency overlaps the stream instead of heading every launch of the dependent chain.
-    if (done && *done) return;
+    if (done && *done) {
+        if constexpr (Ld::kNorm) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the LDS-DMA of gamma / beta must not land in a released allocation
+        return;
+    }
 
     ld.template stats<XB>(xr, smem, ks, ksplit, rtl == 0, lane);
     TL_PREP
@@ -362,15 +367,17 @@ __global__ void __launch_bounds__(640)
 k_ln_tiles(Ld ld, int ksplit, bf16_t* __restrict__ xg, size_t plane, const int* __restrict__ done, int nmain, PfJob pf)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (done && *done) return;
     // blocks beyond the token tiles: the launch has 22 blocks of work at 32 streams — the rest of the chip pulls the weight matrix of
     // the GEMM that follows into the L2 of the XCD that will read it
-    if ((int)blockIdx.x >= nmain) { pf_block_sliced(pf, (int)blockIdx.x - pf_round8(nmain)); return; }
+    if ((int)blockIdx.x >= nmain) { if (!(done && *done)) pf_block_sliced(pf, (int)blockIdx.x - pf_round8(nmain)); return; }
     const int lane = threadIdx.x & 63;
     const int ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int kt0 = ks * NK;
     typename Ld::template Regs<NK> xr;
     ld.template issue<NK>(xr, smem, kt0, lane, blockIdx.x * 16);
+    // `done` (every stream finished) is looked at once the loads are in flight: as the first instruction it is a dependent scalar
+    // round trip (~1 us) in front of every launch of the chain.  No LDS-DMA may be outstanding when the block leaves.
+    if (done && *done) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
     ld.template stats<NK>(xr, smem, ks, ksplit, true, lane);
     bf16_t* dst = xg + (size_t)blockIdx.x * ld.K32 * 512;
 #pragma unroll
@@ -394,7 +401,6 @@ k_rows_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int 
             const bf16_t* __restrict__ X, size_t plane, int MT, Ep ep)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (done && *done) return;
     const int lane = threadIdx.x & 63;
     const int ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rt0 = blockIdx.x * RT, mt0 = blockIdx.y * TT;
@@ -420,6 +426,9 @@ k_rows_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int 
 #pragma unroll
             for (int i = 0; i < RT; ++i) a[i][u] = ld_wfrag<W8, false>(W, wp[i] + (size_t)(kg + u) * 512);
         }
+        // every stream finished: looked at behind the first group of loads (as the first instruction of the kernel the flag is a
+        // dependent ~1 us scalar round trip in front of every launch of the chain)
+        if (kg == 0 && done && *done) return;
 #pragma unroll
         for (int u = 0; u < G; ++u)
 #pragma unroll
@@ -448,13 +457,24 @@ k_rows_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int 
             }
         }
     } else {
+        // operands of every tile's epilogue in one batch, then the stores (tile-by-tile store4 calls are dependent memory round trips:
+        // loads cannot be hoisted over the previous tile's stores)
+        EpPre pre[RT][TT];
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int j = 0; j < TT; ++j) {
+                pre[i][j].i = 0; pre[i][j].a = make_float4(0.f, 0.f, 0.f, 0.f); pre[i][j].b = pre[i][j].a;
+                if (rt0 + i < N16 && mt0 + j < MT) pre[i][j] = ep.pre((mt0 + j) * 16 + (lane & 15), (rt0 + i) * 16 + 4 * (lane >> 4));
+            }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < RT; ++i)
 #pragma unroll
             for (int j = 0; j < TT; ++j)
                 if (rt0 + i < N16 && mt0 + j < MT) {
                     if constexpr (W8) acc[i][j] = scale4(acc[i][j], wscale, (rt0 + i) * 16 + 4 * (lane >> 4));
-                    ep.store4((mt0 + j) * 16 + (lane & 15), (rt0 + i) * 16 + 4 * (lane >> 4), acc[i][j]);
+                    ep.fin((mt0 + j) * 16 + (lane & 15), (rt0 + i) * 16 + 4 * (lane >> 4), acc[i][j], pre[i][j]);
                 }
     }
 }
@@ -527,6 +547,84 @@ k_skinny2_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, i
     }
     if (ksplit > 1) {
         float4* red = reinterpret_cast<float4*>(smem);
+        red[((rtl * 2 + 0) * ksplit + ks) * 64 + lane] = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
+        red[((rtl * 2 + 1) * ksplit + ks) * 64 + lane] = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);
+        __syncthreads();
+        if (edo) {
+            f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+            for (int k2 = 0; k2 < ksplit; ++k2) {
+                const float4 p = red[(wave * ksplit + k2) * 64 + lane];
+                s[0] += p.x; s[1] += p.y; s[2] += p.z; s[3] += p.w;
+            }
+            if constexpr (W8) s = f32x4_t{s[0] * wsc.x, s[1] * wsc.y, s[2] * wsc.z, s[3] * wsc.w};
+            ep.fin((wave & 1) * 16 + (lane & 15), en, s, pre0);
+        }
+    } else if (edo) {
+        if constexpr (W8) {
+            acc0 = f32x4_t{acc0[0] * wsc.x, acc0[1] * wsc.y, acc0[2] * wsc.z, acc0[3] * wsc.w};
+            acc1 = f32x4_t{acc1[0] * wsc.x, acc1[1] * wsc.y, acc1[2] * wsc.z, acc1[3] * wsc.w};
+        }
+        ep.fin(lane & 15, en, acc0, pre0);
+        ep.fin(16 + (lane & 15), en, acc1, pre1);
+    }
+}
+
+// The LayerNorm-fused form for two token tiles: a wave normalises its K-slice of tile 0 and of tile 1 one after the other with the
+// single-tile kernel's code (same statistics, same slicing: bit-identical operands) against the same weight registers — the three
+// k_ln_tiles launches per decoder layer of a 17..32-row pass (~7 us each, two blocks of work) disappear.  Blocks of <= 6 waves
+// (2 per SIMD: 256 registers per lane hold both tiles' fp32 rows).
+template <int NK, bool W8, class Ld, class Ep>
+__global__ void __launch_bounds__(384)
+k_skinny2_norm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int N16, int K32, int ksplit, int rt_per_wg, int ks_magic,
+               const int* __restrict__ done, Ld ld, Ep ep)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rtl = (wave * ks_magic) >> 8, ks = wave - rtl * ksplit;
+    const int tile0 = blockIdx.x * rt_per_wg + rtl;
+    const int kt0 = ks * NK;
+    typename WRaw<W8>::type a[NK];
+    {
+        const size_t wp = ((size_t)min(tile0, N16 - 1) * K32 + kt0) * 512 + lane * 8;
+#pragma unroll
+        for (int u = 0; u < NK; ++u) a[u] = ld_wraw<W8, true>(W, wp + (size_t)u * 512);
+    }
+    typename Ld::template Regs<NK> x0, x1;
+    ld.template issue<NK>(x0, smem, kt0, lane, 0);
+    ld.template issue<NK>(x1, smem, kt0, lane, 16, true, false);
+    const int nfin = 2 * rt_per_wg;
+    const int tf = (ksplit > 1) ? blockIdx.x * rt_per_wg + (wave >> 1) : tile0;
+    const int en = tf * 16 + 4 * (lane >> 4);
+    const bool edo = ((ksplit > 1) ? (wave < nfin) : true) && tf < N16;
+    EpPre pre0, pre1; pre0.i = 0; pre0.a = make_float4(0.f, 0.f, 0.f, 0.f); pre0.b = pre0.a; pre1 = pre0;
+    float4 wsc = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (edo) {
+        if (ksplit > 1) pre0 = ep.pre((wave & 1) * 16 + (lane & 15), en);
+        else { pre0 = ep.pre(lane & 15, en); pre1 = ep.pre(16 + (lane & 15), en); }
+        if constexpr (W8) wsc = *reinterpret_cast<const float4*>(wscale + en);
+    }
+    if (done && *done) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
+
+    f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    ld.template stats<NK>(x0, smem, ks, ksplit, rtl == 0, lane, 0);
+#pragma unroll
+    for (int u = 0; u < NK; ++u) {
+        bf16x8_t bh, bl;
+        ld.template frag<NK>(x0, smem, u, kt0 + u, lane, bh, bl);
+        const bf16x8_t av = w_expand<W8>(a[u]);
+        acc0 = mfma16(av, bh, acc0); acc0 = mfma16(av, bl, acc0);
+    }
+    ld.template stats<NK>(x1, smem, ks, ksplit, rtl == 0, lane, 1);
+#pragma unroll
+    for (int u = 0; u < NK; ++u) {
+        bf16x8_t bh, bl;
+        ld.template frag<NK>(x1, smem, u, kt0 + u, lane, bh, bl);
+        const bf16x8_t av = w_expand<W8>(a[u]);
+        acc1 = mfma16(av, bh, acc1); acc1 = mfma16(av, bl, acc1);
+    }
+    if (ksplit > 1) {
+        float4* red = reinterpret_cast<float4*>(smem + ld.lds_bytes());
         red[((rtl * 2 + 0) * ksplit + ks) * 64 + lane] = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
         red[((rtl * 2 + 1) * ksplit + ks) * 64 + lane] = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);
         __syncthreads();
@@ -722,6 +820,7 @@ k_tile_gemm(const bf16_t* __restrict__ W, int N16, int K32, int nk, const bf16_t
             pre[i][j].i = 0; pre[i][j].a = make_float4(0.f, 0.f, 0.f, 0.f); pre[i][j].b = pre[i][j].a;
             if (rt < N16 && mt < MT) pre[i][j] = ep.pre(mt * 16 + (lane & 15), rt * 16 + 4 * (lane >> 4));
         }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < F; ++i)
 #pragma unroll
@@ -975,6 +1074,20 @@ static inline hipError_t launch_skinny_norm_t(hipStream_t st, WRef W, int N16, i
     if (p.nk > 8 || K32 * 32 != ld.d) return hipErrorInvalidConfiguration;
     if (R <= 16) return launch_skinny(st, W, N16, K32, p, ld, ep);
     const int MT = (R + 15) / 16;
+    // two token tiles: LayerNorm fused into the two-tile weight-streaming kernel (WM_SKINNY2_NORM=0: LayerNorm launch + unfused kernel)
+    if (MT == 2 && p.ksplit * p.rt <= 6 && p.ksplit <= 8 && p.ksplit * p.nk == K32 && skinny_env("WM_SKINNY2", 1) && skinny_env("WM_SKINNY2_NORM", 1)) {
+        const int grid = (N16 + p.rt - 1) / p.rt, threads = 64 * p.ksplit * p.rt;
+        const size_t lds = (size_t)ld.lds_bytes() + (p.ksplit > 1 ? (size_t)p.rt * 2 * p.ksplit * 1024 : 0);
+        const int magic = (256 + p.ksplit - 1) / p.ksplit;
+        if (W.scale) {
+            if (p.nk == 8) hipLaunchKernelGGL((k_skinny2_norm<8, true, Ld, Ep>), dim3(grid), dim3(threads), lds, st, W.w, W.scale, N16, K32, p.ksplit, p.rt, magic, g_skinny_done, ld, ep);
+            else hipLaunchKernelGGL((k_skinny2_norm<4, true, Ld, Ep>), dim3(grid), dim3(threads), lds, st, W.w, W.scale, N16, K32, p.ksplit, p.rt, magic, g_skinny_done, ld, ep);
+        } else {
+            if (p.nk == 8) hipLaunchKernelGGL((k_skinny2_norm<8, false, Ld, Ep>), dim3(grid), dim3(threads), lds, st, W.w, W.scale, N16, K32, p.ksplit, p.rt, magic, g_skinny_done, ld, ep);
+            else hipLaunchKernelGGL((k_skinny2_norm<4, false, Ld, Ep>), dim3(grid), dim3(threads), lds, st, W.w, W.scale, N16, K32, p.ksplit, p.rt, magic, g_skinny_done, ld, ep);
+        }
+        return hipGetLastError();
+    }
     // weight prefetch riding on the LayerNorm launch (token-tile path with bf16 weights only; WM_LN_PREFETCH=0 turns it off)
     const int ln_pf = skinny_env("WM_LN_PREFETCH", 1);
     PfJob pf{nullptr, nullptr, 0u, 0u, 0ull};
