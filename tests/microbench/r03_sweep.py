@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--streams", type=int, default=32)
     ap.add_argument("--tile-shapes", action="store_true", help="sweep every (F, TT) shape of the tile kernel at the full row count")
     ap.add_argument("--enc-only-batch", action="store_true", help="encoder legs at the full batch only")
+    ap.add_argument("--enc-knobs", action="store_true", help="encoder legs: result-preserving knobs of the pipelined GEMM")
     ap.add_argument("--enc-dbg", action="store_true", help="encoder legs with parts of the pipelined GEMM switched off (WM_ENC_GEMM_DBG)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r03_sweep.json"))
     args = ap.parse_args()
@@ -104,6 +105,10 @@ def main():
                         ("p_persist_ring4", dict(WM_ENC_GEMM_256P=1, WM_ENC_GEMM_PERSIST=1, WM_ENC_GEMM_RING=4)),
                         ("p_persist_ring5", dict(WM_ENC_GEMM_256P=1, WM_ENC_GEMM_PERSIST=1, WM_ENC_GEMM_RING=5))] if nb > 1 else \
                        [("stages2", dict(WM_ENC_GEMM_STAGES=2)), ("stages3", dict(WM_ENC_GEMM_STAGES=3))]
+            if args.enc_knobs and nb > 1:
+                variants = [("default", dict(WM_ENC_GEMM_DBG=0)), ("ring_fill_after_epilogue", dict(WM_ENC_GEMM_DBG=32)), ("setprio", dict(WM_ENC_GEMM_DBG=16)),
+                            ("setprio_ring5", dict(WM_ENC_GEMM_DBG=16, WM_ENC_GEMM_RING=5)), ("one_tile_per_block", dict(WM_ENC_GEMM_PERSIST=0)),
+                            ("no_epilogue", dict(WM_ENC_GEMM_DBG=4))]
             if args.enc_dbg and nb > 1:
                 variants = [("full", dict(WM_ENC_GEMM_DBG=0)), ("no_mfma", dict(WM_ENC_GEMM_DBG=1)), ("no_refill", dict(WM_ENC_GEMM_DBG=2)),
                             ("no_epilogue", dict(WM_ENC_GEMM_DBG=4)), ("no_frag_reads", dict(WM_ENC_GEMM_DBG=8)),

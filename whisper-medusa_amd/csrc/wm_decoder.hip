@@ -987,7 +987,12 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
     // 2. causal self-attention over the contiguous cache (20 blocks: its spare CUs fetch this layer's cross K/V when the
     //    fused cross-attention follows two launches later; otherwise LN2 + cross-q carries that job)
     {
-        const PfJob spf = fuse_cq ? kvjob : PfJob{nullptr, nullptr, 0u, 0u, 0ull};
+        // batched passes (R > 16): the self-attention launch pulls the out-proj weights towards the chip (Infinity Cache), one job per
+        // 64 KB; single-tile passes: LN1 + QKV carried that job (the self-attention launch is tiny there)
+        const bool pf_big = ctx->prefetch && R > 16;
+        const unsigned long long ow = (unsigned long long)d * d * (f8 ? 1 : 2);
+        const PfJob spf = fuse_cq ? kvjob : (pf_big ? PfJob{reinterpret_cast<const char*>(w.out_w), nullptr, 65536u, (unsigned)((ow + 65535) / 65536), ow}
+                                                    : PfJob{nullptr, nullptr, 0u, 0u, 0ull});
         const int main_total = H * nb;
         const int zs = spf.n_jobs ? nb + (pf_round8(main_total) - main_total + (int)spf.n_jobs + H - 1) / H : nb;
         TL_SET(slot * 16 + 2 + 8192 * Mper);
@@ -1012,7 +1017,7 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
     {
         PfJob xpf{nullptr, nullptr, 0u, 0u, 0ull};
         int zs = nb;
-        if (pf) {
+        if (pf || (ctx->prefetch && R > 16)) {
             xpf = pf_for_gemm(w.cout_w, f8, d / 16, K32, false);
             const int main_total = xgrid * H * nb;
             zs = nb + (pf_round8(main_total) - main_total + (int)xpf.n_jobs + xgrid * H - 1) / (xgrid * H);
@@ -1055,6 +1060,7 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
     WM_HIP(launch_skinny_rows(st, WRef{w.cout_w, w.cout_s}, d / 16, K32, R, ctx->xbuf, xpl, EpResidual{h, w.cout_b, d, R}));
     // 7. LN3 + fc1 + GELU
     if (pf) g_pf_job = pf_for_gemm(w.fc2_w, f8, d / 16, F32, false);
+    if (ctx->prefetch && R > 16) g_ln_pf_extra = w.fc2_w;     // batched passes: the LayerNorm launch pulls FC1 and FC2 (same size)
     TL_SET(slot * 16 + 7 + 8192 * Mper);
     WM_HIP(launch_skinny_norm(st, WRef{w.fc1_w, w.fc1_s}, ctx->ffn / 16, K32, h, w.ln3_w, w.ln3_b, d, R, 1, 0, 1,
                               EpPackedAct<1>{ctx->fbuf, ctx->fbuf + fpl, w.fc1_b, F32, R}, ctx->xbuf, xpl));

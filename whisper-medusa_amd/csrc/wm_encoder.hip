@@ -256,8 +256,10 @@ template <int NST, class Ep>
 __global__ void __launch_bounds__(512)
 k_gemm_256p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32, int tiles_m, int tiles_n, int PM, int PN, int persistent, int dbg, Ep ep)
 {
-    // dbg (WM_ENC_GEMM_DBG, measurement only, results are then wrong): bit 0 skips the MFMAs, bit 1 the ring refills inside the K loop,
-    // bit 2 the epilogue, bit 3 the fragment reads of the K loop — what is left shows which part bounds the kernel
+    // dbg (WM_ENC_GEMM_DBG, measurement only): bit 0 skips the MFMAs, bit 1 the ring refills inside the K loop, bit 2 the epilogue,
+    // bit 3 the fragment reads of the K loop (results are then wrong) — what is left shows which part bounds the kernel; bit 4
+    // raises the wave priority around the MFMAs, bit 5 fills the ring of a persistent block's next tile AFTER the epilogue (results
+    // stay right)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int STAGE = 32 * 1024;            // 16 X fragments (token tiles) then 16 W fragments (row tiles), one k-tile
     constexpr int LPW = 4;                      // LDS-DMA pieces per wave per stage
@@ -268,11 +270,10 @@ k_gemm_256p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32,
     const int n_patches = patches_m * (tiles_n / PN);
     const int NT = K32;                         // stages (even; the launcher checks)
     // Tile(s) of this block.  XCD x = blockIdx % 8 (observed placement; only speed depends on it).
-    //  persistent (grid = 8 XCDs x 32 slots, one block per CU): the 32 blocks of an XCD walk the patches x, x+8, ... TOGETHER, slot c
-    //   taking tile c of the patch: equal work, so they stay in step along K and the XCD's L2 only has to hold the current K-window
-    //   of the patch's PM + PN operand panels.  With independently scheduled blocks the residents of an XCD drift apart along K and
-    //   each needs its WHOLE panels (PM + PN panels x 655 KB > 4 MB of L2 at large-v2) — the operands then stream from the Infinity
-    //   Cache at ~11 B/clk per CU, which is what bounded the round-2 kernel (and the first, non-persistent, form of this one).
+    //  persistent (grid = 8 XCDs x 32 slots, one block per CU): the 32 blocks of an XCD walk the patches x, x+8, ... together, slot c
+    //   taking tile c of the patch; a block fills the ring of its next tile before it runs the epilogue of the current one.
+    //   Measured (profiles/r03_pmc_l2_encoder_gemms.md): the patch order halves the L2 misses of the round-2 panel-major order
+    //   (FC1: 24 M -> 11 M per launch, hit rate 0.62 -> 0.80); persistent or not makes no difference to the misses.
     //  otherwise: one tile per block, patch-major order, XCD x owns a contiguous range of it (bijective for any grid).
     int patch, within, patch_step;
     if (persistent) {
@@ -285,43 +286,46 @@ k_gemm_256p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32,
     }
     if (within >= per_patch) return;            // spare slots of a persistent grid (patches of fewer than 32 tiles)
 
-    for (; patch < n_patches; patch += patch_step) {
-        const int pn = patch / patches_m, pm = patch - pn * patches_m;
-        const int tn = pn * PN + within / PM, tm = pm * PM + within % PM;
-        const bf16_t* xg = X + (size_t)tm * 16 * K32 * 512 + lane * 8;
-        const bf16_t* wg = W + (size_t)tn * 16 * K32 * 512 + lane * 8;
+    auto tile_of = [&](int patch_, int& tm_, int& tn_) {
+        const int pn = patch_ / patches_m, pm = patch_ - pn * patches_m;
+        tn_ = pn * PN + within / PM; tm_ = pm * PM + within % PM;
+    };
+    auto stage_load = [&](const bf16_t* xg, const bf16_t* wg, int kt) {
+        char* sb = smem + (kt % NST) * STAGE;
+#pragma unroll
+        for (int i = 0; i < LPW; ++i) {
+            const int blk = wa * LPW + i;              // 0..15 X fragments, 16..31 W fragments
+            const bool isx = blk < 16;
+            const int t = isx ? blk : blk - 16;
+            glds16((isx ? xg : wg) + ((size_t)t * K32 + kt) * 512, sb + blk * 1024);
+        }
+    };
+    auto frag_load = [&](int kt, bf16x8_t (&a)[4], bf16x8_t (&b)[8]) {
+        const bf16_t* xs = reinterpret_cast<const bf16_t*>(smem + (kt % NST) * STAGE);
+        const bf16_t* ws = xs + 16 * 512;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = ld_frag(ws + ((wn * 4 + i) * 64 + lane) * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b[j] = ld_frag(xs + ((wm * 8 + j) * 64 + lane) * 8);
+    };
 
-        auto stage_load = [&](int kt) {
-            char* sb = smem + (kt % NST) * STAGE;
+    int tm, tn;
+    tile_of(patch, tm, tn);
+    const bf16_t* xg = X + (size_t)tm * 16 * K32 * 512 + lane * 8;
+    const bf16_t* wg = W + (size_t)tn * 16 * K32 * 512 + lane * 8;
 #pragma unroll
-            for (int i = 0; i < LPW; ++i) {
-                const int blk = wa * LPW + i;              // 0..15 X fragments, 16..31 W fragments
-                const bool isx = blk < 16;
-                const int t = isx ? blk : blk - 16;
-                glds16((isx ? xg : wg) + ((size_t)t * K32 + kt) * 512, sb + blk * 1024);
-            }
-        };
-        auto frag_load = [&](int kt, bf16x8_t (&a)[4], bf16x8_t (&b)[8]) {
-            const bf16_t* xs = reinterpret_cast<const bf16_t*>(smem + (kt % NST) * STAGE);
-            const bf16_t* ws = xs + 16 * 512;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = ld_frag(ws + ((wn * 4 + i) * 64 + lane) * 8);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) b[j] = ld_frag(xs + ((wm * 8 + j) * 64 + lane) * 8);
-        };
+    for (int s = 0; s < NST; ++s)
+        if (s < NT) stage_load(xg, wg, s);
 
+    for (;;) {
         f32x4_t acc[4][8];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-        // (a later tile of a persistent block: every wave has passed the last barrier of the previous tile, after which no wave
-        //  reads the ring again except for the unused trailing request — the buffers may be refilled)
-#pragma unroll
-        for (int s = 0; s < NST; ++s)
-            if (s < NT) stage_load(s);
-        // stage 0 -> registers
+        // stage 0 -> registers.  (A later tile of a persistent block: its first NST stages were requested before the previous tile's
+        // epilogue; the stores of that epilogue are younger entries of the same counter, which only makes this wait conservative.)
         if (NT >= NST) wait_vmcnt<(NST - 1) * LPW>(); else wait_vmcnt<0>();
         ring_barrier();
         bf16x8_t a0[4], b0[8], a1[4], b1[8];
@@ -336,15 +340,17 @@ k_gemm_256p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32,
             else if (younger == 1) wait_vmcnt<LPW>();
             else wait_vmcnt<0>();
             ring_barrier();                        // everyone's pieces of stage t+1 landed; everyone's reads of stage t (and older) are complete
-            if (t + NST < NT && !(dbg & 2)) stage_load(t + NST);    // into the buffer of stage t: it lives in registers now
+            if (t + NST < NT && !(dbg & 2)) stage_load(xg, wg, t + NST);   // into the buffer of stage t: it lives in registers now
             if (!(dbg & 8)) frag_load(t + 1, an, bn);   // unconditional (after the last step it re-reads a stale buffer, unused): a branch here makes
                                                    // the compiler wait lgkmcnt(0) at the join, i.e. for THESE reads, in front of the MFMAs below
             __builtin_amdgcn_sched_barrier(0);     // keep the requests above the MFMAs
             if (!(dbg & 1)) {
+                if (dbg & 16) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc[i][j] = mfma16(ac[i], bc[j], acc[i][j]);
+                if (dbg & 16) __builtin_amdgcn_s_setprio(0);
             }
         };
         static_assert(NST >= 3 && NST <= 5, "ring depth");
@@ -352,11 +358,34 @@ k_gemm_256p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32,
             step(t, a0, b0, a1, b1);
             step(t + 1, a1, b1, a0, b0);
         }
+        // next tile of a persistent block: its first stages go out BEFORE this tile's epilogue (every wave has passed the last barrier
+        // of the K loop: nobody reads the ring any more, except for the unused trailing request), so the ring fill — and the memory
+        // latency in front of it — hides behind the epilogue's loads and stores
+        const int next = patch + patch_step;
+        const bool more = next < n_patches;
+        int tm2 = tm, tn2 = tn;
+        if (more && !(dbg & 32)) {
+            tile_of(next, tm2, tn2);
+            xg = X + (size_t)tm2 * 16 * K32 * 512 + lane * 8;
+            wg = W + (size_t)tn2 * 16 * K32 * 512 + lane * 8;
+#pragma unroll
+            for (int s = 0; s < NST; ++s)
+                if (s < NT) stage_load(xg, wg, s);
+        }
         const int m0 = tm * 256 + wm * 128 + (lane & 15), n0 = tn * 256 + wn * 64 + 4 * (lane >> 4);
         if (!(dbg & 4)) ep_tiles<4, 8>(ep, m0, n0, acc);
         else if (acc[0][0][0] == 12345.678f) ep.store4(m0, n0, acc[1][1]);      // keeps the accumulators alive
-        // the trailing (unused) fragment request of the last step must not be in flight when the next tile refills the ring
-        __builtin_amdgcn_s_waitcnt(0xC07F);
+        if (!more) break;
+        if (dbg & 32) {                             // measurement: ring fill after the epilogue (the round-3 call-2 form)
+            tile_of(next, tm2, tn2);
+            xg = X + (size_t)tm2 * 16 * K32 * 512 + lane * 8;
+            wg = W + (size_t)tn2 * 16 * K32 * 512 + lane * 8;
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+#pragma unroll
+            for (int s = 0; s < NST; ++s)
+                if (s < NT) stage_load(xg, wg, s);
+        }
+        patch = next; tm = tm2; tn = tn2;
     }
 }
 

@@ -124,6 +124,9 @@ __device__ __forceinline__ void glds16_f(const float* gsrc, char* lds_wave_base)
 // 12-14 us — profiles/r02_timeline_sidestream_prefetch.md.)
 struct PfJob { const char* p0; const char* p1; unsigned job_bytes; unsigned n_jobs; unsigned long long total; };
 static thread_local PfJob g_pf_job = {nullptr, nullptr, 0u, 0u, 0ull};     // host: rides on the next launch, which clears it
+// host: a second matrix OF THE SAME SIZE the next batched LayerNorm launch (R > 16 rows) should also pull in (LN3 + FC1: the FC2 weights, which
+// no launch in between can carry); cleared by that launch
+static thread_local const void* g_ln_pf_extra = nullptr;
 
 __device__ __forceinline__ void pf_block(const PfJob& pf, int job)
 {
@@ -152,8 +155,10 @@ __device__ __forceinline__ void pf_block_sliced(const PfJob& pf, int job)
     const unsigned long long lo = base + (unsigned long long)(job >> 3) * pf.job_bytes;
     const unsigned long long hi = min(min(lo + pf.job_bytes, base + slice), pf.total);
     u32x4_t sink = {0u, 0u, 0u, 0u};
-    for (unsigned long long i = lo + (unsigned long long)threadIdx.x * 16; i < hi; i += (unsigned long long)blockDim.x * 16)
+    for (unsigned long long i = lo + (unsigned long long)threadIdx.x * 16; i < hi; i += (unsigned long long)blockDim.x * 16) {
         asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink) : "v"(pf.p0 + i) : "memory");
+        if (pf.p1) asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink) : "v"(pf.p1 + i) : "memory");
+    }
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) :: "memory");
 }
 
@@ -364,12 +369,19 @@ k_skinny_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, in
 // (one wave per slice), so the operand bits equal those of a 16-row launch.
 template <int NK, class Ld>
 __global__ void __launch_bounds__(640)
-k_ln_tiles(Ld ld, int ksplit, bf16_t* __restrict__ xg, size_t plane, const int* __restrict__ done, int nmain, PfJob pf)
+k_ln_tiles(Ld ld, int ksplit, bf16_t* __restrict__ xg, size_t plane, const int* __restrict__ done, int nmain, PfJob pf, int pf_sliced)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // blocks beyond the token tiles: the launch has 22 blocks of work at 32 streams — the rest of the chip pulls the weight matrix of
-    // the GEMM that follows into the L2 of the XCD that will read it
-    if ((int)blockIdx.x >= nmain) { if (!(done && *done)) pf_block_sliced(pf, (int)blockIdx.x - pf_round8(nmain)); return; }
+    // blocks beyond the token tiles: the launch has 2..22 blocks of work — the rest of the chip pulls the weight matrix of the GEMM that
+    // follows towards the CUs that will read it (per consumer block / XCD for the two-tile kernel, whose block j runs on XCD j % 8; in
+    // eighths for the token-tile kernels, where every XCD ends up reading the whole matrix and the point is the Infinity Cache)
+    if ((int)blockIdx.x >= nmain) {
+        if (!(done && *done)) {
+            const int job = (int)blockIdx.x - pf_round8(nmain);
+            if (pf_sliced) pf_block_sliced(pf, job); else pf_block(pf, job);
+        }
+        return;
+    }
     const int lane = threadIdx.x & 63;
     const int ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int kt0 = ks * NK;
@@ -401,6 +413,9 @@ k_rows_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int 
             const bf16_t* __restrict__ X, size_t plane, int MT, Ep ep)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // (checked first: moving the flag behind the first group of loads — a mid-loop exit — cost the 352-row launches ~3 us each, the
+    //  compiler no longer overlapped the load groups across it: tests/microbench/r03_call4.sh)
+    if (done && *done) return;
     const int lane = threadIdx.x & 63;
     const int ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rt0 = blockIdx.x * RT, mt0 = blockIdx.y * TT;
@@ -426,9 +441,7 @@ k_rows_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int 
 #pragma unroll
             for (int i = 0; i < RT; ++i) a[i][u] = ld_wfrag<W8, false>(W, wp[i] + (size_t)(kg + u) * 512);
         }
-        // every stream finished: looked at behind the first group of loads (as the first instruction of the kernel the flag is a
-        // dependent ~1 us scalar round trip in front of every launch of the chain)
-        if (kg == 0 && done && *done) return;
+
 #pragma unroll
         for (int u = 0; u < G; ++u)
 #pragma unroll
@@ -1074,8 +1087,11 @@ static inline hipError_t launch_skinny_norm_t(hipStream_t st, WRef W, int N16, i
     if (p.nk > 8 || K32 * 32 != ld.d) return hipErrorInvalidConfiguration;
     if (R <= 16) return launch_skinny(st, W, N16, K32, p, ld, ep);
     const int MT = (R + 15) / 16;
-    // two token tiles: LayerNorm fused into the two-tile weight-streaming kernel (WM_SKINNY2_NORM=0: LayerNorm launch + unfused kernel)
-    if (MT == 2 && p.ksplit * p.rt <= 6 && p.ksplit <= 8 && p.ksplit * p.nk == K32 && skinny_env("WM_SKINNY2", 1) && skinny_env("WM_SKINNY2_NORM", 1)) {
+    // two token tiles: LayerNorm fused into the two-tile weight-streaming kernel.  OFF by default (WM_SKINNY2_NORM=1 turns it on): measured
+    // slower than the LayerNorm launch + unfused kernel (vanilla step at 32 streams 4.02 vs 3.68 ms, tests/microbench/r03_call4.sh) — every
+    // one of the 80..320 blocks of a GEMM pulls the 32 fp32 rows (160 KB) through its CU and normalises them again; at two tiles that
+    // L2 -> CU traffic costs more than the three ~7 us launches it removes.  Kept: bit-identical, re-measurable on other shapes.
+    if (MT == 2 && p.ksplit * p.rt <= 6 && p.ksplit <= 8 && p.ksplit * p.nk == K32 && skinny_env("WM_SKINNY2", 1) && skinny_env("WM_SKINNY2_NORM", 0)) {
         const int grid = (N16 + p.rt - 1) / p.rt, threads = 64 * p.ksplit * p.rt;
         const size_t lds = (size_t)ld.lds_bytes() + (p.ksplit > 1 ? (size_t)p.rt * 2 * p.ksplit * 1024 : 0);
         const int magic = (256 + p.ksplit - 1) / p.ksplit;
@@ -1091,15 +1107,23 @@ static inline hipError_t launch_skinny_norm_t(hipStream_t st, WRef W, int N16, i
     // weight prefetch riding on the LayerNorm launch (token-tile path with bf16 weights only; WM_LN_PREFETCH=0 turns it off)
     const int ln_pf = skinny_env("WM_LN_PREFETCH", 1);
     PfJob pf{nullptr, nullptr, 0u, 0u, 0ull};
-    int grid = MT;
-    if (ln_pf && use_tile_gemm(N16, K32, MT, W.scale != nullptr, p.nk)) {
-        const unsigned long long total = (unsigned long long)N16 * K32 * 1024, slice = ((total + 7) / 8 + 1023) & ~1023ull;
+    int grid = MT, pf_sliced = 1;
+    const unsigned long long wbytes = (unsigned long long)N16 * K32 * (W.scale ? 512 : 1024);
+    const char* extra = reinterpret_cast<const char*>(g_ln_pf_extra);
+    g_ln_pf_extra = nullptr;
+    if (ln_pf && MT == 2 && skinny_env("WM_SKINNY2", 1) && p.ksplit * p.rt <= 10) {
+        // consumer = k_skinny2_gemm: block j reads the p.rt row tiles j*p.rt.. — one job per consumer block
+        const unsigned job_bytes = (unsigned)((unsigned long long)p.rt * K32 * (W.scale ? 512 : 1024));
+        pf = PfJob{reinterpret_cast<const char*>(W.w), extra, job_bytes, (unsigned)((N16 + p.rt - 1) / p.rt), wbytes};
+        pf_sliced = 0;
+    } else if (ln_pf && MT >= 3) {
+        const unsigned long long slice = ((wbytes + 7) / 8 + 1023) & ~1023ull;
         const unsigned job_bytes = 64 * 1024;
-        pf = PfJob{reinterpret_cast<const char*>(W.w), nullptr, job_bytes, (unsigned)(8 * ((slice + job_bytes - 1) / job_bytes)), total};
-        grid = pf_round8(MT) + (int)pf.n_jobs;
+        pf = PfJob{reinterpret_cast<const char*>(W.w), extra, job_bytes, (unsigned)(8 * ((slice + job_bytes - 1) / job_bytes)), wbytes};
     }
-    if (p.nk == 8) hipLaunchKernelGGL((k_ln_tiles<8, Ld>), dim3(grid), dim3(64 * p.ksplit), ld.lds_bytes(), st, ld, p.ksplit, xscr, plane, g_skinny_done, MT, pf);
-    else if (p.nk == 4) hipLaunchKernelGGL((k_ln_tiles<4, Ld>), dim3(grid), dim3(64 * p.ksplit), ld.lds_bytes(), st, ld, p.ksplit, xscr, plane, g_skinny_done, MT, pf);
+    if (pf.n_jobs) grid = pf_round8(MT) + (int)pf.n_jobs;
+    if (p.nk == 8) hipLaunchKernelGGL((k_ln_tiles<8, Ld>), dim3(grid), dim3(64 * p.ksplit), ld.lds_bytes(), st, ld, p.ksplit, xscr, plane, g_skinny_done, MT, pf, pf_sliced);
+    else if (p.nk == 4) hipLaunchKernelGGL((k_ln_tiles<4, Ld>), dim3(grid), dim3(64 * p.ksplit), ld.lds_bytes(), st, ld, p.ksplit, xscr, plane, g_skinny_done, MT, pf, pf_sliced);
     else return hipErrorInvalidConfiguration;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
