@@ -60,8 +60,9 @@ typedef struct wm_config {
     int32_t medusa_choices[16]; /* MedusaConfig.medusa_choices = [1, c_1, .., c_K] (utils/config_and_args.py:17-62; consumed by
                                  * generate_medusa_buffers / generate_candidates, medusa_utils.py:305-458): head k contributes its
                                  * top-c_k tokens, the candidate tree is their cartesian product.  All zero or all one = the chain
-                                 * [1]*(K+1) every shipped checkpoint uses.  Limits: sum_i prod_{l<=i} c_l <= 16 nodes (the verify
-                                 * pass of a stream is one 16-row token tile), prod c_l <= 16 paths, c_k <= 4.  Each node attends
+                                 * [1]*(K+1) every shipped checkpoint uses.  Limits: sum_i prod_{l<=i} c_l <= 64 nodes (the verify
+                                 * pass of a stream is up to four 16-row query tiles), prod c_l <= 32 paths, c_k <= 4 — e.g. K = 10
+                                 * with top-2 on the first two heads: [1,2,2,1,1,1,1,1,1,1,1] = 39 nodes.  Each node attends
                                  * to the history and to its own ancestors and sits at position L + depth — the mask / position
                                  * ids the reference builds (medusa_utils.py:343-363) and then never hands to its decoder. */
     int32_t enc_fp8;            /* 1: the encoder GEMMs fed by a LayerNorm (QKV, FC1) and the cross-K/V projection run on the CDNA4

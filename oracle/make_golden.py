@@ -380,6 +380,10 @@ def main_tree():
     out.update(golden_tree_model("micro1221", MedusaConfig.micro(K=3), 21, mu, [1, 2, 2, 1], max_new=36))
     out.update(golden_tree_model("micro132", MedusaConfig.micro(K=2), 22, mu, [1, 3, 2], max_new=36))
     out.update(golden_tree_model("micro1222block", MedusaConfig.micro(K=3, heads_type="medusa_block"), 23, mu, [1, 2, 2, 2], max_new=30))
+    # trees of more than 16 nodes (several 16-row query tiles per stream in the engine): 31 nodes / 16 paths, and the K = 10 shape the shipped
+    # checkpoints have with top-2 on the first two heads (39 nodes / 4 paths)
+    out.update(golden_tree_model("micro12222", MedusaConfig.micro(K=4), 25, mu, [1, 2, 2, 2, 2], max_new=30))
+    out.update(golden_tree_model("micro10_122", MedusaConfig.micro(K=10, d_model=128, layers=2), 26, mu, [1, 2, 2] + [1] * 8, max_new=36))
     np.savez_compressed(os.path.join(GOLD, "reference_tree_runs.npz"), **out)
     print("reference tree-loop vectors written")
 

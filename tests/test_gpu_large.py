@@ -299,6 +299,38 @@ def test_large_block_thirty_two_streams_match_the_oracle(large_block):
         print(f"large block B=32 stream {s_}: accept lengths {accepts}")
 
 
+def test_large_candidate_tree_of_39_nodes_matches_the_oracle(gpu):
+    """The shipped shape with a real candidate tree: large-v2, K = 10, medusa_choices = [1, 2, 2, 1 x 8] — top-2 on
+    the first two heads, 39 nodes in three 16-row query tiles, 4 paths.  One stream and stream 1 of a 3-stream batch against
+    oracle.decode_tree (pinned to the reference's buffers / candidates / posterior by tests/test_tree_golden.py) on the engine's
+    encoder output; typical acceptance, 24 new tokens."""
+    from oracle.whisper_medusa_oracle import Oracle
+    ch = [1, 2, 2] + [1] * 8
+    cfg = MedusaConfig.large_v2("base_head", K=10, medusa_choices=ch)
+    assert cfg.is_tree
+    sd = synth.synth_state_dict(cfg, seed=6, device=str(gpu), logit_std=4.5)
+    model = WhisperMedusaModel(cfg, sd, device=gpu, max_batch=3)
+    eng = model.engine
+    orc = Oracle(cfg, _cpu_sd(sd), sim="bf16")
+    n = cfg.n_mel_frames * 160
+    wav = np.stack([synth.synth_clip(500 + i, n) for i in range(3)])
+    feats = model.extract_features(wav)
+    gp = synth.bench_gen_params(cfg, max_new_tokens=24, accept_mode=ACCEPT_TYPICAL)
+    for B, pick in ((1, 0), (3, 1)):
+        eng.encode(feats[:B].contiguous())
+        enc = eng.encoder_output(B)
+        got = eng.decode(gp, B)[pick]
+        r = orc.decode_tree(enc[pick], gp, engine_ids=got, tol_logit=2e-3)
+        if r.tie is None:
+            assert r.ids == got, (B, r.ids, got)
+        else:
+            print(f"large tree B={B}: first difference at L={r.tie['L']}; oracle margins (units of tolerance): {r.tie['margin']}")
+            assert r.tie["margin"]["min"] < 1.0 and r.verified >= len(gp.prompt) + 4, (B, r.tie)
+        assert len(got) >= len(gp.prompt) + 24 - 11
+        print(f"large tree B={B} stream {pick}: accept lengths {r.accept_lengths}; stats {eng.stats()['accept_hist']}")
+    eng.close()
+
+
 def test_large_fp8_decode_loop_matches_the_fp8_oracle(gpu):
     """configs[4] at the real shape: fp8 e4m3 decoder-layer matrices + per-row scales, Medusa-Linear K=10."""
     from oracle.whisper_medusa_oracle import Oracle

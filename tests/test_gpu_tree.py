@@ -22,6 +22,10 @@ TREES = {
     "micro1222block": (lambda c: MedusaConfig.micro(K=3, heads_type="medusa_block", medusa_choices=c), 23, [1, 2, 2, 2]),
     "micro142": (lambda c: MedusaConfig.micro(K=2, d_model=256, layers=3, medusa_choices=c), 24, [1, 4, 2]),
     "tiny12211": (lambda c: MedusaConfig.from_dict({**MedusaConfig.tiny_en(K=4).to_dict(), "medusa_choices": c}), 2, [1, 2, 2, 1, 1]),
+    # more than 16 nodes: several 16-row query tiles per stream (31 nodes / 16 paths; the K = 10 shape with top-2 on two heads: 39 nodes)
+    "micro12222": (lambda c: MedusaConfig.micro(K=4, medusa_choices=c), 25, [1, 2, 2, 2, 2]),
+    "micro10_122": (lambda c: MedusaConfig.micro(K=10, d_model=128, layers=2, medusa_choices=c), 26, [1, 2, 2] + [1] * 8),
+    "tiny1311": (lambda c: MedusaConfig.from_dict({**MedusaConfig.tiny_en(K=4).to_dict(), "medusa_choices": c}), 3, [1, 3, 2, 1, 1]),
 }
 
 

@@ -96,7 +96,8 @@ def test_config_roundtrip_and_validation(tmp_path):
     with pytest.raises(ValueError, match="is not supported"):          # reference model.py:225-229
         MedusaConfig(medusa_heads_type="bogus")
     with pytest.raises(ValueError):
-        MedusaConfig(medusa_num_heads=3, medusa_choices=[1, 3, 3, 1])   # 1 + 3 + 9 + 9 nodes: beyond the 16-row verify tile
+        MedusaConfig(medusa_num_heads=3, medusa_choices=[1, 4, 4, 3])   # 1 + 4 + 16 + 48 nodes: beyond the four 16-row query tiles
+    assert MedusaConfig(medusa_num_heads=3, medusa_choices=[1, 3, 3, 1]).is_tree      # 1 + 3 + 9 + 9 = 22 nodes (two query tiles)
     assert MedusaConfig(medusa_num_heads=3, medusa_choices=[1, 3, 2, 1]).is_tree      # 1 + 3 + 6 + 6 nodes
     assert MedusaConfig.large_v2(HEADS_BLOCK).n_kv_layers == 33
 

@@ -33,8 +33,10 @@ def test_tree_buffers_match_reference(ch):
 
 
 def test_tree_limits_are_checked():
+    assert MedusaConfig.micro(K=3, medusa_choices=[1, 3, 3, 2]).is_tree   # 1 + 3 + 9 + 18 = 31 nodes, 18 paths: fits since round 3
     with pytest.raises(ValueError):
-        MedusaConfig.micro(K=3, medusa_choices=[1, 3, 3, 2])            # 1 + 3 + 9 + 18 nodes
+        MedusaConfig.micro(K=3, medusa_choices=[1, 4, 4, 4])            # 1 + 4 + 16 + 64 nodes
+    assert MedusaConfig.large_v2(K=10, medusa_choices=[1, 2, 2] + [1] * 8).is_tree      # 39 nodes: top-2 on the first two heads of a K = 10 checkpoint
     with pytest.raises(ValueError):
         MedusaConfig.micro(K=2, medusa_choices=[1, 5, 1])               # top-5
     with pytest.raises(ValueError):
@@ -73,6 +75,8 @@ TREE_MODELS = {
     "micro1221": (lambda: MedusaConfig.micro(K=3), 21, [1, 2, 2, 1], 36),
     "micro132": (lambda: MedusaConfig.micro(K=2), 22, [1, 3, 2], 36),
     "micro1222block": (lambda: MedusaConfig.micro(K=3, heads_type="medusa_block"), 23, [1, 2, 2, 2], 30),
+    "micro12222": (lambda: MedusaConfig.micro(K=4), 25, [1, 2, 2, 2, 2], 30),                                      # 31 nodes, 16 paths
+    "micro10_122": (lambda: MedusaConfig.micro(K=10, d_model=128, layers=2), 26, [1, 2, 2] + [1] * 8, 36),        # 39 nodes, 4 paths
 }
 
 

@@ -16,6 +16,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;           // one MFMA
 
 #define WM_HEAD_DIM 64
 #define WM_MAX_ROWS_SKINNY 16      // token rows (streams x tokens) the weight-streaming GEMM handles per launch
+#define WM_TREE_MAX_NODES 64       // candidate-tree nodes per stream: the verify pass of a stream is up to four 16-row query tiles
+#define WM_TREE_MAX_PATHS 32
+#define WM_CAND_STRIDE 64          // ints per stream in the candidate-token buffer (chain: K + 1 <= 16 used)
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 

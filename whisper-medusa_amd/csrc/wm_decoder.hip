@@ -144,7 +144,7 @@ __device__ __forceinline__ void kv_load(KVStep& t, const bf16_t* kp, const bf16_
 // Visibility of key `kidx` for this lane's query: keys below `limit` (chain: history + causal prefix; tree: history only)
 // plus, for a candidate tree, the provisional rows b0 + n of the query node's ancestors (bit n of `anc`; 0 for the chain).
 __device__ __forceinline__ void attn_step(AttnAcc& st, const KVStep& t, const bf16x8_t (&qhi)[2], const bf16x8_t (&qlo)[2],
-                                          int kb, int g, int limit, int b0 = 0, unsigned anc = 0u)
+                                          int kb, int g, int limit, int b0 = 0, unsigned long long anc = 0ull)
 {
     f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
     s0 = mfma16(t.k00, qhi[0], s0); s0 = mfma16(t.k01, qhi[1], s0); s0 = mfma16(t.k00, qlo[0], s0); s0 = mfma16(t.k01, qlo[1], s0);
@@ -153,8 +153,8 @@ __device__ __forceinline__ void attn_step(AttnAcc& st, const KVStep& t, const bf
     for (int r = 0; r < 4; ++r) {
         const int k0 = kb + 4 * g + r, k1 = k0 + 16;
         const unsigned o0 = (unsigned)(k0 - b0), o1 = (unsigned)(k1 - b0);
-        if (k0 >= limit && !(o0 < 16u && ((anc >> o0) & 1u))) s0[r] = -INFINITY;
-        if (k1 >= limit && !(o1 < 16u && ((anc >> o1) & 1u))) s1[r] = -INFINITY;
+        if (k0 >= limit && !(o0 < 64u && ((anc >> o0) & 1ull))) s0[r] = -INFINITY;
+        if (k1 >= limit && !(o1 < 64u && ((anc >> o1) & 1ull))) s1[r] = -INFINITY;
     }
     float mx = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
     mx = rows4_max(mx);
@@ -259,9 +259,11 @@ k_attn_mfma(const bf16_t* __restrict__ kmat, const bf16_t* __restrict__ vtmat, c
             // entering 1.3 us later than the GEMMs, whose early arguments already sat in the preloaded range) and is first
             // touched after those loads are in flight.
             const int* __restrict__ done, int K32, bf16_t* __restrict__ xout, size_t xplane, float* __restrict__ ml, float* __restrict__ po,
-            int* __restrict__ ticket, PfJob pf, FQ fq, const unsigned* __restrict__ anc_tab TL_ARG)
+            int* __restrict__ ticket, PfJob pf, FQ fq, const unsigned long long* __restrict__ anc_tab TL_ARG)
 {
-    const int Mper = mper_nbz & 0xff, nbz = mper_nbz >> 8, H = h_ns & 0xff, NS = h_ns >> 8;
+    // Mper query rows per stream as nqt tiles of <= 16 (a candidate tree of more than 16 nodes; the chain and every base pass: one tile);
+    // blockIdx.z = stream * nqt + query tile
+    const int Mper = mper_nbz & 0xff, nbz = mper_nbz >> 8, H = h_ns & 0xff, NS = (h_ns >> 8) & 0xff, nqt = max(h_ns >> 16, 1);
     extern __shared__ __attribute__((aligned(16))) char smem_attn[];
     if ((int)blockIdx.z >= nbz) {          // prefetch-only blocks (extra z slices): wm_skinny_gemm.h, PfJob
         const int main_total = gridDim.x * gridDim.y * nbz;
@@ -269,15 +271,16 @@ k_attn_mfma(const bf16_t* __restrict__ kmat, const bf16_t* __restrict__ vtmat, c
         return;
     }
     TL_BEGIN
+    const int s = nqt > 1 ? (int)blockIdx.z / nqt : (int)blockIdx.z, r0 = ((int)blockIdx.z - s * nqt) * 16, rows = min(16, Mper - r0);
     // per-stream skip: the stream carried its hidden state, this base-pass row is not used (its K/V reads are saved)
-    if (sskip && sskip[blockIdx.z]) return;
+    if (sskip && sskip[s]) return;
     typedef AttnLds<CROSS ? WM_XATTN_SPB_MAX : 1> Lds;
     Lds& A = *reinterpret_cast<Lds*>(smem_attn);
     float (&s_m)[4][16] = A.s_m; float (&s_l)[4][16] = A.s_l; int& s_last = A.s_last;
     float (&s_o)[4][16][68] = A.s_o; auto& s_part = A.s_part;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
     const bool aw = w < 4;                  // the four attention waves (the fused variant may carry more waves for its LayerNorm)
-    const int hd = blockIdx.y, s = blockIdx.z, d = H * 64;
+    const int hd = blockIdx.y, d = H * 64;
     // CROSS: the block walks key splits [sp0, sp1); with gridDim.x == NS that is one split per block (single stream:
     // all CUs busy), with fewer blocks per (stream, head) each walks several (large batches: fewer partial hand-offs).
     // The arithmetic per split and the merge order over splits do not depend on the grouping: bit-identical outputs.
@@ -353,7 +356,7 @@ k_attn_mfma(const bf16_t* __restrict__ kmat, const bf16_t* __restrict__ vtmat, c
                 make_float4((tot[0] + qb.x) * 0.125f, (tot[1] + qb.y) * 0.125f, (tot[2] + qb.z) * 0.125f, (tot[3] + qb.w) * 0.125f);
         }
         __syncthreads();                    // q tile complete; the fragment staging is dead: A may be written from here on
-        if (aw && c < Mper) {
+        if (aw && c < rows) {
 #pragma unroll
             for (int ds = 0; ds < 2; ++ds) {
                 const float4* qp = reinterpret_cast<const float4*>(qt + (s * Mper + c) * 64 + ds * 32 + g * 8);
@@ -363,8 +366,8 @@ k_attn_mfma(const bf16_t* __restrict__ kmat, const bf16_t* __restrict__ vtmat, c
     } else {
 #pragma unroll
         for (int ds = 0; ds < 2; ++ds) {
-            if (c < Mper) {
-                const float4* qp = reinterpret_cast<const float4*>(q + (size_t)(s * Mper + c) * d + hd * 64 + ds * 32 + g * 8);
+            if (c < rows) {
+                const float4* qp = reinterpret_cast<const float4*>(q + (size_t)(s * Mper + r0 + c) * d + hd * 64 + ds * 32 + g * 8);
                 qraw[ds][0] = qp[0]; qraw[ds][1] = qp[1];
             }
         }
@@ -372,15 +375,15 @@ k_attn_mfma(const bf16_t* __restrict__ kmat, const bf16_t* __restrict__ vtmat, c
     const int b0 = CROSS ? 0 : base[s];
     if (done && *done) return;          // all streams finished: checked after the batch went out (off the critical path)
     // keys < limit are visible to query c; a candidate-tree node sees the history and (through `anc`) its ancestors' rows
-    const unsigned anc = (!CROSS && anc_tab) ? anc_tab[c] : 0u;
-    const int limit = CROSS ? S : ((!CROSS && anc_tab) ? min(b0, rows_alloc) : min(b0 + c + 1, rows_alloc));
+    const unsigned long long anc = (!CROSS && anc_tab && c < rows) ? anc_tab[r0 + c] : 0ull;
+    const int limit = CROSS ? S : ((!CROSS && anc_tab) ? min(b0, rows_alloc) : min(b0 + r0 + c + 1, rows_alloc));
     int kend = CROSS ? min(S, kb + 64) : min(b0 + Mper, rows_alloc);
     bf16x8_t qhi[2], qlo[2];
 #pragma unroll
     for (int ds = 0; ds < 2; ++ds) split_hilo8(qraw[ds][0], qraw[ds][1], qhi[ds], qlo[ds]);
     TL_PREP
     const int qr = threadIdx.x >> 4, ch = (threadIdx.x & 15) * 4;
-    const int row = s * Mper + qr;
+    const int row = s * Mper + r0 + qr;
     typedef unsigned long long u64;
     float M = -INFINITY, L = 0.f; float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 
@@ -414,7 +417,7 @@ k_attn_mfma(const bf16_t* __restrict__ kmat, const bf16_t* __restrict__ vtmat, c
         }
         __syncthreads();
         M = -INFINITY; L = 0.f; acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (qr < Mper) {
+        if (qr < rows) {
             M = fmaxf(fmaxf(s_m[0][qr], s_m[1][qr]), fmaxf(s_m[2][qr], s_m[3][qr]));
 #pragma unroll
             for (int ww = 0; ww < 4; ++ww) {
@@ -425,7 +428,7 @@ k_attn_mfma(const bf16_t* __restrict__ kmat, const bf16_t* __restrict__ vtmat, c
             }
         }
         if (!CROSS) break;
-        if (qr < Mper) {
+        if (qr < rows) {
             // keep the partial for this block's own merge (LDS) and, when other blocks share the (stream, head),
             // publish it: relaxed agent-scope atomics (write-through sc1), see the hand-off note below
             *reinterpret_cast<float4*>(&s_part[sp - sp0][qr][ch]) = acc;
@@ -443,7 +446,7 @@ k_attn_mfma(const bf16_t* __restrict__ kmat, const bf16_t* __restrict__ vtmat, c
     }
     TL_MID
     if (!CROSS) {
-        if (qr < Mper) {
+        if (qr < rows) {
             const float inv = 1.0f / L;
             const size_t oi = packed_index(row, hd * 64 + ch, K32);
             st_hilo4(xout + oi, xout + xplane + oi, make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv));
@@ -459,15 +462,15 @@ k_attn_mfma(const bf16_t* __restrict__ kmat, const bf16_t* __restrict__ vtmat, c
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
-            const int t = __hip_atomic_fetch_add(ticket + s * H + hd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int t = __hip_atomic_fetch_add(ticket + blockIdx.z * H + hd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int last = (t == (int)gridDim.x - 1);
-            if (last) __hip_atomic_store(ticket + s * H + hd, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch / replay
+            if (last) __hip_atomic_store(ticket + blockIdx.z * H + hd, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch / replay
             s_last = last;
         }
         __syncthreads();
         if (!s_last) { TL_END return; }
     } else __syncthreads();
-    if (qr < Mper) {
+    if (qr < rows) {
         // merge the NS partials in split order (the same arithmetic whether they come from LDS or from other blocks)
         float ms[WM_XATTN_NS_MAX], ls[WM_XATTN_NS_MAX]; float4 ov[WM_XATTN_NS_MAX];
         if (gridDim.x > 1) {
@@ -621,14 +624,14 @@ k_select2(const float* __restrict__ logits, GenDev gp, const unsigned char* __re
                 for (int j = 0; j < 4; ++j) {
                     const int ch = tree->children[i][j];
                     if (ch < 0) break;
-                    const int c = cand[s * 16 + ch];
+                    const int c = cand[s * WM_CAND_STRIDE + ch];
                     const float vc = proc_logit(x[c], c, cur_len, gp, mask, exppen);
                     pc[out_row0 + s * rps + ch] = (vc == -INFINITY) ? 0.f : expf((vc - mx) * gp.inv_temp) * invz;
                 }
             } else {
                 float pcv = 0.f;
                 if (i + 1 < rps) {
-                    const int c = cand[s * 16 + i + 1];
+                    const int c = cand[s * WM_CAND_STRIDE + i + 1];
                     const float vc = proc_logit(x[c], c, cur_len, gp, mask, exppen);
                     pcv = (vc == -INFINITY) ? 0.f : expf((vc - mx) * gp.inv_temp) * invz;
                 }
@@ -668,7 +671,7 @@ __global__ void k_rows_take_carried(float* __restrict__ dst, const float* __rest
 __global__ void k_set_cand(const int* __restrict__ amax, int* __restrict__ cand, int rps, int n)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < n) cand[(e / rps) * 16 + (e % rps)] = amax[e];
+    if (e < n) cand[(e / rps) * WM_CAND_STRIDE + (e % rps)] = amax[e];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -688,7 +691,7 @@ __global__ void k_accept(GenDev gp, const int* __restrict__ cand, const int* __r
     const int K = gp.K, rps = K + 1;
     bool ok = false;
     if (lane < K) {
-        if (gp.accept_mode == WM_ACCEPT_GREEDY) ok = (cand[s * 16 + lane + 1] == amax[s * rps + lane]);
+        if (gp.accept_mode == WM_ACCEPT_GREEDY) ok = (cand[s * WM_CAND_STRIDE + lane + 1] == amax[s * rps + lane]);
         else {
             const float* hp = part2 + (size_t)(s * rps + lane) * SEL_SP;
             float hsum = 0.f;
@@ -707,7 +710,7 @@ __global__ void k_accept(GenDev gp, const int* __restrict__ cand, const int* __r
     const int n_emit = (a == 0) ? 2 : a + 1;
     int tok = -1;
     if (lane < n_emit) {
-        tok = (a == 0 && lane == 1) ? amax[s * rps + 0] : cand[s * 16 + lane];
+        tok = (a == 0 && lane == 1) ? amax[s * rps + 0] : cand[s * WM_CAND_STRIDE + lane];
         if (Lcur + lane < gp.Tids) ids[(size_t)s * gp.Tids + Lcur + lane] = tok;
     }
     const bool hit_eos = __ballot(lane < n_emit && tok == gp.eos) != 0ull;
@@ -787,7 +790,7 @@ k_tree_cand(const float* __restrict__ logits, GenDev gp, const unsigned char* __
         if (i0 == mi && mi != 0x7fffffff) { t0 = t1; i0 = i1; t1 = t2; i1 = i2; t2 = t3; i2 = i3; t3 = -INFINITY; i3 = 0x7fffffff; }
         __syncthreads();
     }
-    if (tid < tree->cumprod[k]) cand[s * 16 + tree->start[k] + tid] = s_top[tid % c];
+    if (tid < tree->cumprod[k]) cand[s * WM_CAND_STRIDE + tree->start[k] + tid] = s_top[tid % c];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -825,7 +828,7 @@ __global__ void k_accept_tree(GenDev gp, const TreeDev* __restrict__ tree, const
         const int node = tree->retrieve[p][i], par = tree->retrieve[p][i - 1];
         const float thr = __shfl(thr_n, par, 64);
         bool ok; float pcv = 1.f;
-        if (gp.accept_mode == WM_ACCEPT_GREEDY) ok = cand[s * 16 + node] == amax[s * tn + par];
+        if (gp.accept_mode == WM_ACCEPT_GREEDY) ok = cand[s * WM_CAND_STRIDE + node] == amax[s * tn + par];
         else { pcv = pc[s * tn + node]; ok = pcv > thr; }
         if (alive && ok) { a_p += 1; lik += logf(pcv); } else alive = false;
     }
@@ -849,7 +852,7 @@ __global__ void k_accept_tree(GenDev gp, const TreeDev* __restrict__ tree, const
     const int n_emit = (a == 0) ? 2 : a + 1;
     int tok = -1;
     if (lane < n_emit) {
-        tok = (a == 0 && lane == 1) ? amax[s * tn + 0] : cand[s * 16 + tree->retrieve[best][lane]];
+        tok = (a == 0 && lane == 1) ? amax[s * tn + 0] : cand[s * WM_CAND_STRIDE + tree->retrieve[best][lane]];
         if (Lcur + lane < gp.Tids) ids[(size_t)s * gp.Tids + Lcur + lane] = tok;
     }
     const bool hit_eos = __ballot(lane < n_emit && tok == gp.eos) != 0ull;
@@ -963,7 +966,9 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
     const bool pf = ctx->prefetch && R <= 16 && !kv_only;
     const bool f8 = w.qkv_s != nullptr;
     static const int skip_div = [] { const char* v = std::getenv("WM_XATTN_SKIP_DIV"); return v ? std::max(1, std::atoi(v)) : 3; }();
-    const int xheads = sskip ? std::max(1, H * nb / skip_div) : H * nb;
+    const int nqt = (Mper + 15) / 16;            // query tiles per stream (a candidate tree of more than 16 nodes; otherwise 1)
+    const int nz = nb * nqt;                     // (stream, query tile) pairs = z-blocks of the attention launches
+    const int xheads = sskip ? std::max(1, H * nb / skip_div) : H * nz;
     const int xgrid = xattn_blocks_per_head(ctx->NS, xheads);
     // 1. LN1 + QKV; k rows / transposed v rows straight into the cache
     if (pf) g_pf_job = pf_for_gemm(w.out_w, f8, d / 16, K32, false);
@@ -979,8 +984,8 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
     static const bool fuse_env = [] { const char* v = std::getenv("WM_FUSE_CQ"); return v && std::atoi(v) != 0; }();
     const SkinnyPlan cqp = skinny_plan(d / 16, K32, true);
     const bool fuse_shape = (cqp.nk == 8 && cqp.ksplit >= 1 && cqp.ksplit <= 5) || (cqp.nk == 4 && (cqp.ksplit == 1 || cqp.ksplit == 3));
-    const bool fuse_cq = fuse_env && R <= 16 && !f8 && fuse_shape && H * 4 == d / 16;
-    const PfJob kvjob = (pf && ctx->NS % xgrid == 0 && ctx->Spad == ctx->NS * 256)
+    const bool fuse_cq = fuse_env && R <= 16 && !f8 && fuse_shape && H * 4 == d / 16;       // single tile: nqt == 1
+    const PfJob kvjob = (pf && nqt == 1 && ctx->NS % xgrid == 0 && ctx->Spad == ctx->NS * 256)
         ? PfJob{reinterpret_cast<const char*>(kx), reinterpret_cast<const char*>(vx), (unsigned)(ctx->NS / xgrid) * 256 * 128,
                 (unsigned)(xgrid * H * nb), (unsigned long long)H * nb * ctx->Spad * 128}
         : PfJob{nullptr, nullptr, 0u, 0u, 0ull};
@@ -993,11 +998,11 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
         const unsigned long long ow = (unsigned long long)d * d * (f8 ? 1 : 2);
         const PfJob spf = fuse_cq ? kvjob : (pf_big ? PfJob{reinterpret_cast<const char*>(w.out_w), nullptr, 65536u, (unsigned)((ow + 65535) / 65536), ow}
                                                     : PfJob{nullptr, nullptr, 0u, 0u, 0ull});
-        const int main_total = H * nb;
-        const int zs = spf.n_jobs ? nb + (pf_round8(main_total) - main_total + (int)spf.n_jobs + H - 1) / H : nb;
+        const int main_total = H * nz;
+        const int zs = spf.n_jobs ? nz + (pf_round8(main_total) - main_total + (int)spf.n_jobs + H - 1) / H : nz;
         TL_SET(slot * 16 + 2 + 8192 * Mper);
         hipLaunchKernelGGL((k_attn_mfma<false, false, NoFuseQ>), dim3(1, H, zs), dim3(256), sizeof(AttnLds<1>), st, kc, vc, ctx->qbuf, base, sskip,
-                           Mper | (nb << 8), H | (1 << 8), ctx->Tal, 0, g_skinny_done, K32, ctx->xbuf, xpl, nullptr, nullptr, nullptr, spf, NoFuseQ{}, ctx->cur_anc TL_PASS);
+                           Mper | (nz << 8), H | (1 << 8) | (nqt << 16), ctx->Tal, 0, g_skinny_done, K32, ctx->xbuf, xpl, nullptr, nullptr, nullptr, spf, NoFuseQ{}, ctx->cur_anc TL_PASS);
         WM_HIP(hipGetLastError());
     }
     // 3. out_proj + residual
@@ -1016,11 +1021,11 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
     // mix): the key-split grouping is sized for the blocks that actually run
     {
         PfJob xpf{nullptr, nullptr, 0u, 0u, 0ull};
-        int zs = nb;
+        int zs = nz;
         if (pf || (ctx->prefetch && R > 16)) {
             xpf = pf_for_gemm(w.cout_w, f8, d / 16, K32, false);
-            const int main_total = xgrid * H * nb;
-            zs = nb + (pf_round8(main_total) - main_total + (int)xpf.n_jobs + xgrid * H - 1) / (xgrid * H);
+            const int main_total = xgrid * H * nz;
+            zs = nz + (pf_round8(main_total) - main_total + (int)xpf.n_jobs + xgrid * H - 1) / (xgrid * H);
         }
         TL_SET(slot * 16 + 5 + 8192 * Mper);
         static const bool xattn_nt = [] { const char* v = std::getenv("WM_XATTN_NT"); return v ? std::atoi(v) != 0 : true; }();
@@ -1035,7 +1040,7 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
                 auto kern = k_attn_mfma<true, true, FQ>;                                                                      \
                 WM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
                 hipLaunchKernelGGL(kern, dim3(xgrid, H, zs), dim3(64 * (KSv > 4 ? KSv : 4)), lds, st, kx, vx, ctx->qbuf, base, sskip, \
-                                   Mper | (nb << 8), H | (ctx->NS << 8), ctx->Spad, ctx->S, g_skinny_done, K32, ctx->xbuf, xpl, ctx->cml, ctx->co, ctx->ticket, xpf, \
+                                   Mper | (nz << 8), H | (ctx->NS << 8) | (nqt << 16), ctx->Spad, ctx->S, g_skinny_done, K32, ctx->xbuf, xpl, ctx->cml, ctx->co, ctx->ticket, xpf, \
                                    FQ{ln, w.cq_w, w.cq_b}, nullptr TL_PASS);                                                         \
             } while (0)
             if (cqp.nk == 8 && cqp.ksplit == 5) WM_XFUSE(8, 5);
@@ -1048,10 +1053,10 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
 #undef WM_XFUSE
         } else if (xattn_nt)
             hipLaunchKernelGGL((k_attn_mfma<true, true, NoFuseQ>), dim3(xgrid, H, zs), dim3(256), sizeof(AttnLds<WM_XATTN_SPB_MAX>), st, kx, vx, ctx->qbuf, base, sskip,
-                               Mper | (nb << 8), H | (ctx->NS << 8), ctx->Spad, ctx->S, g_skinny_done, K32, ctx->xbuf, xpl, ctx->cml, ctx->co, ctx->ticket, xpf, NoFuseQ{}, nullptr TL_PASS);
+                               Mper | (nz << 8), H | (ctx->NS << 8) | (nqt << 16), ctx->Spad, ctx->S, g_skinny_done, K32, ctx->xbuf, xpl, ctx->cml, ctx->co, ctx->ticket, xpf, NoFuseQ{}, nullptr TL_PASS);
         else
             hipLaunchKernelGGL((k_attn_mfma<true, false, NoFuseQ>), dim3(xgrid, H, zs), dim3(256), sizeof(AttnLds<WM_XATTN_SPB_MAX>), st, kx, vx, ctx->qbuf, base, sskip,
-                               Mper | (nb << 8), H | (ctx->NS << 8), ctx->Spad, ctx->S, g_skinny_done, K32, ctx->xbuf, xpl, ctx->cml, ctx->co, ctx->ticket, xpf, NoFuseQ{}, nullptr TL_PASS);
+                               Mper | (nz << 8), H | (ctx->NS << 8) | (nqt << 16), ctx->Spad, ctx->S, g_skinny_done, K32, ctx->xbuf, xpl, ctx->cml, ctx->co, ctx->ticket, xpf, NoFuseQ{}, nullptr TL_PASS);
         WM_HIP(hipGetLastError());
     }
     // 6. out_proj + residual
@@ -1080,13 +1085,13 @@ int wm_dec_stage_layers(wm_ctx* ctx, int b0, int nb, int Mper, int mode)
     g_skinny_done = ctx->use_done ? ctx->done : nullptr;
     const int d = ctx->d, R = nb * Mper;
     const int* base = (mode == 0 ? ctx->kvlen : ctx->L) + b0;
-    if (R > ctx->Rcap || Mper > 16) { ctx->err = "decode pass exceeds the row capacity of the context"; return WM_ERR_ARG; }
+    if (R > ctx->Rcap || Mper > ctx->Mmax) { ctx->err = "decode pass exceeds the row capacity of the context"; return WM_ERR_ARG; }
     if (mode == 0)
         hipLaunchKernelGGL(k_embed, dim3(R), dim3(256), 0, st, ctx->h, ctx->tok_emb, ctx->dec_pos, base,
                            ctx->ids + (size_t)b0 * ctx->gp.Tids, ctx->gp.Tids, 1, Mper, d, ctx->V, ctx->Tmax, nullptr);
     else
         hipLaunchKernelGGL(k_embed, dim3(R), dim3(256), 0, st, ctx->h, ctx->tok_emb, ctx->dec_pos, base,
-                           ctx->cand + (size_t)b0 * 16, 16, 0, Mper, d, ctx->V, ctx->Tmax, ctx->tn ? ctx->tree->depth : nullptr);
+                           ctx->cand + (size_t)b0 * WM_CAND_STRIDE, WM_CAND_STRIDE, 0, Mper, d, ctx->V, ctx->Tmax, ctx->tn ? ctx->tree->depth : nullptr);
     WM_HIP(hipGetLastError());
     ctx->cur_anc = (mode == 1 && ctx->tn) ? ctx->tree->anc : nullptr;
     // batched hidden-state carry: a stream whose previous verify pass accepted a > 0 candidates already has the state

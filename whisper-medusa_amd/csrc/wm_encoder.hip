@@ -252,8 +252,11 @@ k_gemm_256(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32, 
 //     share PM token panels and PN weight panels through its L2 (PM + PN panels enter the L2 per patch instead of PM*PN + 1:
 //     with the panel-major order every resident block streamed its own token panel from the Infinity Cache).
 // =============================================================================================
-template <int NST, class Ep>
-__global__ void __launch_bounds__(512)
+// WN = feature-wave columns: 4 -> 256 x 256 tile, 8 waves, one block per CU; 2 -> 256 tokens x 128 features, 4 waves (one per SIMD),
+// 24 KiB stages, TWO blocks per CU: the epilogue of one block (HBM stores, GELU: ~a third of the one-block-per-CU kernel's time,
+// during which its CU's matrix pipes idle) overlaps the K loop of the other, at 1.5x the L2 -> LDS bytes per flop.
+template <int NST, int WN, class Ep>
+__global__ void __launch_bounds__(128 * WN, 2)
 k_gemm_256p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32, int tiles_m, int tiles_n, int PM, int PN, int persistent, int dbg, Ep ep)
 {
     // dbg (WM_ENC_GEMM_DBG, measurement only): bit 0 skips the MFMAs, bit 1 the ring refills inside the K loop, bit 2 the epilogue,
@@ -261,11 +264,13 @@ k_gemm_256p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32,
     // raises the wave priority around the MFMAs, bit 5 fills the ring of a persistent block's next tile AFTER the epilogue (results
     // stay right)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int STAGE = 32 * 1024;            // 16 X fragments (token tiles) then 16 W fragments (row tiles), one k-tile
-    constexpr int LPW = 4;                      // LDS-DMA pieces per wave per stage
+    constexpr int NPIECE = 16 + 4 * WN;         // 16 X fragments (token tiles) then 4 WN W fragments (row tiles), one k-tile
+    constexpr int STAGE = NPIECE * 1024;
+    constexpr int LPW = NPIECE / (2 * WN);      // LDS-DMA pieces per wave per stage
+    static_assert(NPIECE % (2 * WN) == 0, "pieces split evenly over the waves");
     const int lane = threadIdx.x & 63;
     const int wa = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wa >> 2, wn = wa & 3;
+    const int wm = wa / WN, wn = wa - wm * WN;
     const int per_patch = PM * PN, patches_m = tiles_m / PM;        // the launcher picks PM | tiles_m, PN | tiles_n
     const int n_patches = patches_m * (tiles_n / PN);
     const int NT = K32;                         // stages (even; the launcher checks)
@@ -276,7 +281,7 @@ k_gemm_256p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32,
     //   (FC1: 24 M -> 11 M per launch, hit rate 0.62 -> 0.80); persistent or not makes no difference to the misses.
     //  otherwise: one tile per block, patch-major order, XCD x owns a contiguous range of it (bijective for any grid).
     int patch, within, patch_step;
-    if (persistent) {
+    if (persistent) {                           // grid = 8 XCDs x (32 CUs x blocks per CU) slots
         patch = blockIdx.x & 7; within = blockIdx.x >> 3; patch_step = 8;
     } else {
         const int nwg = tiles_m * tiles_n;
@@ -294,7 +299,7 @@ k_gemm_256p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32,
         char* sb = smem + (kt % NST) * STAGE;
 #pragma unroll
         for (int i = 0; i < LPW; ++i) {
-            const int blk = wa * LPW + i;              // 0..15 X fragments, 16..31 W fragments
+            const int blk = wa * LPW + i;              // 0..15 X fragments, then the W fragments
             const bool isx = blk < 16;
             const int t = isx ? blk : blk - 16;
             glds16((isx ? xg : wg) + ((size_t)t * K32 + kt) * 512, sb + blk * 1024);
@@ -312,7 +317,7 @@ k_gemm_256p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32,
     int tm, tn;
     tile_of(patch, tm, tn);
     const bf16_t* xg = X + (size_t)tm * 16 * K32 * 512 + lane * 8;
-    const bf16_t* wg = W + (size_t)tn * 16 * K32 * 512 + lane * 8;
+    const bf16_t* wg = W + (size_t)tn * (4 * WN) * K32 * 512 + lane * 8;
 #pragma unroll
     for (int s = 0; s < NST; ++s)
         if (s < NT) stage_load(xg, wg, s);
@@ -367,19 +372,19 @@ k_gemm_256p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32,
         if (more && !(dbg & 32)) {
             tile_of(next, tm2, tn2);
             xg = X + (size_t)tm2 * 16 * K32 * 512 + lane * 8;
-            wg = W + (size_t)tn2 * 16 * K32 * 512 + lane * 8;
+            wg = W + (size_t)tn2 * (4 * WN) * K32 * 512 + lane * 8;
 #pragma unroll
             for (int s = 0; s < NST; ++s)
                 if (s < NT) stage_load(xg, wg, s);
         }
-        const int m0 = tm * 256 + wm * 128 + (lane & 15), n0 = tn * 256 + wn * 64 + 4 * (lane >> 4);
+        const int m0 = tm * 256 + wm * 128 + (lane & 15), n0 = tn * (64 * WN) + wn * 64 + 4 * (lane >> 4);
         if (!(dbg & 4)) ep_tiles<4, 8>(ep, m0, n0, acc);
         else if (acc[0][0][0] == 12345.678f) ep.store4(m0, n0, acc[1][1]);      // keeps the accumulators alive
         if (!more) break;
         if (dbg & 32) {                             // measurement: ring fill after the epilogue (the round-3 call-2 form)
             tile_of(next, tm2, tn2);
             xg = X + (size_t)tm2 * 16 * K32 * 512 + lane * 8;
-            wg = W + (size_t)tn2 * 16 * K32 * 512 + lane * 8;
+            wg = W + (size_t)tn2 * (4 * WN) * K32 * 512 + lane * 8;
             __builtin_amdgcn_s_waitcnt(0xC07F);
 #pragma unroll
             for (int s = 0; s < NST; ++s)
@@ -389,15 +394,15 @@ k_gemm_256p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32,
     }
 }
 
-// patch of the XCD-aware tile order: PM | tiles_m, PN | tiles_n, PM * PN <= 32 (the blocks resident on one XCD) as large as possible;
+// patch of the XCD-aware tile order: PM | tiles_m, PN | tiles_n, PM * PN <= cap (the blocks resident on one XCD) as large as possible;
 // among equals the most square one (PM + PN operand panels enter the L2 per patch)
-static inline void gemm256_patch(int tiles_m, int tiles_n, int& PM, int& PN)
+static inline void gemm256_patch(int tiles_m, int tiles_n, int cap, int& PM, int& PN)
 {
     PM = 1; PN = 1;
     int best = 0, best_sum = 1 << 30;
-    for (int pn = 1; pn <= 32 && pn <= tiles_n; ++pn) {
+    for (int pn = 1; pn <= cap && pn <= tiles_n; ++pn) {
         if (tiles_n % pn) continue;
-        for (int pm = 1; pm * pn <= 32 && pm <= tiles_m; ++pm) {
+        for (int pm = 1; pm * pn <= cap && pm <= tiles_m; ++pm) {
             if (tiles_m % pm) continue;
             const int prod = pm * pn, sum = pm + pn;
             if (prod > best || (prod == best && sum < best_sum)) { best = prod; best_sum = sum; PM = pm; PN = pn; }
@@ -405,30 +410,38 @@ static inline void gemm256_patch(int tiles_m, int tiles_n, int& PM, int& PN)
     }
 }
 
-template <int NST, class Ep>
+template <int NST, int WN, class Ep>
 static inline hipError_t launch_gemm_256p_nst(hipStream_t st, const bf16_t* X, const bf16_t* W, int K32, int tiles_m, int tiles_n, const Ep& ep)
 {
+    constexpr int per_cu = WN == 4 ? 1 : 2;          // resident blocks per CU (LDS: NST stages of 16 + 4 WN KiB)
+    constexpr int lds = NST * (16 + 4 * WN) * 1024;
     int PM, PN;
-    gemm256_patch(tiles_m, tiles_n, PM, PN);
-    // persistent patch-lockstep grid (one block per CU) once there are more tiles than CUs; WM_ENC_GEMM_PERSIST=0: one tile per block
+    gemm256_patch(tiles_m, tiles_n, 32 * per_cu, PM, PN);
+    // persistent grid (8 XCDs x 32 CUs x blocks per CU) once there are more tiles than that; WM_ENC_GEMM_PERSIST=0: one tile per block
     const int persist_env = [] { const char* v = std::getenv("WM_ENC_GEMM_PERSIST"); return v ? std::atoi(v) : 1; }();
-    const int persistent = (persist_env && tiles_m * tiles_n > 256) ? 1 : 0;
+    const int persistent = (persist_env && tiles_m * tiles_n > 256 * per_cu) ? 1 : 0;
     const int dbg = [] { const char* v = std::getenv("WM_ENC_GEMM_DBG"); return v ? std::atoi(v) : 0; }();
-    auto kern = k_gemm_256p<NST, Ep>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, NST * 32 * 1024);
+    auto kern = k_gemm_256p<NST, WN, Ep>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(persistent ? 256 : tiles_m * tiles_n), dim3(512), NST * 32 * 1024, st, X, W, K32, tiles_m, tiles_n, PM, PN, persistent, dbg, ep);
+    hipLaunchKernelGGL(kern, dim3(persistent ? 256 * per_cu : tiles_m * tiles_n), dim3(128 * WN), lds, st, X, W, K32, tiles_m, tiles_n, PM, PN, persistent, dbg, ep);
     return hipGetLastError();
 }
 
 template <class Ep>
 static inline hipError_t launch_gemm_256p(hipStream_t st, const bf16_t* X, const bf16_t* W, int Mrows, int N, int K32, const Ep& ep)
 {
+    const int nst = [] { const char* v = std::getenv("WM_ENC_GEMM_RING"); return v ? std::atoi(v) : 0; }();      // read per launch (sweeps); 0 = default
+    const int wn = [] { const char* v = std::getenv("WM_ENC_GEMM_WN"); return v ? std::atoi(v) : 4; }();         // 2: 256 x 128 tiles, two blocks per CU
+    if (wn == 2) {
+        const int tiles_m = Mrows / 256, tiles_n = N / 128;
+        if (nst == 2) return launch_gemm_256p_nst<3, 2>(st, X, W, K32, tiles_m, tiles_n, ep);     // (3 is the minimum ring)
+        return launch_gemm_256p_nst<3, 2>(st, X, W, K32, tiles_m, tiles_n, ep);
+    }
     const int tiles_m = Mrows / 256, tiles_n = N / 256;
-    const int nst = [] { const char* v = std::getenv("WM_ENC_GEMM_RING"); return v ? std::atoi(v) : 4; }();      // read per launch (sweeps)
-    if (nst == 5) return launch_gemm_256p_nst<5>(st, X, W, K32, tiles_m, tiles_n, ep);
-    if (nst == 3) return launch_gemm_256p_nst<3>(st, X, W, K32, tiles_m, tiles_n, ep);
-    return launch_gemm_256p_nst<4>(st, X, W, K32, tiles_m, tiles_n, ep);
+    if (nst == 5) return launch_gemm_256p_nst<5, 4>(st, X, W, K32, tiles_m, tiles_n, ep);
+    if (nst == 3) return launch_gemm_256p_nst<3, 4>(st, X, W, K32, tiles_m, tiles_n, ep);
+    return launch_gemm_256p_nst<4, 4>(st, X, W, K32, tiles_m, tiles_n, ep);
 }
 
 template <class Ep>

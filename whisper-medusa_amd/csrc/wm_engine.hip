@@ -66,15 +66,15 @@ extern "C" int wm_create(const wm_config* cfg, const wm_weights* w, int device, 
             for (int i = 0; i <= K; ++i) ok = ok && c[i] >= 1 && c[i] <= 4;
             for (int i = K + 1; i < 16; ++i) ok = ok && c[i] == 0;
             long nodes = 0, prod = 1;
-            for (int i = 0; ok && i <= K; ++i) { prod *= c[i]; nodes += prod; if (prod > 16 || nodes > 16) ok = false; }
-            if (!ok) { g_create_err = "wm_create: medusa_choices must be [1, c_1..c_K] with c_k in 1..4, <= 16 tree nodes and <= 16 paths"; return WM_ERR_ARG; }
+            for (int i = 0; ok && i <= K; ++i) { prod *= c[i]; nodes += prod; if (prod > WM_TREE_MAX_PATHS || nodes > WM_TREE_MAX_NODES) ok = false; }
+            if (!ok) { g_create_err = "wm_create: medusa_choices must be [1, c_1..c_K] with c_k in 1..4, <= 64 tree nodes and <= 32 paths"; return WM_ERR_ARG; }
             // generate_medusa_buffers (medusa_utils.py:305-421): node (depth i, index j) has parent (i-1, j / c_i) and takes
             // the (j % c_i)-th of head i's top-c_i tokens; path p visits node (i, p / (n_paths / cumprod_i)) at depth i
             tree.K = K; tree.n_paths = (int)prod; tree.n_nodes = (int)nodes;
             int cp = 1;
             tree.start[0] = 0;
             for (int i = 0; i <= K; ++i) { cp *= c[i]; tree.cumprod[i] = cp; tree.topk[i] = c[i]; tree.start[i + 1] = tree.start[i] + cp; }
-            for (int n = 0; n < 16; ++n) { tree.parent[n] = -1; for (int j = 0; j < 4; ++j) tree.children[n][j] = -1; }
+            for (int n = 0; n < WM_TREE_MAX_NODES; ++n) { tree.parent[n] = -1; for (int j = 0; j < 4; ++j) tree.children[n][j] = -1; }
             for (int i = 0; i <= K; ++i)
                 for (int j = 0; j < tree.cumprod[i]; ++j) {
                     const int n = tree.start[i] + j;
@@ -84,7 +84,7 @@ extern "C" int wm_create(const wm_config* cfg, const wm_weights* w, int device, 
                         tree.parent[n] = par;
                         tree.children[par][j % c[i]] = n;
                     }
-                    tree.anc[n] = (1u << n) | (i > 0 ? tree.anc[tree.parent[n]] : 0u);
+                    tree.anc[n] = (1ull << n) | (i > 0 ? tree.anc[tree.parent[n]] : 0ull);
                 }
             for (int p = 0; p < tree.n_paths; ++p)
                 for (int i = 0; i <= K; ++i) tree.retrieve[p][i] = tree.start[i] + p / (tree.n_paths / tree.cumprod[i]);
@@ -107,7 +107,8 @@ extern "C" int wm_create(const wm_config* cfg, const wm_weights* w, int device, 
     const int d = ctx->d = cfg->d_model;
     ctx->H = cfg->n_heads; ctx->ffn = cfg->ffn_dim; ctx->V = cfg->vocab; ctx->Vpad = rup(cfg->vocab, 128);
     ctx->S = cfg->n_ctx; ctx->Spad = rup(cfg->n_ctx, 128); ctx->Tm = 2 * cfg->n_ctx; ctx->Tmpad = rup(ctx->Tm, 128);
-    ctx->Tmax = cfg->n_tgt; ctx->Tal = rup(cfg->n_tgt + 16, 32); ctx->K = cfg->medusa_heads;
+    ctx->Mmax = std::max(16, rup(tn, 16));      // rows per stream of a pass: the chain's K + 1 <= 16, or the tree's nodes in 16-row query tiles
+    ctx->Tmax = cfg->n_tgt; ctx->Tal = rup(cfg->n_tgt + ctx->Mmax, 32); ctx->K = cfg->medusa_heads;
     ctx->block = cfg->heads_type == WM_HEADS_BLOCK;
     ctx->nkv = cfg->dec_layers + (ctx->block ? 1 : 0);
     ctx->nres = ctx->K + (ctx->block ? 0 : 1);
@@ -177,7 +178,7 @@ extern "C" int wm_create(const wm_config* cfg, const wm_weights* w, int device, 
     CREATE_HIP(dev_alloc(&ctx->vx, (size_t)ctx->nkv * Menc * d, st));
     CREATE_HIP(dev_alloc(&ctx->kc, (size_t)ctx->nkv * B * H * Tal * 64, st));
     CREATE_HIP(dev_alloc(&ctx->vc, (size_t)ctx->nkv * B * H * Tal * 64, st));
-    ctx->Rcap = 16 * ctx->maxB;
+    ctx->Rcap = ctx->Mmax * ctx->maxB;
     const size_t RW = ctx->Rcap;
     CREATE_HIP(dev_alloc(&ctx->h, RW * d, st));
     CREATE_HIP(dev_alloc(&ctx->hblk, RW * d, st));
@@ -198,18 +199,18 @@ extern "C" int wm_create(const wm_config* cfg, const wm_weights* w, int device, 
     CREATE_HIP(dev_alloc(&ctx->ybuf, 2 * RW * d, st));
     CREATE_HIP(dev_alloc(&ctx->cml, RW * H * ctx->NS * 2, st));
     CREATE_HIP(dev_alloc(&ctx->co, RW * H * ctx->NS * 64, st));
-    CREATE_HIP(dev_alloc(&ctx->ticket, B * 32, st));
+    CREATE_HIP(dev_alloc(&ctx->ticket, B * 32 * (WM_TREE_MAX_NODES / 16), st));
     CREATE_HIP(dev_alloc(&ctx->logits, RW * ctx->Vpad, st));
-    CREATE_HIP(dev_alloc(&ctx->amax, B * 16, st));
-    CREATE_HIP(dev_alloc(&ctx->pc, B * 16, st));
+    CREATE_HIP(dev_alloc(&ctx->amax, B * WM_TREE_MAX_NODES, st));
+    CREATE_HIP(dev_alloc(&ctx->pc, B * WM_TREE_MAX_NODES, st));
     CREATE_HIP(dev_alloc(&ctx->part1, RW * 16 * 4, st));
-    CREATE_HIP(dev_alloc(&ctx->part2, B * 16 * 16, st));
+    CREATE_HIP(dev_alloc(&ctx->part2, B * WM_TREE_MAX_NODES * 16, st));
     const size_t Tids = ctx->Tal;
     CREATE_HIP(dev_alloc(&ctx->ids, B * Tids, st));
     CREATE_HIP(dev_alloc(&ctx->L, B, st));
     CREATE_HIP(dev_alloc(&ctx->kvlen, B, st));
     CREATE_HIP(dev_alloc(&ctx->finished, B, st));
-    CREATE_HIP(dev_alloc(&ctx->cand, B * 16, st));
+    CREATE_HIP(dev_alloc(&ctx->cand, B * WM_CAND_STRIDE, st));
     CREATE_HIP(dev_alloc(&ctx->niter, B, st));
     CREATE_HIP(dev_alloc(&ctx->hist, 32, st));
     CREATE_HIP(dev_alloc(&ctx->supmask, (size_t)ctx->Vpad, st));

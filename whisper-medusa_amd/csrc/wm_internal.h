@@ -42,11 +42,11 @@ struct TreeDev {
     int topk[16];           // c_k of logits row k (row 0 = base head: 1)
     int start[17];          // first node of depth i
     int cumprod[16];        // nodes at depth i
-    int depth[16];          // medusa_position_ids
-    unsigned anc[16];       // bit n of anc[m]: node n is m or one of its ancestors (rows of medusa_attn_mask)
-    int parent[16];
-    int children[16][4];    // -1 padded
-    int retrieve[16][16];   // [path][depth] -> node (retrieve_indices)
+    int depth[WM_TREE_MAX_NODES];                   // medusa_position_ids
+    unsigned long long anc[WM_TREE_MAX_NODES];      // bit n of anc[m]: node n is m or one of its ancestors (rows of medusa_attn_mask)
+    int parent[WM_TREE_MAX_NODES];
+    int children[WM_TREE_MAX_NODES][4];             // -1 padded
+    int retrieve[WM_TREE_MAX_PATHS][16];            // [path][depth] -> node (retrieve_indices)
 };
 
 struct wm_ctx {
@@ -61,7 +61,8 @@ struct wm_ctx {
     int Tmax = 0 /* n_tgt */, Tal = 0 /* cache rows allocated */, K = 0, nkv = 0, nres = 0, maxB = 0;
     bool block = false;
     int NS = 1;         // cross-attention key splits (256 keys per block)
-    int Rcap = 16;      // token-row capacity of the decode scratch (16 rows per stream)
+    int Rcap = 16;      // token-row capacity of the decode scratch (16 rows per stream; a candidate tree of more than 16 nodes: its node count rounded up to 16)
+    int Mmax = 16;      // rows per stream a pass may carry
 
     // ---- parameters (pointers into the caller's blob) ----
     const float *win = nullptr, *twiddle = nullptr, *melfb = nullptr;
@@ -103,7 +104,7 @@ struct wm_ctx {
     int tn = 0, tp = 0;
     TreeDev tree_host{};
     TreeDev* tree = nullptr;
-    const unsigned* cur_anc = nullptr;                                      // ancestor masks of the pass being enqueued (verify pass of a tree)
+    const unsigned long long* cur_anc = nullptr;                            // ancestor masks of the pass being enqueued (verify pass of a tree)
     int *sel_src = nullptr, *sel_n = nullptr, *sel_base = nullptr;          // K/V rows of the chosen path to move: [maxB*16], [maxB], [maxB]
     bool fuse = true;
     bool host_carry = false;                                                // single-stream runs: the host skips the base pass

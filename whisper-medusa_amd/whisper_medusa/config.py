@@ -65,8 +65,8 @@ HEADS_LINEAR = "base_head"      # reference: model.py:221-230
 HEADS_BLOCK = "medusa_block"
 
 
-MAX_TREE_NODES = 16      # the verify pass of a stream is one 16-row MFMA token tile
-MAX_TREE_PATHS = 16
+MAX_TREE_NODES = 64      # the verify pass of a stream is up to four 16-row MFMA query tiles
+MAX_TREE_PATHS = 32
 MAX_TREE_TOPK = 4
 
 
@@ -178,7 +178,7 @@ class MedusaConfig:
             raise ValueError("engine supports at most 15 Medusa heads (verify pass is one 16-row MFMA tile)")
         if ch != [1] * (K + 1):
             # a real candidate tree (top-k > 1): beyond the reference, which builds the tree mask and never applies it
-            # (medusa_utils.py:494-516).  The verify pass is one 16-row token tile per stream.
+            # (medusa_utils.py:494-516).  The verify pass is up to four 16-row query tiles per stream.
             tb = tree_buffers(ch)
             if tb["n_nodes"] > MAX_TREE_NODES or tb["n_paths"] > MAX_TREE_PATHS or max(tb["topk"]) > MAX_TREE_TOPK:
                 raise ValueError(f"candidate tree {ch}: {tb['n_nodes']} nodes / {tb['n_paths']} paths / top-{max(tb['topk'])}; the engine "
