@@ -108,7 +108,9 @@ def main():
             if args.enc_knobs and nb > 1:
                 variants = [("default", dict(WM_ENC_GEMM_DBG=0)), ("ring_fill_after_epilogue", dict(WM_ENC_GEMM_DBG=32)), ("setprio", dict(WM_ENC_GEMM_DBG=16)),
                             ("setprio_ring5", dict(WM_ENC_GEMM_DBG=16, WM_ENC_GEMM_RING=5)), ("one_tile_per_block", dict(WM_ENC_GEMM_PERSIST=0)),
-                            ("no_epilogue", dict(WM_ENC_GEMM_DBG=4))]
+                            ("no_epilogue", dict(WM_ENC_GEMM_DBG=4)),
+                            ("wn2_two_blocks_per_cu", dict(WM_ENC_GEMM_WN=2)), ("wn2_one_tile_per_block", dict(WM_ENC_GEMM_WN=2, WM_ENC_GEMM_PERSIST=0)),
+                            ("wn2_no_epilogue", dict(WM_ENC_GEMM_WN=2, WM_ENC_GEMM_DBG=4))]
             if args.enc_dbg and nb > 1:
                 variants = [("full", dict(WM_ENC_GEMM_DBG=0)), ("no_mfma", dict(WM_ENC_GEMM_DBG=1)), ("no_refill", dict(WM_ENC_GEMM_DBG=2)),
                             ("no_epilogue", dict(WM_ENC_GEMM_DBG=4)), ("no_frag_reads", dict(WM_ENC_GEMM_DBG=8)),
