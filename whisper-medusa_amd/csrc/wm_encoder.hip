@@ -755,43 +755,66 @@ k_flash_enc(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kt, const b
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) va[dt] = ld_frag(sb + 4096 + ((4 * hh + dt) * 64 + lane) * 8);
             const bool tail = kb + 32 > S;
+            // The query tiles of the wave go through each phase in GROUPS — the score MFMAs of the group, then its softmax arithmetic,
+            // ONE rescale decision, then its PV MFMAs — so the tiles' dependent chains (MFMA -> row max across lanes -> exp -> row sum
+            // -> convert -> MFMA) interleave.  Tile by tile with a rescale branch inside (round 2), every tile was its own scheduling
+            // region and its chain latency was exposed: the kernel sat at ~37 % of its VALU bound.
+            constexpr int G = QT >= 2 ? 2 : 1;             // tiles per phase group (4 at once needed 264 registers: one block per CU)
 #pragma unroll
-            for (int t = 0; t < QT; ++t) {
-                f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-                s0 = mfma16(a00, qb[t][0], s0); s0 = mfma16(a01, qb[t][1], s0);
-                s1 = mfma16(a10, qb[t][0], s1); s1 = mfma16(a11, qb[t][1], s1);
+            for (int t0 = 0; t0 < QT; t0 += G) {
+                f32x4_t s0[G], s1[G];
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    s0[u] = f32x4_t{0.f, 0.f, 0.f, 0.f}; s1[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                    s0[u] = mfma16(a00, qb[t0 + u][0], s0[u]); s0[u] = mfma16(a01, qb[t0 + u][1], s0[u]);
+                    s1[u] = mfma16(a10, qb[t0 + u][0], s1[u]); s1[u] = mfma16(a11, qb[t0 + u][1], s1[u]);
+                }
                 if (tail) {
 #pragma unroll
+                    for (int u = 0; u < G; ++u)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if (kb + 4 * g + r >= S) s0[u][r] = -INFINITY;
+                            if (kb + 16 + 4 * g + r >= S) s1[u][r] = -INFINITY;
+                        }
+                }
+                float alpha[G];
+                bf16x8_t pb[G];
+                bool any_rescale = false;
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const int t = t0 + u;
+                    float mx = fmaxf(fmaxf(fmaxf(s0[u][0], s0[u][1]), fmaxf(s0[u][2], s0[u][3])), fmaxf(fmaxf(s1[u][0], s1[u][1]), fmaxf(s1[u][2], s1[u][3])));
+                    mx = rows4_max(mx);
+                    const float m_new = fmaxf(m_run[t], mx);
+                    alpha[u] = __expf(m_run[t] - m_new);
+                    float p0[4], p1[4], rs = 0.f;
+#pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        if (kb + 4 * g + r >= S) s0[r] = -INFINITY;
-                        if (kb + 16 + 4 * g + r >= S) s1[r] = -INFINITY;
+                        p0[r] = __expf(s0[u][r] - m_new); p1[r] = __expf(s1[u][r] - m_new);
+                        rs += p0[r] + p1[r];
                     }
+                    rs = rows4_sum(rs);
+                    l_run[t] = l_run[t] * alpha[u] + rs;
+                    m_run[t] = m_new;
+                    uint4 pw;
+                    pw.x = pack_bf2(p0[0], p0[1]); pw.y = pack_bf2(p0[2], p0[3]);
+                    pw.z = pack_bf2(p1[0], p1[1]); pw.w = pack_bf2(p1[2], p1[3]);
+                    pb[u] = __builtin_bit_cast(bf16x8_t, pw);
+                    any_rescale = any_rescale || (alpha[u] != 1.0f);
                 }
-                float mx = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
-                mx = rows4_max(mx);
-                const float m_new = fmaxf(m_run[t], mx);
-                const float alpha = __expf(m_run[t] - m_new);
-                float p0[4], p1[4], rs = 0.f;
+                // lazy rescale: once the running maxima have settled alpha is exactly 1 for every query of the wave and the 16 multiplies
+                // per tile are skipped (one wave-uniform branch per group; x * 1.0f == x, results unchanged)
+                if (__builtin_amdgcn_ballot_w64(any_rescale) != 0ull) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    p0[r] = __expf(s0[r] - m_new); p1[r] = __expf(s1[r] - m_new);
-                    rs += p0[r] + p1[r];
-                }
-                rs = rows4_sum(rs);
-                l_run[t] = l_run[t] * alpha + rs;
-                m_run[t] = m_new;
-                uint4 pw;
-                pw.x = pack_bf2(p0[0], p0[1]); pw.y = pack_bf2(p0[2], p0[3]);
-                pw.z = pack_bf2(p1[0], p1[1]); pw.w = pack_bf2(p1[2], p1[3]);
-                const bf16x8_t pb = __builtin_bit_cast(bf16x8_t, pw);
-                // lazy rescale: once the running maxima have settled alpha is exactly 1 for every query of the wave and the 16
-                // multiplies per tile are skipped (wave-uniform branch; x * 1.0f == x, results unchanged)
-                if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0ull) {
+                    for (int u = 0; u < G; ++u)
 #pragma unroll
-                    for (int dt = 0; dt < 4; ++dt) { o[t][dt][0] *= alpha; o[t][dt][1] *= alpha; o[t][dt][2] *= alpha; o[t][dt][3] *= alpha; }
+                        for (int dt = 0; dt < 4; ++dt) { o[t0 + u][dt][0] *= alpha[u]; o[t0 + u][dt][1] *= alpha[u]; o[t0 + u][dt][2] *= alpha[u]; o[t0 + u][dt][3] *= alpha[u]; }
                 }
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) o[t][dt] = mfma16(va[dt], pb, o[t][dt]);
+                for (int u = 0; u < G; ++u)
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) o[t0 + u][dt] = mfma16(va[dt], pb[u], o[t0 + u][dt]);
             }
         }
     }
