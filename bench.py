@@ -324,15 +324,16 @@ def main():
 
     # HBM traffic per iteration from the PMC pass (profiles/): only if that pass was taken on THESE kernels (sha over csrc/)
     traffic = None; traffic_src = None
-    tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    tname = next((n for n in ("r03_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", n))), "r03_pmc_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", tname)
     if args.model == "large-v2" and B == 1 and args.heads == "linear" and not args.fp8_weights and os.path.exists(tpath):
         tj = json.load(open(tpath))
         if tj.get("kernels_sha") == kernels_sha():
             traffic = tj["medusa_iteration_bytes"]      # PMC FETCH_SIZE x2, see profiles/
-            traffic_src = {"file": "profiles/r02_pmc_traffic.json", "command": tj.get("command"), "kernels_sha": tj.get("kernels_sha"),
+            traffic_src = {"file": "profiles/" + tname, "command": tj.get("command"), "kernels_sha": tj.get("kernels_sha"),
                            "counts": tj.get("counts"), "without_prefetch_blocks": tj.get("without_prefetch_blocks")}
         else:
-            traffic_src = {"file": "profiles/r02_pmc_traffic.json", "stale": True, "file_kernels_sha": tj.get("kernels_sha"), "kernels_sha": kernels_sha()}
+            traffic_src = {"file": "profiles/" + tname, "stale": True, "file_kernels_sha": tj.get("kernels_sha"), "kernels_sha": kernels_sha()}
     t_iter_ms = ms_dec / max(iters, 1)
     mean_len = len(gp.prompt) + args.max_new / 2
     bytes_iter = decode_iter_bytes(cfg, B, mean_len, args.fp8_weights)

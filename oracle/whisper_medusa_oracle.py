@@ -278,6 +278,7 @@ class DecodeResult:
     trace: List[dict] = field(default_factory=list)
     verified: int = 0                   # decode_tree(engine_ids=...): ids confirmed identical to the engine's
     tie: Optional[dict] = None          # ... and the first differing iteration's decision margins
+    ties: List[dict] = field(default_factory=list)   # decode_tree(engine_groups=...): every iteration whose outcome differed from the engine's
 
 
 class Oracle:
@@ -535,7 +536,8 @@ class Oracle:
     # ---- the decode loop over a candidate tree ----------------------------------------------------------
     @torch.no_grad()
     def decode_tree(self, enc: torch.Tensor, gp, choices: Optional[List[int]] = None, engine_ids: Optional[List[int]] = None,
-                    tol_logit: float = 5e-4, tol_rel_p: float = 2e-3, max_iters: Optional[int] = None) -> DecodeResult:
+                    tol_logit: float = 5e-4, tol_rel_p: float = 2e-3, max_iters: Optional[int] = None,
+                    engine_groups: Optional[List[List[int]]] = None) -> DecodeResult:
         """model.py:634-793 with ``medusa_choices = [1, c_1, .., c_K]``: candidates = cartesian product of the base argmax and
         every head's top-c_k (medusa_utils.py:424-458), ONE verify pass over the tree's nodes at positions L + depth with the
         ancestor mask (tree_decoding :494-521 — the reference builds that mask and never passes it on; a node's logits are
@@ -544,7 +546,11 @@ class Oracle:
         With ``engine_ids`` the run doubles as a parity check that survives numerical ties: res.trace receives, for the first
         iteration whose strict outcome differs from the engine's tokens, the smallest decision margin of that iteration
         (``tie`` entry) — a divergence is a numerical tie iff that margin is below the tolerances — and the walk stops there
-        (``res.verified`` = number of ids confirmed identical)."""
+        (``res.verified`` = number of ids confirmed identical).
+        With ``engine_groups`` (the tokens the engine emitted in each of its iterations, from its streaming callback) the walk does NOT
+        stop: every iteration is run from the ENGINE's prefix (teacher forcing) and compared with the engine's group; a mismatch is
+        recorded in ``res.ties`` with that iteration's margins and the walk continues from the engine's tokens (their K/V rows are
+        recomputed by the next base pass), so every iteration after a tie is still checked."""
         cfg = self.cfg
         choices = [int(x) for x in (choices if choices is not None else cfg.medusa_choices)]
         K, P, eos = cfg.medusa_num_heads, len(gp.prompt), gp.eos_token_id
@@ -554,8 +560,11 @@ class Oracle:
         st = self.new_state(enc)
         ids = list(gp.prompt)
         res = DecodeResult(ids=[], new_tokens=[])
-        res.verified, res.tie = len(ids), None
+        res.verified, res.tie, res.ties = len(ids), None, []
+        it_no = 0
         while True:
+            if engine_groups is not None and it_no >= len(engine_groups):
+                break
             L, kv = len(ids), st["kv_len"]
             z = self.decoder_pass(st, ids[kv:L], kv, disable_medusa=False, last_only=True)[:, 0]
             st["kv_len"] = L
@@ -573,6 +582,21 @@ class Oracle:
             else:
                 emit = [int(t) for t in cands[best, : a + 1]]
                 keep = [int(n) for n in retrieve[best, :a]]
+            if engine_groups is not None:
+                grp = [int(t) for t in engine_groups[it_no]]
+                it_no += 1
+                if grp != emit:
+                    res.ties.append(dict(L=L, oracle_emit=emit, engine=grp,
+                                         margin=self._tree_margins(z, vt, v, cands, choices, retrieve, best, a, dbg, gp, tol_logit, tol_rel_p)))
+                    ids += grp                       # follow the engine; the provisional rows are dropped, the next base pass recomputes them
+                    for slot, (kc, vc) in enumerate(st["self_kv"]):
+                        st["self_kv"][slot] = (kc[:, :L], vc[:, :L])
+                    st["kv_len"] = L
+                    res.n_iters += 1
+                    L = len(ids)
+                    if (eos in grp) or (L >= gp.max_length) or (L + K >= gp.hard_max_length):
+                        break
+                    continue
             if engine_ids is not None:
                 tail = engine_ids[L: L + len(emit)]
                 if tail != emit[: len(tail)] or not tail:

@@ -11,7 +11,7 @@ c = sqlite3.connect(sys.argv[1])
 rows = c.execute("select name, count(*), sum(counter_value), sum(end-start)/1e3 from pmc_events where counter_name='FETCH_SIZE' "
                  "group by name order by 3 desc").fetchall()
 ours = [(re.sub(r"\(.*", "", n)[:90], k, v, t) for n, k, v, t in rows
-        if re.search(r"k_skinny|k_attn|k_select|k_embed|k_rows_norm|k_accept|k_set_cand", n)]
+        if re.search(r"k_skinny|k_attn|k_select|k_embed|k_rows_norm|k_accept|k_set_cand|k_rows_gemm|k_ln_tiles|k_tile_gemm", n)]
 n_iter = sum(k for n, k, v, t in ours if n.startswith("k_accept") and "vanilla" not in n)
 n_van = sum(k for n, k, v, t in ours if "k_accept_vanilla" in n)
 lines = [f"Medusa iterations profiled: {n_iter}; vanilla steps: {n_van}", "",

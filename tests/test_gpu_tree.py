@@ -57,15 +57,38 @@ def trig(request, gpu):
     r.eng.close()
 
 
-def check_tree_tokens(orc, enc_b, gp, got, label):
+def check_tree_tokens(orc, enc_b, gp, got, label, groups=None):
+    """Strict comparison first.  If it differs and the engine's per-iteration token groups are known (streaming callback), EVERY
+    iteration is compared: the oracle runs each iteration from the engine's prefix (teacher forcing, Oracle.decode_tree
+    engine_groups); iterations whose outcome differs must hold a decision within the numerical tolerance (margins printed, at most
+    two per run) and all others must match exactly — a bug that appears after (or inside) a near-tie iteration no longer passes
+    (ADVICE r02).  Without groups: the round-2 check (ids up to the first tie)."""
     r = orc.decode_tree(enc_b, gp, engine_ids=got)
     if r.tie is None:
         assert r.ids == got, (label, r.ids, got)
         return r.accept_lengths, True
     print(f"tree parity[{label}]: first difference in the iteration at L={r.tie['L']}; oracle margins (units of tolerance): {r.tie['margin']}")
     assert r.tie["margin"]["min"] < 1.0, (label, r.tie, got)
+    if groups is not None:
+        rf = orc.decode_tree(enc_b, gp, engine_groups=groups)
+        assert 1 <= len(rf.ties) <= 2 and all(t["margin"]["min"] < 1.0 for t in rf.ties), (label, rf.ties)
+        assert rf.n_iters == len(groups), (label, rf.n_iters, len(groups))
+        print(f"tree parity[{label}]: {rf.n_iters - len(rf.ties)} of {rf.n_iters} iterations identical from the engine's prefix, {len(rf.ties)} numerical tie(s)")
+        return rf.accept_lengths, False
     assert r.verified >= len(gp.prompt) + 4, (label, r.tie)
     return r.accept_lengths, False
+
+
+def decode_with_groups(eng, gp, B):
+    """engine.decode in streaming mode: (final sequences, per-stream list of the tokens every iteration emitted)."""
+    groups = [[] for _ in range(B)]
+
+    def on_it(new):
+        for b in range(B):
+            if new[b]:
+                groups[b].append(list(new[b]))
+    seqs = eng.decode(gp, B, on_iteration=on_it)
+    return seqs, groups
 
 
 @pytest.mark.parametrize("mode", [ACCEPT_TYPICAL, ACCEPT_GREEDY])
@@ -74,10 +97,13 @@ def test_tree_decode_tokens(trig, mode):
     trig.encode()
     seqs = trig.eng.decode(gp, trig.B)
     st = trig.eng.stats()
+    trig.encode()
+    streamed, groups = decode_with_groups(trig.eng, gp, trig.B)        # one iteration per call: the tokens of every iteration
+    assert streamed == seqs
     hist = np.zeros(trig.cfg.medusa_num_heads + 1, dtype=np.int64)
     full = True
     for b in range(trig.B):
-        accepts, complete = check_tree_tokens(trig.orc, trig.enc[b], gp, seqs[b], (b, mode))
+        accepts, complete = check_tree_tokens(trig.orc, trig.enc[b], gp, seqs[b], (b, mode), groups=groups[b])
         full = full and complete
         for a in accepts:
             hist[a] += 1
