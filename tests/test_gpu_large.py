@@ -233,7 +233,8 @@ def test_large_token_agreement_with_the_pinned_fp32_oracle(large, mode, capsys):
     record_table(name, agree=agree, total=total, frac=round(agree / max(total, 1), 3),
                  first_divergence=[r[1] for r in rows], top2_margin=[None if r[3] != r[3] else round(r[3], 4) for r in rows])
     assert all(f >= 1 for _, f, _, _ in rows)                # never on the first token
-    assert agree >= 0.5 * total, (agree, total)              # floor until a measured value is on record (then: measured - 5 %)
+    # measured on MI355X (round 3, tests/parity_report.json of gpurun call 8): 86 / 86 (exact-match) and 95 / 95 (typical); floor = measured - 5 %
+    assert agree >= 0.95 * total, (agree, total)
 
 
 @pytest.fixture(scope="module")

@@ -41,18 +41,19 @@ class GenerateEncoderDecoderOutput(dict):
                "cross_attentions", "decoder_hidden_states", "past_key_values")
 
     def __init__(self, sequences, **extra):
-        super().__init__({k: None for k in self._fields})
+        super().__init__()                       # like ModelOutput: only the fields that are not None are keys
         self["sequences"] = sequences
-        self.update(extra)
+        self.update({k: v for k, v in extra.items() if v is not None})
 
     def __getattr__(self, k):
-        try:
-            return self[k]
-        except KeyError as e:
-            raise AttributeError(k) from e
+        if k in self:
+            return dict.__getitem__(self, k)
+        if k in self._fields:
+            return None
+        raise AttributeError(k)
 
     def to_tuple(self):
-        return tuple(self[k] for k in self.keys() if self[k] is not None)
+        return tuple(dict.__getitem__(self, k) for k in self.keys())
 
     def __getitem__(self, k):
         if isinstance(k, int):
