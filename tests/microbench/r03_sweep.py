@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--tile-shapes", action="store_true", help="sweep every (F, TT) shape of the tile kernel at the full row count")
     ap.add_argument("--enc-only-batch", action="store_true", help="encoder legs at the full batch only")
     ap.add_argument("--enc-knobs", action="store_true", help="encoder legs: result-preserving knobs of the pipelined GEMM")
+    ap.add_argument("--enc-now", action="store_true", help="encoder legs: the shipped configuration, and the V tiles feature-major (one launch, DPP transpose)")
     ap.add_argument("--enc-dbg", action="store_true", help="encoder legs with parts of the pipelined GEMM switched off (WM_ENC_GEMM_DBG)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r03_sweep.json"))
     args = ap.parse_args()
@@ -111,6 +112,8 @@ def main():
                             ("no_epilogue", dict(WM_ENC_GEMM_DBG=4)),
                             ("wn2_two_blocks_per_cu", dict(WM_ENC_GEMM_WN=2)), ("wn2_one_tile_per_block", dict(WM_ENC_GEMM_WN=2, WM_ENC_GEMM_PERSIST=0)),
                             ("wn2_no_epilogue", dict(WM_ENC_GEMM_WN=2, WM_ENC_GEMM_DBG=4))]
+            if args.enc_now:
+                variants = [("default", dict(WM_ENC_GEMM_DBG=0)), ("v_tiles_feature_major", dict(WM_ENC_GEMM_DBG=64))]
             if args.enc_dbg and nb > 1:
                 variants = [("full", dict(WM_ENC_GEMM_DBG=0)), ("no_mfma", dict(WM_ENC_GEMM_DBG=1)), ("no_refill", dict(WM_ENC_GEMM_DBG=2)),
                             ("no_epilogue", dict(WM_ENC_GEMM_DBG=4)), ("no_frag_reads", dict(WM_ENC_GEMM_DBG=8)),

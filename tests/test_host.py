@@ -344,3 +344,29 @@ def test_generate_output_object_mirrors_the_reference_model_output():
     assert m._wrap_outputs(t, [1, 1], m_cfg.pad_token_id, m_cfg.eos_token_id, False, False) is t
     d = m._wrap_outputs(t, [1, 1], m_cfg.pad_token_id, m_cfg.eos_token_id, False, True)
     assert set(d) == {"sequences", "segments"}
+
+
+def test_encoder_gelu_formula_is_within_fp32_rounding_of_the_exact_gelu():
+    """csrc/wm_common.h gelu_phi (the encoder epilogues' GELU): x * erfc(-x / sqrt 2) / 2 with the Chebyshev-fitted erfc.  numpy float32
+    restatement of its arithmetic (same coefficients, same Horner order, exponent through 2^u) against the float64 value of the
+    exact-erf GELU the reference uses (HF activations.GELUActivation): no worse than the fp32 evaluation of 0.5 x (1 + erf(x / sqrt 2))."""
+    from scipy.special import erf, erfc
+    f = np.float32
+    x = np.linspace(-12, 12, 400001).astype(f)
+    z = np.abs(x) * f(0.70710678118654752440)
+    t = f(1) / (f(0.5) * z + f(1))
+    coef = [0.17087277, -0.82215223, 1.48851587, -1.13520398, 0.27886807, -0.18628806, 0.09678418, 0.37409196, 1.00002368, -1.26551223]
+    L = 1.4426950408889634
+    p = np.full_like(x, f(coef[0] * L))
+    for c in coef[1:]:
+        p = (p * t + f(c * L)).astype(f)
+    u = ((z * f(-L)) * z + p).astype(f)
+    he = (f(0.5) * t * np.exp2(u).astype(f)).astype(f)
+    got = (x * np.where(x < 0, he, f(1) - he)).astype(np.float64)
+    want = x.astype(np.float64) * 0.5 * erfc(-x.astype(np.float64) / np.sqrt(2.0))
+    err = np.abs(got - want)
+    assert err.max() < 5e-7
+    inner = np.abs(x) < 8                                             # relative accuracy holds in the negative tail too
+    assert (err[inner] / np.maximum(np.abs(want[inner]), 1e-30)).max() < 2e-5
+    plain = (f(0.5) * x * (f(1) + erf((x * f(0.70710678)).astype(f)).astype(f))).astype(np.float64)
+    assert err.max() <= np.abs(plain - want).max()

@@ -20,6 +20,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # compatibility prologue for firmware without the feature.  WM_NO_KERNARG_PRELOAD=1 builds without it (A/B runs).
 if not os.environ.get("WM_NO_KERNARG_PRELOAD"):
     FLAGS += ["-mllvm", "-amdgpu-kernarg-preload-count=16"]
+# MFMA results in architectural VGPRs.  By default the register allocator parks MFMA destinations in AGPRs; every kernel whose VALU
+# code consumes them (attention: scores -> softmax, lazily rescaled outputs) then pays v_accvgpr_read / _write / _mov copies — 45 % of
+# the VALU instructions of the encoder flash-attention loop, 16 % of the decode self-attention kernel (ISA counts).
+# All kernels here fit the 256 VGPRs their occupancy allows without AGPRs, so nothing is lost.  WM_MFMA_AGPR=1 builds the old form.
+if not os.environ.get("WM_MFMA_AGPR"):
+    FLAGS += ["-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
 def _newest_src():

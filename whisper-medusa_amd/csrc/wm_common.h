@@ -108,6 +108,30 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// The encoder's GELU (exact erf form, HF:activations.py GELUActivation) = x * Phi(x), Phi(x) = erfc(-x / sqrt 2) / 2, with erfc from
+// the Chebyshev fit  erfc(z) = t exp(-z^2 + P(t)), t = 1 / (1 + z / 2), z >= 0  (fractional error < 1.2e-7 everywhere): one
+// branch-free path of ~21 VALU instructions (two of them quarter-rate: v_rcp_f32, v_exp_f32) where the library erff costs ~44 per
+// element with both of its branches executed — the FC1 epilogue of the big-batch GEMM spent 5.8 k VALU instructions per wave and
+// tile on it, as long as its MFMAs take (profiles/r03_encoder_gemm_parts.md).  Against the float64 value: |error| < 4e-7 over
+// the whole line and relatively accurate in the negative tail, where 0.5 x (1 + erf) in fp32 cancels (tests/test_host.py checks
+// the numpy restatement of this function).  The coefficients are P's times log2(e): the exponential is v_exp_f32 = 2^u.
+__device__ __forceinline__ float gelu_phi(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.5f, z, 1.0f));
+    float p = 0.17087277f * 1.4426950408889634f;
+    p = fmaf(p, t, -0.82215223f * 1.4426950408889634f);
+    p = fmaf(p, t, 1.48851587f * 1.4426950408889634f);
+    p = fmaf(p, t, -1.13520398f * 1.4426950408889634f);
+    p = fmaf(p, t, 0.27886807f * 1.4426950408889634f);
+    p = fmaf(p, t, -0.18628806f * 1.4426950408889634f);
+    p = fmaf(p, t, 0.09678418f * 1.4426950408889634f);
+    p = fmaf(p, t, 0.37409196f * 1.4426950408889634f);
+    p = fmaf(p, t, 1.00002368f * 1.4426950408889634f);
+    p = fmaf(p, t, -1.26551223f * 1.4426950408889634f);
+    const float u = fmaf(z * -1.4426950408889634f, z, p);
+    const float he = 0.5f * t * __builtin_amdgcn_exp2f(u);       // erfc(z) / 2
+    return x * (x < 0.f ? he : 1.0f - he);
+}
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 
 __device__ __forceinline__ f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {

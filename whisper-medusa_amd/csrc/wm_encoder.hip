@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <vector>
+#include <type_traits>
 #include "wm_epilogues.h"
 
 // =============================================================================================
@@ -255,14 +256,20 @@ k_gemm_256(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32, 
 // WN = feature-wave columns: 4 -> 256 x 256 tile, 8 waves, one block per CU; 2 -> 256 tokens x 128 features, 4 waves (one per SIMD),
 // 24 KiB stages, TWO blocks per CU: the epilogue of one block (HBM stores, GELU: ~a third of the one-block-per-CU kernel's time,
 // during which its CU's matrix pipes idle) overlaps the K loop of the other, at 1.5x the L2 -> LDS bytes per flop.
-template <int NST, int WN, class Ep>
+// SW: the launch computes its tiles with the MFMA operands exchanged (tokens as the A operand): a lane then owns 4 consecutive TOKENS
+// of one feature, the store unit of the V^T fragment layout (wm_epilogues.h: ep_tiles_swapped).  The launcher splits a GEMM whose
+// epilogue wants that for some of its feature tiles into two launches over disjoint tile subsets: tile column index c of a launch
+// is the matrix's feature tile (c / tn_take) * tn_period + tn_off + c % tn_take.  (One kernel with both K loops behind a block-uniform
+// branch spilled accumulators inside the loops.)
+template <int NST, int WN, bool SW, class Ep>
 __global__ void __launch_bounds__(128 * WN, 2)
-k_gemm_256p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32, int tiles_m, int tiles_n, int PM, int PN, int persistent, int dbg, Ep ep)
+k_gemm_256p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32, int tiles_m, int tiles_n, int PM, int PN, int persistent, int dbg,
+            int tn_period, int tn_take, int tn_off, Ep ep)
 {
     // dbg (WM_ENC_GEMM_DBG, measurement only): bit 0 skips the MFMAs, bit 1 the ring refills inside the K loop, bit 2 the epilogue,
     // bit 3 the fragment reads of the K loop (results are then wrong) — what is left shows which part bounds the kernel; bit 4
-    // raises the wave priority around the MFMAs, bit 5 fills the ring of a persistent block's next tile AFTER the epilogue (results
-    // stay right)
+    // raises the wave priority around the MFMAs, bit 5 fills the ring of a persistent block's next tile AFTER the epilogue (results stay
+    // right); bit 6 (launcher): V tiles feature-major like every other tile, one launch (results stay right)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NPIECE = 16 + 4 * WN;         // 16 X fragments (token tiles) then 4 WN W fragments (row tiles), one k-tile
     constexpr int STAGE = NPIECE * 1024;
@@ -293,7 +300,8 @@ k_gemm_256p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32,
 
     auto tile_of = [&](int patch_, int& tm_, int& tn_) {
         const int pn = patch_ / patches_m, pm = patch_ - pn * patches_m;
-        tn_ = pn * PN + within / PM; tm_ = pm * PM + within % PM;
+        const int c = pn * PN + within / PM;
+        tn_ = (c / tn_take) * tn_period + tn_off + c % tn_take; tm_ = pm * PM + within % PM;
     };
     auto stage_load = [&](const bf16_t* xg, const bf16_t* wg, int kt) {
         char* sb = smem + (kt % NST) * STAGE;
@@ -354,7 +362,7 @@ k_gemm_256p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32,
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[i][j] = mfma16(ac[i], bc[j], acc[i][j]);
+                    for (int i = 0; i < 4; ++i) acc[i][j] = SW ? mfma16(bc[j], ac[i], acc[i][j]) : mfma16(ac[i], bc[j], acc[i][j]);
                 if (dbg & 16) __builtin_amdgcn_s_setprio(0);
             }
         };
@@ -378,8 +386,10 @@ k_gemm_256p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32,
                 if (s < NT) stage_load(xg, wg, s);
         }
         const int m0 = tm * 256 + wm * 128 + (lane & 15), n0 = tn * (64 * WN) + wn * 64 + 4 * (lane >> 4);
-        if (!(dbg & 4)) ep_tiles<4, 8>(ep, m0, n0, acc);
-        else if (acc[0][0][0] == 12345.678f) ep.store4(m0, n0, acc[1][1]);      // keeps the accumulators alive
+        if (!(dbg & 4)) {
+            if constexpr (SW) ep_tiles_swapped<4, 8>(ep, m0, n0, acc);
+            else ep_tiles<4, 8>(ep, m0, n0, acc);
+        } else if (acc[0][0][0] == 12345.678f) ep.store4(m0, n0, acc[1][1]);      // keeps the accumulators alive
         if (!more) break;
         if (dbg & 32) {                             // measurement: ring fill after the epilogue (the round-3 call-2 form)
             tile_of(next, tm2, tn2);
@@ -410,8 +420,9 @@ static inline void gemm256_patch(int tiles_m, int tiles_n, int cap, int& PM, int
     }
 }
 
-template <int NST, int WN, class Ep>
-static inline hipError_t launch_gemm_256p_nst(hipStream_t st, const bf16_t* X, const bf16_t* W, int K32, int tiles_m, int tiles_n, const Ep& ep)
+template <int NST, int WN, bool SW, class Ep>
+static inline hipError_t launch_gemm_256p_sub(hipStream_t st, const bf16_t* X, const bf16_t* W, int K32, int tiles_m, int tiles_n, int tn_period, int tn_take,
+                                              int tn_off, int dbg, const Ep& ep)
 {
     constexpr int per_cu = WN == 4 ? 1 : 2;          // resident blocks per CU (LDS: NST stages of 16 + 4 WN KiB)
     constexpr int lds = NST * (16 + 4 * WN) * 1024;
@@ -420,12 +431,29 @@ static inline hipError_t launch_gemm_256p_nst(hipStream_t st, const bf16_t* X, c
     // persistent grid (8 XCDs x 32 CUs x blocks per CU) once there are more tiles than that; WM_ENC_GEMM_PERSIST=0: one tile per block
     const int persist_env = [] { const char* v = std::getenv("WM_ENC_GEMM_PERSIST"); return v ? std::atoi(v) : 1; }();
     const int persistent = (persist_env && tiles_m * tiles_n > 256 * per_cu) ? 1 : 0;
-    const int dbg = [] { const char* v = std::getenv("WM_ENC_GEMM_DBG"); return v ? std::atoi(v) : 0; }();
-    auto kern = k_gemm_256p<NST, WN, Ep>;
+    auto kern = k_gemm_256p<NST, WN, SW, Ep>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(persistent ? 256 * per_cu : tiles_m * tiles_n), dim3(128 * WN), lds, st, X, W, K32, tiles_m, tiles_n, PM, PN, persistent, dbg, ep);
+    hipLaunchKernelGGL(kern, dim3(persistent ? 256 * per_cu : tiles_m * tiles_n), dim3(128 * WN), lds, st, X, W, K32, tiles_m, tiles_n, PM, PN, persistent, dbg,
+                       tn_period, tn_take, tn_off, ep);
     return hipGetLastError();
+}
+
+template <int NST, int WN, class Ep>
+static inline hipError_t launch_gemm_256p_nst(hipStream_t st, const bf16_t* X, const bf16_t* W, int K32, int tiles_m, int tiles_n, const Ep& ep)
+{
+    const int dbg = [] { const char* v = std::getenv("WM_ENC_GEMM_DBG"); return v ? std::atoi(v) : 0; }();
+    // feature tiles the epilogue wants token-major (V of the attention projections): every `period` tiles, the last `period - plain`
+    if constexpr (EpWantsSwap<Ep>::value) {
+        int period = 0, plain = 0;
+        if (!(dbg & 64) && ep_swap_split(ep, 64 * WN, period, plain) && tiles_n % period == 0) {
+            const int reps = tiles_n / period;
+            hipError_t e = launch_gemm_256p_sub<NST, WN, false>(st, X, W, K32, tiles_m, reps * plain, period, plain, 0, dbg, ep);
+            if (e != hipSuccess) return e;
+            return launch_gemm_256p_sub<NST, WN, true>(st, X, W, K32, tiles_m, reps * (period - plain), period, period - plain, plain, dbg, ep);
+        }
+    }
+    return launch_gemm_256p_sub<NST, WN, false>(st, X, W, K32, tiles_m, tiles_n, tiles_n, tiles_n, 0, dbg, ep);
 }
 
 template <class Ep>
@@ -697,6 +725,7 @@ k_flash_enc(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kt, const b
     // ring — two steps are in flight while one is consumed — and read back with lane-linear ds_read_b128.
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NST = 3, STAGE = 16 * 1024;
+    constexpr float kLog2e = 1.4426950408889634f;
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, c = lane & 15;
     const int hd = blockIdx.y, b = blockIdx.z;
@@ -787,15 +816,17 @@ k_flash_enc(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kt, const b
                     float mx = fmaxf(fmaxf(fmaxf(s0[u][0], s0[u][1]), fmaxf(s0[u][2], s0[u][3])), fmaxf(fmaxf(s1[u][0], s1[u][1]), fmaxf(s1[u][2], s1[u][3])));
                     mx = rows4_max(mx);
                     const float m_new = fmaxf(m_run[t], mx);
-                    alpha[u] = __expf(m_run[t] - m_new);
+                    // exp(s - m) = 2^(s log2e - m log2e): one fma + v_exp_f32 per score (the sub / mul / exp form was a fifth more VALU issue
+                    // in a kernel bound by it: ~500 VALU + 72 exp against 64 MFMAs per 64-key step and wave)
+                    const float nml = -m_new * kLog2e;
+                    alpha[u] = __builtin_amdgcn_exp2f(fmaf(m_run[t], kLog2e, nml));
                     float p0[4], p1[4], rs = 0.f;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        p0[r] = __expf(s0[u][r] - m_new); p1[r] = __expf(s1[u][r] - m_new);
+                        p0[r] = __builtin_amdgcn_exp2f(fmaf(s0[u][r], kLog2e, nml)); p1[r] = __builtin_amdgcn_exp2f(fmaf(s1[u][r], kLog2e, nml));
                         rs += p0[r] + p1[r];
                     }
-                    rs = rows4_sum(rs);
-                    l_run[t] = l_run[t] * alpha[u] + rs;
+                    l_run[t] = fmaf(l_run[t], alpha[u], rs);          // this lane's 8 keys per step only: the four g-lanes of a row meet once, at the end
                     m_run[t] = m_new;
                     uint4 pw;
                     pw.x = pack_bf2(p0[0], p0[1]); pw.y = pack_bf2(p0[2], p0[3]);
@@ -820,7 +851,7 @@ k_flash_enc(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kt, const b
     }
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-        const float inv = 1.0f / l_run[t];
+        const float inv = 1.0f / rows4_sum(l_run[t]);
         const int row = b * Spad + q0 + t * 16 + c;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
@@ -833,46 +864,76 @@ k_flash_enc(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kt, const b
 }
 
 // =============================================================================================
-// LayerNorm over many rows -> packed bf16 (one wave per row)
+// LayerNorm over many rows -> packed bf16.  One block per 16-row group of the packed layout; lane (r, g) of wave w holds, for the
+// k-tiles f = w, w + 4, ..., the 8 values k = 32 f + 8 g .. + 7 of row r — the lane layout of the MFMA fragment itself, so the
+// normalised tile leaves as ONE lane-linear 16-byte store per lane: a wave instruction writes a whole 1-KiB fragment.  (The
+// one-wave-per-row form of rounds 1-2 scattered a row over 40 fragments, 16 bytes at a 256-byte stride and 32 requests per store
+// instruction: 119 us per launch at 32 clips = 3.1 TB/s for a kernel that only streams, profiles/r03_kernel_trace_bench_b32.md.)
+// Row statistics: each lane sums its <= 80 values, rows4_sum adds the four g-lanes of a row inside the wave, the four waves' partials
+// meet in LDS (two block barriers: mean, then the centred second moment — the two-pass form of the reference LayerNorm).
 // =============================================================================================
+template <int LN16_MAXF>                           // k-tiles per wave: d <= 4 * 32 * LN16_MAXF
 __global__ void __launch_bounds__(256)
 k_enc_ln(const float* __restrict__ src, const float* __restrict__ gamma, const float* __restrict__ beta,
          bf16_t* __restrict__ out_p, int K32, int d, int M)
 {
-    const int lane = threadIdx.x & 63;
-    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (m >= M) return;
-    const int nv = d >> 2;
-    const float4* sp = reinterpret_cast<const float4*>(src + (size_t)m * d);
-    float4 v[8];
+    __shared__ float part[2][4][16];
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const int w = threadIdx.x >> 6;
+    const int row = blockIdx.x * 16 + r;            // M % 16 == 0 (rows are clips x Spad)
+    const float* sp = src + (size_t)row * d + 8 * g;
+    float4 v[LN16_MAXF][2];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int j = lane + 64 * i;
-        v[i] = (j < nv) ? sp[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-        s += v[i].x + v[i].y + v[i].z + v[i].w;
+    for (int i = 0; i < LN16_MAXF; ++i) {
+        const int f = w + 4 * i;
+        if (f < K32) {
+            v[i][0] = *reinterpret_cast<const float4*>(sp + f * 32);
+            v[i][1] = *reinterpret_cast<const float4*>(sp + f * 32 + 4);
+        } else {
+            v[i][0] = make_float4(0.f, 0.f, 0.f, 0.f); v[i][1] = v[i][0];
+        }
     }
-    const float mean = wave_sum(s) / (float)d;
+#pragma unroll
+    for (int i = 0; i < LN16_MAXF; ++i)
+        s += ((v[i][0].x + v[i][0].y) + (v[i][0].z + v[i][0].w)) + ((v[i][1].x + v[i][1].y) + (v[i][1].z + v[i][1].w));
+    s = rows4_sum(s);
+    if (g == 0) part[0][w][r] = s;
+    __syncthreads();
+    const float mean = ((part[0][0][r] + part[0][1][r]) + (part[0][2][r] + part[0][3][r])) / (float)d;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-        if (lane + 64 * i < nv) {
-            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, e = v[i].w - mean;
-            q += a * a + b * b + c * c + e * e;
+    for (int i = 0; i < LN16_MAXF; ++i)
+        if (w + 4 * i < K32) {
+            const float a0 = v[i][0].x - mean, a1 = v[i][0].y - mean, a2 = v[i][0].z - mean, a3 = v[i][0].w - mean;
+            const float a4 = v[i][1].x - mean, a5 = v[i][1].y - mean, a6 = v[i][1].z - mean, a7 = v[i][1].w - mean;
+            q += ((a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3)) + ((a4 * a4 + a5 * a5) + (a6 * a6 + a7 * a7));
         }
-    const float rstd = rsqrtf(wave_sum(q) / (float)d + 1e-5f);
+    q = rows4_sum(q);
+    if (g == 0) part[1][w][r] = q;
+    __syncthreads();
+    const float rstd = rsqrtf(((part[1][0][r] + part[1][1][r]) + (part[1][2][r] + part[1][3][r])) / (float)d + 1e-5f);
+    bf16_t* op = out_p + (size_t)blockIdx.x * K32 * 512 + lane * 8;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int j = lane + 64 * i;
-        if (j < nv) {
-            const float4 g = reinterpret_cast<const float4*>(gamma)[j];
-            const float4 b = reinterpret_cast<const float4*>(beta)[j];
-            uint2 o;
-            o.x = pack_bf2((v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y);
-            o.y = pack_bf2((v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w);
-            *reinterpret_cast<uint2*>(out_p + packed_index(m, j * 4, K32)) = o;
+    for (int i = 0; i < LN16_MAXF; ++i) {
+        const int f = w + 4 * i;
+        if (f < K32) {
+            const float4 g0 = *reinterpret_cast<const float4*>(gamma + f * 32 + 8 * g), g1 = *reinterpret_cast<const float4*>(gamma + f * 32 + 8 * g + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(beta + f * 32 + 8 * g), b1 = *reinterpret_cast<const float4*>(beta + f * 32 + 8 * g + 4);
+            uint4 o;
+            o.x = pack_bf2((v[i][0].x - mean) * rstd * g0.x + b0.x, (v[i][0].y - mean) * rstd * g0.y + b0.y);
+            o.y = pack_bf2((v[i][0].z - mean) * rstd * g0.z + b0.z, (v[i][0].w - mean) * rstd * g0.w + b0.w);
+            o.z = pack_bf2((v[i][1].x - mean) * rstd * g1.x + b1.x, (v[i][1].y - mean) * rstd * g1.y + b1.y);
+            o.w = pack_bf2((v[i][1].z - mean) * rstd * g1.z + b1.z, (v[i][1].w - mean) * rstd * g1.w + b1.w);
+            *reinterpret_cast<uint4*>(op + (size_t)f * 512) = o;
         }
     }
+}
+
+static inline void launch_enc_ln(hipStream_t st, const float* src, const float* gamma, const float* beta, bf16_t* out_p, int K32, int d, int M)
+{
+    if (K32 <= 40) hipLaunchKernelGGL(k_enc_ln<10>, dim3(M / 16), dim3(256), 0, st, src, gamma, beta, out_p, K32, d, M);
+    else hipLaunchKernelGGL(k_enc_ln<16>, dim3(M / 16), dim3(256), 0, st, src, gamma, beta, out_p, K32, d, M);     // d <= 2048 (wm_create)
 }
 
 // LayerNorm -> fp8 e4m3 operand + one fp32 scale per row (fp8 MFMA GEMMs above).  RB: the LayerNorm output is first rounded to
@@ -1209,7 +1270,7 @@ int wm_enc_encode(wm_ctx* ctx, const float* feats, int B)
             WM_HIP(launch_gemm_f8(st, ctx->exn8, w.qkv_w8, M, 3 * d, K32 / 2,
                                   EpScaled<EpQKVEnc>{EpQKVEnc{ctx->eq, ctx->ek, ctx->evt, w.qkv_b, Spad, H, d}, ctx->exs, w.qkv_ws}));
         } else {
-            hipLaunchKernelGGL(k_enc_ln, dim3((M + 3) / 4), dim3(256), 0, st, ctx->eh, w.ln1_w, w.ln1_b, ctx->exn, K32, d, M);
+            launch_enc_ln(st, ctx->eh, w.ln1_w, w.ln1_b, ctx->exn, K32, d, M);
             WM_HIP(hipGetLastError());
             WM_HIP(launch_gemm_tiled(st, ctx->exn, w.qkv_w, M, 3 * d, K32, EpQKVEnc{ctx->eq, ctx->ek, ctx->evt, w.qkv_b, Spad, H, d}));
         }
@@ -1229,11 +1290,11 @@ int wm_enc_encode(wm_ctx* ctx, const float* feats, int B)
             hipLaunchKernelGGL(k_enc_ln_f8<false>, dim3((M + 3) / 4), dim3(256), 0, st, ctx->eh, w.ln2_w, w.ln2_b, ctx->exn8, ctx->exs, nullptr, K32, d, M);
             WM_HIP(hipGetLastError());
             WM_HIP(launch_gemm_f8(st, ctx->exn8, w.fc1_w8, M, ffn, K32 / 2,
-                                  EpScaled<EpPackedAct<1>>{EpPackedAct<1>{ctx->eff, nullptr, w.fc1_b, ffn / 32, M}, ctx->exs, w.fc1_ws}));
+                                  EpScaled<EpPackedAct<2>>{EpPackedAct<2>{ctx->eff, nullptr, w.fc1_b, ffn / 32, M}, ctx->exs, w.fc1_ws}));
         } else {
-            hipLaunchKernelGGL(k_enc_ln, dim3((M + 3) / 4), dim3(256), 0, st, ctx->eh, w.ln2_w, w.ln2_b, ctx->exn, K32, d, M);
+            launch_enc_ln(st, ctx->eh, w.ln2_w, w.ln2_b, ctx->exn, K32, d, M);
             WM_HIP(hipGetLastError());
-            WM_HIP(launch_gemm_tiled(st, ctx->exn, w.fc1_w, M, ffn, K32, EpPackedAct<1>{ctx->eff, nullptr, w.fc1_b, ffn / 32, M}));
+            WM_HIP(launch_gemm_tiled(st, ctx->exn, w.fc1_w, M, ffn, K32, EpPackedAct<2>{ctx->eff, nullptr, w.fc1_b, ffn / 32, M}));
         }
         WM_HIP(launch_gemm_tiled(st, ctx->eff, w.fc2_w, M, d, ffn / 32, EpResidual{ctx->eh, w.fc2_b, d, M}));
     }
@@ -1245,7 +1306,7 @@ int wm_enc_encode(wm_ctx* ctx, const float* feats, int B)
         WM_HIP(launch_gemm_f8(st, ctx->exn8, ctx->ckv_w8, M, ctx->nkv * 2 * d, K32 / 2,
                               EpScaled<EpCrossKV>{EpCrossKV{ctx->kx, ctx->vx, ctx->ckv_b, Spad, H, d, B}, ctx->exs, ctx->ckv_ws}));
     } else {
-        hipLaunchKernelGGL(k_enc_ln, dim3((M + 3) / 4), dim3(256), 0, st, ctx->eh, ctx->enc_lnf_w, ctx->enc_lnf_b, ctx->enc_out, K32, d, M);
+        launch_enc_ln(st, ctx->eh, ctx->enc_lnf_w, ctx->enc_lnf_b, ctx->enc_out, K32, d, M);
         WM_HIP(hipGetLastError());
         WM_HIP(launch_gemm_tiled(st, ctx->enc_out, ctx->ckv_w, M, ctx->nkv * 2 * d, K32,
                                  EpCrossKV{ctx->kx, ctx->vx, ctx->ckv_b, Spad, H, d, B}));

@@ -41,7 +41,7 @@ struct EpF32 {                 // out[m][n] = (v + bias[n]) * scale   (cross-att
     __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const { fin(m, n, v, pre(m, n)); }
 };
 
-template <int ACT>             // packed bf16 out = act(v + bias)   (fc1 + GELU -> next GEMM's operand)
+template <int ACT>             // packed bf16 out = act(v + bias)   (fc1 + GELU -> next GEMM's operand); ACT 1: decoder (erff), 2: encoder (gelu_phi)
 struct EpPackedAct {           // out_lo != nullptr: decoder path, value kept as a bf16 hi/lo pair
     bf16_t* out; bf16_t* out_lo; const float* bias; int K32out; int M;
     __device__ __forceinline__ EpPre pre(int m, int n) const {
@@ -53,6 +53,7 @@ struct EpPackedAct {           // out_lo != nullptr: decoder path, value kept as
         if (m >= M) return;
         float x0 = v[0] + p.a.x, x1 = v[1] + p.a.y, x2 = v[2] + p.a.z, x3 = v[3] + p.a.w;
         if (ACT == 1) { x0 = gelu_erf(x0); x1 = gelu_erf(x1); x2 = gelu_erf(x2); x3 = gelu_erf(x3); }
+        if (ACT == 2) { x0 = gelu_phi(x0); x1 = gelu_phi(x1); x2 = gelu_phi(x2); x3 = gelu_phi(x3); }
         const size_t o = packed_index(m, n, K32out);
         if (out_lo) { st_hilo4(out + o, out_lo + o, make_float4(x0, x1, x2, x3)); return; }
         uint2 u; u.x = pack_bf2(x0, x1); u.y = pack_bf2(x2, x3);
@@ -143,8 +144,8 @@ struct EpConv1 {               // a1[b][t][n] = gelu(conv1) as row-major bf16 (i
         if (t >= T) return;
         const float4 bb = p.a;
         uint2 o;
-        o.x = pack_bf2(gelu_erf(v[0] + bb.x), gelu_erf(v[1] + bb.y));
-        o.y = pack_bf2(gelu_erf(v[2] + bb.z), gelu_erf(v[3] + bb.w));
+        o.x = pack_bf2(gelu_phi(v[0] + bb.x), gelu_phi(v[1] + bb.y));
+        o.y = pack_bf2(gelu_phi(v[2] + bb.z), gelu_phi(v[3] + bb.w));
         *reinterpret_cast<uint2*>(a1 + ((size_t)b * T + t) * d + n) = o;
     }
 };
@@ -164,8 +165,8 @@ struct EpConv2 {               // h = gelu(conv2) + embed_positions   (HF:modeli
         if (s < S) {
             const float4 bb = p.a;
             const float4 pp = p.b;
-            o = make_float4(gelu_erf(v[0] + bb.x) + pp.x, gelu_erf(v[1] + bb.y) + pp.y,
-                            gelu_erf(v[2] + bb.z) + pp.z, gelu_erf(v[3] + bb.w) + pp.w);
+            o = make_float4(gelu_phi(v[0] + bb.x) + pp.x, gelu_phi(v[1] + bb.y) + pp.y,
+                            gelu_phi(v[2] + bb.z) + pp.z, gelu_phi(v[3] + bb.w) + pp.w);
         }
         *reinterpret_cast<float4*>(h + (size_t)m * d + n) = o;
     }
@@ -241,4 +242,138 @@ __device__ __forceinline__ void ep_tiles(const Ep& ep, int m0, int n0, f32x4_t (
         for (int j = 0; j < NJ; ++j) ep.fin(m0 + j * 16, n0 + i * 16, acc[i][j], pre[j]);
         __builtin_amdgcn_sched_barrier(0);
     }
+}
+
+// ---- wave-level epilogues of the encoder's attention projections -----------------------------------------------------------
+// The per-tile functors above recompute, for each of a wave's 32 output tiles, what is the same for all of them: which clip
+// the token belongs to (an integer division by a run-time Spad per tile), which of q / k / v and which head the feature belongs
+// to, 64-bit slab addresses — ~120 VALU instructions per tile, 3.9 k per wave and 256 x 256 tile, during which the CU's matrix
+// pipes idle (tests/microbench/r03_call10.sh).  A wave's NJ x 16 <= 128 tokens lie in ONE clip (Spad % 128 == 0 and the span is
+// aligned to its size) and its NI x 16 = 64 features in ONE head of ONE of q / k / v (d % 64 == 0, span 64-aligned): the overloads
+// below derive clip, head and slab once per wave and leave two adds and a store per tile.  Same values, same stores: results are
+// bit-identical to the per-tile functors (which the fp8 wrappers and the unit tests still use).
+//
+// `swapped` tiles: the pipelined 256 x 256 kernel computes the feature tiles of V (a launch of their own) with the MFMA operands exchanged
+// (tokens as the A operand), so a lane owns 4 consecutive TOKENS of one feature — exactly the 8-byte unit of the V^T fragment
+// layout (vfrag_index): one plain store per tile where the feature-major orientation needs 12 DPP row shifts, four packs and four
+// masked stores per tile to transpose inside the wave.  a x b and b x a give the same products in the same k order: bit-identical.
+
+template <int NI, int NJ>      // [s][64] slab of one (clip, head): lane (r, g) stores features 4g .. 4g+3 of token r of each tile
+__device__ __forceinline__ void wave_store_rows(bf16_t* __restrict__ row0, const float* __restrict__ bias_w, float scale, bool scaled,
+                                                f32x4_t (&acc)[NI][NJ])
+{
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    float4 bb[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) bb[i] = *reinterpret_cast<const float4*>(bias_w + i * 16 + 4 * g);
+    bf16_t* lp = row0 + r * 64 + 4 * g;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            float x0 = acc[i][j][0] + bb[i].x, x1 = acc[i][j][1] + bb[i].y, x2 = acc[i][j][2] + bb[i].z, x3 = acc[i][j][3] + bb[i].w;
+            if (scaled) { x0 *= scale; x1 *= scale; x2 *= scale; x3 *= scale; }
+            uint2 o; o.x = pack_bf2(x0, x1); o.y = pack_bf2(x2, x3);
+            *reinterpret_cast<uint2*>(lp + j * 1024 + i * 16) = o;
+        }
+}
+
+template <int NI, int NJ>      // V^T fragments from the feature-major orientation (DPP transpose inside the wave, vt_store4)
+__device__ __forceinline__ void wave_store_vt(bf16_t* __restrict__ slab, int s0, const float* __restrict__ bias_w, f32x4_t (&acc)[NI][NJ])
+{
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const bool lead = (r & 3) == 0;              // s0 is a multiple of 16
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const float4 bb = *reinterpret_cast<const float4*>(bias_w + i * 16 + 4 * g);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            vt_store4(slab, s0 + j * 16 + r, i * 16 + 4 * g, acc[i][j][0] + bb.x, acc[i][j][1] + bb.y, acc[i][j][2] + bb.z, acc[i][j][3] + bb.w,
+                      true, lead, !lead);
+    }
+}
+
+template <int NI, int NJ>      // V^T fragments from the token-major (`swapped`) orientation: lane (r, g) holds tokens 4g .. 4g+3 of feature r
+__device__ __forceinline__ void wave_store_vt_swapped(bf16_t* __restrict__ slab, int s0, const float* __restrict__ bias_w, f32x4_t (&acc)[NI][NJ])
+{
+    const int lane = threadIdx.x & 63, r = lane & 15;
+    float bb[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) bb[i] = bias_w[i * 16 + r];
+    bf16_t* lp = slab + lane * 8;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int sj = s0 + j * 16;              // vfrag_index(sj + 4g + e, 16 i + r) = ((sj >> 5) * 4 + i) * 512 + lane * 8 + ((sj >> 4) & 1) * 4 + e
+        bf16_t* pj = lp + (sj >> 5) * 2048 + ((sj >> 4) & 1) * 4;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            uint2 o;
+            o.x = pack_bf2(acc[i][j][0] + bb[i], acc[i][j][1] + bb[i]);
+            o.y = pack_bf2(acc[i][j][2] + bb[i], acc[i][j][3] + bb[i]);
+            *reinterpret_cast<uint2*>(pj + i * 512) = o;
+        }
+    }
+}
+
+struct WaveTile { int b, s0, nt0; };             // clip, first position in the clip and first feature of a wave's tiles (all wave-uniform)
+__device__ __forceinline__ WaveTile wave_tile(int m0, int n0, int Spad) {
+    const int lane = threadIdx.x & 63;
+    const int mt0 = __builtin_amdgcn_readfirstlane(m0 - (lane & 15));
+    WaveTile w; w.nt0 = __builtin_amdgcn_readfirstlane(n0 - 4 * (lane >> 4));
+    w.b = mt0 / Spad; w.s0 = mt0 - w.b * Spad;
+    return w;
+}
+
+// Which feature tiles (of `width` features) an epilogue wants token-major: of every `period` consecutive tiles the last period - plain.
+// Host side: the launcher of the pipelined 256 x 256 kernel splits such a GEMM into two launches (EpWantsSwap<Ep>::value).
+template <class Ep> struct EpWantsSwap { static constexpr bool value = false; };
+template <> struct EpWantsSwap<EpQKVEnc> { static constexpr bool value = true; };
+template <> struct EpWantsSwap<EpCrossKV> { static constexpr bool value = true; };
+static inline bool ep_swap_split(const EpQKVEnc& ep, int width, int& period, int& plain) {
+    if (ep.d % width) return false;
+    period = 3 * ep.d / width; plain = 2 * ep.d / width; return true;
+}
+static inline bool ep_swap_split(const EpCrossKV& ep, int width, int& period, int& plain) {
+    if (ep.d % width) return false;
+    period = 2 * ep.d / width; plain = ep.d / width; return true;
+}
+template <int NI, int NJ, class Ep>              // only reached for the epilogues that ask for swapped tiles
+__device__ __forceinline__ void ep_tiles_swapped(const Ep&, int, int, f32x4_t (&)[NI][NJ]) {}
+
+template <int NI, int NJ>
+__device__ __forceinline__ void ep_tiles(const EpQKVEnc& ep, int m0, int n0, f32x4_t (&acc)[NI][NJ])
+{
+    static_assert(NI == 4, "a wave's features are one 64-wide head");
+    const WaveTile w = wave_tile(m0, n0, ep.Spad);
+    const int seg = w.nt0 / ep.d, c0 = w.nt0 - seg * ep.d;                     // 0: q, 1: k, 2: v;  c0 = 64 * head
+    const size_t head = (size_t)w.b * ep.H + (c0 >> 6);
+    if (seg < 2) wave_store_rows<NI, NJ>((seg == 0 ? ep.q : ep.k) + (head * ep.Spad + w.s0) * 64, ep.bias + w.nt0, 0.125f, seg == 0, acc);
+    else wave_store_vt<NI, NJ>(ep.vt + head * 64 * ep.Spad, w.s0, ep.bias + w.nt0, acc);
+}
+template <int NI, int NJ>
+__device__ __forceinline__ void ep_tiles_swapped(const EpQKVEnc& ep, int m0, int n0, f32x4_t (&acc)[NI][NJ])
+{
+    const WaveTile w = wave_tile(m0, n0, ep.Spad);
+    const int c0 = w.nt0 - 2 * ep.d;
+    wave_store_vt_swapped<NI, NJ>(ep.vt + ((size_t)w.b * ep.H + (c0 >> 6)) * 64 * ep.Spad, w.s0, ep.bias + w.nt0, acc);
+}
+
+template <int NI, int NJ>
+__device__ __forceinline__ void ep_tiles(const EpCrossKV& ep, int m0, int n0, f32x4_t (&acc)[NI][NJ])
+{
+    static_assert(NI == 4, "a wave's features are one 64-wide head");
+    const WaveTile w = wave_tile(m0, n0, ep.Spad);
+    const int kvl = w.nt0 / (2 * ep.d), rem = w.nt0 - kvl * 2 * ep.d;
+    const bool isv = rem >= ep.d;
+    const int c0 = isv ? rem - ep.d : rem;
+    const size_t slab = (((size_t)kvl * ep.B + w.b) * ep.H + (c0 >> 6)) * ep.Spad * 64;
+    if (!isv) wave_store_rows<NI, NJ>(ep.kx + slab + (size_t)w.s0 * 64, ep.bias + w.nt0, 1.0f, false, acc);
+    else wave_store_vt<NI, NJ>(ep.vx + slab, w.s0, ep.bias + w.nt0, acc);
+}
+template <int NI, int NJ>
+__device__ __forceinline__ void ep_tiles_swapped(const EpCrossKV& ep, int m0, int n0, f32x4_t (&acc)[NI][NJ])
+{
+    const WaveTile w = wave_tile(m0, n0, ep.Spad);
+    const int kvl = w.nt0 / (2 * ep.d), c0 = w.nt0 - kvl * 2 * ep.d - ep.d;
+    wave_store_vt_swapped<NI, NJ>(ep.vx + (((size_t)kvl * ep.B + w.b) * ep.H + (c0 >> 6)) * ep.Spad * 64, w.s0, ep.bias + w.nt0, acc);
 }
