@@ -38,6 +38,9 @@ def main():
     ap.add_argument("--enc-only-batch", action="store_true", help="encoder legs at the full batch only")
     ap.add_argument("--enc-knobs", action="store_true", help="encoder legs: result-preserving knobs of the pipelined GEMM")
     ap.add_argument("--enc-now", action="store_true", help="encoder legs: the shipped configuration, and the V tiles feature-major (one launch, DPP transpose)")
+    ap.add_argument("--enc-r3b", action="store_true", help="encoder legs: residual GEMMs with the classic epilogue; flash-attention variants")
+    ap.add_argument("--enc-default", action="store_true", help="encoder legs: the shipped configuration only (profiling runs)")
+    ap.add_argument("--enc-stagger", action="store_true", help="encoder legs: every other block of the pipelined GEMM starts late (epilogues out of phase)")
     ap.add_argument("--enc-dbg", action="store_true", help="encoder legs with parts of the pipelined GEMM switched off (WM_ENC_GEMM_DBG)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r03_sweep.json"))
     args = ap.parse_args()
@@ -114,6 +117,14 @@ def main():
                             ("wn2_no_epilogue", dict(WM_ENC_GEMM_WN=2, WM_ENC_GEMM_DBG=4))]
             if args.enc_now:
                 variants = [("default", dict(WM_ENC_GEMM_DBG=0)), ("v_tiles_feature_major", dict(WM_ENC_GEMM_DBG=64))]
+            if args.enc_r3b:
+                variants = [("default", dict(WM_ENC_GEMM_DBG=0)), ("residual_classic_epilogue", dict(WM_ENC_GEMM_DBG=128)),
+                            ("flash_groups_of_4", dict(WM_FLASH_VARIANT=1)), ("flash_3_blocks_per_cu", dict(WM_FLASH_VARIANT=2)),
+                            ("flash_3_blocks_per_cu_groups_of_1", dict(WM_FLASH_VARIANT=3))]
+            if args.enc_default:
+                variants = [("default", dict(WM_ENC_GEMM_DBG=0))]
+            if args.enc_stagger:
+                variants = [("default", dict(WM_ENC_GEMM_DBG=0))] + [(f"odd_blocks_late_{n * 3.4:.0f}us", dict(WM_ENC_GEMM_DBG=n << 8)) for n in (3, 6, 10)]
             if args.enc_dbg and nb > 1:
                 variants = [("full", dict(WM_ENC_GEMM_DBG=0)), ("no_mfma", dict(WM_ENC_GEMM_DBG=1)), ("no_refill", dict(WM_ENC_GEMM_DBG=2)),
                             ("no_epilogue", dict(WM_ENC_GEMM_DBG=4)), ("no_frag_reads", dict(WM_ENC_GEMM_DBG=8)),

@@ -269,7 +269,8 @@ k_gemm_256p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32,
     // dbg (WM_ENC_GEMM_DBG, measurement only): bit 0 skips the MFMAs, bit 1 the ring refills inside the K loop, bit 2 the epilogue,
     // bit 3 the fragment reads of the K loop (results are then wrong) — what is left shows which part bounds the kernel; bit 4
     // raises the wave priority around the MFMAs, bit 5 fills the ring of a persistent block's next tile AFTER the epilogue (results stay
-    // right); bit 6 (launcher): V tiles feature-major like every other tile, one launch (results stay right)
+    // right); bit 6 (launcher): V tiles feature-major like every other tile, one launch (results stay right); bit 7: residual GEMMs
+    // with zeroed accumulators and the read-modify-write epilogue (results right, summation order of the few-clip kernels)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NPIECE = 16 + 4 * WN;         // 16 X fragments (token tiles) then 4 WN W fragments (row tiles), one k-tile
     constexpr int STAGE = NPIECE * 1024;
@@ -297,6 +298,10 @@ k_gemm_256p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32,
         patch = id / per_patch; within = id - patch * per_patch; patch_step = n_patches;
     }
     if (within >= per_patch) return;            // spare slots of a persistent grid (patches of fewer than 32 tiles)
+    // measurement (dbg >> 8 = n): every other block of an XCD starts n x 3.4 us late, so that the blocks are not all in their
+    // epilogue (the HBM-heavy phase) at the same time
+    if ((dbg >> 8) && ((blockIdx.x >> 3) & 1))
+        for (int i = 0; i < (dbg >> 8); ++i) __builtin_amdgcn_s_sleep(127);
 
     auto tile_of = [&](int patch_, int& tm_, int& tn_) {
         const int pn = patch_ / patches_m, pm = patch_ - pn * patches_m;
@@ -330,12 +335,20 @@ k_gemm_256p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32,
     for (int s = 0; s < NST; ++s)
         if (s < NT) stage_load(xg, wg, s);
 
+    // residual GEMMs: the accumulators start as the residual tile (wm_epilogues.h: EpAccInit); dbg bit 7 keeps the classic epilogue
+    constexpr bool kAccInit = EpAccInit<Ep>::value && !SW;
+    const bool acc_init = kAccInit && !(dbg & 128);
     for (;;) {
         f32x4_t acc[4][8];
+        const int m0 = tm * 256 + wm * 128 + (lane & 15), n0 = tn * (64 * WN) + wn * 64 + 4 * (lane >> 4);
+        if (acc_init) {
+            ep_acc_init<4, 8>(ep, m0, n0, acc);
+        } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
 
         // stage 0 -> registers.  (A later tile of a persistent block: its first NST stages were requested before the previous tile's
         // epilogue; the stores of that epilogue are younger entries of the same counter, which only makes this wait conservative.)
@@ -385,9 +398,9 @@ k_gemm_256p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32,
             for (int s = 0; s < NST; ++s)
                 if (s < NT) stage_load(xg, wg, s);
         }
-        const int m0 = tm * 256 + wm * 128 + (lane & 15), n0 = tn * (64 * WN) + wn * 64 + 4 * (lane >> 4);
         if (!(dbg & 4)) {
             if constexpr (SW) ep_tiles_swapped<4, 8>(ep, m0, n0, acc);
+            else if (acc_init) ep_tiles_init<4, 8>(ep, m0, n0, acc);
             else ep_tiles<4, 8>(ep, m0, n0, acc);
         } else if (acc[0][0][0] == 12345.678f) ep.store4(m0, n0, acc[1][1]);      // keeps the accumulators alive
         if (!more) break;
@@ -715,8 +728,10 @@ static inline hipError_t launch_gemm_f8(hipStream_t st, const unsigned char* X, 
 //   k-slot <-> key assignment is permuted identically in the V^T fragment and the P fragment, so no
 //   cross-lane movement is needed.  q is pre-scaled; fp32 softmax; P rounded to bf16.
 // =============================================================================================
-template <int QT>                 // QT x 16 queries per wave: every K / V^T fragment is reused by QT query tiles
-__global__ void __launch_bounds__(256)
+// QT x 16 queries per wave: every K / V^T fragment is reused by QT query tiles; G = query tiles per softmax phase group; OCC = waves per
+// SIMD the register allocation aims at (3: <= 168 VGPRs, three resident blocks per CU)
+template <int QT, int G = (QT >= 2 ? 2 : 1), int OCC = 2>
+__global__ void __launch_bounds__(256, OCC)
 k_flash_enc(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kt, const bf16_t* __restrict__ Vf,
             bf16_t* __restrict__ out, int S, int Spad, int H, int K32out)
 {
@@ -788,7 +803,6 @@ k_flash_enc(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kt, const b
             // ONE rescale decision, then its PV MFMAs — so the tiles' dependent chains (MFMA -> row max across lanes -> exp -> row sum
             // -> convert -> MFMA) interleave.  Tile by tile with a rescale branch inside (round 2), every tile was its own scheduling
             // region and its chain latency was exposed: the kernel sat at ~37 % of its VALU bound.
-            constexpr int G = QT >= 2 ? 2 : 1;             // tiles per phase group (4 at once needed 264 registers: one block per CU)
 #pragma unroll
             for (int t0 = 0; t0 < QT; t0 += G) {
                 f32x4_t s0[G], s1[G];
@@ -1278,8 +1292,14 @@ int wm_enc_encode(wm_ctx* ctx, const float* feats, int B)
         // blocks; with one or two clips 64 (QT = 1): twice the blocks of the 128-query form, two or three resident per CU, so
         // one block's softmax (VALU) overlaps another's MFMAs — at one wave per SIMD nothing did
         static const int qt1_below = [] { const char* v = std::getenv("WM_FLASH_QT1_BELOW"); return v ? std::atoi(v) : 256; }();     // one clip: 6.63 -> 6.42 ms per encoder pass
-        if (B * (Spad / 128) * H >= 256 && Spad % 256 == 0)
-            hipLaunchKernelGGL(k_flash_enc<4>, dim3(Spad / 256, H, B), dim3(256), 3 * 16 * 1024, st, ctx->eq, ctx->ek, ctx->evt, ctx->exn, S, Spad, H, K32);
+        const int flash_var = [] { const char* v = std::getenv("WM_FLASH_VARIANT"); return v ? std::atoi(v) : 0; }();   // measurement: 1 = groups of 4, 2 = three blocks per CU, 3 = both
+        if (B * (Spad / 128) * H >= 256 && Spad % 256 == 0) {
+            const dim3 grid(Spad / 256, H, B);
+            if (flash_var == 1) hipLaunchKernelGGL((k_flash_enc<4, 4, 2>), grid, dim3(256), 3 * 16 * 1024, st, ctx->eq, ctx->ek, ctx->evt, ctx->exn, S, Spad, H, K32);
+            else if (flash_var == 2) hipLaunchKernelGGL((k_flash_enc<4, 2, 3>), grid, dim3(256), 3 * 16 * 1024, st, ctx->eq, ctx->ek, ctx->evt, ctx->exn, S, Spad, H, K32);
+            else if (flash_var == 3) hipLaunchKernelGGL((k_flash_enc<4, 1, 3>), grid, dim3(256), 3 * 16 * 1024, st, ctx->eq, ctx->ek, ctx->evt, ctx->exn, S, Spad, H, K32);
+            else hipLaunchKernelGGL(k_flash_enc<4>, grid, dim3(256), 3 * 16 * 1024, st, ctx->eq, ctx->ek, ctx->evt, ctx->exn, S, Spad, H, K32);
+        }
         else if (B * (Spad / 128) * H < qt1_below)
             hipLaunchKernelGGL(k_flash_enc<1>, dim3(Spad / 64, H, B), dim3(256), 3 * 16 * 1024, st, ctx->eq, ctx->ek, ctx->evt, ctx->exn, S, Spad, H, K32);
         else

@@ -377,3 +377,60 @@ __device__ __forceinline__ void ep_tiles_swapped(const EpCrossKV& ep, int m0, in
     const int kvl = w.nt0 / (2 * ep.d), c0 = w.nt0 - kvl * 2 * ep.d - ep.d;
     wave_store_vt_swapped<NI, NJ>(ep.vx + (((size_t)kvl * ep.B + w.b) * ep.H + (c0 >> 6)) * ep.Spad * 64, w.s0, ep.bias + w.nt0, acc);
 }
+
+// Residual GEMMs (out-proj, FC2: h += bias + X W^T) in the pipelined 256 x 256 kernel: the accumulators START as the residual tile.
+// The generic epilogue reads h in NI batches of NJ loads per wave, 64 KiB in flight per CU, each batch a memory round trip (and the
+// acknowledgement of the previous batch's stores: loads and stores share one counter) with the CU's matrix pipes idle: 34 us per
+// block tile, half of the K = 1280 GEMM's time (596 TFLOP/s against 840-930 for the other GEMMs, profiles/r03_kernel_trace_encoder_b32.md;
+// starting every other block late did not help — it is latency x bytes-in-flight per CU, not HBM contention).  More loads in flight
+// need registers the epilogue does not have (128 accumulators; batches of 16 loads made the allocator spill the accumulators).  Loading
+// the tile INTO the accumulators before the K loop costs no register, puts all 32 loads of a wave in flight at once, and leaves an
+// epilogue of one add and one store per tile, behind no load.  Numerics: h + (p_1 + ... + p_n) + bias becomes ((h + p_1) + ... + p_n)
+// + bias — the same fp32 terms in another order (one rounding per MFMA at the magnitude of h instead of one at the end; the residual
+// stream is O(1-100), so <= 1e-5 absolute per layer against bf16-rounded operands downstream) — inside the encoder tolerance of the
+// parity tests, and the few-clip kernels keep the classic order (big-batch and few-clip outputs never were bit-identical: different
+// tile shapes).
+template <class Ep> struct EpAccInit { static constexpr bool value = false; };
+template <> struct EpAccInit<EpResidual> { static constexpr bool value = true; };
+
+template <int NI, int NJ, class Ep>
+__device__ __forceinline__ void ep_acc_init(const Ep&, int, int, f32x4_t (&)[NI][NJ]) {}
+template <int NI, int NJ, class Ep>
+__device__ __forceinline__ void ep_tiles_init(const Ep&, int, int, f32x4_t (&)[NI][NJ]) {}
+
+template <int NI, int NJ>
+__device__ __forceinline__ void ep_acc_init(const EpResidual& ep, int m0, int n0, f32x4_t (&acc)[NI][NJ])
+{
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const int mt0 = __builtin_amdgcn_readfirstlane(m0 - r), nt0 = __builtin_amdgcn_readfirstlane(n0 - 4 * g);
+    const char* hb = reinterpret_cast<const char*>(ep.h + (size_t)mt0 * ep.ld + nt0);      // wave-uniform base, 32-bit lane offsets
+    // the lane offsets are recomputed per tile on purpose (opaque copy of the lane's row): as loop invariants they were hoisted out of
+    // the tile loop, spilled across the 256-VGPR K loop, and every reload's s_waitcnt vmcnt(0) cut the 32 loads into 8 round trips
+    int rv = r;
+    asm volatile("" : "+v"(rv));
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const unsigned off = (unsigned)(((j * 16 + rv) * ep.ld + 4 * g) * 4);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) acc[i][j] = *reinterpret_cast<const f32x4_t*>(hb + off + i * 64);
+    }
+}
+template <int NI, int NJ>
+__device__ __forceinline__ void ep_tiles_init(const EpResidual& ep, int m0, int n0, f32x4_t (&acc)[NI][NJ])
+{
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const int mt0 = __builtin_amdgcn_readfirstlane(m0 - r), nt0 = __builtin_amdgcn_readfirstlane(n0 - 4 * g);
+    char* hb = reinterpret_cast<char*>(ep.h + (size_t)mt0 * ep.ld + nt0);
+    float4 bb[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) bb[i] = *reinterpret_cast<const float4*>(ep.bias + nt0 + 4 * g + i * 16);
+    int rv = r;
+    asm volatile("" : "+v"(rv));                   // (see ep_acc_init)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const unsigned off = (unsigned)(((j * 16 + rv) * ep.ld + 4 * g) * 4);
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            *reinterpret_cast<float4*>(hb + off + i * 64) = make_float4(acc[i][j][0] + bb[i].x, acc[i][j][1] + bb[i].y, acc[i][j][2] + bb[i].z, acc[i][j][3] + bb[i].w);
+    }
+}
