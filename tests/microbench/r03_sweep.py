@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--enc-knobs", action="store_true", help="encoder legs: result-preserving knobs of the pipelined GEMM")
     ap.add_argument("--enc-now", action="store_true", help="encoder legs: the shipped configuration, and the V tiles feature-major (one launch, DPP transpose)")
     ap.add_argument("--enc-r3b", action="store_true", help="encoder legs: residual GEMMs with the classic epilogue; flash-attention variants")
+    ap.add_argument("--enc-order", action="store_true", help="encoder legs: strip-major tile order against strips of one column (the old 32 x 1 patches)")
     ap.add_argument("--enc-default", action="store_true", help="encoder legs: the shipped configuration only (profiling runs)")
     ap.add_argument("--enc-stagger", action="store_true", help="encoder legs: every other block of the pipelined GEMM starts late (epilogues out of phase)")
     ap.add_argument("--enc-dbg", action="store_true", help="encoder legs with parts of the pipelined GEMM switched off (WM_ENC_GEMM_DBG)")
@@ -121,6 +122,8 @@ def main():
                 variants = [("default", dict(WM_ENC_GEMM_DBG=0)), ("residual_classic_epilogue", dict(WM_ENC_GEMM_DBG=128)),
                             ("flash_groups_of_4", dict(WM_FLASH_VARIANT=1)), ("flash_3_blocks_per_cu", dict(WM_FLASH_VARIANT=2)),
                             ("flash_3_blocks_per_cu_groups_of_1", dict(WM_FLASH_VARIANT=3))]
+            if args.enc_order:
+                variants = [("default", dict(WM_ENC_GEMM_PN=0)), ("strips_of_1_like_32x1_patches", dict(WM_ENC_GEMM_PN=1)), ("flash_groups_of_4", dict(WM_FLASH_VARIANT=1))]
             if args.enc_default:
                 variants = [("default", dict(WM_ENC_GEMM_DBG=0))]
             if args.enc_stagger:

@@ -249,9 +249,9 @@ k_gemm_256(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32, 
 //     and then issues the 32 MFMAs of step t from the registers filled one step earlier — LDS latency and the LDS pipe's
 //     transfer time (8 waves x 12 KiB per step) sit under the matrix pipe instead of in front of it.  PMC of the round-2
 //     kernel: matrix pipes 29-33 % busy, waves parked in s_waitcnt / s_barrier half of their cycles.
-//   * blockIdx -> tile: an XCD (32 CUs, one private L2) walks PM x PN patches of tiles, so the ~32 blocks resident on it
-//     share PM token panels and PN weight panels through its L2 (PM + PN panels enter the L2 per patch instead of PM*PN + 1:
-//     with the panel-major order every resident block streamed its own token panel from the Infinity Cache).
+//   * blockIdx -> tile: an XCD (32 CUs, one private L2) walks the tiles strip-major, so the ~32 blocks resident on it work on a
+//     compact patch and share ~6 token panels and ~5 weight panels through its L2 (with the panel-major order every resident block
+//     streamed its own token panel from the Infinity Cache).
 // =============================================================================================
 // WN = feature-wave columns: 4 -> 256 x 256 tile, 8 waves, one block per CU; 2 -> 256 tokens x 128 features, 4 waves (one per SIMD),
 // 24 KiB stages, TWO blocks per CU: the epilogue of one block (HBM stores, GELU: ~a third of the one-block-per-CU kernel's time,
@@ -263,7 +263,7 @@ k_gemm_256(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32, 
 // branch spilled accumulators inside the loops.)
 template <int NST, int WN, bool SW, class Ep>
 __global__ void __launch_bounds__(128 * WN, 2)
-k_gemm_256p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32, int tiles_m, int tiles_n, int PM, int PN, int persistent, int dbg,
+k_gemm_256p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32, int tiles_m, int tiles_n, int PN, int persistent, int dbg,
             int tn_period, int tn_take, int tn_off, Ep ep)
 {
     // dbg (WM_ENC_GEMM_DBG, measurement only): bit 0 skips the MFMAs, bit 1 the ring refills inside the K loop, bit 2 the epilogue,
@@ -279,34 +279,35 @@ k_gemm_256p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32,
     const int lane = threadIdx.x & 63;
     const int wa = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wa / WN, wn = wa - wm * WN;
-    const int per_patch = PM * PN, patches_m = tiles_m / PM;        // the launcher picks PM | tiles_m, PN | tiles_n
-    const int n_patches = patches_m * (tiles_n / PN);
     const int NT = K32;                         // stages (even; the launcher checks)
-    // Tile(s) of this block.  XCD x = blockIdx % 8 (observed placement; only speed depends on it).
-    //  persistent (grid = 8 XCDs x 32 slots, one block per CU): the 32 blocks of an XCD walk the patches x, x+8, ... together, slot c
-    //   taking tile c of the patch; a block fills the ring of its next tile before it runs the epilogue of the current one.
-    //   Measured (profiles/r03_pmc_l2_encoder_gemms.md): the patch order halves the L2 misses of the round-2 panel-major order
-    //   (FC1: 24 M -> 11 M per launch, hit rate 0.62 -> 0.80); persistent or not makes no difference to the misses.
-    //  otherwise: one tile per block, patch-major order, XCD x owns a contiguous range of it (bijective for any grid).
-    int patch, within, patch_step;
-    if (persistent) {                           // grid = 8 XCDs x (32 CUs x blocks per CU) slots
-        patch = blockIdx.x & 7; within = blockIdx.x >> 3; patch_step = 8;
-    } else {
-        const int nwg = tiles_m * tiles_n;
-        const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
-        const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-        patch = id / per_patch; within = id - patch * per_patch; patch_step = n_patches;
+    // Tile order.  Tiles are numbered strip-major: the feature tiles are cut into strips of PN columns and, inside a strip, tile
+    // (tm, tn) has the number tm * PN + tn % PN — any 32 consecutive numbers are ~32 / PN token panels x PN weight panels, a compact
+    // patch.  XCD x = blockIdx % 8 (observed placement; only speed depends on it) owns a contiguous eighth of the numbers:
+    //  persistent (grid = 8 XCDs x 32 CUs x blocks per CU): the S blocks of an XCD take the numbers start + slot, + S, + 2 S, ...: at any
+    //   time they work on S consecutive numbers and share ~32 / PN + PN operand panels through the XCD's L2;
+    //  otherwise one tile per block, XCD x walking its eighth in order (bijective for any grid).
+    // (Until call 12 of round 3 a patch was PM x PN tiles with PM * PN as close to 32 as the divisors allowed: for 5 feature tiles that
+    // is 32 x 1 — 33 panels per 32 tiles, every token panel read 5 times from beyond the L2: the residual and QKV GEMMs pulled 4.1-4.5
+    // TB/s through the fabric at L2 hit rates of 0.53 / 0.69, profiles/r03_pmc_l2_encoder_gemms.md.)
+    const int T = tiles_m * tiles_n;
+    int id, id_end, id_step;
+    {
+        const int xcd = blockIdx.x & 7, q = T >> 3, r = T & 7;
+        const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        if (persistent) { id = start + (blockIdx.x >> 3); id_end = start + q + (xcd < r ? 1 : 0); id_step = gridDim.x >> 3; }
+        else { id = start + (blockIdx.x >> 3); id_end = id + 1; id_step = 1; }
     }
-    if (within >= per_patch) return;            // spare slots of a persistent grid (patches of fewer than 32 tiles)
+    if (id >= id_end) return;
     // measurement (dbg >> 8 = n): every other block of an XCD starts n x 3.4 us late, so that the blocks are not all in their
-    // epilogue (the HBM-heavy phase) at the same time
+    // epilogue at the same time (no gain: profiles/r03_encoder_gemm_parts.md)
     if ((dbg >> 8) && ((blockIdx.x >> 3) & 1))
         for (int i = 0; i < (dbg >> 8); ++i) __builtin_amdgcn_s_sleep(127);
-
-    auto tile_of = [&](int patch_, int& tm_, int& tn_) {
-        const int pn = patch_ / patches_m, pm = patch_ - pn * patches_m;
-        const int c = pn * PN + within / PM;
-        tn_ = (c / tn_take) * tn_period + tn_off + c % tn_take; tm_ = pm * PM + within % PM;
+    const int strip = tiles_m * PN;
+    auto tile_of = [&](int id_, int& tm_, int& tn_) {
+        const int sb = id_ / strip, rem = id_ - sb * strip;
+        tm_ = rem / PN;
+        const int c = sb * PN + (rem - tm_ * PN);
+        tn_ = (c / tn_take) * tn_period + tn_off + c % tn_take;
     };
     auto stage_load = [&](const bf16_t* xg, const bf16_t* wg, int kt) {
         char* sb = smem + (kt % NST) * STAGE;
@@ -328,7 +329,7 @@ k_gemm_256p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32,
     };
 
     int tm, tn;
-    tile_of(patch, tm, tn);
+    tile_of(id, tm, tn);
     const bf16_t* xg = X + (size_t)tm * 16 * K32 * 512 + lane * 8;
     const bf16_t* wg = W + (size_t)tn * (4 * WN) * K32 * 512 + lane * 8;
 #pragma unroll
@@ -387,8 +388,8 @@ k_gemm_256p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32,
         // next tile of a persistent block: its first stages go out BEFORE this tile's epilogue (every wave has passed the last barrier
         // of the K loop: nobody reads the ring any more, except for the unused trailing request), so the ring fill — and the memory
         // latency in front of it — hides behind the epilogue's loads and stores
-        const int next = patch + patch_step;
-        const bool more = next < n_patches;
+        const int next = id + id_step;
+        const bool more = next < id_end;
         int tm2 = tm, tn2 = tn;
         if (more && !(dbg & 32)) {
             tile_of(next, tm2, tn2);
@@ -413,24 +414,22 @@ k_gemm_256p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32,
             for (int s = 0; s < NST; ++s)
                 if (s < NT) stage_load(xg, wg, s);
         }
-        patch = next; tm = tm2; tn = tn2;
+        id = next; tm = tm2; tn = tn2;
     }
 }
 
-// patch of the XCD-aware tile order: PM | tiles_m, PN | tiles_n, PM * PN <= cap (the blocks resident on one XCD) as large as possible;
-// among equals the most square one (PM + PN operand panels enter the L2 per patch)
-static inline void gemm256_patch(int tiles_m, int tiles_n, int cap, int& PM, int& PN)
+// strip width of the tile order: the divisor PN of tiles_n that minimises the operand panels per 32 consecutive tiles, 32 / PN + PN
+static inline int gemm256_strip(int tiles_n)
 {
-    PM = 1; PN = 1;
-    int best = 0, best_sum = 1 << 30;
-    for (int pn = 1; pn <= cap && pn <= tiles_n; ++pn) {
+    const int forced = [] { const char* v = std::getenv("WM_ENC_GEMM_PN"); return v ? std::atoi(v) : 0; }();      // measurement (1 = the 32 x 1 patches of before)
+    if (forced > 0 && tiles_n % forced == 0) return forced;
+    int best = 1; float best_cost = 33.f;
+    for (int pn = 1; pn <= tiles_n && pn <= 32; ++pn) {
         if (tiles_n % pn) continue;
-        for (int pm = 1; pm * pn <= cap && pm <= tiles_m; ++pm) {
-            if (tiles_m % pm) continue;
-            const int prod = pm * pn, sum = pm + pn;
-            if (prod > best || (prod == best && sum < best_sum)) { best = prod; best_sum = sum; PM = pm; PN = pn; }
-        }
+        const float cost = 32.f / pn + pn;
+        if (cost < best_cost) { best_cost = cost; best = pn; }
     }
+    return best;
 }
 
 template <int NST, int WN, bool SW, class Ep>
@@ -439,15 +438,14 @@ static inline hipError_t launch_gemm_256p_sub(hipStream_t st, const bf16_t* X, c
 {
     constexpr int per_cu = WN == 4 ? 1 : 2;          // resident blocks per CU (LDS: NST stages of 16 + 4 WN KiB)
     constexpr int lds = NST * (16 + 4 * WN) * 1024;
-    int PM, PN;
-    gemm256_patch(tiles_m, tiles_n, 32 * per_cu, PM, PN);
+    const int PN = gemm256_strip(tiles_n);
     // persistent grid (8 XCDs x 32 CUs x blocks per CU) once there are more tiles than that; WM_ENC_GEMM_PERSIST=0: one tile per block
     const int persist_env = [] { const char* v = std::getenv("WM_ENC_GEMM_PERSIST"); return v ? std::atoi(v) : 1; }();
     const int persistent = (persist_env && tiles_m * tiles_n > 256 * per_cu) ? 1 : 0;
     auto kern = k_gemm_256p<NST, WN, SW, Ep>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(persistent ? 256 * per_cu : tiles_m * tiles_n), dim3(128 * WN), lds, st, X, W, K32, tiles_m, tiles_n, PM, PN, persistent, dbg,
+    hipLaunchKernelGGL(kern, dim3(persistent ? 256 * per_cu : tiles_m * tiles_n), dim3(128 * WN), lds, st, X, W, K32, tiles_m, tiles_n, PN, persistent, dbg,
                        tn_period, tn_take, tn_off, ep);
     return hipGetLastError();
 }
