@@ -6,7 +6,7 @@
 #include <cstdlib>
 #include <vector>
 #include <type_traits>
-#include "wm_epilogues.h"
+#include "wm_enc_epilogues.h"
 
 // =============================================================================================
 // Tiled GEMM  out[m][n] = sum_k X[m][k] W[n][k],  X/W packed bf16.  128x128 tile, BK=64, 4 waves (2x2),
