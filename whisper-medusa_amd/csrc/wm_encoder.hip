@@ -942,8 +942,53 @@ k_enc_ln(const float* __restrict__ src, const float* __restrict__ gamma, const f
     }
 }
 
+// One wave per row (the form of rounds 1-2): with one or two clips the 16-row-group kernel is only 96-192 blocks of serial phases
+// (10.3 us per launch against 6.8 for this one, profiles/r03_kernel_trace_bench_b1.md); its scattered 16-byte stores do not matter at
+// that size.  Same two-pass statistics, another summation order (big-batch and few-clip encoder outputs are not bit-identical anyway).
+__global__ void __launch_bounds__(256)
+k_enc_ln_rows(const float* __restrict__ src, const float* __restrict__ gamma, const float* __restrict__ beta,
+              bf16_t* __restrict__ out_p, int K32, int d, int M)
+{
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int nv = d >> 2;
+    const float4* sp = reinterpret_cast<const float4*>(src + (size_t)m * d);
+    float4 v[8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int j = lane + 64 * i;
+        v[i] = (j < nv) ? sp[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (lane + 64 * i < nv) {
+            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, e = v[i].w - mean;
+            q += a * a + b * b + c * c + e * e;
+        }
+    const float rstd = rsqrtf(wave_sum(q) / (float)d + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int j = lane + 64 * i;
+        if (j < nv) {
+            const float4 g = reinterpret_cast<const float4*>(gamma)[j];
+            const float4 b = reinterpret_cast<const float4*>(beta)[j];
+            uint2 o;
+            o.x = pack_bf2((v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y);
+            o.y = pack_bf2((v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w);
+            *reinterpret_cast<uint2*>(out_p + packed_index(m, j * 4, K32)) = o;
+        }
+    }
+}
+
 static inline void launch_enc_ln(hipStream_t st, const float* src, const float* gamma, const float* beta, bf16_t* out_p, int K32, int d, int M)
 {
+    static const int rows_below = [] { const char* v = std::getenv("WM_ENC_LN_ROWS_BELOW"); return v ? std::atoi(v) : 256; }();   // 16-row groups
+    if (M / 16 < rows_below) { hipLaunchKernelGGL(k_enc_ln_rows, dim3((M + 3) / 4), dim3(256), 0, st, src, gamma, beta, out_p, K32, d, M); return; }
     if (K32 <= 40) hipLaunchKernelGGL(k_enc_ln<10>, dim3(M / 16), dim3(256), 0, st, src, gamma, beta, out_p, K32, d, M);
     else hipLaunchKernelGGL(k_enc_ln<16>, dim3(M / 16), dim3(256), 0, st, src, gamma, beta, out_p, K32, d, M);     // d <= 2048 (wm_create)
 }
