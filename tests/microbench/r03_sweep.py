@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--streams", type=int, default=32)
     ap.add_argument("--tile-shapes", action="store_true", help="sweep every (F, TT) shape of the tile kernel at the full row count")
     ap.add_argument("--enc-only-batch", action="store_true", help="encoder legs at the full batch only")
+    ap.add_argument("--enc-one-clip", action="store_true", help="encoder legs at one clip only (process-wide knobs come from the environment)")
     ap.add_argument("--enc-knobs", action="store_true", help="encoder legs: result-preserving knobs of the pipelined GEMM")
     ap.add_argument("--enc-now", action="store_true", help="encoder legs: the shipped configuration, and the V tiles feature-major (one launch, DPP transpose)")
     ap.add_argument("--enc-r3b", action="store_true", help="encoder legs: residual GEMMs with the classic epilogue; flash-attention variants")
@@ -105,6 +106,8 @@ def main():
             wav = torch.from_numpy(np.stack([synth.synth_clip(900 + j, n_samp) for j in range(nb)])).to(dev)
             feats = eng.logmel(wav)
             if nb == 1 and args.enc_only_batch:
+                continue
+            if nb > 1 and args.enc_one_clip:
                 continue
             variants = [("r02_256", dict(WM_ENC_GEMM_256P=0)), ("p_tile_per_block", dict(WM_ENC_GEMM_256P=1, WM_ENC_GEMM_PERSIST=0)),
                         ("p_persist_ring4", dict(WM_ENC_GEMM_256P=1, WM_ENC_GEMM_PERSIST=1, WM_ENC_GEMM_RING=4)),
