@@ -558,6 +558,26 @@ struct EpScaled {              // fp8 GEMM: dequantise the accumulator (token-ro
     __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const { fin(m, n, v, pre(m, n)); }
 };
 
+// A wave's tiles of an fp8 GEMM: dequantise the accumulators in place (token-row scale, then weight-row scale: the order of
+// EpScaled::fin), then the wave-level epilogue of the wrapped functor (wm_enc_epilogues.h) — bit-identical to the per-tile path.
+template <int NI, int NJ, class E>
+__device__ __forceinline__ void ep_tiles(const EpScaled<E>& e, int m0, int n0, f32x4_t (&acc)[NI][NJ])
+{
+    float xs[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) xs[j] = e.xs[m0 + j * 16];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const float4 w = *reinterpret_cast<const float4*>(e.ws + n0 + i * 16);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            f32x4_t& a = acc[i][j];
+            a[0] = (a[0] * xs[j]) * w.x; a[1] = (a[1] * xs[j]) * w.y; a[2] = (a[2] * xs[j]) * w.z; a[3] = (a[3] * xs[j]) * w.w;
+        }
+    }
+    ep_tiles<NI, NJ>(e.ep, m0, n0, acc);
+}
+
 struct F8Frag { long lo, hi; };
 __device__ __forceinline__ F8Frag ld_f8(const unsigned char* p) {
     const uint4 v = *reinterpret_cast<const uint4*>(p);
@@ -636,17 +656,21 @@ k_gemm_f8(const unsigned char* __restrict__ X, const unsigned char* __restrict__
 // 256 x 256 tile, 8 waves (2 x 4), wave = 128 tokens x 64 features; a 64-k step is 32 KiB (16 X + 16 W units): three stages
 template <class Ep>
 __global__ void __launch_bounds__(512)
-k_gemm_f8_256(const unsigned char* __restrict__ X, const unsigned char* __restrict__ W, int K64, int tiles_m, int tiles_n, Ep ep)
+k_gemm_f8_256(const unsigned char* __restrict__ X, const unsigned char* __restrict__ W, int K64, int tiles_m, int tiles_n, int PN, Ep ep)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int STAGE = 32 * 1024, NST = 3, LPW = 4;
     const int lane = threadIdx.x & 63;
     const int wa = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wa >> 2, wn = wa & 3;
-    int bid = blockIdx.x;
-    const int nwg = tiles_m * tiles_n;
-    if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
-    const int tn = bid / tiles_m, tm = bid - tn * tiles_m;
+    // strip-major tile order, XCD x = blockIdx % 8 walking a contiguous eighth of it (see k_gemm_256p)
+    int tm, tn;
+    {
+        const int nwg = tiles_m * tiles_n, b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+        const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+        const int strip = tiles_m * PN, sb = id / strip, rem = id - sb * strip;
+        tm = rem / PN; tn = sb * PN + (rem - tm * PN);
+    }
     const unsigned char* xg = X + (size_t)tm * 16 * K64 * 1024 + lane * 16;
     const unsigned char* wg = W + (size_t)tn * 16 * K64 * 1024 + lane * 16;
 
@@ -712,7 +736,7 @@ static inline hipError_t launch_gemm_f8(hipStream_t st, const unsigned char* X, 
         auto kern = k_gemm_f8_256<Ep>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3((Mrows / 256) * (N / 256)), dim3(512), 96 * 1024, st, X, W, K64, Mrows / 256, N / 256, ep);
+        hipLaunchKernelGGL(kern, dim3((Mrows / 256) * (N / 256)), dim3(512), 96 * 1024, st, X, W, K64, Mrows / 256, N / 256, gemm256_strip(N / 256), ep);
         return hipGetLastError();
     }
     if ((Mrows / 128) * (N / GT_BN) < 200) return launch_gemm_f8_bm<64, 4>(st, X, W, Mrows, N, K64, ep);
