@@ -370,3 +370,52 @@ def test_encoder_gelu_formula_is_within_fp32_rounding_of_the_exact_gelu():
     assert (err[inner] / np.maximum(np.abs(want[inner]), 1e-30)).max() < 2e-5
     plain = (f(0.5) * x * (f(1) + erf((x * f(0.70710678)).astype(f)).astype(f))).astype(np.float64)
     assert err.max() <= np.abs(plain - want).max()
+
+
+class _FakeEngine:
+    """Records the calls generate() makes; logits put every clip's language on `lang_ids[clip]`."""
+
+    def __init__(self, cfg, lang_ids):
+        self.cfg, self.lang_ids, self.calls, self._B = cfg, lang_ids, [], None
+
+    def encode(self, feats):
+        self.calls.append(("encode", feats.shape[0])); self._B = feats.shape[0]
+
+    def forward_logits(self, tokens, pos0, disable_medusa):
+        self.calls.append(("forward_logits", len(tokens)))
+        z = torch.zeros(1, len(tokens), 1, self.cfg.vocab_size)
+        for b, t in enumerate(self.lang_ids[: len(tokens)]):
+            z[0, b, 0, t] = 5.0
+        return z
+
+    def decode(self, gp, B, **kw):
+        self.calls.append(("decode", B, tuple(gp.prompt)))
+        return [list(gp.prompt) + [7, gp.eos_token_id] for _ in range(B)]
+
+    def stats(self):
+        return {}
+
+
+def test_language_detection_reuses_the_encoder_pass_for_a_single_language_batch():
+    """generate(language=None): detect_language() encodes the batch; when every clip is of one language the decode runs from that
+    encoder pass (one wm_encode per call), clips of several languages are re-encoded per language group."""
+    from whisper_medusa import WhisperMedusaModel
+    cfg = MedusaConfig.micro(K=4)
+    cfg.is_multilingual = True
+    cfg.vocab_size = 51865
+    cfg.lang_to_id = {"<|en|>": 50259, "<|de|>": 50261}
+    cfg.task_to_id = {"transcribe": 50359, "translate": 50358}
+    m = WhisperMedusaModel(cfg, {})
+    m._max_batch = 4
+    feats = torch.zeros(4, cfg.num_mel_bins, cfg.n_mel_frames)
+    m._engine = eng = _FakeEngine(cfg, [50261] * 4)
+    out = m.generate(feats, return_dict_in_generate=True, return_segments=True)
+    assert [c[0] for c in eng.calls] == ["encode", "forward_logits", "decode"] and m.detected_languages == ["<|de|>"] * 4
+    assert out.sequences.shape[0] == 4 and len(out.segments) == 4 and 50261 in out.sequences[0].tolist()
+    m._engine = eng = _FakeEngine(cfg, [50261, 50259, 50261, 50259])
+    m.generate(feats)
+    assert [c[:2] for c in eng.calls] == [("encode", 4), ("forward_logits", 4), ("encode", 2), ("decode", 2), ("encode", 2), ("decode", 2)]
+    # an explicit language never takes the detection path: one encode, one decode
+    m._engine = eng = _FakeEngine(cfg, [50259] * 4)
+    m.generate(feats, language="en")
+    assert [c[0] for c in eng.calls] == ["encode", "decode"]

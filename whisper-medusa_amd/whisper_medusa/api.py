@@ -425,7 +425,10 @@ class WhisperMedusaModel:
             self.last_stats = pool.last_stats
             return self._outputs(seqs, gp, return_dict_in_generate, return_segments)
         eng = self.engine
-        eng.encode(feats)                                                   # F1 + F2
+        # language detection just encoded exactly these clips on this engine (one language group, same order): its encoder output and
+        # cross-K/V are still resident — decode from them instead of running the encoder a second time
+        if not (kwargs.get("_encoded_batch") == B and getattr(eng, "_B", None) == B):
+            eng.encode(feats)                                               # F1 + F2
         streamer = kwargs.get("streamer")
         if streamer is not None:
             # model.py:1034-1035 (prompt), :758-759 (tokens of every iteration), :795-796 (end); HF streamers are batch-1
@@ -504,7 +507,9 @@ class WhisperMedusaModel:
         rows: List[Optional[torch.Tensor]] = [None] * len(langs)
         plens = [0] * len(langs)
         for l, idx in groups.items():
-            out = self.generate(input_features[idx], language=l, _language_resolved=True, **kw)
+            # one group = every clip in its original order: the engine still holds the encoder pass detect_language() ran
+            reuse = {"_encoded_batch": len(langs)} if len(groups) == 1 else {}
+            out = self.generate(input_features[idx], language=l, _language_resolved=True, **reuse, **kw)
             for j, i in enumerate(idx):
                 rows[i] = out[j]
                 plens[i] = len(self._last_prompt)
