@@ -108,6 +108,30 @@ def test_language_detection_groups_clips(gpu):
     model.engine.close()
 
 
+def test_language_detection_of_a_single_language_batch_decodes_from_its_own_encoder_pass(gpu):
+    """Every clip of one language: generate(language=None) decodes from the encoder pass detect_language() ran (no second wm_encode);
+    tokens equal the explicit-language call's, at one stream and at four (one batched context)."""
+    cfg = MedusaConfig.micro(K=4)
+    cfg.is_multilingual = True
+    cfg.lang_to_id = {"<|en|>": 20, "<|de|>": 21, "<|fr|>": 22}
+    cfg.task_to_id = {"transcribe": 30, "translate": 31}
+    sd = synth.synth_state_dict(cfg, seed=43)
+    model = WhisperMedusaModel(cfg, sd, device=gpu, max_batch=4)
+    one = model.extract_features([clip_for(cfg, 1)])
+    for feats in (one, one.repeat(4, 1, 1)):
+        encodes = []
+        real = model.engine.encode
+        model.engine.encode = lambda f, real=real: (encodes.append(f.shape[0]), real(f))[1]
+        try:
+            out = model.generate(feats, max_new_tokens=12)
+        finally:
+            model.engine.encode = real
+        assert encodes == [feats.shape[0]] and len(set(model.detected_languages)) == 1
+        want = model.generate(feats, language=model.detected_languages[0], max_new_tokens=12)
+        assert out.tolist() == want.tolist()
+    model.engine.close()
+
+
 def _shard_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
