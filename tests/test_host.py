@@ -419,3 +419,35 @@ def test_language_detection_reuses_the_encoder_pass_for_a_single_language_batch(
     m._engine = eng = _FakeEngine(cfg, [50259] * 4)
     m.generate(feats, language="en")
     assert [c[0] for c in eng.calls] == ["encode", "decode"]
+
+
+def test_automatic_micro_batching_keeps_one_pool_for_two_and_three_clips(monkeypatch):
+    """Automatic policy: two or three clips run as that many single-stream contexts; ONE pool of three contexts serves both sizes
+    (alternating batch sizes rebuilt every context before), an explicit set_micro_batches(n) still gets exactly n."""
+    import whisper_medusa.pool as pool_mod
+    from whisper_medusa import WhisperMedusaModel
+    built, closed = [], []
+
+    class FakePool:
+        def __init__(self, cfg, blob, offsets, contexts, max_batch, *a):
+            built.append((contexts, max_batch)); self.n = contexts; self.last_stats = {}
+
+        def close(self):
+            closed.append(self.n)
+
+        def run(self, x, gp, from_wav=False):
+            return [list(gp.prompt) + [gp.eos_token_id] for _ in range(x.shape[0])]
+
+    monkeypatch.setattr(pool_mod, "ContextPool", FakePool)
+    cfg = MedusaConfig.micro(K=4)
+    m = WhisperMedusaModel(cfg, {})
+    m._engine = _FakeEngine(cfg, [])
+    m._max_batch, m._offsets = 3, None
+    m.set_micro_batches(None)
+    f = torch.zeros(3, cfg.num_mel_bins, cfg.n_mel_frames)
+    for B in (2, 3, 2, 3):
+        assert m.generate(f[:B]).shape[0] == B
+    assert built == [(3, 3)] and closed == []
+    m.set_micro_batches(2)
+    m.generate(f[:2])
+    assert built == [(3, 3), (2, 3)] and closed == [3]

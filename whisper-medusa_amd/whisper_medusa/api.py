@@ -273,13 +273,19 @@ class WhisperMedusaModel:
             self._pool = None
 
     def _get_pool(self, n: int):
-        if self._pool is not None and getattr(self, "_pool_n", None) != n:
+        """Pool of n contexts.  Under the automatic policy (two or three clips -> as many single-stream contexts) ONE pool of three
+        contexts serves both sizes — a batch of two uses the first two (ContextPool shards over at most as many contexts as clips) —
+        so alternating batch sizes do not tear the contexts (KV caches, scratch, captured graphs) down and up again."""
+        auto = self._micro_batches is None
+        want = max(n, 3) if auto else n
+        have = getattr(self, "_pool_n", None)
+        if self._pool is not None and (have != want if not auto else have < n):
             self._drop_pool()
         if self._pool is None:
             from .pool import ContextPool
             _ = self.engine                                         # raises when not on a HIP device
-            self._pool = ContextPool(self.config, self._blob, self._offsets, n, max(self._max_batch, n), self._fp8, self._enc_fp8)
-            self._pool_n = n
+            self._pool = ContextPool(self.config, self._blob, self._offsets, want, max(self._max_batch, want), self._fp8, self._enc_fp8)
+            self._pool_n = want
         return self._pool
 
     @property
