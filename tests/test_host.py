@@ -451,3 +451,45 @@ def test_automatic_micro_batching_keeps_one_pool_for_two_and_three_clips(monkeyp
     m.set_micro_batches(2)
     m.generate(f[:2])
     assert built == [(3, 3), (2, 3)] and closed == [3]
+
+
+def test_strip_major_tile_order_is_a_bijection_with_compact_patches():
+    """csrc/wm_encoder.hip k_gemm_256p / k_gemm_f8_256 (restated): tiles are numbered strip-major (strips of PN feature tiles, PN the
+    divisor of tiles_n minimising 32 / PN + PN), XCD x = blockIdx % 8 owns a contiguous eighth, a persistent grid's S blocks per XCD take
+    start + slot, + S, ...  Every tile exactly once for any shape (also the split launches over a subset of the feature tiles), and
+    the 32 tiles an XCD works on at a time span ~32 / PN token panels x PN weight panels instead of 32 x 1."""
+    def strip(tiles_n):
+        best, bc = 1, 33.0
+        for pn in range(1, min(tiles_n, 32) + 1):
+            if tiles_n % pn == 0 and 32.0 / pn + pn < bc:
+                bc, best = 32.0 / pn + pn, pn
+        return best
+
+    def order(tiles_m, tiles_n, persistent, period, take, off):
+        PN, T = strip(tiles_n), tiles_m * tiles_n
+        grid = 256 if persistent else T
+        per_block = {}
+        for b in range(grid):
+            xcd, q, r = b & 7, T >> 3, T & 7
+            start = xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q
+            i, end, step = start + (b >> 3), (start + q + (1 if xcd < r else 0)) if persistent else start + (b >> 3) + 1, (grid >> 3) if persistent else 1
+            while i < end:
+                sb, rem = divmod(i, tiles_m * PN)
+                tm, c = rem // PN, sb * PN + rem % PN
+                per_block.setdefault(b, []).append((tm, (c // take) * period + off + c % take))
+                i += step
+        return per_block, PN
+
+    for tiles_m, tiles_n, period, take, off in [(192, 5, 5, 5, 0), (192, 20, 20, 20, 0), (192, 10, 15, 10, 0), (192, 5, 15, 5, 10), (6, 160, 10, 5, 5),
+                                                 (72, 15, 15, 15, 0), (7, 3, 3, 3, 0), (33, 7, 7, 7, 0)]:
+        for persistent in (False, True):
+            if persistent and tiles_m * tiles_n <= 256:
+                continue
+            pb, PN = order(tiles_m, tiles_n, persistent, period, take, off)
+            seen = [t for v in pb.values() for t in v]
+            want = {(m, (c // take) * period + off + c % take) for c in range(tiles_n) for m in range(tiles_m)}
+            assert len(seen) == len(want) and set(seen) == want
+            if persistent:                       # first round of XCD 0: its 32 blocks' first tiles
+                first = [pb[b][0] for b in range(0, 256, 8)]
+                assert len({t[0] for t in first}) <= 32 // PN + 2 and len({t[1] for t in first}) <= PN
+    assert strip(5) == 5 and strip(10) == 5 and strip(15) == 5 and strip(20) in (4, 5) and strip(160) in (4, 5, 8)
