@@ -33,3 +33,17 @@ def test_prefill_flops_match_the_survey_figure():
     b = _bench()
     lin = MedusaConfig.large_v2("base_head", K=10)
     assert abs(b.prefill_flops(lin) - 2.59e12) / 2.59e12 < 0.01    # encoder 2.273 + cross-KV projection 0.315 TFLOP
+
+
+def test_committed_traffic_counters_were_taken_on_the_committed_decode_sources():
+    """bench.py only reports `roofline.traffic` from a PMC pass stamped with the hash of the decode-path sources it was measured on
+    (profiles/rNN_pmc_traffic.json, written by tests/pmc_summary.py on the GPU).  The newest committed file must match the committed
+    sources — an edit to csrc/ after the last GPU pass would silently turn the figure into null in the next bench line."""
+    import glob
+    import json
+    import bench
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    assert files
+    tj = json.load(open(files[-1]))
+    assert tj["kernels_sha"] == bench.kernels_sha(), f"{os.path.basename(files[-1])} is stale: re-run the FETCH_SIZE pass or undo the source edit"
+    assert tj["medusa_iteration_bytes"] > 3e9

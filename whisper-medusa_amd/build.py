@@ -26,9 +26,6 @@ if not os.environ.get("WM_NO_KERNARG_PRELOAD"):
 # All kernels here fit the 256 VGPRs their occupancy allows without AGPRs, so nothing is lost.  WM_MFMA_AGPR=1 builds the old form.
 if not os.environ.get("WM_MFMA_AGPR"):
     FLAGS += ["-mllvm", "-amdgpu-mfma-vgpr-form"]
-# experiments prepared for the next round (csrc/: off = the measured code, byte for byte)
-if os.environ.get("WM_EP_WAIT_ONCE"):
-    FLAGS += ["-DWM_EP_WAIT_ONCE"]
 
 
 def _newest_src():

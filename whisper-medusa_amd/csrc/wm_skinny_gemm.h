@@ -24,17 +24,6 @@
 // kernel (R > 16 rows) keeps that order and shares the LayerNorm code, so a B-stream run is bit-identical to B
 // single-stream runs.
 #pragma once
-
-// Experiment for the next round (build with WM_EP_WAIT_ONCE=1; off = the measured code, byte for byte): the guarded per-tile epilogues
-// (`if (tile exists) fin(...)`) put every tile's store in a basic block of its own, and the compiler opens each with s_waitcnt vmcnt(0)
-// because on the path that skipped the previous tile nobody has waited for the batched operand loads yet — so every store after the
-// first also waits for the previous STORE's acknowledgement (5-9 dependent round trips per wave in the 352-row GEMMs and the
-// vocabulary projection, ISA of round 3).  One explicit wait in front of the guards settles the loads for every path.
-#ifdef WM_EP_WAIT_ONCE
-#define WM_EP_WAIT_ONCE_HERE() __builtin_amdgcn_s_waitcnt(0x0F70)      /* vmcnt(0), other counters untouched */
-#else
-#define WM_EP_WAIT_ONCE_HERE() ((void)0)
-#endif
 #include <algorithm>
 #include <cstdlib>
 #include "wm_common.h"
@@ -491,7 +480,6 @@ k_rows_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int 
                 pre[i][j].i = 0; pre[i][j].a = make_float4(0.f, 0.f, 0.f, 0.f); pre[i][j].b = pre[i][j].a;
                 if (rt0 + i < N16 && mt0 + j < MT) pre[i][j] = ep.pre((mt0 + j) * 16 + (lane & 15), (rt0 + i) * 16 + 4 * (lane >> 4));
             }
-        WM_EP_WAIT_ONCE_HERE();
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < RT; ++i)
@@ -845,7 +833,6 @@ k_tile_gemm(const bf16_t* __restrict__ W, int N16, int K32, int nk, const bf16_t
             pre[i][j].i = 0; pre[i][j].a = make_float4(0.f, 0.f, 0.f, 0.f); pre[i][j].b = pre[i][j].a;
             if (rt < N16 && mt < MT) pre[i][j] = ep.pre(mt * 16 + (lane & 15), rt * 16 + 4 * (lane >> 4));
         }
-    WM_EP_WAIT_ONCE_HERE();
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < F; ++i)
