@@ -493,3 +493,33 @@ def test_strip_major_tile_order_is_a_bijection_with_compact_patches():
                 first = [pb[b][0] for b in range(0, 256, 8)]
                 assert len({t[0] for t in first}) <= 32 // PN + 2 and len({t[1] for t in first}) <= PN
     assert strip(5) == 5 and strip(10) == 5 and strip(15) == 5 and strip(20) in (4, 5) and strip(160) in (4, 5, 8)
+
+
+def test_forward_of_more_than_sixteen_positions_goes_through_in_chunks():
+    """forward(): the engine's pass evaluates <= 16 positions; a longer decoder_input_ids is fed in 16-token chunks at increasing
+    positions (K/V rows accumulate in the engine) and the logits are concatenated along T."""
+    from whisper_medusa import WhisperMedusaModel
+    cfg = MedusaConfig.micro(K=4)
+    m = WhisperMedusaModel(cfg, {})
+
+    class Eng(_FakeEngine):
+        def forward_logits(self, tokens, pos0, disable_medusa):
+            self.calls.append(("forward_logits", len(tokens), len(tokens[0]), pos0))
+            z = torch.zeros(1 if disable_medusa else cfg.medusa_num_heads + 1, len(tokens), len(tokens[0]), 8)
+            for b, row in enumerate(tokens):
+                for t, tok in enumerate(row):
+                    z[:, b, t, 0] = tok                     # marks which token produced the row
+                    z[:, b, t, 1] = pos0 + t
+            return z
+
+    m._engine = eng = Eng(cfg, [])
+    ids = torch.arange(2 * 37).view(2, 37) % 50
+    out = m.forward(decoder_input_ids=ids, disable_medusa=True).logits
+    assert out.shape == (1, 2, 37, 8)
+    assert [c[2:] for c in eng.calls] == [(16, 0), (16, 16), (5, 32)]
+    assert out[0, :, :, 0].long().tolist() == ids.tolist() and out[0, 1, :, 1].tolist() == list(range(37))
+    eng.calls.clear()
+    m.forward(decoder_input_ids=ids[:, :9], decoder_position_ids=torch.arange(4, 13))
+    assert eng.calls == [("forward_logits", 2, 9, 4)]
+    with pytest.raises(ValueError, match="max_target_positions"):
+        m.forward(decoder_input_ids=torch.zeros(1, cfg.max_target_positions + 1, dtype=torch.long))

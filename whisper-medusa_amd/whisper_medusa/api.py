@@ -613,8 +613,10 @@ class WhisperMedusaModel:
     def forward(self, input_features: Optional[torch.Tensor] = None, attention_mask=None,
                 decoder_input_ids: Optional[torch.Tensor] = None, decoder_position_ids=None,
                 disable_medusa: bool = False, **kwargs) -> MedusaForwardOutput:
-        """Cache-free forward of the decoder over ``decoder_input_ids`` [B, T<=16] (model.py:1223-1347).
-        If ``input_features`` is given the encoder runs first; otherwise the last encoded batch is reused."""
+        """Cache-free forward of the decoder over ``decoder_input_ids`` [B, T] (model.py:1223-1347).
+        If ``input_features`` is given the encoder runs first; otherwise the last encoded batch is reused.
+        The engine evaluates at most 16 positions per pass (its token tile): longer inputs go through in 16-token chunks, each
+        appending its K/V rows behind the previous chunk's — the way the engine itself consumes a long prompt."""
         if decoder_input_ids is None:
             raise ValueError("decoder_input_ids is required")
         if kwargs.get("labels") is not None:
@@ -625,7 +627,14 @@ class WhisperMedusaModel:
         if decoder_position_ids is not None:
             pos0 = int(torch.as_tensor(decoder_position_ids).flatten()[0])
         toks = decoder_input_ids.tolist()
-        return MedusaForwardOutput(logits=self.engine.forward_logits(toks, pos0, disable_medusa))
+        T = len(toks[0])
+        if pos0 + T > self.config.max_target_positions:
+            raise ValueError(f"decoder_input_ids of length {T} at position {pos0} exceed max_target_positions "
+                             f"{self.config.max_target_positions}")
+        if T <= 16:
+            return MedusaForwardOutput(logits=self.engine.forward_logits(toks, pos0, disable_medusa))
+        parts = [self.engine.forward_logits([row[c: c + 16] for row in toks], pos0 + c, disable_medusa) for c in range(0, T, 16)]
+        return MedusaForwardOutput(logits=torch.cat(parts, dim=2))
 
     __call__ = forward
 
