@@ -98,3 +98,53 @@ def test_wer_cer_known_answers_worked_by_hand():
     #    ref "hello world" (2 words) vs hyp "empty" (1 word): 1 substitution + 1 deletion = 2 / 2
     w, per = compute_wer([""], ["hello world"])
     assert per == [pytest.approx(1.0)]
+
+
+def _byte_level_whisper_tokenizer():
+    """A real `transformers.WhisperTokenizer` (byte-level BPE with Whisper's special tokens) built from a vocabulary made here — no
+    checkpoint files exist offline.  It encodes / decodes any text; what the evaluation loop needs from the checkpoint's tokenizer."""
+    from transformers import WhisperTokenizer
+    bs = list(range(ord("!"), ord("~") + 1)) + list(range(ord("¡"), ord("¬") + 1)) + list(range(ord("®"), ord("ÿ") + 1))
+    cs, n = bs[:], 0
+    for b in range(256):
+        if b not in bs:
+            bs.append(b); cs.append(256 + n); n += 1
+    vocab = {chr(c): i for i, c in enumerate(cs)}
+    merges = [("t", "h"), ("th", "e"), ("Ġ", "the"), ("i", "n"), ("Ġ", "a"), ("o", "r"), ("Ġ", "w")]
+    for a, b in merges:
+        vocab[a + b] = len(vocab)
+    specials = ["<|endoftext|>", "<|startoftranscript|>", "<|en|>", "<|de|>", "<|transcribe|>", "<|notimestamps|>"]
+    for t in specials:
+        vocab[t] = len(vocab)
+    tok = WhisperTokenizer(vocab=vocab, merges=merges)
+    tok.add_special_tokens({"additional_special_tokens": specials[1:]})
+    return tok, vocab
+
+
+def test_evaluate_loop_with_a_real_hf_whisper_tokenizer(tmp_path):
+    """eval_whisper_medusa.py:21-97 end to end on the host: token ids as generate() returns them (prompt, text, EOS, padding) ->
+    `WhisperTokenizer.decode(skip_special_tokens=True)` -> the jiwer-style normalisation -> WER / CER, with an actual transformers
+    tokenizer object instead of a stub (the engine side is a stand-in: there is no GPU in this test)."""
+    import pandas as pd
+    import torch
+    from whisper_medusa.evaluate import evaluate_model
+    tok, vocab = _byte_level_whisper_tokenizer()
+    prompt = [vocab[t] for t in ("<|startoftranscript|>", "<|en|>", "<|transcribe|>", "<|notimestamps|>")]
+    eos = vocab["<|endoftext|>"]
+    said = {"a.wav": " The quick brown fox, in a hat.", "b.wav": " the world is wide", "c.wav": " Grüße aus Köln!"}
+
+    class Model:
+        def features_from_file(self, path):
+            return path
+
+        def generate(self, feats, language=None, exponential_decay_length_penalty=None):
+            ids = prompt + tok.encode(said[feats], add_special_tokens=False) + [eos]
+            return torch.tensor([ids + [eos] * 3])                      # right-padded with the pad (= EOS) id, as generate() pads
+
+    data = pd.DataFrame({"audio": list(said), "sentence": ["the quick brown fox in a hat", "The world is white.", "Grüße aus Köln"]})
+    res = evaluate_model(Model(), tok, data, language="en", out_file_path=str(tmp_path / "r.csv"))
+    assert res.prediction.tolist() == [" The quick brown fox, in a hat.", " the world is wide", " Grüße aus Köln!"]
+    assert res.wer.tolist() == [0.0, 0.25, 0.0]                          # one substitution in four reference words
+    assert abs(res.attrs["wer"] - 1 / 14) < 1e-12 and res.cer.tolist()[0] == 0.0 and 0 < res.cer.tolist()[1] < 0.3
+    back = pd.read_csv(tmp_path / "r.csv")
+    assert back.prediction.tolist()[2].strip() == "Grüße aus Köln!"      # byte-level round trip of non-ASCII text through the CSV
