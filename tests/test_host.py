@@ -523,3 +523,30 @@ def test_forward_of_more_than_sixteen_positions_goes_through_in_chunks():
     assert eng.calls == [("forward_logits", 2, 9, 4)]
     with pytest.raises(ValueError, match="max_target_positions"):
         m.forward(decoder_input_ids=torch.zeros(1, cfg.max_target_positions + 1, dtype=torch.long))
+
+
+def test_from_pretrained_resolves_hub_names_through_huggingface_hub(tmp_path, monkeypatch):
+    """from_pretrained("org/name"): not a directory -> huggingface_hub.snapshot_download (cache first, then the network); a directory
+    is used as it is; an unresolvable name is an OSError that says so."""
+    import huggingface_hub
+    from whisper_medusa import WhisperMedusaModel, synth
+    cfg = MedusaConfig.micro(K=4)
+    sd = synth.synth_state_dict(cfg, seed=3)
+    ckpt = tmp_path / "snap"
+    WhisperMedusaModel(cfg, sd).save_pretrained(str(ckpt))
+    calls = []
+
+    def fake(repo_id, revision=None, cache_dir=None, allow_patterns=None, local_files_only=False):
+        calls.append((repo_id, revision, local_files_only))
+        if local_files_only:
+            raise FileNotFoundError("not cached")
+        return str(ckpt)
+
+    monkeypatch.setattr(huggingface_hub, "snapshot_download", fake)
+    m = WhisperMedusaModel.from_pretrained("aiola/whisper-medusa-linear-libri", revision="main")
+    assert calls == [("aiola/whisper-medusa-linear-libri", "main", True), ("aiola/whisper-medusa-linear-libri", "main", False)]
+    assert m.config.medusa_num_heads == 4 and "whisper_model.model.encoder.conv1.weight" in m._sd
+    calls.clear()
+    assert WhisperMedusaModel.from_pretrained(str(ckpt)).config.d_model == cfg.d_model and calls == []
+    with pytest.raises(OSError, match="neither a checkpoint directory nor a hub repository"):
+        WhisperMedusaModel.from_pretrained("aiola/whisper-medusa-linear-libri", local_files_only=True)

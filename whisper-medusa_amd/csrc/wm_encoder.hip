@@ -524,7 +524,8 @@ static inline hipError_t launch_gemm_tiled(hipStream_t st, const bf16_t* X, cons
 
 // =============================================================================================
 // fp8 (OCP e4m3) MFMA GEMMs of the encoder (BASELINE configs[4]): out[m][n] = xs[m] * ws[n] * sum_k X8[m][k] W8[n][k] on
-// v_mfma_f32_16x16x32_fp8_fp8 (twice the bf16 rate, half the operand bytes through L2 -> LDS -> registers).
+// v_mfma_f32_16x16x32_fp8_fp8 (the bf16 MFMA rate on gfx950 — only the f8f6f4 16x16x128 form doubles it — at half the operand bytes
+// through L2 -> LDS -> registers).
 //   X8: the LayerNorm output of a token row, quantised to e4m3 with ONE fp32 scale per row (xs[m] = max|row| / 448): the
 //       LayerNorm kernel has the whole row in one wave, so the scale costs one wave reduction.  Only the GEMMs whose operand
 //       IS a LayerNorm output take this path (QKV, FC1, cross-K/V projection: 7/12 of the encoder's GEMM flops + the

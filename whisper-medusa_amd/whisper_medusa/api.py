@@ -107,6 +107,30 @@ def lower_processors(gp: GenParams, logits_processor, stopping_criteria) -> GenP
     return gp
 
 
+def _resolve_checkpoint(name_or_path, revision=None, cache_dir=None, local_files_only=False) -> str:
+    """A checkpoint directory as it is; anything else is taken as a hub repo id and resolved with huggingface_hub.snapshot_download
+    (cached snapshot first; config, weights and tokenizer files only)."""
+    import os
+    path = os.fspath(name_or_path)
+    if os.path.isdir(path):
+        return path
+    try:
+        from huggingface_hub import snapshot_download
+    except ImportError as e:                                    # pragma: no cover - huggingface_hub ships with transformers
+        raise OSError(f"{path!r} is not a checkpoint directory and huggingface_hub is not installed to resolve it as a hub name") from e
+    patterns = ["*.json", "*.safetensors", "pytorch_model.bin", "*.txt", "*.model"]
+    try:
+        try:
+            return snapshot_download(path, revision=revision, cache_dir=cache_dir, allow_patterns=patterns, local_files_only=True)
+        except Exception:
+            if local_files_only:
+                raise
+            return snapshot_download(path, revision=revision, cache_dir=cache_dir, allow_patterns=patterns)
+    except Exception as e:
+        raise OSError(f"{path!r} is neither a checkpoint directory nor a hub repository that could be resolved "
+                      f"({type(e).__name__}: {e})") from e
+
+
 class WhisperMedusaModel:
     def __init__(self, config: MedusaConfig, state_dict: Dict[str, torch.Tensor], device: Union[str, torch.device, None] = None,
                  max_batch: int = 1, dec_weight_fp8: bool = False, enc_fp8: bool = False):
@@ -128,8 +152,11 @@ class WhisperMedusaModel:
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path, *args, device=None, max_batch: int = 1, dec_weight_fp8: bool = False,
                         enc_fp8: bool = False, **kwargs):
-        """Load ``config.json`` + ``model.safetensors`` from a local checkpoint directory
-        (reference model.py:265-291; there is no hub access in this environment)."""
+        """Load ``config.json`` + ``model.safetensors`` from a checkpoint directory, or from a Hugging Face hub name
+        (``aiola/whisper-medusa-linear-libri``, README.md:101-104 of the reference) resolved through ``huggingface_hub`` — its
+        local cache first, a download when the machine has network access (reference model.py:265-291)."""
+        pretrained_model_name_or_path = _resolve_checkpoint(pretrained_model_name_or_path, kwargs.get("revision"),
+                                                            kwargs.get("cache_dir"), kwargs.get("local_files_only", False))
         config = MedusaConfig.from_pretrained(pretrained_model_name_or_path)
         sd = _weights.load_state_dict_from_dir(pretrained_model_name_or_path)
         return cls(config, sd, device=device, max_batch=max_batch, dec_weight_fp8=dec_weight_fp8, enc_fp8=enc_fp8)
