@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define WM_ABI_VERSION 6
+#define WM_ABI_VERSION 7
 
 #define WM_OK 0
 #define WM_ERR_ARG (-1)      /* bad argument / unsupported configuration (reference: ValueError, model.py:225-229) */
@@ -144,6 +144,11 @@ int wm_logmel(wm_ctx* ctx, const float* wav, int B, int n_samples, float* feats)
  * _prepare_encoder_decoder_kwargs_for_generation, model.py:1005-1011, and the cross K/V
  * projection hidden in the first decoder pass).  feats: DEV float32 [B][n_mels][2*n_ctx]. */
 int wm_encode(wm_ctx* ctx, const float* feats, int B);
+/* forward(encoder_outputs=...) (model.py:1223-1243, :1232: a caller-supplied `encoder_outputs[0]` replaces the encoder pass, HF
+ * WhisperModel.forward): hidden = DEV float32 [B][n_ctx][d_model] last hidden state (after the encoder's final LayerNorm).  It is
+ * stored bf16 like wm_encode's own output and the cross K/V of every decoder layer are projected from it; afterwards the context
+ * is in the state wm_encode leaves.  Not available on an enc_fp8 context (WM_ERR_ARG). */
+int wm_set_encoder_output(wm_ctx* ctx, const float* hidden, int B);
 
 /* ---- F3..F14 the Medusa decode loop (replaces _medusa_greedy_search, model.py:404-835) ---- */
 int wm_decode_begin(wm_ctx* ctx, const wm_gen_params* gp, int B);

@@ -14,6 +14,8 @@ evaluates that formula DIRECTLY in float64 with exact rational sample times — 
 float32 kernel table / conv1d path — and stores inputs and outputs in tests/golden/resample_f64.npz.
 The oracle (float32 taps, float32 accumulation) must agree to float32 round-off (tests/test_audio_cpu.py).
 """
+import sys as _sys
+_sys.dont_write_bytecode = True          # never write .pyc files into /root/reference
 import math
 import os
 from fractions import Fraction

@@ -1,6 +1,10 @@
 import os
 import sys
 
+# never leave bytecode behind — above all not in /root/reference, which oracle/make_golden.py and the KAT tests import from
+# (the environment variable below only reaches child processes: the flag is what counts for this interpreter)
+sys.dont_write_bytecode = True
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

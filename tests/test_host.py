@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     lib = ctypes.CDLL(built_lib)
     for name in declared:
         assert hasattr(lib, name), f"libwm.so does not export {name}"
-    assert lib.wm_abi_version() == 6
+    assert lib.wm_abi_version() == 7
     from whisper_medusa import engine
     assert sorted(engine.EXPORTS) == declared
     engine.load_library()          # prototypes resolve
@@ -322,6 +322,13 @@ def test_hf_processors_and_criteria_are_lowered_into_generation_params():
     gp = lower_processors(gp, procs, StoppingCriteriaList([MaxLengthCriteria(P + 20)]))
     assert gp.suppress_tokens == [5, 7, 9] and gp.begin_suppress_tokens == [220, 50257] and gp.begin_index == P
     assert gp.exp_decay == (10, 1.25) and gp.max_length == P + 20
+    # a caller's begin_index does not survive: the reference resets it to the number of init tokens (model.py:1537, :1640-1644)
+    gp2 = m._gen_params("en", None, None, 64, None, None, False, None, None, None, None, [50361, 11, 12])
+    gp2 = lower_processors(gp2, [SuppressTokensAtBeginLogitsProcessor([220], begin_index=1)], None)
+    assert gp2.begin_suppress_tokens == [220] and gp2.begin_index == P and len(gp2.prompt) == P + 3
+    # a penalty whose start lies inside the prompt cannot be expressed (negative relative start = off in wm_gen_params): refuse, do not drop it
+    with pytest.raises(NotImplementedError, match="regulation_start"):
+        lower_processors(gp2, [ExponentialDecayLengthPenalty((2, 1.25), big.eos_token_id, 0)], None)
     with pytest.raises(NotImplementedError, match="TemperatureLogitsWarper"):
         lower_processors(gp, [TemperatureLogitsWarper(0.7)], None)
     with pytest.raises(NotImplementedError, match="MaxTimeCriteria"):
@@ -339,8 +346,10 @@ def test_generate_output_object_mirrors_the_reference_model_output():
     m_cfg = MedusaConfig.micro(K=4)
     from whisper_medusa import WhisperMedusaModel
     m = WhisperMedusaModel(m_cfg, {})
+    # return_dict_in_generate wins over return_segments: the reference returns the plain ModelOutput there (model.py:1715-1745),
+    # so positions / to_tuple() stay HF's (no extra "segments" key)
     out = m._wrap_outputs(t, [1, 1], m_cfg.pad_token_id, m_cfg.eos_token_id, True, True)
-    assert isinstance(out, GenerateEncoderDecoderOutput) and len(out.segments) == 2 and out.segments[0][0]["result"].tolist() == [0, 1, 2]
+    assert isinstance(out, GenerateEncoderDecoderOutput) and list(out.keys()) == ["sequences"] and out.to_tuple() == (t,)
     assert m._wrap_outputs(t, [1, 1], m_cfg.pad_token_id, m_cfg.eos_token_id, False, False) is t
     d = m._wrap_outputs(t, [1, 1], m_cfg.pad_token_id, m_cfg.eos_token_id, False, True)
     assert set(d) == {"sequences", "segments"}
@@ -377,9 +386,10 @@ class _FakeEngine:
 
     def __init__(self, cfg, lang_ids):
         self.cfg, self.lang_ids, self.calls, self._B = cfg, lang_ids, [], None
+        self._enc_stamp, self._kv_stamp = object(), object()       # test doubles start "encoded" (the real Engine starts with None)
 
     def encode(self, feats):
-        self.calls.append(("encode", feats.shape[0])); self._B = feats.shape[0]
+        self.calls.append(("encode", feats.shape[0])); self._B = feats.shape[0]; self._enc_stamp = object()
 
     def forward_logits(self, tokens, pos0, disable_medusa):
         self.calls.append(("forward_logits", len(tokens)))
@@ -411,7 +421,7 @@ def test_language_detection_reuses_the_encoder_pass_for_a_single_language_batch(
     m._engine = eng = _FakeEngine(cfg, [50261] * 4)
     out = m.generate(feats, return_dict_in_generate=True, return_segments=True)
     assert [c[0] for c in eng.calls] == ["encode", "forward_logits", "decode"] and m.detected_languages == ["<|de|>"] * 4
-    assert out.sequences.shape[0] == 4 and len(out.segments) == 4 and 50261 in out.sequences[0].tolist()
+    assert out.sequences.shape[0] == 4 and "segments" not in out and 50261 in out.sequences[0].tolist()
     m._engine = eng = _FakeEngine(cfg, [50261, 50259, 50261, 50259])
     m.generate(feats)
     assert [c[:2] for c in eng.calls] == [("encode", 4), ("forward_logits", 4), ("encode", 2), ("decode", 2), ("encode", 2), ("decode", 2)]
@@ -422,15 +432,19 @@ def test_language_detection_reuses_the_encoder_pass_for_a_single_language_batch(
 
 
 def test_automatic_micro_batching_keeps_one_pool_for_two_and_three_clips(monkeypatch):
-    """Automatic policy: two or three clips run as that many single-stream contexts; ONE pool of three contexts serves both sizes
-    (alternating batch sizes rebuilt every context before), an explicit set_micro_batches(n) still gets exactly n."""
+    """Automatic policy: two or three clips run as that many single-stream contexts; ONE pool serves both sizes — built with two
+    contexts for a batch of two, GROWN (not rebuilt) to three when a batch of three arrives — and an explicit set_micro_batches(n)
+    still gets exactly n."""
     import whisper_medusa.pool as pool_mod
     from whisper_medusa import WhisperMedusaModel
-    built, closed = [], []
+    built, closed, grown = [], [], []
 
     class FakePool:
         def __init__(self, cfg, blob, offsets, contexts, max_batch, *a):
             built.append((contexts, max_batch)); self.n = contexts; self.last_stats = {}
+
+        def grow(self, contexts):
+            grown.append((self.n, contexts)); self.n = contexts
 
         def close(self):
             closed.append(self.n)
@@ -447,10 +461,10 @@ def test_automatic_micro_batching_keeps_one_pool_for_two_and_three_clips(monkeyp
     f = torch.zeros(3, cfg.num_mel_bins, cfg.n_mel_frames)
     for B in (2, 3, 2, 3):
         assert m.generate(f[:B]).shape[0] == B
-    assert built == [(3, 3)] and closed == []
+    assert built == [(2, 2)] and grown == [(2, 3)] and closed == []          # one-stream contexts; the third one only when needed
     m.set_micro_batches(2)
     m.generate(f[:2])
-    assert built == [(3, 3), (2, 3)] and closed == [3]
+    assert built == [(2, 2), (2, 3)] and closed == [3]
 
 
 def test_strip_major_tile_order_is_a_bijection_with_compact_patches():
@@ -523,6 +537,63 @@ def test_forward_of_more_than_sixteen_positions_goes_through_in_chunks():
     assert eng.calls == [("forward_logits", 2, 9, 4)]
     with pytest.raises(ValueError, match="max_target_positions"):
         m.forward(decoder_input_ids=torch.zeros(1, cfg.max_target_positions + 1, dtype=torch.long))
+
+
+def test_forward_keyword_surface_follows_the_reference():
+    """forward(encoder_outputs=, past_key_values=, use_cache=, return_dict=) as in model.py:1223-1243: encoder_outputs replaces the
+    encoder pass (our own handle costs nothing, a foreign tensor goes through wm_set_encoder_output), the returned cache handle makes
+    the next call append behind the cached positions, stale handles are refused, masks / embeds / attentions raise."""
+    from whisper_medusa import WhisperMedusaModel
+    from whisper_medusa.api import EngineKVCache, EngineEncoderOutput
+    cfg = MedusaConfig.micro(K=4)
+    m = WhisperMedusaModel(cfg, {})
+
+    class Eng(_FakeEngine):
+        def forward_logits(self, tokens, pos0, disable_medusa):
+            self.calls.append(("forward_logits", len(tokens), len(tokens[0]), pos0))
+            return torch.zeros(1 if disable_medusa else cfg.medusa_num_heads + 1, len(tokens), len(tokens[0]), 8)
+
+        def set_encoder_output(self, hidden):
+            self.calls.append(("set_encoder_output", tuple(hidden.shape))); self._B = hidden.shape[0]; self._enc_stamp = object()
+
+        def encoder_output(self, B):
+            self.calls.append(("encoder_output", B))
+            return torch.ones(B, cfg.max_source_positions, cfg.d_model)
+
+    m._engine = eng = Eng(cfg, [])
+    m._max_batch = 2
+    feats = torch.zeros(2, cfg.num_mel_bins, cfg.n_mel_frames)
+    ids = torch.tensor([[1, 2, 3], [4, 5, 6]])
+    o1 = m.forward(input_features=feats, decoder_input_ids=ids, use_cache=True)
+    assert [c[0] for c in eng.calls] == ["encode", "forward_logits"] and eng.calls[1][3] == 0
+    assert isinstance(o1.past_key_values, EngineKVCache) and o1.past_key_values.get_seq_length() == 3
+    assert isinstance(o1.encoder_outputs, EngineEncoderOutput)
+    # next token(s) behind the cache; our own encoder_outputs handle is recognised: no encoder call of any kind
+    eng.calls.clear()
+    o2 = m.forward(encoder_outputs=o1.encoder_outputs, decoder_input_ids=ids[:, :1], past_key_values=o1.past_key_values)
+    assert eng.calls == [("forward_logits", 2, 1, 3)] and o2.past_key_values.get_seq_length() == 4
+    # the hidden state is only fetched when somebody looks at it, once
+    assert o2.encoder_last_hidden_state.shape == (2, cfg.max_source_positions, cfg.d_model) and o2.encoder_outputs[0] is o2.encoder_last_hidden_state
+    assert [c[0] for c in eng.calls] == ["forward_logits", "encoder_output"]
+    # a foreign tensor (or HF-style tuple) replaces the encoder pass through the engine, and invalidates older cache handles
+    eng.calls.clear()
+    hid = torch.zeros(2, cfg.max_source_positions, cfg.d_model)
+    o3 = m.forward(encoder_outputs=(hid,), decoder_input_ids=ids, return_dict=False)
+    assert [c[0] for c in eng.calls] == ["set_encoder_output", "forward_logits", "encoder_output"] and isinstance(o3, tuple) and len(o3) == 2
+    with pytest.raises(ValueError, match="another engine, encoder pass"):
+        m.forward(decoder_input_ids=ids[:, :1], past_key_values=o2.past_key_values)
+    o4 = m.forward(decoder_input_ids=ids, use_cache=True, return_dict=False)
+    assert len(o4) == 3 and o4[1].get_seq_length() == 3
+    eng._kv_stamp = object()                                     # what Engine.decode() does: generate() rewrote the cache
+    with pytest.raises(ValueError, match="generate"):
+        m.forward(decoder_input_ids=ids[:, :1], past_key_values=o4[1])
+    with pytest.raises(NotImplementedError, match="EngineKVCache"):
+        m.forward(decoder_input_ids=ids, past_key_values=((torch.zeros(1),),))
+    for kw in ("decoder_attention_mask", "head_mask", "decoder_inputs_embeds"):
+        with pytest.raises(NotImplementedError, match=kw):
+            m.forward(decoder_input_ids=ids, **{kw: torch.zeros(1)})
+    with pytest.raises(NotImplementedError, match="labels"):
+        m.forward(decoder_input_ids=ids, labels=ids)
 
 
 def test_from_pretrained_resolves_hub_names_through_huggingface_hub(tmp_path, monkeypatch):

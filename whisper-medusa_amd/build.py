@@ -26,6 +26,9 @@ if not os.environ.get("WM_NO_KERNARG_PRELOAD"):
 # All kernels here fit the 256 VGPRs their occupancy allows without AGPRs, so nothing is lost.  WM_MFMA_AGPR=1 builds the old form.
 if not os.environ.get("WM_MFMA_AGPR"):
     FLAGS += ["-mllvm", "-amdgpu-mfma-vgpr-form"]
+# experiments prepared for the next round (csrc/: off = the measured code, byte for byte)
+if os.environ.get("WM_EP_WAIT_ONCE"):
+    FLAGS += ["-DWM_EP_WAIT_ONCE"]
 
 
 def _newest_src():
@@ -45,14 +48,20 @@ def _compile(src, extra=(), suffix=""):
 def build(force=False, verbose=True):
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest_src():
         return LIB
+    return build_variant(LIB, verbose=verbose)
+
+
+def build_variant(lib, extra=(), suffix="", verbose=True):
+    """Compile the three sources (objects get `suffix`) and link them as `lib`.  The product build is build_variant(LIB);
+    A/B arms of tests/microbench call it with another path (`--variant NAME [-DFLAG ...]` -> libwm_NAME.so, loaded through WM_LIB)."""
     with cf.ThreadPoolExecutor(len(SOURCES)) as ex:
-        objs = list(ex.map(_compile, SOURCES))
-    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs, capture_output=True, text=True)
+        objs = list(ex.map(lambda s: _compile(s, extra, suffix), SOURCES))
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     if verbose:
-        print(f"built {LIB} ({os.path.getsize(LIB) / 1e6:.1f} MB)")
-    return LIB
+        print(f"built {lib} ({os.path.getsize(lib) / 1e6:.1f} MB)")
+    return lib
 
 
 def build_timeline(verbose=True):
@@ -70,6 +79,11 @@ def build_timeline(verbose=True):
 
 
 if __name__ == "__main__":
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        name = sys.argv[i + 1]
+        build_variant(os.path.join(OUT_DIR, f"libwm_{name}.so"), tuple(a for a in sys.argv[i + 2:] if a.startswith("-D")), "_" + name)
+        sys.exit(0)
     build(force="--force" in sys.argv)
     if "--timeline" in sys.argv:
         build_timeline()

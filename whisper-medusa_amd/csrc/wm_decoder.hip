@@ -1313,10 +1313,13 @@ int wm_dec_profile(wm_ctx* ctx, int kernel, int rows, int reps, float* ms, doubl
     WM_HIP(hipMemsetAsync(ctx->h, 0, (size_t)ctx->Rcap * d * sizeof(float), st));
     WM_HIP(hipMemsetAsync(ctx->kvlen, 0, sizeof(int) * ctx->maxB, st));
     const bool all = kernel == 0;
+    // the QKV epilogue scatters K / V rows into the self-attention cache: the rows go in as the verify pass would put them, Rcap / maxB
+    // rows per stream from position 0 (<= 64 <= Tal; all of them on one stream would run past a head's slab once rows > Tal)
+    const int mper = ctx->Rcap / ctx->maxB;
     auto body = [&]() -> int {
         if (all || kernel == 1)
             WM_HIP(launch_skinny_norm(st, WRef{w.qkv_w, w.qkv_s}, 3 * d / 16, K32, ctx->h, w.ln1_w, w.ln1_b, d, R, 1, 0, 1,
-                                      EpQKVDec{ctx->qbuf, ctx->kc, ctx->vc, w.qkv_b, ctx->kvlen, R, d, H, ctx->Tal, R}, ctx->xbuf, xpl));
+                                      EpQKVDec{ctx->qbuf, ctx->kc, ctx->vc, w.qkv_b, ctx->kvlen, mper, d, H, ctx->Tal, R}, ctx->xbuf, xpl));
         if (all || kernel == 2)
             WM_HIP(launch_skinny_rows(st, WRef{w.out_w, w.out_s}, d / 16, K32, R, ctx->xbuf, xpl, EpResidual{ctx->h, w.out_b, d, R}));
         if (all || kernel == 3)

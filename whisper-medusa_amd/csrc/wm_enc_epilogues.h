@@ -254,3 +254,25 @@ __device__ __forceinline__ void ep_tiles(const EpResidual& ep, int m0, int n0, f
                                 (rr[i][j].z + bb[i].z) + acc[i][j][2], (rr[i][j].w + bb[i].w) + acc[i][j][3]);
     }
 }
+
+// FC1 epilogue of a wave's NI x NJ tiles: bias + GELU + packed bf16 store.  The per-tile functor guards its bias load and its store by
+// row validity, so every tile is a basic block of its own that opens with s_waitcnt vmcnt(0) — i.e. waits for the previous tile's STORE
+// to be acknowledged: 25-32 dependent round trips per wave and block tile in the largest GEMM of the encoder (ISA of round 3).  The
+// encoder's row count is a multiple of every tile height (and its FC1 output is plain bf16): four bias loads, then NI x NJ x (GELU, pack,
+// store) with nothing to wait for.  ACT = 2 is the encoder's functor only.
+template <int NI, int NJ>
+__device__ __forceinline__ void ep_tiles(const EpPackedAct<2>& ep, int m0, int n0, f32x4_t (&acc)[NI][NJ])
+{
+    float4 bb[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) bb[i] = *reinterpret_cast<const float4*>(ep.bias + n0 + i * 16);
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const float x0 = gelu_phi(acc[i][j][0] + bb[i].x), x1 = gelu_phi(acc[i][j][1] + bb[i].y);
+            const float x2 = gelu_phi(acc[i][j][2] + bb[i].z), x3 = gelu_phi(acc[i][j][3] + bb[i].w);
+            uint2 u; u.x = pack_bf2(x0, x1); u.y = pack_bf2(x2, x3);
+            *reinterpret_cast<uint2*>(ep.out + packed_index(m0 + j * 16, n0 + i * 16, ep.K32out)) = u;
+        }
+}

@@ -37,6 +37,9 @@ __device__ __forceinline__ void ring_barrier()
 {
     __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0); vmcnt / expcnt fields left at their maxima (no wait)
     __builtin_amdgcn_s_barrier();
+    // Both builtins are "no memory" intrinsics for the optimiser: without this (instruction-free) compiler barrier the plain LDS reads of
+    // the stage that other waves' LDS-DMA has just landed could legally be hoisted above the s_barrier.
+    asm volatile("" ::: "memory");
 }
 
 // BM = token rows per tile: 128 (default) or 64 (doubles the block count of the N=d GEMMs).
@@ -261,11 +264,14 @@ k_gemm_256(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32, 
 // epilogue wants that for some of its feature tiles into two launches over disjoint tile subsets: tile column index c of a launch
 // is the matrix's feature tile (c / tn_take) * tn_period + tn_off + c % tn_take.  (One kernel with both K loops behind a block-uniform
 // branch spilled accumulators inside the loops.)
-template <int NST, int WN, bool SW, class Ep>
+template <int NST, int WN, bool SW, bool DBGK, class Ep>
 __global__ void __launch_bounds__(128 * WN, 2)
-k_gemm_256p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32, int tiles_m, int tiles_n, int PN, int persistent, int dbg,
+k_gemm_256p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32, int tiles_m, int tiles_n, int PN, int persistent, int dbg_arg,
             int tn_period, int tn_take, int tn_off, Ep ep)
 {
+    // DBGK = false (every production launch): the measurement switches below are compile-time zero — as run-time tests they cut each K step
+    // into ~8 basic blocks with a scalar branch in front of the DMA issue, the fragment reads and the MFMAs
+    const int dbg = DBGK ? dbg_arg : 0;
     // dbg (WM_ENC_GEMM_DBG, measurement only): bit 0 skips the MFMAs, bit 1 the ring refills inside the K loop, bit 2 the epilogue,
     // bit 3 the fragment reads of the K loop (results are then wrong) — what is left shows which part bounds the kernel; bit 4
     // raises the wave priority around the MFMAs, bit 5 fills the ring of a persistent block's next tile AFTER the epilogue (results stay
@@ -381,9 +387,45 @@ k_gemm_256p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32,
             }
         };
         static_assert(NST >= 3 && NST <= 5, "ring depth");
-        for (int t = 0; t < NT; t += 2) {
-            step(t, a0, b0, a1, b1);
-            step(t + 1, a1, b1, a0, b0);
+        if constexpr (NST == 4 && !DBGK) {
+            // production form: the steady state (NST - 2 stages in flight behind the one needed, one refill per step) is a loop without a test
+            // inside, the last four steps (nothing left to refill, the ring drains) are peeled with their waits as constants.  The generic
+            // step() chooses its wait and its refill at run time: three scalar branches per step in front of the barrier.
+            auto steady = [&](int t, bf16x8_t (&ac)[4], bf16x8_t (&bc)[8], bf16x8_t (&an)[4], bf16x8_t (&bn)[8]) {
+                wait_vmcnt<2 * LPW>();
+                ring_barrier();
+                stage_load(xg, wg, t + NST);
+                frag_load(t + 1, an, bn);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i][j] = SW ? mfma16(bc[j], ac[i], acc[i][j]) : mfma16(ac[i], bc[j], acc[i][j]);
+            };
+            auto drain = [&](int t, auto younger, bf16x8_t (&ac)[4], bf16x8_t (&bc)[8], bf16x8_t (&an)[4], bf16x8_t (&bn)[8]) {
+                wait_vmcnt<decltype(younger)::value * LPW>();
+                ring_barrier();
+                frag_load(t + 1, an, bn);              // (after the last step: a stale buffer, unused)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i][j] = SW ? mfma16(bc[j], ac[i], acc[i][j]) : mfma16(ac[i], bc[j], acc[i][j]);
+            };
+            int t = 0;
+            for (; t < NT - NST; t += 2) {             // NT is even and >= NST (the launcher checks)
+                steady(t, a0, b0, a1, b1);
+                steady(t + 1, a1, b1, a0, b0);
+            }
+            drain(t, std::integral_constant<int, 2>{}, a0, b0, a1, b1);
+            drain(t + 1, std::integral_constant<int, 1>{}, a1, b1, a0, b0);
+            drain(t + 2, std::integral_constant<int, 0>{}, a0, b0, a1, b1);
+            drain(t + 3, std::integral_constant<int, 0>{}, a1, b1, a0, b0);
+        } else {
+            for (int t = 0; t < NT; t += 2) {
+                step(t, a0, b0, a1, b1);
+                step(t + 1, a1, b1, a0, b0);
+            }
         }
         // next tile of a persistent block: its first stages go out BEFORE this tile's epilogue (every wave has passed the last barrier
         // of the K loop: nobody reads the ring any more, except for the unused trailing request), so the ring fill — and the memory
@@ -442,7 +484,7 @@ static inline hipError_t launch_gemm_256p_sub(hipStream_t st, const bf16_t* X, c
     // persistent grid (8 XCDs x 32 CUs x blocks per CU) once there are more tiles than that; WM_ENC_GEMM_PERSIST=0: one tile per block
     const int persist_env = [] { const char* v = std::getenv("WM_ENC_GEMM_PERSIST"); return v ? std::atoi(v) : 1; }();
     const int persistent = (persist_env && tiles_m * tiles_n > 256 * per_cu) ? 1 : 0;
-    auto kern = k_gemm_256p<NST, WN, SW, Ep>;
+    auto kern = dbg ? k_gemm_256p<NST, WN, SW, true, Ep> : k_gemm_256p<NST, WN, SW, false, Ep>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(persistent ? 256 * per_cu : tiles_m * tiles_n), dim3(128 * WN), lds, st, X, W, K32, tiles_m, tiles_n, PN, persistent, dbg,
@@ -502,7 +544,7 @@ static inline hipError_t launch_gemm_tiled(hipStream_t st, const bf16_t* X, cons
     const int blocks128 = (Mrows / 128) * (N / GT_BN);
     static const int use256 = [] { const char* v = std::getenv("WM_ENC_GEMM_256"); return v ? std::atoi(v) : 1; }();
     const int use256p = [] { const char* v = std::getenv("WM_ENC_GEMM_256P"); return v ? std::atoi(v) : 1; }();   // 0: the round-2 two-stage kernel (read per launch: A/B inside one process)
-    if (use256 && Mrows % 256 == 0 && N % 256 == 0 && K32 % 2 == 0 && (Mrows / 256) * (N / 256) >= 200)
+    if (use256 && Mrows % 256 == 0 && N % 256 == 0 && K32 % 2 == 0 && K32 >= 4 && (Mrows / 256) * (N / 256) >= 200)
         return use256p ? launch_gemm_256p(st, X, W, Mrows, N, K32, ep) : launch_gemm_256(st, X, W, Mrows, N, K32, ep);
     // fewer than ~one block per CU with 128-row tiles: halve the tile to fill the chip and split K inside the block
     // tuning knob; 600 / 1000 (64-row tiles for the one-clip QKV / FC1 GEMMs too) measured 7.9 ms per encoder pass against 6.4
@@ -915,6 +957,14 @@ k_enc_ln(const float* __restrict__ src, const float* __restrict__ gamma, const f
          bf16_t* __restrict__ out_p, int K32, int d, int M)
 {
     __shared__ float part[2][4][16];
+    // gamma / beta staged in LDS (one coalesced pass per block, under the row loads): read from global inside the output loop, every
+    // k-tile's parameter loads put an s_waitcnt vmcnt(0) in front of its store — which also waits for the previous k-tile's store to be
+    // acknowledged: 10 dependent round trips per wave (ISA of round 3)
+    __shared__ __attribute__((aligned(16))) float gbs[2][LN16_MAXF * 128];
+    for (int t = threadIdx.x; t < (d >> 2); t += 256) {
+        reinterpret_cast<float4*>(gbs[0])[t] = reinterpret_cast<const float4*>(gamma)[t];
+        reinterpret_cast<float4*>(gbs[1])[t] = reinterpret_cast<const float4*>(beta)[t];
+    }
     const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
     const int w = threadIdx.x >> 6;
     const int row = blockIdx.x * 16 + r;            // M % 16 == 0 (rows are clips x Spad)
@@ -955,8 +1005,8 @@ k_enc_ln(const float* __restrict__ src, const float* __restrict__ gamma, const f
     for (int i = 0; i < LN16_MAXF; ++i) {
         const int f = w + 4 * i;
         if (f < K32) {
-            const float4 g0 = *reinterpret_cast<const float4*>(gamma + f * 32 + 8 * g), g1 = *reinterpret_cast<const float4*>(gamma + f * 32 + 8 * g + 4);
-            const float4 b0 = *reinterpret_cast<const float4*>(beta + f * 32 + 8 * g), b1 = *reinterpret_cast<const float4*>(beta + f * 32 + 8 * g + 4);
+            const float4 g0 = *reinterpret_cast<const float4*>(gbs[0] + f * 32 + 8 * g), g1 = *reinterpret_cast<const float4*>(gbs[0] + f * 32 + 8 * g + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(gbs[1] + f * 32 + 8 * g), b1 = *reinterpret_cast<const float4*>(gbs[1] + f * 32 + 8 * g + 4);
             uint4 o;
             o.x = pack_bf2((v[i][0].x - mean) * rstd * g0.x + b0.x, (v[i][0].y - mean) * rstd * g0.y + b0.y);
             o.y = pack_bf2((v[i][0].z - mean) * rstd * g0.z + b0.z, (v[i][0].w - mean) * rstd * g0.w + b0.w);
@@ -979,14 +1029,23 @@ k_enc_ln_rows(const float* __restrict__ src, const float* __restrict__ gamma, co
     if (m >= M) return;
     const int nv = d >> 2;
     const float4* sp = reinterpret_cast<const float4*>(src + (size_t)m * d);
-    float4 v[8];
+    float4 v[8], gv[8], bv[8];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int j = lane + 64 * i;
         v[i] = (j < nv) ? sp[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-        s += v[i].x + v[i].y + v[i].z + v[i].w;
     }
+    // gamma / beta requested with the row (one batch): loaded inside the output loop, every iteration's parameter loads put an
+    // s_waitcnt vmcnt(0) in front of its store, which also waits for the previous iteration's store — 5 dependent round trips per row
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int j = lane + 64 * i;
+        gv[i] = (j < nv) ? reinterpret_cast<const float4*>(gamma)[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        bv[i] = (j < nv) ? reinterpret_cast<const float4*>(beta)[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += v[i].x + v[i].y + v[i].z + v[i].w;
     const float mean = wave_sum(s) / (float)d;
     float q = 0.f;
 #pragma unroll
@@ -1000,8 +1059,7 @@ k_enc_ln_rows(const float* __restrict__ src, const float* __restrict__ gamma, co
     for (int i = 0; i < 8; ++i) {
         const int j = lane + 64 * i;
         if (j < nv) {
-            const float4 g = reinterpret_cast<const float4*>(gamma)[j];
-            const float4 b = reinterpret_cast<const float4*>(beta)[j];
+            const float4 g = gv[i], b = bv[i];
             uint2 o;
             o.x = pack_bf2((v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y);
             o.y = pack_bf2((v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w);
@@ -1032,14 +1090,23 @@ k_enc_ln_f8(const float* __restrict__ src, const float* __restrict__ gamma, cons
     if (m >= M) return;
     const int nv = d >> 2;
     const float4* sp = reinterpret_cast<const float4*>(src + (size_t)m * d);
-    float4 v[8];
+    float4 v[8], gv[8], bv[8];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int j = lane + 64 * i;
         v[i] = (j < nv) ? sp[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-        s += v[i].x + v[i].y + v[i].z + v[i].w;
     }
+    // gamma / beta requested with the row (one batch): loaded inside the output loop, every iteration's parameter loads put an
+    // s_waitcnt vmcnt(0) in front of its store, which also waits for the previous iteration's store — 5 dependent round trips per row
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int j = lane + 64 * i;
+        gv[i] = (j < nv) ? reinterpret_cast<const float4*>(gamma)[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        bv[i] = (j < nv) ? reinterpret_cast<const float4*>(beta)[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += v[i].x + v[i].y + v[i].z + v[i].w;
     const float mean = wave_sum(s) / (float)d;
     float q = 0.f;
 #pragma unroll
@@ -1317,6 +1384,44 @@ int wm_enc_logmel(wm_ctx* ctx, const float* wav, int B, int n_samples, float* fe
     WM_HIP(hipEventRecord(ctx->ev1, st));
     WM_HIP(hipEventSynchronize(ctx->ev1));
     WM_HIP(hipEventElapsedTime(&ctx->ms_logmel, ctx->ev0, ctx->ev1));
+    return WM_OK;
+}
+
+// forward(encoder_outputs=...) (reference model.py:1223-1243 -> HF WhisperModel: a caller-supplied encoder_outputs[0] replaces the
+// encoder pass): fp32 [B][S][d] rows -> the packed bf16 operand the encoder's last LayerNorm would have written (rows S..Spad of a
+// clip are padding: zero), 8 consecutive k of one row per thread.
+__global__ void __launch_bounds__(256)
+k_pack_hidden(const float* __restrict__ hid, bf16_t* __restrict__ out_p, int S, int Spad, int d, long n8)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const int d8 = d >> 3;
+    const long row = i / d8; const int k = (int)(i - row * d8) * 8;
+    const int b = (int)(row / Spad), s = (int)(row - (long)b * Spad);
+    uint4 o = make_uint4(0u, 0u, 0u, 0u);
+    if (s < S) {
+        const float4* p = reinterpret_cast<const float4*>(hid + ((size_t)b * S + s) * d + k);
+        const float4 a = p[0], c = p[1];
+        o.x = pack_bf2(a.x, a.y); o.y = pack_bf2(a.z, a.w); o.z = pack_bf2(c.x, c.y); o.w = pack_bf2(c.z, c.w);
+    }
+    *reinterpret_cast<uint4*>(out_p + packed_index((int)row, k, d / 32)) = o;
+}
+
+int wm_enc_set_output(wm_ctx* ctx, const float* hidden, int B)
+{
+    hipStream_t st = ctx->stream;
+    if (B < 1 || B > ctx->maxB) { ctx->err = "wm_set_encoder_output: B out of range"; return WM_ERR_ARG; }
+    if (ctx->enc_f8) { ctx->err = "wm_set_encoder_output: not available on an enc_fp8 context (its cross-K/V projection reads the fp8 LayerNorm output)"; return WM_ERR_ARG; }
+    const int d = ctx->d, H = ctx->H, S = ctx->S, Spad = ctx->Spad, K32 = d / 32, M = B * Spad;
+    WM_HIP(hipEventRecord(ctx->ev0, st));
+    const long n8 = (long)M * d / 8;
+    hipLaunchKernelGGL(k_pack_hidden, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, hidden, ctx->enc_out, S, Spad, d, n8);
+    WM_HIP(hipGetLastError());
+    WM_HIP(launch_gemm_tiled(st, ctx->enc_out, ctx->ckv_w, M, ctx->nkv * 2 * d, K32, EpCrossKV{ctx->kx, ctx->vx, ctx->ckv_b, Spad, H, d, B}));
+    ctx->Benc = B;
+    WM_HIP(hipEventRecord(ctx->ev1, st));
+    WM_HIP(hipEventSynchronize(ctx->ev1));
+    WM_HIP(hipEventElapsedTime(&ctx->ms_encode, ctx->ev0, ctx->ev1));
     return WM_OK;
 }
 

@@ -252,6 +252,14 @@ extern "C" int wm_encode(wm_ctx* ctx, const float* feats, int B)
     return wm_enc_encode(ctx, feats, B);
 }
 
+extern "C" int wm_set_encoder_output(wm_ctx* ctx, const float* hidden, int B)
+{
+    if (!ctx || !hidden) return WM_ERR_ARG;
+    WM_HIP(hipSetDevice(ctx->device));
+    ctx->began = false;
+    return wm_enc_set_output(ctx, hidden, B);
+}
+
 extern "C" int wm_decode_begin(wm_ctx* ctx, const wm_gen_params* gp, int B)
 {
     if (!ctx || !gp) return WM_ERR_ARG;

@@ -146,6 +146,7 @@ long wm_enc_resample_len(long n_in, int sr_in, int sr_out);
 int wm_enc_resample(wm_ctx* ctx, const float* in, int B, int channels, int n_in, int sr_in, int sr_out, float* out);
 int wm_enc_logmel(wm_ctx* ctx, const float* wav, int B, int n_samples, float* feats);
 int wm_enc_encode(wm_ctx* ctx, const float* feats, int B);
+int wm_enc_set_output(wm_ctx* ctx, const float* hidden, int B);
 // implemented in wm_decoder.hip
 int wm_dec_stage_layers(wm_ctx* ctx, int b0, int nb, int Mper, int mode /*0 base, 1 verify*/);
 int wm_dec_stage_final(wm_ctx* ctx, int b0, int nb, int Mper, int mode, int medusa);

@@ -782,6 +782,7 @@ k_tile_gemm(const bf16_t* __restrict__ W, int N16, int K32, int nk, const bf16_t
     wm_wait_younger<LPW>(min(NS, R) - 1);
     __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0) as the builtin: the compiler's wait-count pass sees it (wm_encoder.hip ring_barrier)
     __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");             // compiler-only: the fragment reads below must not be hoisted above the barrier
     Frags f0, f1;
     frag_load(0, f0);
 
@@ -793,6 +794,7 @@ k_tile_gemm(const bf16_t* __restrict__ W, int N16, int K32, int nk, const bf16_t
         wm_wait_younger<LPW>(max(min(NS - 1, s + R - 1) - (s + 1), 0));
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");         // compiler-only: the fragment reads below must not be hoisted above the barrier
         if (s + R < NS) issue(s + R);
         frag_load(s + 1, nxt);
         __builtin_amdgcn_sched_barrier(0);

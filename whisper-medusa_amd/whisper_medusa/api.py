@@ -27,9 +27,54 @@ from . import weights as _weights
 from . import synth as _synth
 
 
+class EngineKVCache:
+    """``past_key_values`` of ``forward(use_cache=True)``: the self-attention K/V rows themselves stay in the engine's contiguous cache
+    (DESIGN.md §3); this handle records which engine / encoder pass / batch they belong to and how many positions are filled, which
+    is all a following ``forward(past_key_values=...)`` needs to append behind them (HF's Cache.get_seq_length())."""
+
+    def __init__(self, engine_id: int, enc_stamp, kv_stamp, batch: int, seq_length: int):
+        self.engine_id, self.enc_stamp, self.kv_stamp, self.batch, self._len = engine_id, enc_stamp, kv_stamp, batch, int(seq_length)
+
+    def get_seq_length(self, layer_idx: int = 0) -> int:
+        return self._len
+
+    def __len__(self):
+        return self._len
+
+
+class EngineEncoderOutput:
+    """``encoder_outputs`` as ``forward`` hands them back (HF BaseModelOutput shape: ``[0]`` / ``.last_hidden_state``).  The hidden
+    state is fetched from the engine only when somebody looks at it; passed back into ``forward(encoder_outputs=...)`` while the
+    engine still holds that encoder pass, it is recognised by its stamp and nothing is recomputed."""
+
+    def __init__(self, engine, batch: int, stamp):
+        self._engine, self._batch, self._wm_stamp, self._t = engine, batch, stamp, None
+
+    @property
+    def last_hidden_state(self) -> torch.Tensor:
+        if self._t is None:
+            if getattr(self._engine, "_enc_stamp", None) is not self._wm_stamp:
+                raise RuntimeError("this encoder pass is no longer resident in the engine")
+            self._t = self._engine.encoder_output(self._batch)
+        return self._t
+
+    def __getitem__(self, i):
+        if i != 0:
+            raise IndexError(i)
+        return self.last_hidden_state
+
+
 @dataclass
 class MedusaForwardOutput:
+    """Seq2SeqLMOutput fields the engine can fill (model.py:1336-1347)."""
     logits: torch.Tensor                 # [K+1 (or 1), B, T, V]  (model.py:1301)
+    past_key_values: Optional[EngineKVCache] = None
+    encoder_outputs: Optional[EngineEncoderOutput] = None
+    loss: Optional[torch.Tensor] = None
+
+    @property
+    def encoder_last_hidden_state(self):
+        return None if self.encoder_outputs is None else self.encoder_outputs.last_hidden_state
 
 
 class GenerateEncoderDecoderOutput(dict):
@@ -87,12 +132,19 @@ def lower_processors(gp: GenParams, logits_processor, stopping_criteria) -> GenP
         if name == "SuppressTokensLogitsProcessor":
             gp.suppress_tokens = _as_int_list(proc.suppress_tokens)
         elif name == "SuppressTokensAtBeginLogitsProcessor":
+            # only the token list is the caller's: the reference overwrites begin_index on every processor that has set_begin_index
+            # with the number of init tokens (model.py:1537, :1640-1644) — _gen_params has already put that number in gp
             gp.begin_suppress_tokens = _as_int_list(proc.begin_suppress_tokens)
-            gp.begin_suppress_index = int(proc.begin_index)
         elif name == "ExponentialDecayLengthPenalty":
             if _as_int_list(proc.eos_token_id) != [gp.eos_token_id]:
                 raise NotImplementedError("ExponentialDecayLengthPenalty on a token other than eos_token_id is not supported by the HIP engine")
-            gp.exp_decay = (int(proc.regulation_start) - P, float(proc.regulation_factor))     # regulation_start is absolute in HF
+            start = int(proc.regulation_start) - P                   # regulation_start is absolute in HF, relative to the prompt in wm_gen_params
+            if start < 0:
+                # HF would already be penalising at the first generated token with exponent P - regulation_start; the engine's
+                # field cannot say that (negative = off), and silently dropping the penalty would change the tokens
+                raise NotImplementedError(f"ExponentialDecayLengthPenalty.regulation_start ({int(proc.regulation_start)}) lies inside the "
+                                          f"decoder prompt ({P} tokens): build it with input_ids_seq_length = the prompt length")
+            gp.exp_decay = (start, float(proc.regulation_factor))
         else:
             raise NotImplementedError(f"logits processor {name} is not supported by the HIP engine (supported: {', '.join(_LOWERABLE_PROCESSORS)})")
     for crit in (stopping_criteria or []):
@@ -300,19 +352,22 @@ class WhisperMedusaModel:
             self._pool = None
 
     def _get_pool(self, n: int):
-        """Pool of n contexts.  Under the automatic policy (two or three clips -> as many single-stream contexts) ONE pool of three
-        contexts serves both sizes — a batch of two uses the first two (ContextPool shards over at most as many contexts as clips) —
-        so alternating batch sizes do not tear the contexts (KV caches, scratch, captured graphs) down and up again."""
+        """Pool of n contexts.  Under the automatic policy (two or three clips -> as many single-stream contexts) ONE pool serves both
+        sizes: it is built with as many contexts as the first batch needs — two clips do not pay for a third context's KV caches and
+        scratch — and GROWS to three when a batch of three arrives (the existing contexts, their caches and captured graphs stay)."""
         auto = self._micro_batches is None
-        want = max(n, 3) if auto else n
         have = getattr(self, "_pool_n", None)
-        if self._pool is not None and (have != want if not auto else have < n):
+        if self._pool is not None and not auto and have != n:
             self._drop_pool()
         if self._pool is None:
             from .pool import ContextPool
             _ = self.engine                                         # raises when not on a HIP device
-            self._pool = ContextPool(self.config, self._blob, self._offsets, want, max(self._max_batch, want), self._fp8, self._enc_fp8)
-            self._pool_n = want
+            # automatic policy: contexts of ONE stream each (per_ctx = ceil(max_batch / contexts) must not depend on the first batch's size)
+            self._pool = ContextPool(self.config, self._blob, self._offsets, n, n if auto else max(self._max_batch, n), self._fp8, self._enc_fp8)
+            self._pool_n = n
+        elif auto and have < n:
+            self._pool.grow(n)
+            self._pool_n = n
         return self._pool
 
     @property
@@ -452,6 +507,10 @@ class WhisperMedusaModel:
         self._last_prompt = list(gp.prompt)
         feats = input_features.to(self.device, torch.float32).contiguous()
         n_ctx = self._micro_batches_for(B) if kwargs.get("streamer") is None else 1
+        # language detection has just encoded exactly this batch on the model's own engine: decoding there saves the pool's second
+        # encoder pass over the same clips (the automatic policy's gain at 2-3 clips is smaller than an encoder pass)
+        if self._micro_batches is None and kwargs.get("_encoded_batch") == B and getattr(self._engine, "_B", None) == B:
+            n_ctx = 1
         if n_ctx > 1 and B >= 2:
             pool = self._get_pool(n_ctx)
             seqs = pool.run(feats, gp)                                      # F1..F14 per micro-batch, concurrently
@@ -487,12 +546,14 @@ class WhisperMedusaModel:
         if not return_dict_in_generate and not return_segments:
             return t
         segs = None
-        if return_segments:
+        if return_segments and not return_dict_in_generate:
             segs = [[{"start": torch.tensor(0.0), "end": torch.tensor(30.0 * self.config.max_source_positions / 1500.0),
                       "tokens": t[i, P:][t[i, P:] != pad] if pad != eos else t[i, P:],
                       "result": t[i]}] for i, P in enumerate(prompt_lens)]
         if return_dict_in_generate:
-            return GenerateEncoderDecoderOutput(t, **({"segments": segs} if segs is not None else {}))
+            # the reference returns the plain ModelOutput here (model.py:1715-1745 returns before the segments dict is built):
+            # no extra key, so to_tuple() / integer indexing keep HF's positions
+            return GenerateEncoderDecoderOutput(t)
         return {"sequences": t, "segments": segs}
 
     def _pad(self, seqs: List[List[int]], gp: GenParams) -> torch.Tensor:
@@ -638,19 +699,64 @@ class WhisperMedusaModel:
     # ---- forward ----------------------------------------------------------------------------
     @torch.no_grad()
     def forward(self, input_features: Optional[torch.Tensor] = None, attention_mask=None,
-                decoder_input_ids: Optional[torch.Tensor] = None, decoder_position_ids=None,
-                disable_medusa: bool = False, **kwargs) -> MedusaForwardOutput:
-        """Cache-free forward of the decoder over ``decoder_input_ids`` [B, T] (model.py:1223-1347).
-        If ``input_features`` is given the encoder runs first; otherwise the last encoded batch is reused.
-        The engine evaluates at most 16 positions per pass (its token tile): longer inputs go through in 16-token chunks, each
-        appending its K/V rows behind the previous chunk's — the way the engine itself consumes a long prompt."""
+                decoder_input_ids: Optional[torch.Tensor] = None, decoder_attention_mask=None, head_mask=None,
+                decoder_head_mask=None, cross_attn_head_mask=None, encoder_outputs=None, past_key_values=None,
+                decoder_inputs_embeds=None, decoder_position_ids=None, labels=None, use_cache: Optional[bool] = None,
+                output_attentions: Optional[bool] = None, output_hidden_states: Optional[bool] = None,
+                return_dict: Optional[bool] = None, disable_medusa: Optional[bool] = False, **kwargs):
+        """One decoder pass over ``decoder_input_ids`` [B, T] — the reference's ``forward`` (model.py:1223-1347), same keywords:
+
+        * ``input_features``: the encoder runs first; ``encoder_outputs`` (a tuple / ModelOutput whose first element is the last
+          hidden state [B, n_ctx, d], or that tensor) replaces the encoder pass (model.py:1232 -> HF WhisperModel.forward) — the
+          object a previous ``forward`` returned is recognised and costs nothing; neither: the last encoded batch is reused;
+        * ``past_key_values`` / ``use_cache``: the KV cache lives in the engine (contiguous rows per layer / stream / head); the
+          returned ``past_key_values`` is an ``EngineKVCache`` handle saying how many positions are cached, and a following call that
+          passes it back appends its tokens behind them (``get_seq_length()`` like HF's cache classes).  ``decoder_position_ids``
+          override the start position as in the reference;
+        * ``return_dict=False`` gives the reference's tuple ``(logits, past_key_values, encoder_last_hidden_state)``;
+        * masks, ``decoder_inputs_embeds``, attentions / hidden states and ``labels`` (training) are not part of the engine: they raise.
+
+        ``logits`` are ``[K+1 (1 with disable_medusa), B, T, V]``.  The engine evaluates 16 positions per pass: longer inputs go
+        through in 16-token chunks, each appending its K/V rows behind the previous chunk's."""
         if decoder_input_ids is None:
             raise ValueError("decoder_input_ids is required")
-        if kwargs.get("labels") is not None:
+        if labels is not None or kwargs.get("labels") is not None:
             raise NotImplementedError("training (labels / loss) is out of scope for the inference engine")
-        if input_features is not None:
-            self.engine.encode(input_features.to(self.device, torch.float32).contiguous())
+        for name, v in (("decoder_attention_mask", decoder_attention_mask), ("head_mask", head_mask), ("decoder_head_mask", decoder_head_mask),
+                        ("cross_attn_head_mask", cross_attn_head_mask), ("decoder_inputs_embeds", decoder_inputs_embeds)):
+            if v is not None:
+                raise NotImplementedError(f"forward({name}=...) is not supported by the HIP engine")
+        if output_attentions or output_hidden_states:
+            raise NotImplementedError("attention weights / hidden states are not materialised by the HIP engine")
+        B = int(decoder_input_ids.shape[0])
+        if B > self._max_batch and (input_features is not None or encoder_outputs is not None):
+            self.set_max_batch(B)                                           # a new encoder pass for more streams than the context holds
+        eng = self.engine
+        # ---- encoder side
+        enc_ref = None
+        if encoder_outputs is not None:
+            stamp = getattr(encoder_outputs, "_wm_stamp", None)
+            if stamp is not None and stamp is getattr(eng, "_enc_stamp", None):
+                enc_ref = encoder_outputs                                   # our own handle, still resident: nothing to do
+            else:
+                first = encoder_outputs if isinstance(encoder_outputs, torch.Tensor) else (
+                    encoder_outputs.last_hidden_state if hasattr(encoder_outputs, "last_hidden_state") else encoder_outputs[0])
+                eng.set_encoder_output(first)
+        elif input_features is not None:
+            eng.encode(input_features.to(self.device, torch.float32).contiguous())
+        elif getattr(eng, "_enc_stamp", None) is None:
+            raise ValueError("forward() needs input_features or encoder_outputs (nothing has been encoded on this model yet)")
+        # ---- start position
         pos0 = 0
+        if past_key_values is not None:
+            if not isinstance(past_key_values, EngineKVCache):
+                raise NotImplementedError("past_key_values must be the EngineKVCache a previous forward(use_cache=True) returned: "
+                                          "the KV cache is engine state (contiguous HBM rows), not a tuple of tensors")
+            if past_key_values.engine_id != id(eng) or past_key_values.enc_stamp is not eng._enc_stamp or past_key_values.batch != B \
+                    or past_key_values.kv_stamp is not eng._kv_stamp:
+                raise ValueError("past_key_values belongs to another engine, encoder pass or batch size, or a generate() call has "
+                                 "reused the cache since")
+            pos0 = past_key_values.get_seq_length()
         if decoder_position_ids is not None:
             pos0 = int(torch.as_tensor(decoder_position_ids).flatten()[0])
         toks = decoder_input_ids.tolist()
@@ -658,10 +764,18 @@ class WhisperMedusaModel:
         if pos0 + T > self.config.max_target_positions:
             raise ValueError(f"decoder_input_ids of length {T} at position {pos0} exceed max_target_positions "
                              f"{self.config.max_target_positions}")
+        dm = bool(disable_medusa)
         if T <= 16:
-            return MedusaForwardOutput(logits=self.engine.forward_logits(toks, pos0, disable_medusa))
-        parts = [self.engine.forward_logits([row[c: c + 16] for row in toks], pos0 + c, disable_medusa) for c in range(0, T, 16)]
-        return MedusaForwardOutput(logits=torch.cat(parts, dim=2))
+            logits = eng.forward_logits(toks, pos0, dm)
+        else:
+            logits = torch.cat([eng.forward_logits([row[c: c + 16] for row in toks], pos0 + c, dm) for c in range(0, T, 16)], dim=2)
+        want_cache = bool(use_cache) or past_key_values is not None
+        pkv = EngineKVCache(id(eng), eng._enc_stamp, eng._kv_stamp, B, pos0 + T) if want_cache else None
+        if enc_ref is None:
+            enc_ref = EngineEncoderOutput(eng, B, eng._enc_stamp)
+        if return_dict is False:
+            return (logits, pkv, enc_ref.last_hidden_state) if pkv is not None else (logits, enc_ref.last_hidden_state)
+        return MedusaForwardOutput(logits=logits, past_key_values=pkv, encoder_outputs=enc_ref)
 
     __call__ = forward
 

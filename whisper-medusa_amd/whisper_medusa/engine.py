@@ -16,7 +16,7 @@ from .config import MedusaConfig, GenParams, HEADS_BLOCK
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwm.so")      # the product library; tests/microbench scripts may point WM_LIB at a debug build
-WM_ABI_VERSION = 6
+WM_ABI_VERSION = 7
 
 
 class WmConfig(C.Structure):
@@ -49,7 +49,7 @@ class WmStats(C.Structure):
                 ("graph_replays", C.c_int32)]
 
 
-EXPORTS = ["wm_create", "wm_destroy", "wm_last_error", "wm_abi_version", "wm_resample_len", "wm_resample", "wm_logmel", "wm_encode",
+EXPORTS = ["wm_create", "wm_destroy", "wm_last_error", "wm_abi_version", "wm_resample_len", "wm_resample", "wm_logmel", "wm_encode", "wm_set_encoder_output",
            "wm_decode_begin", "wm_decode_run", "wm_get_tokens", "wm_get_stats", "wm_sync",
            "wm_get_encoder_output", "wm_forward_logits", "wm_get_cross_kv", "wm_profile_kernel"]
 
@@ -75,6 +75,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.wm_resample.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
     lib.wm_logmel.argtypes = [vp, vp, i32, i32, vp]
     lib.wm_encode.argtypes = [vp, vp, i32]
+    lib.wm_set_encoder_output.argtypes = [vp, vp, i32]
     lib.wm_decode_begin.argtypes = [vp, C.POINTER(WmGenParams), i32]
     lib.wm_decode_run.argtypes = [vp, i32, i32p]
     lib.wm_get_tokens.argtypes = [vp, i32, i32p, i32, i32p]
@@ -128,6 +129,9 @@ class Engine:
         if rc != 0:
             raise RuntimeError(f"wm_create failed ({rc}): {self.lib.wm_last_error(None).decode()}")
         self.h = h
+        self._B = None
+        self._enc_stamp = None
+        self._kv_stamp = object()
 
     def close(self):
         if getattr(self, "h", None):
@@ -190,6 +194,18 @@ class Engine:
         self._inputs_ready()
         self._check(self.lib.wm_encode(self.h, C.c_void_p(feats.data_ptr()), B), "wm_encode")
         self._B = B
+        self._enc_stamp = object()            # identity of the resident encoder pass (api.forward: encoder_outputs / past_key_values handles)
+
+    def set_encoder_output(self, hidden: torch.Tensor) -> None:
+        """hidden [B, n_ctx, d_model] (the encoder's last hidden state, e.g. ``encoder_outputs[0]`` of a previous forward) replaces
+        the encoder pass: stored bf16, cross K/V projected from it (reference forward(encoder_outputs=...), model.py:1232)."""
+        hidden = hidden.to(self.device, torch.float32).contiguous()
+        if hidden.dim() != 3 or tuple(hidden.shape[1:]) != (self.cfg.max_source_positions, self.cfg.d_model):
+            raise ValueError(f"encoder_outputs[0] must be [B, {self.cfg.max_source_positions}, {self.cfg.d_model}], got {tuple(hidden.shape)}")
+        self._inputs_ready()
+        self._check(self.lib.wm_set_encoder_output(self.h, C.c_void_p(hidden.data_ptr()), hidden.shape[0]), "wm_set_encoder_output")
+        self._B = hidden.shape[0]
+        self._enc_stamp = object()
 
     # ---- F3..F14 ------------------------------------------------------------------------------
     def decode(self, gp: GenParams, B: int, max_iters: int = 1 << 30, on_iteration=None) -> List[List[int]]:
@@ -200,6 +216,7 @@ class Engine:
                         float(gp.exp_decay[1]) if gp.exp_decay is not None else 1.0,
                         gp.posterior_threshold, gp.posterior_alpha, gp.temperature if gp.temperature else 0.0,
                         gp.accept_mode, 1 if gp.vanilla else 0, int(gp.begin_index), int(getattr(gp, "force_accept", -1)))
+        self._kv_stamp = object()             # the decode loop rewrites the self-attention cache: forward()'s cache handles go stale
         self._check(self.lib.wm_decode_begin(self.h, C.byref(g), B), "wm_decode_begin")
         left = C.c_int32(0)
         if on_iteration is None:

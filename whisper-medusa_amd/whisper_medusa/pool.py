@@ -57,10 +57,19 @@ class ContextPool:
             raise ValueError("contexts must be >= 1")
         self.cfg = cfg
         self.per_ctx = (max_batch + contexts - 1) // contexts
-        self.engines = [Engine(cfg, blob, offsets, max_batch=self.per_ctx, device=blob.device, dec_weight_fp8=dec_weight_fp8, enc_fp8=enc_fp8)
-                        for _ in range(contexts)]
+        self._mk = lambda: Engine(cfg, blob, offsets, max_batch=self.per_ctx, device=blob.device, dec_weight_fp8=dec_weight_fp8, enc_fp8=enc_fp8)
+        self.engines = [self._mk() for _ in range(contexts)]
         self._ex = ThreadPoolExecutor(max_workers=contexts, thread_name_prefix="wm-ctx") if contexts > 1 else None
         self.last_stats: dict = {}
+
+    def grow(self, contexts: int) -> None:
+        """Add contexts of the same size (KV caches, scratch, captured graphs of the existing ones are kept)."""
+        if contexts <= len(self.engines):
+            return
+        self.engines += [self._mk() for _ in range(contexts - len(self.engines))]
+        if self._ex is not None:
+            self._ex.shutdown(wait=True)
+        self._ex = ThreadPoolExecutor(max_workers=contexts, thread_name_prefix="wm-ctx")
 
     def close(self):
         if self._ex is not None:
