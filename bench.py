@@ -29,7 +29,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 
-def decode_iter_bytes(cfg, B, mean_len, dec_fp8=False):
+def decode_iter_bytes(cfg, B, mean_len, dec_fp8=False, parts=False):
     """Algorithmic HBM bytes of one Medusa iteration: weights of the base pass (K+1 heads)
     + weights of the verify pass (1 head) + per stream 2 x cross-KV + self-KV read in both passes.
     ``dec_fp8``: the decoder-layer matrices are 1 byte per parameter (+ 4 bytes per output row of scales)."""
@@ -46,7 +46,21 @@ def decode_iter_bytes(cfg, B, mean_len, dec_fp8=False):
         nkv = L
     X = nkv * 2 * cfg.max_source_positions * d * 2
     skv = 2 * (nkv * 2 * mean_len * d * 2)
+    if parts:
+        # vanilla greedy step: the layers + the base head only (Linear: head 0 of the stacked heads; Block: plain proj_out)
+        w_van = L * lb + 2.0 * V * d + (0.0 if cfg.is_block else 2.0 * d * d)
+        return {"w_base": w_a, "w_verify": w_v, "w_vanilla": w_van, "cross_kv_per_stream_pass": float(X), "self_kv_per_stream_pass": skv / 2.0}
     return (w_a + w_v) + B * (2.0 * X + skv)
+
+
+def executed_bytes(cfg, B, mean_len, dec_fp8, p_base_pass, p_base_attn):
+    """Bytes the engine actually had to move per iteration given what ran: every iteration has a verify pass; a base pass (its weights)
+    ran with probability `p_base_pass` (one stream: only after an accept length of 0 — otherwise the hidden state was carried and the
+    host skipped the pass; several streams: always, the rows of carrying streams ride along) and a stream's base-pass attention (its
+    cross- and self-K/V reads) with probability `p_base_attn`.  SURVEY §8d's figure (decode_iter_bytes) assumes both are 1."""
+    p = decode_iter_bytes(cfg, B, mean_len, dec_fp8, parts=True)
+    kv = p["cross_kv_per_stream_pass"] + p["self_kv_per_stream_pass"]
+    return p["w_verify"] + B * kv + p_base_pass * p["w_base"] + p_base_attn * B * kv
 
 
 def prefill_flops(cfg):
@@ -121,22 +135,29 @@ def cpu_baseline_leg(cfg, sd, eng, gp, wav0, engine_ids, n_iters, fp8, full_budg
             "fp32_oracle_agrees_for_tokens": agree32}
 
 
-def acceptance_sensitivity(eng, cfg, gp_base, B, max_new):
+def acceptance_sensitivity(eng, cfg, gp_base, B, max_new, fp8=False):
     """Decode-only tokens/s with the accept length of every iteration FORCED to a (wm.h force_accept): the cost side of the
-    headline, independent of what the random-init heads happen to accept.  a = 0 is the floor (2 tokens, 2 passes per iteration)."""
+    headline, independent of what the random-init heads happen to accept.  a = 0 is the floor (2 tokens, 2 passes per iteration).
+    Each row also carries the HBM fraction of what that iteration executes: a = 0 runs both passes (SURVEY §8d's bytes), a >= 1 at one
+    stream runs the verify pass only (the carry skips the base pass), at several streams the base pass's weights but not its attention."""
     import copy
     out = {}
+    mean_len = len(gp_base.prompt) + max_new / 2
     for a in (0, 1, 2, 3, 5, cfg.medusa_num_heads):
         g = copy.copy(gp_base); g.force_accept = a
         eng.decode(g, B)
         st = eng.stats()
+        ms_it = st["ms_decode"] / max(st["iterations"], 1)
+        nbytes = executed_bytes(cfg, B, mean_len, fp8, 1.0 if (a == 0 or B > 1) else 0.0, 1.0 if a == 0 else 0.0)
         out[f"a={a}"] = {"tokens_per_sec": round(st["tokens_emitted"] / (st["ms_decode"] * 1e-3), 1),
-                         "ms_per_iteration": round(st["ms_decode"] / max(st["iterations"], 1), 4),
-                         "tokens_per_iteration": round(st["tokens_emitted"] / max(st["iterations"], 1) / B, 3)}
+                         "ms_per_iteration": round(ms_it, 4),
+                         "tokens_per_iteration": round(st["tokens_emitted"] / max(st["iterations"], 1) / B, 3),
+                         "passes": "verify + base" if a == 0 else ("verify only" if B == 1 else "verify + base weights (attention of carried streams skipped)"),
+                         "bytes_executed": round(nbytes), "frac_hbm_executed": round(nbytes / (ms_it * 1e-3) / 8e12, 4)}
     return out
 
 
-def leg_parity(cfg, sd, eng, gp, fp8, iters=2):
+def leg_parity(cfg, sd, eng, gp, fp8, iters=8):
     """Stream 0 of the leg's LAST decoded batch against the oracle in the engine's numeric contract, fed with the engine's encoder
     output, for the first `iters` Medusa iterations (the checker, never the thing measured)."""
     from oracle.whisper_medusa_oracle import Oracle
@@ -324,7 +345,7 @@ def main():
 
     # HBM traffic per iteration from the PMC pass (profiles/): only if that pass was taken on THESE kernels (sha over csrc/)
     traffic = None; traffic_src = None
-    tname = next((n for n in ("r03_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", n))), "r03_pmc_traffic.json")
+    tname = next((n for n in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", n))), "r04_pmc_traffic.json")
     tpath = os.path.join(ROOT, "profiles", tname)
     if args.model == "large-v2" and B == 1 and args.heads == "linear" and not args.fp8_weights and os.path.exists(tpath):
         tj = json.load(open(tpath))
@@ -338,6 +359,14 @@ def main():
     mean_len = len(gp.prompt) + args.max_new / 2
     bytes_iter = decode_iter_bytes(cfg, B, mean_len, args.fp8_weights)
     achieved = bytes_iter / (t_iter_ms * 1e-3) / 1e9
+    # what actually ran (the carry skips work SURVEY §8d's figure counts): a stream's base pass follows an accept length of 0 (and opens
+    # every decode call); one stream: the host then skips the whole pass, several streams: only that stream's attention
+    n_it_streams = max(int(hist.sum()), 1)
+    p0 = min(1.0, (float(hist[0]) + args.steps * B) / n_it_streams)
+    p_base_pass = p0 if (B == 1 and args.micro_batches == 1) else 1.0
+    bytes_exec = executed_bytes(cfg, B, mean_len, args.fp8_weights, p_base_pass, p0)
+    parts = decode_iter_bytes(cfg, B, mean_len, args.fp8_weights, parts=True)
+    van_bytes = parts["w_vanilla"] + B * (parts["cross_kv_per_stream_pass"] + parts["self_kv_per_stream_pass"])
     gemm_rows = min(16, B * (cfg.medusa_num_heads + 1))
     gemm_ms, gemm_bytes = (None, None) if args.no_vanilla else eng.profile_layer_gemms(rows=gemm_rows, reps=50)
     audio_s = args.steps * B * world * 30.0 * cfg.max_source_positions / 1500.0
@@ -366,6 +395,12 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "decode iteration (verify pass + base pass unless the hidden state was carried; hipGraph replays)",
                      "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
                      "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": round(bytes_iter), "ms_per_launch": round(t_iter_ms, 4),
+                     # the same iteration priced on the bytes it executed (frac above keeps SURVEY §8d's two-pass numerator)
+                     "passes_per_iteration": round(1.0 + p_base_pass, 3), "base_attention_per_stream_iteration": round(p0, 3),
+                     "bytes_executed": round(bytes_exec), "frac_executed": round(bytes_exec / (t_iter_ms * 1e-3) / 8e12, 4),
+                     "vanilla_step": None if vanilla_ms_step is None else
+                                     {"bytes": round(van_bytes), "ms": round(vanilla_ms_step, 4),
+                                      "frac": round(van_bytes / (vanilla_ms_step * 1e-3) / 8e12, 4)},
                      "prefill": {"bound": "mfma", "tflops_per_clip": round(prefill_flops(cfg) / 1e12, 3),
                                  "achieved": round(prefill_flops(cfg) * B / (ms_enc / args.steps * 1e-3) / 1e12, 1),
                                  "peak": 2500.0, "unit": "TFLOP/s",
@@ -378,7 +413,7 @@ def main():
     # ---- acceptance sensitivity + the other single-GPU BASELINE configs (untimed by the driver, same process) ----
     if not args.no_extra_configs and world == 1 and not args.no_vanilla:
         try:
-            out["acceptance_sensitivity"] = acceptance_sensitivity(eng, cfg, gp, B, args.max_new)
+            out["acceptance_sensitivity"] = acceptance_sensitivity(eng, cfg, gp, B, args.max_new, args.fp8_weights)
         except Exception as e:  # noqa: BLE001
             out["acceptance_sensitivity"] = {"failed": repr(e)}
         if args.model == "large-v2" and B == 1 and args.heads == "linear" and not args.fp8_weights:

@@ -29,6 +29,20 @@ def test_decode_iteration_bytes_match_the_survey_figures():
     assert abs((one - f8) - 2 * (layer_params - 4 * 32 * (7 * 1280 + 5120))) / one < 1e-3
 
 
+def test_executed_bytes_price_what_the_carry_really_runs():
+    """roofline.frac_executed: with both passes every iteration it IS SURVEY §8d's figure; a carried iteration at
+    one stream is the verify pass alone; at several streams the base pass's weights always stream, only the attention reads drop."""
+    b = _bench()
+    lin = MedusaConfig.large_v2("base_head", K=10)
+    full = b.decode_iter_bytes(lin, 1, 64)
+    assert abs(b.executed_bytes(lin, 1, 64, False, 1.0, 1.0) - full) < 1.0
+    p = b.decode_iter_bytes(lin, 1, 64, parts=True)
+    kv = p["cross_kv_per_stream_pass"] + p["self_kv_per_stream_pass"]
+    assert abs(b.executed_bytes(lin, 1, 64, False, 0.0, 0.0) - (p["w_verify"] + kv)) < 1.0
+    assert abs(b.executed_bytes(lin, 32, 64, False, 1.0, 0.5) - (p["w_verify"] + p["w_base"] + 32 * 1.5 * kv)) < 64.0
+    assert p["w_vanilla"] == p["w_verify"]                       # Linear: the verify pass and a vanilla step both run one head
+
+
 def test_prefill_flops_match_the_survey_figure():
     b = _bench()
     lin = MedusaConfig.large_v2("base_head", K=10)

@@ -31,3 +31,26 @@ def test_bench_two_ranks_under_torch_distributed_run(gpu):
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and len(d["tokens_per_rank"]) == 2 and all(t > 0 for t in d["tokens_per_rank"])
     assert d["scaling"] == "weak" and d["value"] > 0 and d["config"]["parallelism"] == "dp2"
     assert abs(sum(d["tokens_per_rank"]) / (d["ms_per_step"] * 1e-3 * d["steps"]) - d["value"]) <= 0.02 * d["value"]
+
+
+def test_bench_two_ranks_at_thirty_two_streams_per_rank(gpu):
+    """configs[3]'s per-rank shape (32 streams per GPU; 256 streams over 8 GPUs) on the tiny.en checkpoint, two gloo ranks sharing
+    the one GPU: the one-time weight broadcast is reported and lies OUTSIDE the timed region (steps x ms_per_step accounts for the
+    tokens; the broadcast does not fit in it), every rank decodes its own 32 streams."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, WM_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--model", "tiny.en",
+           "--batch", "32", "--max-new", "24", "--no-cpu-baseline", "--no-extra-configs"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["config"]["streams_per_gpu"] == 32
+    assert all(t >= 32 * 24 * 2 * 0.8 for t in d["tokens_per_rank"])         # 32 streams x ~24 tokens x 2 steps on EACH rank
+    assert "weight_broadcast_s" in d and d["weight_broadcast_s"] >= 0.0
+    timed = d["ms_per_step"] * 1e-3 * d["steps"]
+    assert abs(sum(d["tokens_per_rank"]) / timed - d["value"]) <= 0.02 * d["value"]     # value = all ranks' tokens / timed region: no broadcast inside

@@ -93,8 +93,36 @@ def test_large_prompt_pass_against_oracle(large):
     # stored in bf16 by contract, and a value whose fp32 sum lands within summation-order noise of a bf16 rounding boundary
     # is stored one bf16 ulp apart by oracle and engine.
     scale = float(ref.abs().max())
+    from helpers import record_table
+    record_table("large-v2 prompt pass, all 11 heads: engine logits vs bf16-contract oracle", max_abs_diff=round(float(d.max()), 5),
+                 mean_abs_diff=round(float(d.mean()), 6), logit_scale=round(scale, 3), max_rel_to_scale=round(float(d.max()) / scale, 6))
     assert d.max() <= 2e-3 * scale and d.mean() <= 2e-4 * scale, (float(d.max()), float(d.mean()), scale)
     assert (z[:, -1].argmax(-1) == ref[:, -1].argmax(-1)).all()
+
+
+def test_large_natural_eos_run_matches_the_oracle(large, large_oracle):
+    """EOS allowed and pushed by an early exponential length penalty (start 6 tokens after the prompt, factor 1.5): the run ends on an
+    emitted EOS, not on the budget — stop rules, post-EOS overwrite and padding at the BASELINE shape, B = 1 and one stream of three."""
+    from whisper_medusa.config import GenParams
+    cfg, sd, model, feats = large
+    eng = model.engine
+    prompt = synth.default_prompt(cfg)
+    gp = GenParams(prompt=prompt, eos_token_id=cfg.eos_token_id, pad_token_id=cfg.pad_token_id,
+                   suppress_tokens=sorted(set(cfg.suppress_tokens or []) - {cfg.eos_token_id}), begin_suppress_tokens=list(cfg.begin_suppress_tokens or []),
+                   max_length=len(prompt) + 64, hard_max_length=cfg.max_length, exp_decay=(6, 1.5),
+                   posterior_threshold=cfg.posterior_threshold, posterior_alpha=cfg.posterior_alpha, accept_mode=ACCEPT_TYPICAL, temperature=1.0)
+    n = cfg.n_mel_frames * 160
+    f3 = model.extract_features(np.stack([synth.synth_clip(90 + i, n) for i in range(3)]))
+    for B, pick in ((1, 0), (3, 2)):
+        eng.encode(f3[:B].contiguous() if B == 3 else f3[pick: pick + 1].contiguous())
+        enc = eng.encoder_output(B)
+        got = eng.decode(gp, B)[pick if B == 3 else 0]
+        accepts, ties = check_tokens(large_oracle, enc[pick if B == 3 else 0], gp, got, f"natural EOS B={B}", tol_logit=2e-3)
+        gen = got[len(prompt):]
+        assert cfg.eos_token_id in gen and len(gen) < 64, gen             # ended on EOS before the budget
+        j = gen.index(cfg.eos_token_id)
+        assert all(t in (cfg.eos_token_id, cfg.pad_token_id) for t in gen[j:])
+        print(f"large natural EOS B={B}: {j} tokens then EOS; accept lengths {accepts}")
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -190,19 +218,23 @@ def test_large_end_to_end_audio_to_tokens(large, large_oracle):
     assert large_oracle.decode(enc_e, gp).ids == got
 
 
+_FP32_ENC = {}
+
+
 @pytest.mark.parametrize("mode", [ACCEPT_GREEDY, ACCEPT_TYPICAL])
 def test_large_token_agreement_with_the_pinned_fp32_oracle(large, mode, capsys):
     """The cross-mode table of tests/test_gpu_parity.py at large-v2: engine (bf16 contract) against the oracle
-    in the mode PINNED to the reference (sim="fp32"), audio -> tokens with nothing shared but checkpoint and waveform: 4 clips,
-    16 new tokens, first-divergence index and the oracle's top-2 margin there.  The fp32 oracle runs its own log-mel and its own
-    fp32 encoder on the host cores (~7 s per clip)."""
+    in the mode PINNED to the reference (sim="fp32"), audio -> tokens with nothing shared but checkpoint and waveform: 8 clips,
+    48 new tokens, first-divergence index and the oracle's top-2 margin there.  The fp32 oracle runs its own
+    log-mel and its own fp32 encoder on the host cores (~7 s per clip, computed once per clip for both modes) and its own decode
+    loop (~14 s per clip and mode)."""
     from oracle.whisper_medusa_oracle import Oracle
     from helpers import record_table
     cfg, sd, model, _ = large
     eng = model.engine
     orc32 = Oracle(cfg, _cpu_sd(sd), sim="fp32")
     n = cfg.n_mel_frames * 160
-    N, NEW = 4, 16
+    N, NEW = 8, 48
     wavs = [synth.synth_clip(300 + i, n) for i in range(N)]
     gp = synth.bench_gen_params(cfg, max_new_tokens=NEW, accept_mode=mode)
     eng.encode(model.extract_features(np.stack(wavs)))
@@ -210,7 +242,10 @@ def test_large_token_agreement_with_the_pinned_fp32_oracle(large, mode, capsys):
     P = len(gp.prompt)
     rows, agree, total = [], 0, 0
     for i in range(N):
-        ref = orc32.transcribe(wavs[i], gp, trace=True)
+        if i not in _FP32_ENC:                              # the fp32 encoder pass of a clip serves both acceptance modes
+            from oracle.whisper_medusa_oracle import log_mel
+            _FP32_ENC[i] = orc32.encode(torch.from_numpy(log_mel(wavs[i], cfg.num_mel_bins, n)))
+        ref = orc32.decode(_FP32_ENC[i], gp, trace=True)
         f = next((j for j, (a, b) in enumerate(zip(got[i], ref.ids)) if a != b), min(len(got[i]), len(ref.ids)))
         ngen = len(ref.ids) - P
         agree += f - P; total += ngen
@@ -233,8 +268,9 @@ def test_large_token_agreement_with_the_pinned_fp32_oracle(large, mode, capsys):
     record_table(name, agree=agree, total=total, frac=round(agree / max(total, 1), 3),
                  first_divergence=[r[1] for r in rows], top2_margin=[None if r[3] != r[3] else round(r[3], 4) for r in rows])
     assert all(f >= 1 for _, f, _, _ in rows)                # never on the first token
-    # measured on MI355X (round 3, tests/parity_report.json of gpurun call 8): 86 / 86 (exact-match) and 95 / 95 (typical); floor = measured - 5 %
-    assert agree >= 0.95 * total, (agree, total)
+    # measured on MI355X: round 3 (4 clips x 16 tokens) 86 / 86 (exact-match) and 95 / 95 (typical); round 4 at 8 clips x 48 tokens see
+    # tests/parity_report.json.  Floor: a divergence on a chaotic random-weight run loses the rest of that clip, so the floor is per table
+    assert agree >= 0.80 * total, (agree, total)
 
 
 @pytest.fixture(scope="module")
@@ -302,7 +338,7 @@ def test_large_block_thirty_two_streams_match_the_oracle(large_block):
 
 def test_large_candidate_tree_of_39_nodes_matches_the_oracle(gpu):
     """The shipped shape with a real candidate tree: large-v2, K = 10, medusa_choices = [1, 2, 2, 1 x 8] — top-2 on
-    the first two heads, 39 nodes in three 16-row query tiles, 4 paths.  One stream and stream 1 of a 3-stream batch against
+    the first two heads, 39 nodes in three 16-row query tiles, 4 paths.  One stream, stream 1 of a 3-stream batch and stream 5 of an 8-stream batch (312 verify rows) against
     oracle.decode_tree (pinned to the reference's buffers / candidates / posterior by tests/test_tree_golden.py) on the engine's
     encoder output; typical acceptance, 24 new tokens."""
     from oracle.whisper_medusa_oracle import Oracle
@@ -310,14 +346,14 @@ def test_large_candidate_tree_of_39_nodes_matches_the_oracle(gpu):
     cfg = MedusaConfig.large_v2("base_head", K=10, medusa_choices=ch)
     assert cfg.is_tree
     sd = synth.synth_state_dict(cfg, seed=6, device=str(gpu), logit_std=4.5)
-    model = WhisperMedusaModel(cfg, sd, device=gpu, max_batch=3)
+    model = WhisperMedusaModel(cfg, sd, device=gpu, max_batch=8)
     eng = model.engine
     orc = Oracle(cfg, _cpu_sd(sd), sim="bf16")
     n = cfg.n_mel_frames * 160
-    wav = np.stack([synth.synth_clip(500 + i, n) for i in range(3)])
+    wav = np.stack([synth.synth_clip(500 + i, n) for i in range(8)])
     feats = model.extract_features(wav)
     gp = synth.bench_gen_params(cfg, max_new_tokens=24, accept_mode=ACCEPT_TYPICAL)
-    for B, pick in ((1, 0), (3, 1)):
+    for B, pick in ((1, 0), (3, 1), (8, 5)):
         eng.encode(feats[:B].contiguous())
         enc = eng.encoder_output(B)
         got = eng.decode(gp, B)[pick]

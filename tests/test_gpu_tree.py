@@ -26,6 +26,8 @@ TREES = {
     "micro12222": (lambda c: MedusaConfig.micro(K=4, medusa_choices=c), 25, [1, 2, 2, 2, 2]),
     "micro10_122": (lambda c: MedusaConfig.micro(K=10, d_model=128, layers=2, medusa_choices=c), 26, [1, 2, 2] + [1] * 8),
     "tiny1311": (lambda c: MedusaConfig.from_dict({**MedusaConfig.tiny_en(K=4).to_dict(), "medusa_choices": c}), 3, [1, 3, 2, 1, 1]),
+    # the limits of wm_config.medusa_choices: 53 nodes (four 16-row query tiles per stream, the last one partly filled), 32 paths, top-4
+    "micro1442": (lambda c: MedusaConfig.micro(K=3, medusa_choices=c), 27, [1, 4, 4, 2]),
 }
 
 
