@@ -66,7 +66,9 @@ typedef struct wm_config {
                                  * to the history and to its own ancestors and sits at position L + depth — the mask / position
                                  * ids the reference builds (medusa_utils.py:343-363) and then never hands to its decoder. */
     int32_t enc_fp8;            /* 1: the encoder GEMMs fed by a LayerNorm (QKV, FC1) and the cross-K/V projection run on the CDNA4
-                                 * fp8 MFMA (BASELINE.json configs[4]): e4m3 weights with one fp32 scale per output row — 4 table
+                                 * fp8 MFMA v_mfma_f32_16x16x128_f8f6f4 (twice the bf16 MFMA rate; BASELINE.json configs[4]), operands in
+                                 * the 128-k unit layout [R/16][Kp/128][2][64 lanes][16 B] (K zero-padded to Kp = 128 ceil(K / 128);
+                                 * whisper_medusa/weights.py pack_matrix_fp8_k128): e4m3 weights with one fp32 scale per output row — 4 table
                                  * entries per encoder layer (qkv, qkv scales, fc1, fc1 scales) + 2 (cross-K/V) appended after the
                                  * decoder scales, the bf16 entries of those matrices may then be 16-byte placeholders — and the
                                  * LayerNorm output quantised to e4m3 with one scale per token row; 0: bf16 */

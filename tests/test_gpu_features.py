@@ -177,3 +177,43 @@ def test_packed_fp8_export_loads_and_decodes_identically(gpu, tmp_path):
     ib = b.generate(feats, max_new_tokens=24)
     assert torch.equal(ia, ib) and ia.shape[1] > 8
     a.engine.close(); b.engine.close()
+
+
+def test_forward_with_encoder_outputs_and_cache_handles(gpu):
+    """forward(encoder_outputs=, past_key_values=, use_cache=) (reference model.py:1223-1243): a foreign last-hidden-state tensor goes
+    through wm_set_encoder_output (stored bf16, cross K/V projected from it) and must give the logits of the input_features call;
+    a prompt fed in two cached calls must give the logits of the one-call pass; the oracle agrees on the cached continuation."""
+    from oracle.whisper_medusa_oracle import Oracle, log_mel
+    cfg = MedusaConfig.tiny_en(K=4)
+    sd = synth.synth_state_dict(cfg, seed=0)
+    model = WhisperMedusaModel(cfg, sd, device=gpu, max_batch=2)
+    n = cfg.n_mel_frames * 160
+    feats = torch.from_numpy(np.stack([log_mel(synth.synth_clip(i, n), cfg.num_mel_bins, n) for i in range(2)])).to(gpu)
+    ids = torch.tensor([synth.default_prompt(cfg) + [11, 12, 13], synth.default_prompt(cfg) + [21, 22, 23]])
+    P = ids.shape[1]
+    o_all = model.forward(input_features=feats, decoder_input_ids=ids, use_cache=True)
+    assert o_all.logits.shape == (cfg.medusa_num_heads + 1, 2, P, cfg.vocab_size) and o_all.past_key_values.get_seq_length() == P
+    hid = o_all.encoder_last_hidden_state.clone()                 # [2, S, d] fp32 of the bf16-stored encoder output
+    # (1) a foreign tensor replaces the encoder pass: same stored values -> identical cross K/V -> identical logits
+    model.forward(input_features=torch.zeros_like(feats), decoder_input_ids=ids[:, :1])      # clobber the resident encoder pass
+    o_ext = model.forward(encoder_outputs=(hid,), decoder_input_ids=ids)
+    assert torch.equal(o_ext.logits, o_all.logits)
+    assert (o_ext.encoder_last_hidden_state - hid).abs().max() == 0
+    # (2) cached continuation: first P - 2 tokens, then the last two behind them; our own encoder handle is free
+    o1 = model.forward(encoder_outputs=o_ext.encoder_outputs, decoder_input_ids=ids[:, : P - 2], use_cache=True)
+    o2 = model.forward(encoder_outputs=o_ext.encoder_outputs, decoder_input_ids=ids[:, P - 2:], past_key_values=o1.past_key_values)
+    assert o2.past_key_values.get_seq_length() == P
+    d = (o2.logits - o_all.logits[:, :, P - 2:]).abs().max()
+    assert d <= 1e-4 * float(o_all.logits.abs().max()), float(d)   # same rows through a 2-row pass instead of a P-row pass: fp32 order only
+    # (3) the oracle on the engine's encoder output agrees with the cached continuation (logit tolerance of test_forward_logits_all_heads)
+    orc = Oracle(cfg, sd, sim="bf16")
+    st = orc.new_state(hid[1])
+    ref = orc.decoder_pass(st, ids[1].tolist(), 0, disable_medusa=False)            # [K+1, P, V]
+    scale = float(ref.abs().max())
+    assert (o2.logits[:, 1] - ref[:, P - 2:]).abs().max() <= 2e-3 * scale
+    # enc_fp8 contexts cannot take a foreign encoder output (their cross-K/V projection reads the fp8 LayerNorm output)
+    m8 = WhisperMedusaModel(cfg, sd, device=gpu, max_batch=1, enc_fp8=True)
+    with pytest.raises(ValueError, match="enc_fp8"):
+        m8.forward(encoder_outputs=(hid[:1],), decoder_input_ids=ids[:1])
+    m8.engine.close()
+    model.engine.close()

@@ -25,6 +25,24 @@ def test_library_exports_every_declared_symbol(built_lib):
     engine.load_library()          # prototypes resolve
 
 
+def test_fp8_mfma_operand_layout_matches_the_kernel_index_function():
+    """weights.pack_matrix_fp8_k128 against csrc/wm_encoder.hip f8k_index restated: lane (row & 15, g) of a 128-k unit holds the 32
+    consecutive k = 32 g .. + 31, half h of the unit = bytes 16 h .. + 15 of every lane, K zero-padded to 128."""
+    def f8k_index(row, k, K128):
+        kk, b = k & 127, (k & 127) & 31
+        return ((row >> 4) * K128 + (k >> 7)) * 2048 + (b >> 4) * 1024 + ((row & 15) + 16 * (kk >> 5)) * 16 + (b & 15)
+    for n, k in ((32, 256), (16, 64), (48, 384)):
+        raw = torch.arange(n * k, dtype=torch.int64).remainder(251).to(torch.uint8).view(n, k)
+        packed = weights.pack_matrix_fp8_k128(raw.view(torch.float8_e4m3fn)).numpy()
+        K128 = (k + 127) // 128
+        assert packed.size == n * K128 * 128
+        for r in range(0, n, 5):
+            for kk in range(0, k, 7):
+                assert packed[f8k_index(r, kk, K128)] == raw[r, kk].item(), (n, k, r, kk)
+        if k % 128:
+            assert packed[f8k_index(3, k + 1, K128)] == 0         # padding is e4m3 zero
+
+
 def test_create_rejects_bad_arguments(built_lib):
     from whisper_medusa import engine
     lib = engine.load_library()

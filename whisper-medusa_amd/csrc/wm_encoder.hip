@@ -566,22 +566,28 @@ static inline hipError_t launch_gemm_tiled(hipStream_t st, const bf16_t* X, cons
 
 // =============================================================================================
 // fp8 (OCP e4m3) MFMA GEMMs of the encoder (BASELINE configs[4]): out[m][n] = xs[m] * ws[n] * sum_k X8[m][k] W8[n][k] on
-// v_mfma_f32_16x16x32_fp8_fp8 (the bf16 MFMA rate on gfx950 — only the f8f6f4 16x16x128 form doubles it — at half the operand bytes
-// through L2 -> LDS -> registers).
+// v_mfma_f32_16x16x128_f8f6f4 — the CDNA4 fp8 form that runs at TWICE the bf16 MFMA rate (the 16x16x32 fp8 form of rounds 2-3 runs
+// at the bf16 rate) — with zero scale operands (the compiler then emits the unscaled opcode; layout and semantics confirmed on the
+// GPU by tests/microbench/mfma128_probe.hip, profiles/r04_call1_patches.md): half the operand bytes through L2 -> LDS -> registers
+// AND half the matrix-pipe time per flop.
 //   X8: the LayerNorm output of a token row, quantised to e4m3 with ONE fp32 scale per row (xs[m] = max|row| / 448): the
 //       LayerNorm kernel has the whole row in one wave, so the scale costs one wave reduction.  Only the GEMMs whose operand
 //       IS a LayerNorm output take this path (QKV, FC1, cross-K/V projection: 7/12 of the encoder's GEMM flops + the
 //       projection); out-proj and FC2 read attention / GELU outputs whose row maximum is spread over blocks and stay bf16.
 //   W8: e4m3 with one fp32 scale per output row (weights.quantize_rows_e4m3).
-// Packed fp8 layout (both operands): [R/16][K/64][64 lanes][16 B] — lane l holds row l & 15, and for the two 32-wide k-tiles
-// of the 64-k unit the 8 values k = 8 (l >> 4) .. +8 (bytes 0..7: first k-tile, 8..15: second).  One unit = 1 KiB = one
-// LDS-DMA instruction; one 16-B ds_read feeds two MFMAs.  The kernels are the bf16 ones with half the fragments per k-step
-// and deeper rings in the same LDS.
+// Packed fp8 layout (both operands, ABI layout 7): [R/16][Kp/128][2 halves][64 lanes][16 B], Kp = K rounded up to 128 (zero-filled).
+// Lane l of the MFMA holds row l & 15 and the 32 consecutive k = 32 (l >> 4) .. + 31 of a 128-k unit; half h of the unit is the
+// [64 lanes][16 B] image of bytes 16 h .. + 15 of every lane.  One half = 1 KiB = one LDS-DMA instruction, lane-linear in LDS: a
+// fragment is two conflict-free ds_read_b128.
 // =============================================================================================
-__device__ __forceinline__ f32x4_t mfma16_f8(long a, long b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a, b, c, 0, 0, 0); }
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+__device__ __forceinline__ f32x4_t mfma128_f8(i32x8_t a, i32x8_t b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0, 0, 0);       // cbsz = blgp = 0: e4m3 x e4m3; no scales
+}
 
-__device__ __host__ __forceinline__ size_t f8_index(int row, int k, int K64) {       // byte index of (row, k) in the packed fp8 layout
-    return ((size_t)(row >> 4) * K64 + (k >> 6)) * 1024 + (size_t)(((row & 15) + 16 * ((k & 31) >> 3)) * 16 + ((k >> 5) & 1) * 8 + (k & 7));
+__device__ __host__ __forceinline__ size_t f8k_index(int row, int k, int K128) {       // byte index of (row, k) in the packed fp8 layout
+    const int kk = k & 127, b = kk & 31;
+    return ((size_t)(row >> 4) * K128 + (k >> 7)) * 2048 + (size_t)(b >> 4) * 1024 + (size_t)(((row & 15) + 16 * (kk >> 5)) * 16 + (b & 15));
 }
 
 template <class Ep>
@@ -621,26 +627,24 @@ __device__ __forceinline__ void ep_tiles(const EpScaled<E>& e, int m0, int n0, f
     ep_tiles<NI, NJ>(e.ep, m0, n0, acc);
 }
 
-struct F8Frag { long lo, hi; };
-__device__ __forceinline__ F8Frag ld_f8(const unsigned char* p) {
-    const uint4 v = *reinterpret_cast<const uint4*>(p);
-    F8Frag f;
-    f.lo = (long)(((unsigned long long)v.y << 32) | v.x);
-    f.hi = (long)(((unsigned long long)v.w << 32) | v.z);
-    return f;
+__device__ __forceinline__ i32x8_t ld_f8k(const unsigned char* unit_lane) {      // unit base + lane * 16
+    const uint4 lo = *reinterpret_cast<const uint4*>(unit_lane), hi = *reinterpret_cast<const uint4*>(unit_lane + 1024);
+    return i32x8_t{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
 }
 
+// (64 or 128 tokens) x 128 features, 4 waves (wn = wave >> 1: 64 features, wm = wave & 1: BM / 2 tokens); a stage = one 128-k unit of
+// every operand tile (BM / 16 + 8 units of 2 KiB), NST-deep LDS-DMA ring, one barrier per 128 k.
 template <int BM, int NST, class Ep>
 __global__ void __launch_bounds__(256)
-k_gemm_f8(const unsigned char* __restrict__ X, const unsigned char* __restrict__ W, int K64, int tiles_m, int tiles_n, Ep ep)
+k_gemm_f8k(const unsigned char* __restrict__ X, const unsigned char* __restrict__ W, int K128, int tiles_m, int tiles_n, Ep ep)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int XB = BM / 16;                // X units per stage (one 64-k unit per token tile)
+    constexpr int XB = BM / 16;                // X units per stage
     constexpr int NB = XB + 8;                 // + 8 W units (128 features)
-    constexpr int STAGE = NB * 1024;
-    constexpr int LPW = NB / 4;
+    constexpr int STAGE = NB * 2048;
+    constexpr int LPW = NB * 2 / 4;            // 1-KiB pieces per wave per stage
     constexpr int MJ = BM / 32;
-    static_assert(NB % 4 == 0, "stage must split evenly over 4 waves");
+    static_assert((NB * 2) % 4 == 0 && NST >= 2 && NST <= 4, "stage must split evenly over 4 waves");
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wn = w >> 1, wm = w & 1;
@@ -648,19 +652,20 @@ k_gemm_f8(const unsigned char* __restrict__ X, const unsigned char* __restrict__
     const int nwg = tiles_m * tiles_n;
     if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
     const int tn = bid / tiles_m, tm = bid - tn * tiles_m;
-    const unsigned char* xg = X + (size_t)tm * XB * K64 * 1024 + lane * 16;
-    const unsigned char* wg = W + (size_t)tn * 8 * K64 * 1024 + lane * 16;
+    const unsigned char* xg = X + (size_t)tm * XB * K128 * 2048 + lane * 16;
+    const unsigned char* wg = W + (size_t)tn * 8 * K128 * 2048 + lane * 16;
 
     auto stage_load = [&](int stage, int kt) {
         char* sb = smem + stage * STAGE;
 #pragma unroll
         for (int i = 0; i < LPW; ++i) {
-            const int blk = w * LPW + i;
-            const bool isx = blk < XB;
-            const int t = isx ? blk : blk - XB;
-            const unsigned char* src = (isx ? xg : wg) + ((size_t)t * K64 + kt) * 1024;
+            const int pc = w * LPW + i;                // piece = (unit, half)
+            const int u = pc >> 1, h = pc & 1;
+            const bool isx = u < XB;
+            const int t = isx ? u : u - XB;
+            const unsigned char* src = (isx ? xg : wg) + ((size_t)t * K128 + kt) * 2048 + h * 1024;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(sb + blk * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(sb + pc * 1024), 16, 0, 0);
         }
     };
 
@@ -671,42 +676,44 @@ k_gemm_f8(const unsigned char* __restrict__ X, const unsigned char* __restrict__
         for (int j = 0; j < MJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int st = 0; st < NST - 1; ++st)
-        if (st < K64) stage_load(st, st);
+        if (st < K128) stage_load(st, st);
 
-    for (int kt = 0; kt < K64; ++kt) {
-        const int younger = min(K64 - 1, kt + NST - 2) - kt;
+    for (int kt = 0; kt < K128; ++kt) {
+        const int younger = min(K128 - 1, kt + NST - 2) - kt;
         if (NST >= 4 && younger >= 2) wait_vmcnt<2 * LPW>();
         else if (NST >= 3 && younger >= 1) wait_vmcnt<LPW>();
         else wait_vmcnt<0>();
         ring_barrier();
-        if (kt + NST - 1 < K64) stage_load((kt + NST - 1) % NST, kt + NST - 1);
-        const unsigned char* xs = reinterpret_cast<const unsigned char*>(smem + (kt % NST) * STAGE);
-        const unsigned char* ws = xs + XB * 1024;
-        F8Frag a[4], b[MJ];
+        if (kt + NST - 1 < K128) stage_load((kt + NST - 1) % NST, kt + NST - 1);
+        const unsigned char* xs = reinterpret_cast<const unsigned char*>(smem + (kt % NST) * STAGE) + lane * 16;
+        const unsigned char* ws = xs + XB * 2048;
+        i32x8_t a[4], b[MJ];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = ld_f8(ws + ((wn * 4 + i) * 64 + lane) * 16);
+        for (int i = 0; i < 4; ++i) a[i] = ld_f8k(ws + (wn * 4 + i) * 2048);
 #pragma unroll
-        for (int j = 0; j < MJ; ++j) b[j] = ld_f8(xs + ((wm * MJ + j) * 64 + lane) * 16);
+        for (int j = 0; j < MJ; ++j) b[j] = ld_f8k(xs + (wm * MJ + j) * 2048);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < MJ; ++j)
 #pragma unroll
-            for (int j = 0; j < MJ; ++j) { acc[i][j] = mfma16_f8(a[i].lo, b[j].lo, acc[i][j]); acc[i][j] = mfma16_f8(a[i].hi, b[j].hi, acc[i][j]); }
+            for (int i = 0; i < 4; ++i) acc[i][j] = mfma128_f8(a[i], b[j], acc[i][j]);
     }
     const int m0 = tm * BM + wm * (BM / 2) + (lane & 15), n0 = tn * GT_BN + wn * 64 + 4 * (lane >> 4);
     ep_tiles<4, MJ>(ep, m0, n0, acc);
 }
 
-// 256 x 256 tile, 8 waves (2 x 4), wave = 128 tokens x 64 features; a 64-k step is 32 KiB (16 X + 16 W units): three stages
+// 256 x 256 tile, 8 waves (2 x 4), wave = 128 tokens x 64 features.  A 128-k stage is 64 KiB (16 X + 16 W units): TWO stages — stage
+// t + 1 lands in the buffer stage t - 1 was read from while the 32 MFMAs per wave of stage t run (1024 matrix-pipe cycles per wave, two
+// waves per SIMD: 2048 cycles per step against ~64 KiB of L2 -> LDS fill per CU).  The token fragments of a step are read in two halves,
+// the second behind the first half's MFMAs.  Strip-major XCD tile order as k_gemm_256p.
 template <class Ep>
 __global__ void __launch_bounds__(512)
-k_gemm_f8_256(const unsigned char* __restrict__ X, const unsigned char* __restrict__ W, int K64, int tiles_m, int tiles_n, int PN, Ep ep)
+k_gemm_f8k_256(const unsigned char* __restrict__ X, const unsigned char* __restrict__ W, int K128, int tiles_m, int tiles_n, int PN, Ep ep)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int STAGE = 32 * 1024, NST = 3, LPW = 4;
+    constexpr int STAGE = 64 * 1024, LPW = 8;
     const int lane = threadIdx.x & 63;
     const int wa = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wa >> 2, wn = wa & 3;
-    // strip-major tile order, XCD x = blockIdx % 8 walking a contiguous eighth of it (see k_gemm_256p)
     int tm, tn;
     {
         const int nwg = tiles_m * tiles_n, b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
@@ -714,19 +721,20 @@ k_gemm_f8_256(const unsigned char* __restrict__ X, const unsigned char* __restri
         const int strip = tiles_m * PN, sb = id / strip, rem = id - sb * strip;
         tm = rem / PN; tn = sb * PN + (rem - tm * PN);
     }
-    const unsigned char* xg = X + (size_t)tm * 16 * K64 * 1024 + lane * 16;
-    const unsigned char* wg = W + (size_t)tn * 16 * K64 * 1024 + lane * 16;
+    const unsigned char* xg = X + (size_t)tm * 16 * K128 * 2048 + lane * 16;
+    const unsigned char* wg = W + (size_t)tn * 16 * K128 * 2048 + lane * 16;
 
     auto stage_load = [&](int stage, int kt) {
         char* sb = smem + stage * STAGE;
 #pragma unroll
         for (int i = 0; i < LPW; ++i) {
-            const int blk = wa * LPW + i;              // 0..15 X units, 16..31 W units
-            const bool isx = blk < 16;
-            const int t = isx ? blk : blk - 16;
-            const unsigned char* src = (isx ? xg : wg) + ((size_t)t * K64 + kt) * 1024;
+            const int pc = wa * LPW + i;               // pieces 0..31: the 16 X units' halves, 32..63: the W units'
+            const int u = pc >> 1, h = pc & 1;
+            const bool isx = u < 16;
+            const int t = isx ? u : u - 16;
+            const unsigned char* src = (isx ? xg : wg) + ((size_t)t * K128 + kt) * 2048 + h * 1024;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(sb + blk * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(sb + pc * 1024), 16, 0, 0);
         }
     };
 
@@ -736,54 +744,61 @@ k_gemm_f8_256(const unsigned char* __restrict__ X, const unsigned char* __restri
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     stage_load(0, 0);
-    if (K64 > 1) stage_load(1, 1);
-    for (int kt = 0; kt < K64; ++kt) {
-        if (kt + 1 < K64) wait_vmcnt<LPW>(); else wait_vmcnt<0>();
-        ring_barrier();
-        if (kt + 2 < K64) stage_load((kt + 2) % NST, kt + 2);
-        const unsigned char* xs = reinterpret_cast<const unsigned char*>(smem + (kt % NST) * STAGE);
-        const unsigned char* ws = xs + 16 * 1024;
-        F8Frag a[4], b[8];
+    for (int kt = 0; kt < K128; ++kt) {
+        wait_vmcnt<0>();                               // this wave's pieces of stage kt (the only stage in flight)
+        ring_barrier();                                // everyone's pieces landed; everyone's reads of stage kt - 1 are complete
+        if (kt + 1 < K128) stage_load((kt + 1) & 1, kt + 1);
+        const unsigned char* xs = reinterpret_cast<const unsigned char*>(smem + (kt & 1) * STAGE) + lane * 16;
+        const unsigned char* ws = xs + 16 * 2048;
+        i32x8_t a[4], b0[4], b1[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = ld_f8(ws + ((wn * 4 + i) * 64 + lane) * 16);
+        for (int i = 0; i < 4; ++i) a[i] = ld_f8k(ws + (wn * 4 + i) * 2048);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) b[j] = ld_f8(xs + ((wm * 8 + j) * 64 + lane) * 16);
+        for (int j = 0; j < 4; ++j) b0[j] = ld_f8k(xs + (wm * 8 + j) * 2048);
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < 4; ++j) b1[j] = ld_f8k(xs + (wm * 8 + 4 + j) * 2048);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { acc[i][j] = mfma16_f8(a[i].lo, b[j].lo, acc[i][j]); acc[i][j] = mfma16_f8(a[i].hi, b[j].hi, acc[i][j]); }
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = mfma128_f8(a[i], b0[j], acc[i][j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][4 + j] = mfma128_f8(a[i], b1[j], acc[i][4 + j]);
     }
     const int m0 = tm * 256 + wm * 128 + (lane & 15), n0 = tn * 256 + wn * 64 + 4 * (lane >> 4);
     ep_tiles<4, 8>(ep, m0, n0, acc);
 }
 
 template <int BM, int NST, class Ep>
-static inline hipError_t launch_gemm_f8_bm(hipStream_t st, const unsigned char* X, const unsigned char* W, int Mrows, int N, int K64, const Ep& ep)
+static inline hipError_t launch_gemm_f8_bm(hipStream_t st, const unsigned char* X, const unsigned char* W, int Mrows, int N, int K128, const Ep& ep)
 {
     const int tiles_m = Mrows / BM, tiles_n = N / GT_BN;
-    constexpr int lds = NST * (BM / 16 + 8) * 1024;
-    auto kern = k_gemm_f8<BM, NST, Ep>;
+    constexpr int lds = NST * (BM / 16 + 8) * 2048;
+    auto kern = k_gemm_f8k<BM, NST, Ep>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), lds, st, X, W, K64, tiles_m, tiles_n, ep);
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), lds, st, X, W, K128, tiles_m, tiles_n, ep);
     return hipGetLastError();
 }
 
+// K128 = 128-k units per row (K rounded up to 128)
 template <class Ep>
-static inline hipError_t launch_gemm_f8(hipStream_t st, const unsigned char* X, const unsigned char* W, int Mrows, int N, int K64, const Ep& ep)
+static inline hipError_t launch_gemm_f8(hipStream_t st, const unsigned char* X, const unsigned char* W, int Mrows, int N, int K128, const Ep& ep)
 {
     static const int use256 = [] { const char* v = std::getenv("WM_ENC_GEMM_256"); return v ? std::atoi(v) : 1; }();
     if (use256 && Mrows % 256 == 0 && N % 256 == 0 && (Mrows / 256) * (N / 256) >= 200) {
-        auto kern = k_gemm_f8_256<Ep>;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        auto kern = k_gemm_f8k_256<Ep>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3((Mrows / 256) * (N / 256)), dim3(512), 96 * 1024, st, X, W, K64, Mrows / 256, N / 256, gemm256_strip(N / 256), ep);
+        hipLaunchKernelGGL(kern, dim3((Mrows / 256) * (N / 256)), dim3(512), 128 * 1024, st, X, W, K128, Mrows / 256, N / 256, gemm256_strip(N / 256), ep);
         return hipGetLastError();
     }
-    if ((Mrows / 128) * (N / GT_BN) < 200) return launch_gemm_f8_bm<64, 4>(st, X, W, Mrows, N, K64, ep);
-    return launch_gemm_f8_bm<128, 4>(st, X, W, Mrows, N, K64, ep);
+    // few clips: 24 KiB (64 tokens) / 32 KiB (128 tokens) stages, two resident blocks per CU
+    if ((Mrows / 128) * (N / GT_BN) < 200) return launch_gemm_f8_bm<64, 3>(st, X, W, Mrows, N, K128, ep);
+    return launch_gemm_f8_bm<128, 2>(st, X, W, Mrows, N, K128, ep);
 }
 
 // =============================================================================================
@@ -1137,7 +1152,7 @@ k_enc_ln_f8(const float* __restrict__ src, const float* __restrict__ gamma, cons
     amax = wave_max(amax);
     const float scale = amax > 0.f ? amax / 448.0f : 1.0f;
     if (lane == 0) xs[m] = scale;
-    const int K64 = K32 >> 1;
+    const int K128 = (K32 + 3) >> 2;            // 128-k units per row; the bytes k >= d of the last unit stay zero (allocation-time memset)
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int j = lane + 64 * i;
@@ -1146,7 +1161,7 @@ k_enc_ln_f8(const float* __restrict__ src, const float* __restrict__ gamma, cons
             const float q2 = fminf(fmaxf(v[i].z / scale, -448.f), 448.f), q3 = fminf(fmaxf(v[i].w / scale, -448.f), 448.f);
             int pk = __builtin_amdgcn_cvt_pk_fp8_f32(q0, q1, 0, false);
             pk = __builtin_amdgcn_cvt_pk_fp8_f32(q2, q3, pk, true);
-            *reinterpret_cast<int*>(out8 + f8_index(m, j * 4, K64)) = pk;
+            *reinterpret_cast<int*>(out8 + f8k_index(m, j * 4, K128)) = pk;
         }
     }
 }
@@ -1454,7 +1469,7 @@ int wm_enc_encode(wm_ctx* ctx, const float* feats, int B)
         if (f8) {
             hipLaunchKernelGGL(k_enc_ln_f8<false>, dim3((M + 3) / 4), dim3(256), 0, st, ctx->eh, w.ln1_w, w.ln1_b, ctx->exn8, ctx->exs, nullptr, K32, d, M);
             WM_HIP(hipGetLastError());
-            WM_HIP(launch_gemm_f8(st, ctx->exn8, w.qkv_w8, M, 3 * d, K32 / 2,
+            WM_HIP(launch_gemm_f8(st, ctx->exn8, w.qkv_w8, M, 3 * d, (K32 + 3) / 4,
                                   EpScaled<EpQKVEnc>{EpQKVEnc{ctx->eq, ctx->ek, ctx->evt, w.qkv_b, Spad, H, d}, ctx->exs, w.qkv_ws}));
         } else {
             launch_enc_ln(st, ctx->eh, w.ln1_w, w.ln1_b, ctx->exn, K32, d, M);
@@ -1482,7 +1497,7 @@ int wm_enc_encode(wm_ctx* ctx, const float* feats, int B)
         if (f8) {
             hipLaunchKernelGGL(k_enc_ln_f8<false>, dim3((M + 3) / 4), dim3(256), 0, st, ctx->eh, w.ln2_w, w.ln2_b, ctx->exn8, ctx->exs, nullptr, K32, d, M);
             WM_HIP(hipGetLastError());
-            WM_HIP(launch_gemm_f8(st, ctx->exn8, w.fc1_w8, M, ffn, K32 / 2,
+            WM_HIP(launch_gemm_f8(st, ctx->exn8, w.fc1_w8, M, ffn, (K32 + 3) / 4,
                                   EpScaled<EpPackedAct<2>>{EpPackedAct<2>{ctx->eff, nullptr, w.fc1_b, ffn / 32, M}, ctx->exs, w.fc1_ws}));
         } else {
             launch_enc_ln(st, ctx->eh, w.ln2_w, w.ln2_b, ctx->exn, K32, d, M);
@@ -1496,7 +1511,7 @@ int wm_enc_encode(wm_ctx* ctx, const float* feats, int B)
         hipLaunchKernelGGL(k_enc_ln_f8<true>, dim3((M + 3) / 4), dim3(256), 0, st, ctx->eh, ctx->enc_lnf_w, ctx->enc_lnf_b, ctx->exn8, ctx->exs,
                            ctx->enc_out, K32, d, M);
         WM_HIP(hipGetLastError());
-        WM_HIP(launch_gemm_f8(st, ctx->exn8, ctx->ckv_w8, M, ctx->nkv * 2 * d, K32 / 2,
+        WM_HIP(launch_gemm_f8(st, ctx->exn8, ctx->ckv_w8, M, ctx->nkv * 2 * d, (K32 + 3) / 4,
                               EpScaled<EpCrossKV>{EpCrossKV{ctx->kx, ctx->vx, ctx->ckv_b, Spad, H, d, B}, ctx->exs, ctx->ckv_ws}));
     } else {
         launch_enc_ln(st, ctx->eh, ctx->enc_lnf_w, ctx->enc_lnf_b, ctx->enc_out, K32, d, M);

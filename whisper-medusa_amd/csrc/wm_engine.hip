@@ -121,7 +121,7 @@ extern "C" int wm_create(const wm_config* cfg, const wm_weights* w, int device, 
     const bool w8 = cfg->dec_weight_fp8 != 0;
     const bool e8 = cfg->enc_fp8 != 0;
     ctx->enc_f8 = e8;
-    if (e8 && (cfg->d_model % 64 || cfg->ffn_dim % 128)) { g_create_err = "wm_create: enc_fp8 needs d_model % 64 == 0"; wm_destroy(ctx); return WM_ERR_ARG; }
+    if (e8 && (cfg->d_model % 64 || cfg->ffn_dim % 128)) { g_create_err = "wm_create: enc_fp8 needs d_model % 64 == 0 and ffn_dim % 128 == 0"; wm_destroy(ctx); return WM_ERR_ARG; }
     const int n_expected = 19 + 12 * cfg->enc_layers + 18 * ctx->nkv + (w8 ? 6 * ctx->nkv : 0) + (e8 ? 4 * cfg->enc_layers + 2 : 0);
     if (w->n_offsets != n_expected || !w->blob || !w->offsets) {
         g_create_err = "wm_create: weight table has " + std::to_string(w->n_offsets) + " entries, expected " + std::to_string(n_expected);
@@ -151,7 +151,7 @@ extern "C" int wm_create(const wm_config* cfg, const wm_weights* w, int device, 
     }
     if (w8)                                    // fp8 e4m3 decoder-layer matrices: one fp32 scale per output row, appended to the table
         for (auto& e : ctx->dec) { e.qkv_s = F(); e.out_s = F(); e.cq_s = F(); e.cout_s = F(); e.fc1_s = F(); e.fc2_s = F(); }
-    if (e8) {                                  // fp8 MFMA encoder: e4m3 matrices (64-k unit layout) + per-row scales, appended last
+    if (e8) {                                  // fp8 MFMA encoder: e4m3 matrices (128-k unit layout, K zero-padded to 128) + per-row scales, appended last
         auto U8 = [&]() { return reinterpret_cast<const unsigned char*>(base + w->offsets[t++]); };
         for (auto& e : ctx->enc) { e.qkv_w8 = U8(); e.qkv_ws = F(); e.fc1_w8 = U8(); e.fc1_ws = F(); }
         ctx->ckv_w8 = U8(); ctx->ckv_ws = F();
@@ -168,7 +168,7 @@ extern "C" int wm_create(const wm_config* cfg, const wm_weights* w, int device, 
     CREATE_HIP(dev_alloc(&ctx->A2, Menc * 3 * d, st));
     CREATE_HIP(dev_alloc(&ctx->eh, Menc * d, st));
     CREATE_HIP(dev_alloc(&ctx->exn, Menc * d, st));
-    if (e8) { CREATE_HIP(dev_alloc(&ctx->exn8, Menc * d, st)); CREATE_HIP(dev_alloc(&ctx->exs, Menc, st)); }
+    if (e8) { CREATE_HIP(dev_alloc(&ctx->exn8, Menc * (size_t)((d + 127) / 128 * 128), st)); CREATE_HIP(dev_alloc(&ctx->exs, Menc, st)); }
     CREATE_HIP(dev_alloc(&ctx->eq, Menc * d, st));
     CREATE_HIP(dev_alloc(&ctx->ek, Menc * d, st));
     CREATE_HIP(dev_alloc(&ctx->evt, Menc * d, st));

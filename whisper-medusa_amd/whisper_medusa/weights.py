@@ -60,14 +60,18 @@ def pack_matrix_fp8(q: torch.Tensor) -> torch.Tensor:
     return t.permute(0, 2, 3, 1, 4).contiguous().view(-1)
 
 
-def pack_matrix_fp8_k64(q: torch.Tensor) -> torch.Tensor:
-    """float8_e4m3fn [N, K] -> uint8 in the fp8-MFMA operand layout [N/16][K/64][64 lanes][16]: lane (r = row & 15, g) holds, for the
-    two 32-wide k-tiles of a 64-k unit, the 8 values k = 8 g .. 8 g + 7 (bytes 0..7 first tile, 8..15 second)  (csrc/wm_encoder.hip,
-    f8_index).  N % 16 == 0, K % 64 == 0."""
+def pack_matrix_fp8_k128(q: torch.Tensor) -> torch.Tensor:
+    """float8_e4m3fn [N, K] -> uint8 in the fp8-MFMA operand layout of v_mfma_f32_16x16x128_f8f6f4,
+    [N/16][Kp/128][2 halves][64 lanes][16]: lane (r = row & 15, g) of a 128-k unit holds the 32 consecutive k = 32 g .. + 31, half h
+    its bytes 16 h .. + 15 (csrc/wm_encoder.hip, f8k_index).  N % 16 == 0; K is zero-padded to a multiple of 128 (Kp)."""
     n, k = q.shape
-    assert n % 16 == 0 and k % 64 == 0, (n, k)
-    t = q.view(torch.uint8).view(n // 16, 16, k // 64, 2, 4, 8)        # (nt, r, u, kt, g, e)
-    return t.permute(0, 2, 4, 1, 3, 5).contiguous().view(-1)            # (nt, u, g, r, kt, e): lane = g*16 + r, byte = kt*8 + e
+    assert n % 16 == 0, (n, k)
+    kp = (k + 127) // 128 * 128
+    u8 = q.view(torch.uint8)
+    if kp != k:
+        u8 = torch.cat([u8, torch.zeros(n, kp - k, dtype=torch.uint8, device=u8.device)], dim=1)      # e4m3 zero is 0x00
+    t = u8.reshape(n // 16, 16, kp // 128, 4, 2, 16)                     # (nt, r, u, g, h, e)
+    return t.permute(0, 2, 4, 3, 1, 5).contiguous().view(-1)              # (nt, u, h, g, r, e): lane = g*16 + r
 
 
 def _pad2(w: torch.Tensor, n: int, k: int) -> torch.Tensor:
@@ -115,7 +119,7 @@ def canonical_tensors(cfg: MedusaConfig, sd: Dict[str, torch.Tensor], device, de
         if not enc_fp8:
             return mat(w)
         q, sc = quantize_rows_e4m3(w)
-        enc8.extend([pack_matrix_fp8_k64(q).to(dev), sc.to(dev).contiguous()])
+        enc8.extend([pack_matrix_fp8_k128(q).to(dev), sc.to(dev).contiguous()])
         return placeholder()
 
     ckv = torch.cat([torch.cat([sd[p + ".encoder_attn.k_proj.weight"].to(dev, torch.float32),
@@ -123,7 +127,7 @@ def canonical_tensors(cfg: MedusaConfig, sd: Dict[str, torch.Tensor], device, de
     ckv8: List[torch.Tensor] = []
     if enc_fp8:
         q, sc = quantize_rows_e4m3(ckv)
-        ckv8 = [pack_matrix_fp8_k64(q).to(dev), sc.to(dev).contiguous()]
+        ckv8 = [pack_matrix_fp8_k128(q).to(dev), sc.to(dev).contiguous()]
     out += [placeholder() if enc_fp8 else mat(ckv),
             torch.cat([torch.cat([zeros(d), f32(sd[p + ".encoder_attn.v_proj.bias"])]) for p in kv_prefixes])]
 
