@@ -270,9 +270,9 @@ __device__ __forceinline__ void ep_tiles(const EpPackedAct<2>& ep, int m0, int n
     for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const float x0 = gelu_phi(acc[i][j][0] + bb[i].x), x1 = gelu_phi(acc[i][j][1] + bb[i].y);
-            const float x2 = gelu_phi(acc[i][j][2] + bb[i].z), x3 = gelu_phi(acc[i][j][3] + bb[i].w);
-            uint2 u; u.x = pack_bf2(x0, x1); u.y = pack_bf2(x2, x3);
+            const f32x2_t g0 = gelu_phi2(f32x2_t{acc[i][j][0] + bb[i].x, acc[i][j][1] + bb[i].y});
+            const f32x2_t g1 = gelu_phi2(f32x2_t{acc[i][j][2] + bb[i].z, acc[i][j][3] + bb[i].w});
+            uint2 u; u.x = pack_bf2(g0[0], g0[1]); u.y = pack_bf2(g1[0], g1[1]);
             *reinterpret_cast<uint2*>(ep.out + packed_index(m0 + j * 16, n0 + i * 16, ep.K32out)) = u;
         }
 }

@@ -770,6 +770,95 @@ k_gemm_f8k_256(const unsigned char* __restrict__ X, const unsigned char* __restr
     ep_tiles<4, 8>(ep, m0, n0, acc);
 }
 
+// The same tile with the two token halves of the block (waves 0-3: wm = 0, waves 4-7: wm = 1; every SIMD hosts one wave of each) running
+// HALF A STEP APART: a step is two phases, each closed by a block barrier; a wave reads the 12 fragments of its stage into registers in one
+// phase and issues its 32 MFMAs in the next, and the other half does the opposite — while one wave of a SIMD waits for the LDS (the lock-step
+// kernel above leaves the matrix pipes idle for the ~770 LDS cycles of every step: 192 KiB of fragment reads per block and step) the other
+// keeps that SIMD's matrix pipe busy.  Phase p:  wm = 0 reads stage p / 2 (p even) and multiplies it (p odd); wm = 1 reads in the odd phases
+// and multiplies in the even ones.  LDS-DMA: the pieces of stage s are issued by every wave in phase 2 s - 2 (its buffer held stage s - 2,
+// last read by wm = 1 in phase 2 s - 3) and waited for (vmcnt(0)) before the barrier that closes phase 2 s - 1; wm = 0 reads them in phase
+// 2 s, wm = 1 in phase 2 s + 1.  Both halves pass 2 K128 + 2 barriers.
+template <class Ep>
+__global__ void __launch_bounds__(512)
+k_gemm_f8k_256s(const unsigned char* __restrict__ X, const unsigned char* __restrict__ W, int K128, int tiles_m, int tiles_n, int PN, Ep ep)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STAGE = 64 * 1024, LPW = 8;
+    const int lane = threadIdx.x & 63;
+    const int wa = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wa >> 2, wn = wa & 3;
+    int tm, tn;
+    {
+        const int nwg = tiles_m * tiles_n, b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+        const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+        const int strip = tiles_m * PN, sb = id / strip, rem = id - sb * strip;
+        tm = rem / PN; tn = sb * PN + (rem - tm * PN);
+    }
+    const unsigned char* xg = X + (size_t)tm * 16 * K128 * 2048 + lane * 16;
+    const unsigned char* wg = W + (size_t)tn * 16 * K128 * 2048 + lane * 16;
+    auto stage_load = [&](int kt) {
+        char* sb = smem + (kt & 1) * STAGE;
+#pragma unroll
+        for (int i = 0; i < LPW; ++i) {
+            const int pc = wa * LPW + i;
+            const int u = pc >> 1, h = pc & 1;
+            const bool isx = u < 16;
+            const int t = isx ? u : u - 16;
+            const unsigned char* src = (isx ? xg : wg) + ((size_t)t * K128 + kt) * 2048 + h * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(sb + pc * 1024), 16, 0, 0);
+        }
+    };
+    i32x8_t a[4], b[8];
+    auto read_frags = [&](int kt) {
+        const unsigned char* xs = reinterpret_cast<const unsigned char*>(smem + (kt & 1) * STAGE) + lane * 16;
+        const unsigned char* ws = xs + 16 * 2048;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = ld_f8k(ws + (wn * 4 + i) * 2048);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b[j] = ld_f8k(xs + (wm * 8 + j) * 2048);
+    };
+    f32x4_t acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    auto mfmas = [&]() {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = mfma128_f8(a[i], b[j], acc[i][j]);
+    };
+    const int NT = K128;
+    stage_load(0);
+    wait_vmcnt<0>();
+    ring_barrier();                                    // stage 0 has landed
+    if (wm == 0) {
+        for (int t = 0; t < NT; ++t) {
+            if (t + 1 < NT) stage_load(t + 1);         // phase 2 t
+            read_frags(t);
+            ring_barrier();                            // (lgkmcnt(0) inside: the fragments are in registers)
+            mfmas();                                   // phase 2 t + 1
+            wait_vmcnt<0>();
+            ring_barrier();
+        }
+        ring_barrier();                                // phase 2 NT: the other half's last products
+    } else {
+        if (NT > 1) stage_load(1);                     // phase 0
+        ring_barrier();
+        for (int t = 0; t < NT; ++t) {
+            read_frags(t);                             // phase 2 t + 1
+            wait_vmcnt<0>();
+            ring_barrier();
+            if (t + 2 < NT) stage_load(t + 2);         // phase 2 t + 2
+            mfmas();
+            ring_barrier();
+        }
+    }
+    const int m0 = tm * 256 + wm * 128 + (lane & 15), n0 = tn * 256 + wn * 64 + 4 * (lane >> 4);
+    ep_tiles<4, 8>(ep, m0, n0, acc);
+}
+
 template <int BM, int NST, class Ep>
 static inline hipError_t launch_gemm_f8_bm(hipStream_t st, const unsigned char* X, const unsigned char* W, int Mrows, int N, int K128, const Ep& ep)
 {
@@ -790,7 +879,11 @@ static inline hipError_t launch_gemm_f8(hipStream_t st, const unsigned char* X, 
 {
     static const int use256 = [] { const char* v = std::getenv("WM_ENC_GEMM_256"); return v ? std::atoi(v) : 1; }();
     if (use256 && Mrows % 256 == 0 && N % 256 == 0 && (Mrows / 256) * (N / 256) >= 200) {
-        auto kern = k_gemm_f8k_256<Ep>;
+        // WM_F8_STAGGER=1: the form with the two token halves half a step apart.  Measured SLOWER (profiles/r04_fp8_encoder.md: FC1 531 vs
+        // 519 us, QKV 443 vs 406 us per launch at 32 clips): the K loop is bound by the L2 -> LDS fill (64 KiB per step and CU at ~66 GB/s
+        // = one step's MFMA time), not by the exposed fragment reads the stagger hides; the extra barrier per step only costs.  Kept as a knob.
+        const int stagger = [] { const char* v = std::getenv("WM_F8_STAGGER"); return v ? std::atoi(v) : 0; }();
+        auto kern = stagger ? k_gemm_f8k_256s<Ep> : k_gemm_f8k_256<Ep>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3((Mrows / 256) * (N / 256)), dim3(512), 128 * 1024, st, X, W, K128, Mrows / 256, N / 256, gemm256_strip(N / 256), ep);

@@ -407,8 +407,18 @@ k_ln_tiles(Ld ld, int ksplit, bf16_t* __restrict__ xg, size_t plane, const int* 
 // traffic of the operand re-reads by RT resp. TT); blockIdx.y walks the token-tile groups, so the chip is filled
 // by tokens as well as by features and the weights are re-read from L2 / Infinity Cache, not HBM.  Per output the
 // accumulation order is the 16-row kernel's (k ascending, hi then lo; K-slices summed in order): bit-identical.
+// Build-time experiment knobs (tests/microbench, `build.py --variant`): WM_ROWS_MINW = minimum waves per SIMD the register allocation of
+// k_rows_gemm must allow (5 -> <= 96 VGPRs: two 10-wave blocks, or four 5-wave blocks, per CU), WM_ROWS_G = k-tiles per load group.
+#ifdef WM_ROWS_MINW
+#define WM_ROWS_BOUNDS __launch_bounds__(640, WM_ROWS_MINW)
+#else
+#define WM_ROWS_BOUNDS __launch_bounds__(640)
+#endif
+#ifndef WM_ROWS_G
+#define WM_ROWS_G 4
+#endif
 template <int NKR, int RT, int TT, bool W8, class Ep>
-__global__ void __launch_bounds__(640)
+__global__ void WM_ROWS_BOUNDS
 k_rows_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int N16, int K32, int ksplit, const int* __restrict__ done,
             const bf16_t* __restrict__ X, size_t plane, int MT, Ep ep)
 {
@@ -430,7 +440,7 @@ k_rows_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int 
     for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int j = 0; j < TT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    constexpr int G = 4;
+    constexpr int G = WM_ROWS_G;
 #pragma unroll
     for (int kg = 0; kg < NKR; kg += G) {
         bf16x8_t a[RT][G], xh[TT][G], xl[TT][G];
