@@ -349,8 +349,50 @@ def test_hf_processors_and_criteria_are_lowered_into_generation_params():
         lower_processors(gp2, [ExponentialDecayLengthPenalty((2, 1.25), big.eos_token_id, 0)], None)
     with pytest.raises(NotImplementedError, match="TemperatureLogitsWarper"):
         lower_processors(gp, [TemperatureLogitsWarper(0.7)], None)
-    with pytest.raises(NotImplementedError, match="MaxTimeCriteria"):
-        lower_processors(gp, None, [MaxTimeCriteria(1.0)])
+    # a criterion that is not a static rule goes to the host list (asked after every iteration), it does not raise
+    g3 = lower_processors(m._gen_params("en", None, None, 64, None, None, False, None, None, None, None, None), None, [MaxTimeCriteria(1.0)])
+    assert [type(c).__name__ for c in g3._host_criteria] == ["MaxTimeCriteria"]
+
+
+def test_dynamic_stopping_criteria_run_on_the_host_after_every_iteration():
+    """generate(stopping_criteria=[custom]): the reference asks the criteria once per Medusa iteration with the ids so far (model.py:786).
+    Here they run on the host between engine iterations; a stream they stop keeps its ids up to that iteration, the others go on."""
+    from transformers.generation.stopping_criteria import StoppingCriteria, StoppingCriteriaList
+    from whisper_medusa import WhisperMedusaModel
+    cfg = MedusaConfig.micro(K=4)
+    m = WhisperMedusaModel(cfg, {})
+    m._max_batch = 2
+
+    class Eng(_FakeEngine):
+        def decode(self, gp, B, on_iteration=None, **kw):
+            self.calls.append(("decode", B, on_iteration is not None))
+            seqs = [list(gp.prompt) for _ in range(B)]
+            for it in range(6):                                    # stream b emits (b + 1) tokens per iteration: 10 it + j
+                new = [[10 * it + j for j in range(b + 1)] for b in range(B)]
+                for b in range(B):
+                    seqs[b] += new[b]
+                if on_iteration is not None and on_iteration(new) is True:
+                    break
+            self.iters = it + 1
+            return seqs
+
+    class StopOn(StoppingCriteria):
+        def __init__(self, tok): self.tok, self.asked = tok, 0
+        def __call__(self, input_ids, scores, **kw):
+            self.asked += 1
+            return torch.tensor([self.tok in input_ids[0].tolist()])
+
+    m._engine = eng = Eng(cfg, [])
+    feats = torch.zeros(2, cfg.num_mel_bins, cfg.n_mel_frames)
+    P = len(m._gen_params("en", None, None, 64, None, None, False, None, None, None, None, None).prompt)
+    crit = StopOn(21)                                              # stream 1 emits 21 in iteration 2 (tokens 20, 21); stream 0 never
+    out = m.generate(feats, language="en", stopping_criteria=StoppingCriteriaList([crit]))
+    assert eng.calls[-1] == ("decode", 2, True) and eng.iters == 6
+    assert out[1, P:].tolist()[:6] == [0, 1, 10, 11, 20, 21] and (out[1, P + 6:] == cfg.pad_token_id).all()      # cut after its iteration 2
+    assert out[0, P:].tolist()[:6] == [0, 10, 20, 30, 40, 50]
+    crit2 = StopOn(10)                                             # both streams emit 10 in iteration 1: the run ends there
+    m.generate(feats, language="en", stopping_criteria=[crit2])
+    assert eng.iters == 2
 
 
 def test_generate_output_object_mirrors_the_reference_model_output():

@@ -125,7 +125,9 @@ def _as_int_list(x) -> List[int]:
 
 def lower_processors(gp: GenParams, logits_processor, stopping_criteria) -> GenParams:
     """Fold caller-supplied HF processors / criteria into the generation parameters.  A custom processor replaces the default of
-    its type (HF's merge rule); anything that is not a static mask / penalty / length rule raises NotImplementedError."""
+    its type (HF's merge rule); a logits processor that is not a static mask / penalty raises NotImplementedError (the logits never
+    leave the device inside an iteration); a stopping criterion that is not a static length / EOS rule is kept for the host
+    (``gp._host_criteria``) and evaluated after every iteration."""
     P = len(gp.prompt)
     for proc in (logits_processor or []):
         name = type(proc).__name__
@@ -155,7 +157,11 @@ def lower_processors(gp: GenParams, logits_processor, stopping_criteria) -> GenP
             if _as_int_list(crit.eos_token_id) != [gp.eos_token_id]:
                 raise NotImplementedError("EosTokenCriteria with other ids than eos_token_id is not supported by the HIP engine")
         else:
-            raise NotImplementedError(f"stopping criterion {name} is not supported by the HIP engine (supported: {', '.join(_LOWERABLE_CRITERIA)})")
+            # anything else is evaluated on the host after every iteration (generate(): the per-iteration path the streamer uses),
+            # exactly where the reference calls it (model.py:786: once per Medusa iteration, on the ids emitted so far)
+            host = getattr(gp, "_host_criteria", None) or []
+            host.append(crit)
+            gp._host_criteria = host
     return gp
 
 
@@ -506,7 +512,7 @@ class WhisperMedusaModel:
             gp = lower_processors(gp, logits_processor, stopping_criteria)
         self._last_prompt = list(gp.prompt)
         feats = input_features.to(self.device, torch.float32).contiguous()
-        n_ctx = self._micro_batches_for(B) if kwargs.get("streamer") is None else 1
+        n_ctx = self._micro_batches_for(B) if (kwargs.get("streamer") is None and not getattr(gp, "_host_criteria", None)) else 1
         # language detection has just encoded exactly this batch on the model's own engine: decoding there saves the pool's second
         # encoder pass over the same clips (the automatic policy's gain at 2-3 clips is smaller than an encoder pass)
         if self._micro_batches is None and kwargs.get("_encoded_batch") == B and getattr(self._engine, "_B", None) == B:
@@ -522,13 +528,37 @@ class WhisperMedusaModel:
         if not (kwargs.get("_encoded_batch") == B and getattr(eng, "_B", None) == B):
             eng.encode(feats)                                               # F1 + F2
         streamer = kwargs.get("streamer")
-        if streamer is not None:
-            # model.py:1034-1035 (prompt), :758-759 (tokens of every iteration), :795-796 (end); HF streamers are batch-1
-            if B != 1:
-                raise ValueError("streamer only supports batch size 1")
-            streamer.put(torch.tensor([gp.prompt], dtype=torch.long))
-            seqs = eng.decode(gp, B, on_iteration=lambda new: streamer.put(torch.tensor(new[0], dtype=torch.long)))
-            streamer.end()
+        host_crit = getattr(gp, "_host_criteria", None)
+        if streamer is not None and B != 1:
+            raise ValueError("streamer only supports batch size 1")        # HF streamers are batch-1
+        if streamer is not None or host_crit:
+            # one iteration per engine call: the streamer gets the tokens of every iteration (model.py:1034-1035 prompt, :758-759
+            # tokens, :795-796 end); stopping criteria that are not static length / EOS rules are asked after every iteration with
+            # the ids emitted so far (model.py:786) — a stream they stop keeps its ids up to that iteration
+            cur = [list(gp.prompt) for _ in range(B)]
+            stop_len: List[Optional[int]] = [None] * B
+            if streamer is not None:
+                streamer.put(torch.tensor([gp.prompt], dtype=torch.long))
+
+            def on_it(new):
+                live = False
+                for b in range(B):
+                    if stop_len[b] is not None or not new[b]:
+                        continue                                            # stopped by a criterion / finished in the engine
+                    cur[b].extend(new[b])
+                    if streamer is not None:
+                        streamer.put(torch.tensor(new[b], dtype=torch.long))
+                    ids_b = torch.tensor([cur[b]], dtype=torch.long)
+                    if host_crit and any(bool(torch.as_tensor(c(ids_b, None)).all()) for c in host_crit):
+                        stop_len[b] = len(cur[b])
+                    else:
+                        live = True
+                return bool(host_crit) and not live                        # True: every stream is stopped or finished
+
+            seqs = eng.decode(gp, B, on_iteration=on_it)
+            seqs = [s_[: stop_len[b]] if stop_len[b] is not None else s_ for b, s_ in enumerate(seqs)]
+            if streamer is not None:
+                streamer.end()
         else:
             seqs = eng.decode(gp, B)                                        # F3..F14
         self.last_stats = eng.stats()

@@ -229,9 +229,9 @@ class Engine:
             self._check(self.lib.wm_decode_run(self.h, 1, C.byref(left)), "wm_decode_run")
             it += 1
             cur = [self.tokens(b) for b in range(B)]
-            on_iteration([cur[b][seen[b]:] for b in range(B)])
+            stop = on_iteration([cur[b][seen[b]:] for b in range(B)])
             seen = [len(c) for c in cur]
-            if left.value == 0:
+            if left.value == 0 or stop is True:                   # the callback may end the run (host-side stopping criteria)
                 break
         return [self.tokens(b) for b in range(B)]
 
