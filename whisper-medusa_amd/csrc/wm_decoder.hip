@@ -319,6 +319,7 @@ k_attn_mfma(const bf16_t* __restrict__ kmat, const bf16_t* __restrict__ vtmat, c
 #pragma unroll
         for (int u = 0; u < KT0; ++u) a[u] = aw ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wq + (size_t)u * 512)) : u32x4_t{0u, 0u, 0u, 0u};
         const float4 qb = aw ? *reinterpret_cast<const float4*>(fq.bq + hd * 64 + 16 * w + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+        fq.ln.template stage<NK>(xr, lnb);                             // gamma | beta registers -> LDS (behind the last request)
         if (done && *done) return;
         fq.ln.template stats<NK>(xr, lnb, w, KS, w < KS, lane);         // block barrier inside
         if (w < KS) {
@@ -1164,7 +1165,7 @@ int wm_dec_stage_heads(wm_ctx* ctx, int nsel, int sel_mul, int sel_off, int medu
     // shared vocabulary projection (tied proj_out, model.py:1277)
     TL_SET(1001);
     WM_HIP(launch_skinny_rows(st, ctx->vocab_w, ctx->Vpad / 16, K32, nsel * nout, ctx->ybuf, ypl,
-                              EpF32{ctx->logits, nullptr, ctx->Vpad, nsel * nout, 1.0f}));
+                              EpLogits{ctx->logits, nullptr, ctx->Vpad, nsel * nout, 1.0f}));
     return WM_OK;
 }
 
@@ -1333,7 +1334,7 @@ int wm_dec_profile(wm_ctx* ctx, int kernel, int rows, int reps, float* ms, doubl
         if (all || kernel == 6)
             WM_HIP(launch_skinny_rows(st, WRef{w.fc2_w, w.fc2_s}, d / 16, F32, R, ctx->fbuf, fpl, EpResidual{ctx->h, w.fc2_b, d, R}));
         if (kernel == 7)
-            WM_HIP(launch_skinny_rows(st, ctx->vocab_w, ctx->Vpad / 16, K32, R, ctx->ybuf, xpl, EpF32{ctx->logits, nullptr, ctx->Vpad, R, 1.0f}));
+            WM_HIP(launch_skinny_rows(st, ctx->vocab_w, ctx->Vpad / 16, K32, R, ctx->ybuf, xpl, EpLogits{ctx->logits, nullptr, ctx->Vpad, R, 1.0f}));
         return WM_OK;
     };
     int rc = body();

@@ -14,8 +14,9 @@ struct EpPre { float4 a, b; int i; };
 struct EpResidual {            // h[m][n] = (h[m][n] + bias[n]) + v      (out_proj / fc2 + residual, HF:modeling_whisper.py:396-413)
     float* h; const float* bias; int ld; int M;
     __device__ __forceinline__ EpPre pre(int m, int n) const {
-        EpPre p; p.i = 0; p.a = make_float4(0.f, 0.f, 0.f, 0.f); p.b = p.a;
-        if (m < M) { p.a = *reinterpret_cast<const float4*>(h + (size_t)m * ld + n); p.b = *reinterpret_cast<const float4*>(bias + n); }
+        // rows >= M read row M - 1 (never stored): no exec-masked loads in the launch's request batch (wm_skinny_gemm.h LdPacked::issue)
+        EpPre p; p.i = 0;
+        p.a = *reinterpret_cast<const float4*>(h + (size_t)min(m, M - 1) * ld + n); p.b = *reinterpret_cast<const float4*>(bias + n);
         return p;
     }
     __device__ __forceinline__ void fin(int m, int n, f32x4_t v, const EpPre& p) const {
@@ -26,11 +27,12 @@ struct EpResidual {            // h[m][n] = (h[m][n] + bias[n]) + v      (out_pr
     __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const { fin(m, n, v, pre(m, n)); }
 };
 
-struct EpF32 {                 // out[m][n] = (v + bias[n]) * scale   (cross-attn q; vocabulary logits with bias == nullptr)
-    float* out; const float* bias; int ld; int M; float scale;
+template <bool BIAS>            // out[m][n] = (v + bias[n]) * scale   (BIAS: cross-attn q;  !BIAS: vocabulary logits, scale 1)
+struct EpF32T {                 // two TYPES, not a run-time null test: a branch around the bias load in the launch's request batch breaks the
+    float* out; const float* bias; int ld; int M; float scale;      // compiler's counted waits apart (wm_skinny_gemm.h LdNormT::issue)
     __device__ __forceinline__ EpPre pre(int m, int n) const {
         EpPre p; p.i = 0; p.a = make_float4(0.f, 0.f, 0.f, 0.f); p.b = p.a;
-        if (bias && m < M) p.a = *reinterpret_cast<const float4*>(bias + n);
+        if constexpr (BIAS) p.a = *reinterpret_cast<const float4*>(bias + n);
         return p;
     }
     __device__ __forceinline__ void fin(int m, int n, f32x4_t v, const EpPre& p) const {
@@ -40,13 +42,15 @@ struct EpF32 {                 // out[m][n] = (v + bias[n]) * scale   (cross-att
     }
     __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const { fin(m, n, v, pre(m, n)); }
 };
+typedef EpF32T<true> EpF32;
+typedef EpF32T<false> EpLogits;
 
 template <int ACT>             // packed bf16 out = act(v + bias)   (fc1 + GELU -> next GEMM's operand); ACT 1: decoder (erff), 2: encoder (gelu_phi)
 struct EpPackedAct {           // out_lo != nullptr: decoder path, value kept as a bf16 hi/lo pair
     bf16_t* out; bf16_t* out_lo; const float* bias; int K32out; int M;
     __device__ __forceinline__ EpPre pre(int m, int n) const {
-        EpPre p; p.i = 0; p.a = make_float4(0.f, 0.f, 0.f, 0.f); p.b = p.a;
-        if (m < M) p.a = *reinterpret_cast<const float4*>(bias + n);
+        EpPre p; p.i = 0; p.b = make_float4(0.f, 0.f, 0.f, 0.f);
+        p.a = *reinterpret_cast<const float4*>(bias + n);
         return p;
     }
     __device__ __forceinline__ void fin(int m, int n, f32x4_t v, const EpPre& p) const {
@@ -69,8 +73,9 @@ struct EpQKVDec {              // K cache [s][h][pos][64]; V cache [s][h] as V^T
     float* q; bf16_t* kc; bf16_t* vc; const float* bias; const int* base;
     int Mper, d, H, Tal, M;
     __device__ __forceinline__ EpPre pre(int m, int n) const {
-        EpPre p; p.i = 0; p.a = make_float4(0.f, 0.f, 0.f, 0.f); p.b = p.a;
-        if (m < M) { p.a = *reinterpret_cast<const float4*>(bias + n); if (n >= d) p.i = base[m / Mper]; }
+        EpPre p; p.b = make_float4(0.f, 0.f, 0.f, 0.f);
+        p.a = *reinterpret_cast<const float4*>(bias + n);
+        p.i = base[min(m, M - 1) / Mper];                                    // rows >= M: the last row's stream (never stored)
         return p;
     }
     // NOTE: must be called by all 64 lanes of a wave together (the V branch exchanges values between lanes)
@@ -113,12 +118,10 @@ struct EpQKVDec {              // K cache [s][h][pos][64]; V cache [s][h] as V^T
 struct EpHead {
     bf16_t* y; bf16_t* y_lo; const float* hf; const float* bias; int d, K32, row_mul, row_off, M, src_mul, src_off;
     __device__ __forceinline__ EpPre pre(int m, int n) const {
-        EpPre p; p.i = 0; p.a = make_float4(0.f, 0.f, 0.f, 0.f); p.b = p.a;
-        if (m < M) {
-            const int k = n / d, c = n - k * d;
-            p.a = *reinterpret_cast<const float4*>(bias + n);
-            p.b = *reinterpret_cast<const float4*>(hf + (size_t)(m * src_mul + src_off) * d + c);
-        }
+        EpPre p; p.i = 0;
+        const int k = n / d, c = n - k * d;
+        p.a = *reinterpret_cast<const float4*>(bias + n);
+        p.b = *reinterpret_cast<const float4*>(hf + (size_t)(min(m, M - 1) * src_mul + src_off) * d + c);
         return p;
     }
     __device__ __forceinline__ void fin(int m, int n, f32x4_t v, const EpPre& p) const {

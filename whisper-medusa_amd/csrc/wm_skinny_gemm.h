@@ -168,18 +168,21 @@ struct LdPacked {
     static constexpr bool kNorm = false;
     template <int NB> struct Regs { bf16x8_t h[NB], l[NB]; };
     __host__ __device__ int lds_bytes() const { return 0; }
+    // Lanes of rows >= M read row M - 1 again (the same 16 bytes as that row's lane: no extra traffic) instead of being switched off: an
+    // exec-masked load into a zero-initialised register made the compiler copy the loaded value inside the masked region — an
+    // s_waitcnt vmcnt(0) in the MIDDLE of the launch's request batch, a full memory round trip (ISA, profiles/r04_ln_prologue.md).  What the
+    // MFMA computes for those token columns is never stored, and a column of the product depends on its own token column only.
     template <int NB>
     __device__ __forceinline__ void issue(Regs<NB>& r, char*, int kt0, int lane, int = 0) const {
-        const bool rv = (lane & 15) < M;
-        const bf16x8_t z = __builtin_bit_cast(bf16x8_t, make_uint4(0u, 0u, 0u, 0u));
+        const int ln = min(lane & 15, M - 1) + (lane & 48);
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
-            const bf16_t* p = X + ((size_t)(kt0 + u) * 64 + lane) * 8;
-            r.h[u] = z; r.l[u] = z;
-            if (rv) { r.h[u] = ld_frag(p); r.l[u] = ld_frag(p + plane); }
+            const bf16_t* p = X + ((size_t)(kt0 + u) * 64 + ln) * 8;
+            r.h[u] = ld_frag(p); r.l[u] = ld_frag(p + plane);
         }
     }
     template <int NB> __device__ __forceinline__ void stats(Regs<NB>&, char*, int, int, bool, int, int = 0) const {}
+    template <int NB> __device__ __forceinline__ void stage(const Regs<NB>&, char*) const {}
     template <int NB>
     __device__ __forceinline__ void frag(const Regs<NB>& r, const char*, int u, int, int, bf16x8_t& bh, bf16x8_t& bl) const { bh = r.h[u]; bl = r.l[u]; }
 };
@@ -197,30 +200,64 @@ struct LdNormT {
     int d, K32, M, row_mul, row_off;
     static constexpr bool kNorm = true;
     static constexpr bool do_norm = NORM;
-    template <int NB> struct Regs { float4 v0[NB], v1[NB]; float mean, rstd; };
+    // gb: the thread's share of gamma | beta on its way to LDS.  A block has >= 64 K32 / NB threads (one wave per K-slice of NB k-tiles, times
+    // the row-tile groups), gamma | beta are d / 2 = 16 K32 float4: ceil(NB / 4) per thread always suffice.
+    template <int NB> struct Regs { float4 v0[NB], v1[NB]; float mean, rstd; float4 gb[(NB + 3) / 4]; int ngb; };
     __host__ __device__ int lds_bytes() const { return 2 * d * (int)sizeof(float) + 2048; }   // gamma, beta, statistics
 
+    // Order of the requests: gamma / beta FIRST (ordinary loads into registers, written to LDS in stats()), the token rows after them; the
+    // caller requests its weight stream AFTER this call.  The vector-memory counter retires in order: the statistics wait for the
+    // token rows only, and run — like the normalisation — while the weights are still arriving.
+    // Rounds 1-3 staged gamma / beta by LDS-DMA (global_load_lds) after the weights and the rows.  Two things followed (ISA and timeline:
+    // profiles/r04_ln_prologue.md): (1) with an LDS-DMA pending next to ordinary loads the compiler's wait-count pass treats the counter as
+    // out of order and turns EVERY wait of the kernel into s_waitcnt vmcnt(0) (cdna_hip_programming.md §5, trap (b): "beside glds it
+    // waits vmcnt(0) for any ordinary VGPR-destination load"), so each LayerNorm-fused launch of the single-stream chain waited for its
+    // complete weight batch before it computed a mean; (2) rows >= M were skipped with exec-masked loads into zero-initialised
+    // registers, which made the compiler copy a loaded value inside the masked region: a full s_waitcnt in the MIDDLE of the request batch.
     // `rows`: false for waves that only help staging gamma / beta (the fused cross-attention kernel has more waves than K-slices)
     template <int NB>
     __device__ __forceinline__ void issue(Regs<NB>& r, char* smem, int kt0, int lane, int row0 = 0, bool rows = true, bool dma = true) const {
         const int rr = lane & 15, g8 = (lane >> 4) * 8;
-        const bool rv = rows && row0 + rr < M;
-        const float* hrow = h + (size_t)((row0 + rr) * row_mul + row_off) * d + (size_t)kt0 * 32 + g8;
+        // rows >= M: the last row again (LdPacked::issue: no exec-masked loads); `rows` is wave-uniform
+        const float* hrow = h + (size_t)(min(row0 + rr, M - 1) * row_mul + row_off) * d + (size_t)kt0 * 32 + g8;
+        r.ngb = dma ? 1 : 0;                                          // (a literal at every call site)
+        if constexpr (NORM) {
+            if (dma) {
+                // always ceil(NB / 4) float4 per thread, indices clamped (a thread beyond the end re-reads the last float4 and re-writes
+                // its LDS slot): no branch and no run-time count in the request batch — a conditional load here went through scratch
+                const int nf4 = d >> 1, nthr = blockDim.x;            // float4 of gamma | beta; d % 4 == 0
 #pragma unroll
-        for (int u = 0; u < NB; ++u) {
-            r.v0[u] = make_float4(0.f, 0.f, 0.f, 0.f); r.v1[u] = r.v0[u];
-            if (rv) { const float4* src = reinterpret_cast<const float4*>(hrow + u * 32); r.v0[u] = src[0]; r.v1[u] = src[1]; }
+                for (int i = 0; i < (NB + 3) / 4; ++i) {
+                    const int f = min((int)threadIdx.x + i * nthr, nf4 - 1);
+                    r.gb[i] = reinterpret_cast<const float4*>(f < (d >> 2) ? gamma : beta)[f < (d >> 2) ? f : f - (d >> 2)];
+                }
+            }
         }
-        if constexpr (NORM) {       // gamma | beta -> LDS, 1 KiB pieces (256 floats) spread over the block's waves
-            const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6, np = dma ? (2 * d + 255) >> 8 : 0;
-            for (int p = wave; p < np; p += nw) {
-                const int idx = p * 256 + lane * 4;
-                if (idx < 2 * d) glds16_f(idx < d ? gamma + idx : beta + (idx - d), smem + (size_t)p * 1024);
+        if (rows) {
+#pragma unroll
+            for (int u = 0; u < NB; ++u) { const float4* src = reinterpret_cast<const float4*>(hrow + u * 32); r.v0[u] = src[0]; r.v1[u] = src[1]; }
+        } else {
+#pragma unroll
+            for (int u = 0; u < NB; ++u) { r.v0[u] = make_float4(0.f, 0.f, 0.f, 0.f); r.v1[u] = r.v0[u]; }
+        }
+    }
+    // gamma | beta registers -> LDS.  Call it right behind the LAST request of the launch's batch: the parameter loads are the oldest
+    // entries of the in-order vector-memory counter, so the wait in front of these LDS writes (vmcnt(number of younger requests)) leaves
+    // rows and weights in flight and costs an L2 round trip that the weight stream's latency covers anyway.  (Left to stats(), the
+    // scheduler sank one of the parameter loads below the weight stream to save registers — and the LDS write then waited for the
+    // YOUNGEST request of the batch, i.e. for everything.)
+    template <int NB>
+    __device__ __forceinline__ void stage(const Regs<NB>& r, char* smem) const {
+        if constexpr (NORM) {
+            if (r.ngb) {
+                const int nf4 = d >> 1, nthr = blockDim.x;
+#pragma unroll
+                for (int i = 0; i < (NB + 3) / 4; ++i) reinterpret_cast<float4*>(smem)[min((int)threadIdx.x + i * nthr, nf4 - 1)] = r.gb[i];
             }
         }
     }
     // per-row statistics over the whole row: needs every K-slice -> LDS exchange (contains the block barrier, which also
-    // makes the LDS-DMA'd gamma / beta visible).  `leader`: this wave publishes its slice's partial (one wave per slice).
+    // makes the staged gamma / beta visible).  `leader`: this wave publishes its slice's partial (one wave per slice).
     // `slot`: which half of the 2 KiB statistics area is used (the two-tile kernel normalises its tiles one after the other: the
     // second tile's partials must not overwrite the first's while a slower wave still reads them; slots hold <= 8 K-slices)
     template <int NB>
@@ -282,15 +319,20 @@ k_skinny_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, in
     const int kt0 = ks * NK;
 
     // ---- the launch's memory batch: weights, token operand, LayerNorm parameters, epilogue operands ----
+    // LayerNorm-fused loaders: parameters and token rows are requested BEFORE the weight stream (LdNormT::issue), so that the statistics do
+    // not wait for the weights; plain loaders: weights first (their latency is the long one and the MFMAs need both anyway).
     typename WRaw<W8>::type a[RT][NK];
+    typename Ld::template Regs<XB> xr;
+    if constexpr (Ld::kNorm) {
+        ld.template issue<XB>(xr, smem, kt0, lane);
+    }
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
         const size_t wp = ((size_t)min(tile0 + i, N16 - 1) * K32 + kt0) * 512 + lane * 8;   // element index (bf16: 2 B, fp8: 1 B per element)
 #pragma unroll
         for (int u = 0; u < NK; ++u) a[i][u] = ld_wraw<W8, true>(W, wp + (size_t)u * 512);
     }
-    typename Ld::template Regs<XB> xr;
-    ld.template issue<XB>(xr, smem, kt0, lane);
+    if constexpr (!Ld::kNorm) ld.template issue<XB>(xr, smem, kt0, lane);
     EpPre pre; pre.i = 0; pre.a = make_float4(0.f, 0.f, 0.f, 0.f); pre.b = pre.a;
     float4 wsc = make_float4(1.f, 1.f, 1.f, 1.f);
     // the element this thread will finish: with K-slices, wave f < rt_per_wg * RT finishes the block's f-th row tile; without,
@@ -298,16 +340,15 @@ k_skinny_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, in
     const int tf = (ksplit > 1) ? blockIdx.x * rt_per_wg * RT + wave : tile0;
     const int em = lane & 15, en = tf * 16 + 4 * (lane >> 4);
     const bool edo = ((ksplit > 1) ? (wave < rt_per_wg * RT) : true) && tf < N16;
-    if (edo) {
-        pre = ep.pre(em, en);
-        if constexpr (W8) wsc = *reinterpret_cast<const float4*>(wscale + en);
+    {   // every wave requests them (a wave that finishes nothing: the last tile's; a few hundred bytes): no branch in the request batch
+        const int enc = min(tf, N16 - 1) * 16 + 4 * (lane >> 4);
+        pre = ep.pre(em, enc);
+        if constexpr (W8) wsc = *reinterpret_cast<const float4*>(wscale + enc);
     }
+    ld.template stage<XB>(xr, smem);
     // done: every stream finished (the rest of this replay is a no-op).  Checked after the batch went out: the flag's
     // latency overlaps the stream instead of heading every launch of the dependent chain.
-    if (done && *done) {
-        if constexpr (Ld::kNorm) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the LDS-DMA of gamma / beta must not land in a released allocation
-        return;
-    }
+    if (done && *done) return;
 
     ld.template stats<XB>(xr, smem, ks, ksplit, rtl == 0, lane);
     TL_PREP
@@ -387,9 +428,10 @@ k_ln_tiles(Ld ld, int ksplit, bf16_t* __restrict__ xg, size_t plane, const int* 
     const int kt0 = ks * NK;
     typename Ld::template Regs<NK> xr;
     ld.template issue<NK>(xr, smem, kt0, lane, blockIdx.x * 16);
+    ld.template stage<NK>(xr, smem);
     // `done` (every stream finished) is looked at once the loads are in flight: as the first instruction it is a dependent scalar
     // round trip (~1 us) in front of every launch of the chain.  No LDS-DMA may be outstanding when the block leaves.
-    if (done && *done) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
+    if (done && *done) return;
     ld.template stats<NK>(xr, smem, ks, ksplit, true, lane);
     bf16_t* dst = xg + (size_t)blockIdx.x * ld.K32 * 512;
 #pragma unroll
@@ -529,17 +571,16 @@ k_skinny2_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, i
 #pragma unroll
         for (int u = 0; u < NK; ++u) a[u] = ld_wraw<W8, true>(W, wp + (size_t)u * 512);
     }
-    const bool rv0 = (lane & 15) < M, rv1 = 16 + (lane & 15) < M;
-    const bf16x8_t z = __builtin_bit_cast(bf16x8_t, make_uint4(0u, 0u, 0u, 0u));
+    // rows >= M of the second tile read its last valid row again (16 < M <= 32; LdPacked::issue: no exec-masked loads)
+    const int ln1 = min(lane & 15, M - 17) + (lane & 48);
     bf16x8_t h0[XB], l0[XB], h1[XB], l1[XB];
     auto issue = [&](int kt) {
 #pragma unroll
         for (int u = 0; u < XB; ++u) {
             const bf16_t* p0 = X + ((size_t)(kt + u) * 64 + lane) * 8;
-            const bf16_t* p1 = p0 + (size_t)K32 * 512;
-            h0[u] = z; l0[u] = z; h1[u] = z; l1[u] = z;
-            if (rv0) { h0[u] = ld_frag(p0); l0[u] = ld_frag(p0 + plane); }
-            if (rv1) { h1[u] = ld_frag(p1); l1[u] = ld_frag(p1 + plane); }
+            const bf16_t* p1 = X + ((size_t)K32 * 64 + (size_t)(kt + u) * 64 + ln1) * 8;
+            h0[u] = ld_frag(p0); l0[u] = ld_frag(p0 + plane);
+            h1[u] = ld_frag(p1); l1[u] = ld_frag(p1 + plane);
         }
     };
     issue(kt0);
@@ -627,7 +668,8 @@ k_skinny2_norm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, i
         else { pre0 = ep.pre(lane & 15, en); pre1 = ep.pre(16 + (lane & 15), en); }
         if constexpr (W8) wsc = *reinterpret_cast<const float4*>(wscale + en);
     }
-    if (done && *done) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
+    ld.template stage<NK>(x0, smem);
+    if (done && *done) return;
 
     f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     ld.template stats<NK>(x0, smem, ks, ksplit, rtl == 0, lane, 0);
@@ -936,6 +978,7 @@ static inline hipError_t launch_skinny_nk(hipStream_t st, WRef W, int N16, int K
 template <bool W8, class Ld, class Ep>
 static inline hipError_t launch_skinny_w(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p, const Ld& ld, const Ep& ep) {
     if (p.ksplit * p.rt > 10 || p.ksplit * p.nk != K32 || (Ld::kNorm && p.nk > 8)) return hipErrorInvalidConfiguration;
+    if (Ld::kNorm && K32 * 16 > ((p.nk + 3) / 4) * 64 * p.ksplit * p.rt) return hipErrorInvalidConfiguration;      // gamma | beta float4 per thread (LdNormT::issue)
     switch (p.nk) {
         case 4: return launch_skinny_nk<4, W8>(st, W, N16, K32, p, ld, ep);
         case 8: return launch_skinny_nk<8, W8>(st, W, N16, K32, p, ld, ep);
@@ -1096,7 +1139,7 @@ template <class Ld, class Ep>
 static inline hipError_t launch_skinny_norm_t(hipStream_t st, WRef W, int N16, int K32, const Ld& ld, const Ep& ep, bf16_t* xscr, size_t plane) {
     const SkinnyPlan p = skinny_plan(N16, K32, true);
     const int R = ld.M;
-    if (p.nk > 8 || K32 * 32 != ld.d) return hipErrorInvalidConfiguration;
+    if (p.nk > 8 || K32 * 32 != ld.d || K32 * 16 > ((p.nk + 3) / 4) * 64 * p.ksplit) return hipErrorInvalidConfiguration;
     if (R <= 16) return launch_skinny(st, W, N16, K32, p, ld, ep);
     const int MT = (R + 15) / 16;
     // two token tiles: LayerNorm fused into the two-tile weight-streaming kernel.  OFF by default (WM_SKINNY2_NORM=1 turns it on): measured
