@@ -23,7 +23,9 @@ if not os.environ.get("WM_NO_KERNARG_PRELOAD"):
 # MFMA results in architectural VGPRs.  By default the register allocator parks MFMA destinations in AGPRs; every kernel whose VALU
 # code consumes them (attention: scores -> softmax, lazily rescaled outputs) then pays v_accvgpr_read / _write / _mov copies — 45 % of
 # the VALU instructions of the encoder flash-attention loop, 16 % of the decode self-attention kernel (ISA counts).
-# All kernels here fit the 256 VGPRs their occupancy allows without AGPRs, so nothing is lost.  WM_MFMA_AGPR=1 builds the old form.
+# The register-bound kernel is the pipelined 256 x 256 encoder GEMM (k_gemm_256p: 128 accumulator + 96 fragment registers): every default
+# instance sits at 256 VGPRs with 20-56 bytes per lane of scratch — in its prologue / epilogue blocks, none in the 32-MFMA K-loop blocks (ISA,
+# -Rpass-analysis=kernel-resource-usage) —, the fp8 16x16x128 GEMMs use 186-216, flash attention 180.  WM_MFMA_AGPR=1 builds the old form.
 if not os.environ.get("WM_MFMA_AGPR"):
     FLAGS += ["-mllvm", "-amdgpu-mfma-vgpr-form"]
 # experiments prepared for the next round (csrc/: off = the measured code, byte for byte)
