@@ -149,10 +149,15 @@ def acceptance_sensitivity(eng, cfg, gp_base, B, max_new, fp8=False):
         st = eng.stats()
         ms_it = st["ms_decode"] / max(st["iterations"], 1)
         nbytes = executed_bytes(cfg, B, mean_len, fp8, 1.0 if (a == 0 or B > 1) else 0.0, 1.0 if a == 0 else 0.0)
+        passes = "verify + base" if a == 0 else ("verify only" if B == 1 else "verify + base weights (attention of carried streams skipped)")
+        if st.get("schedule_steps", 0) > 0:      # merged-step schedule: one pass per step, an accept length of 0 costs the stream a second step
+            spi = st["schedule_steps"] / max(st["iterations"], 1)
+            nbytes = spi * executed_bytes(cfg, B, mean_len, fp8, 0.0, 0.0)
+            passes = f"{spi:.2f} merged steps (one pass each)"
         out[f"a={a}"] = {"tokens_per_sec": round(st["tokens_emitted"] / (st["ms_decode"] * 1e-3), 1),
                          "ms_per_iteration": round(ms_it, 4),
                          "tokens_per_iteration": round(st["tokens_emitted"] / max(st["iterations"], 1) / B, 3),
-                         "passes": "verify + base" if a == 0 else ("verify only" if B == 1 else "verify + base weights (attention of carried streams skipped)"),
+                         "passes": passes,
                          "bytes_executed": round(nbytes), "frac_hbm_executed": round(nbytes / (ms_it * 1e-3) / 8e12, 4)}
     return out
 
@@ -191,9 +196,9 @@ def extra_config(name, heads, B, fp8, dev, logit_std, max_new, steps=2):
         return sum(len(s) - len(gp.prompt) for s in seqs), eng.stats()
     step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    tok = it = 0; ms_dec = ms_enc = 0.0
+    tok = it = sched = 0; ms_dec = ms_enc = 0.0
     for _ in range(steps):
-        n, st = step(); tok += n; it += st["iterations"]; ms_dec += st["ms_decode"]; ms_enc += st["ms_encode"]
+        n, st = step(); tok += n; it += st["iterations"]; ms_dec += st["ms_decode"]; ms_enc += st["ms_encode"]; sched += st.get("schedule_steps", 0)
     torch.cuda.synchronize(); el = time.perf_counter() - t0
     try:
         parity = leg_parity(cfg, sd_cpu, eng, gp, fp8)
@@ -214,6 +219,7 @@ def extra_config(name, heads, B, fp8, dev, logit_std, max_new, steps=2):
                         "achieved": round(bytes_iter / (t_iter * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                         "frac": round(bytes_iter / (t_iter * 1e-3) / 8e12, 4)},
            "roofline_frac_hbm": round(bytes_iter / (t_iter * 1e-3) / 8e12, 4),
+           "merged_steps_per_iteration": round(sched / max(it, 1), 3) if sched else None,
            "prefill_tflops": round(prefill_flops(cfg) * B / (ms_enc / steps * 1e-3) / 1e12, 1),
            "prefill_frac_mfma": round(prefill_flops(cfg) * B / (ms_enc / steps * 1e-3) / 2.5e15, 4)}
     out.update(parity)
@@ -315,6 +321,7 @@ def main():
     ms_dec = ms_enc = ms_mel = 0.0
     hist = np.zeros(cfg.medusa_num_heads + 1, dtype=np.int64)
     replays = 0
+    sched_steps = 0
     for _ in range(args.steps):
         n, st = step()
         tokens += n
@@ -322,6 +329,7 @@ def main():
         ms_dec += st["ms_decode"]; ms_enc += st["ms_encode"]; ms_mel += st["ms_logmel"]
         hist += np.asarray(st["accept_hist"], dtype=np.int64)
         replays += st["graph_replays"]
+        sched_steps += st.get("schedule_steps", 0)
     torch.cuda.synchronize()
     wd.barrier()
     elapsed = wd.max_over_ranks(time.perf_counter() - t0, dev)
@@ -365,6 +373,14 @@ def main():
     p0 = min(1.0, (float(hist[0]) + args.steps * B) / n_it_streams)
     p_base_pass = p0 if (B == 1 and args.micro_batches == 1) else 1.0
     bytes_exec = executed_bytes(cfg, B, mean_len, args.fp8_weights, p_base_pass, p0)
+    passes_per_iter = 1.0 + p_base_pass
+    schedule = "base pass + verify pass per iteration (hidden-state carry skips the base pass / its attention)"
+    if sched_steps > 0:
+        # merged-step schedule (several streams): every step is ONE pass — the weights once, each live stream's cross- / self-K/V once —
+        # and the slowest stream's iteration takes 1 + P(accept length 0) steps
+        passes_per_iter = sched_steps / max(args.micro_batches, 1) / max(iters, 1)
+        bytes_exec = passes_per_iter * executed_bytes(cfg, B, mean_len, args.fp8_weights, 0.0, 0.0)
+        schedule = "merged step: one pass per step; a stream that accepted nothing contributes its one base row to the others' verify pass"
     parts = decode_iter_bytes(cfg, B, mean_len, args.fp8_weights, parts=True)
     van_bytes = parts["w_vanilla"] + B * (parts["cross_kv_per_stream_pass"] + parts["self_kv_per_stream_pass"])
     gemm_rows = min(16, B * (cfg.medusa_num_heads + 1))
@@ -396,7 +412,7 @@ def main():
                      "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
                      "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": round(bytes_iter), "ms_per_launch": round(t_iter_ms, 4),
                      # the same iteration priced on the bytes it executed (frac above keeps SURVEY §8d's two-pass numerator)
-                     "passes_per_iteration": round(1.0 + p_base_pass, 3), "base_attention_per_stream_iteration": round(p0, 3),
+                     "schedule": schedule, "passes_per_iteration": round(passes_per_iter, 3), "base_attention_per_stream_iteration": round(p0, 3),
                      "bytes_executed": round(bytes_exec), "frac_executed": round(bytes_exec / (t_iter_ms * 1e-3) / 8e12, 4),
                      "vanilla_step": None if vanilla_ms_step is None else
                                      {"bytes": round(van_bytes), "ms": round(vanilla_ms_step, 4),

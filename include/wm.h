@@ -119,6 +119,9 @@ typedef struct wm_stats {
     int64_t accept_hist[16];        /* histogram of accept length a (0..K), all streams */
     float ms_logmel, ms_encode, ms_decode;   /* hipEvent-timed on the context's stream, last call of each */
     int32_t graph_replays;          /* decode iterations that ran as hipGraph replays */
+    int32_t schedule_steps;         /* merged-step schedule (several streams, candidate chain): passes that carried rows since
+                                     * wm_decode_begin (a stream's iteration takes one pass, two after an accept length of 0);
+                                     * 0 = lock-step schedule (base pass + verify pass per iteration) */
 } wm_stats;
 
 /* ---- lifecycle (replaces WhisperMedusaModel.from_pretrained / .to(device), model.py:265-291) ---- */

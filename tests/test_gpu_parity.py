@@ -178,6 +178,43 @@ def test_batch_equals_independent_streams(rig):
     rig.encode()
 
 
+@pytest.mark.parametrize("heads", ["base_head", "medusa_block"])
+def test_merged_step_schedule_equals_the_lock_step_iteration(gpu, heads, monkeypatch):
+    """Several streams: the default schedule gives a stream that accepted nothing its one base row inside the other streams' verify pass
+    (wm_dec_step: one pass per step); WM_NO_STEP=1 runs the lock-step iteration (base pass + verify pass for everybody).  Same tokens,
+    same accept histogram, same iterations per stream; EOS allowed (streams finish at different steps), 7 ragged streams, K = 4."""
+    cfg = MedusaConfig.micro(K=4, heads_type=heads)
+    sd = synth.synth_state_dict(cfg, seed=31)
+    model = WhisperMedusaModel(cfg, sd, device=gpu, max_batch=7)
+    eng = model.engine
+    n = cfg.n_mel_frames * 160
+    feats = model.extract_features([clip_for(cfg, i)[: n // (1 + i % 3)] for i in range(7)])
+    runs = {}
+    for eos_free in (True, False):
+        gp = golden_gen_params(cfg, ACCEPT_TYPICAL, 40, suppress_eos=eos_free)
+        for step in (True, False):
+            if step:
+                monkeypatch.delenv("WM_NO_STEP", raising=False)
+            else:
+                monkeypatch.setenv("WM_NO_STEP", "1")
+            eng.encode(feats)
+            seqs = eng.decode(gp, 7)
+            st = eng.stats()
+            runs[step] = (seqs, st["accept_hist"], st["iterations"], st["tokens_emitted"])
+            launched = st["iterations_launched"]
+            if step:
+                steps_launched = launched
+        monkeypatch.delenv("WM_NO_STEP", raising=False)
+        assert runs[True] == runs[False], eos_free
+        assert runs[True][1][0] > 0 and sum(runs[True][1][1:]) > 0          # both kinds of step happened (accept lengths 0 and > 0)
+        assert steps_launched >= runs[True][2]                              # a step is at most one iteration of a stream
+    orc = Oracle(cfg, sd, sim="bf16")
+    enc = eng.encoder_output(7)
+    for b in (0, 3, 6):
+        check_tokens(orc, enc[b], gp, runs[True][0][b], ("merged step", heads, b))
+    eng.close()
+
+
 def test_many_streams_batched_path(gpu):
     """8 ragged streams through the batched kernels (88 verify rows) == 8 independent single-stream runs."""
     cfg = MedusaConfig.micro(K=10)

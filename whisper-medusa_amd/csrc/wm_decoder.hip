@@ -11,16 +11,28 @@
 // ---------------------------------------------------------------------------------------------
 // embed: h[row] = embed_tokens[tok] + embed_positions[pos]        (HF:modeling_whisper.py:745-765)
 // ---------------------------------------------------------------------------------------------
+// rowinfo (merged-step schedule, k_step_begin): the pass runs over DENSE rows; a stream in base mode contributes ONE row — token
+// ids[s][kvlen[s]] at position kvlen[s] — a stream in verify mode its K + 1 candidate rows at L[s] ..
 __global__ void k_embed(float* __restrict__ h, const bf16_t* __restrict__ tok_emb, const float* __restrict__ pos_emb,
                         const int* __restrict__ base, const int* __restrict__ tok_src, int tok_stride, int use_base_off,
-                        int Mper, int d, int V, int Tmax, const int* __restrict__ depth)
+                        int Mper, int d, int V, int Tmax, const int* __restrict__ depth,
+                        const int4* __restrict__ rowinfo = nullptr, const int* __restrict__ ids = nullptr, int ids_stride = 0)
 {
-    const int row = blockIdx.x, s = row / Mper, r = row - s * Mper;
-    const int b0 = base[s];
-    int tok = tok_src[(size_t)s * tok_stride + (use_base_off ? b0 : 0) + r];
+    const int row = blockIdx.x;
+    int s = row / Mper, r = row - s * Mper;
+    bool base_row = false;
+    int b0;
+    if (rowinfo) {                      // merged-step schedule: dense rows (k_step_begin); a stream with ONE row contributes its base token
+        const int4 ri = rowinfo[row];
+        if (ri.w == 0) return;          // no row here in this step
+        s = ri.x; r = ri.y; b0 = ri.z; base_row = ri.w == 1;
+    } else {
+        b0 = base[s];
+    }
+    int tok = base_row ? ids[(size_t)s * ids_stride + b0] : tok_src[(size_t)s * tok_stride + (use_base_off ? b0 : 0) + r];
     tok = min(max(tok, 0), V - 1);
     // candidate tree: node r sits at position L + depth(r) (medusa_position_ids, medusa_utils.py:360-363)
-    const int pos = min(b0 + (depth ? depth[r] : r), Tmax - 1);
+    const int pos = min(b0 + (base_row ? 0 : (depth ? depth[r] : r)), Tmax - 1);
     const bf16_t* te = tok_emb + (size_t)tok * d;
     const float* pe = pos_emb + (size_t)pos * d;
     for (int j = threadIdx.x * 4; j < d; j += blockDim.x * 4) {
@@ -259,7 +271,7 @@ k_attn_mfma(const bf16_t* __restrict__ kmat, const bf16_t* __restrict__ vtmat, c
             // entering 1.3 us later than the GEMMs, whose early arguments already sat in the preloaded range) and is first
             // touched after those loads are in flight.
             const int* __restrict__ done, int K32, bf16_t* __restrict__ xout, size_t xplane, float* __restrict__ ml, float* __restrict__ po,
-            int* __restrict__ ticket, PfJob pf, FQ fq, const unsigned long long* __restrict__ anc_tab TL_ARG)
+            int* __restrict__ ticket, PfJob pf, FQ fq, const unsigned long long* __restrict__ anc_tab, const int4* __restrict__ sinfo TL_ARG)
 {
     // Mper query rows per stream as nqt tiles of <= 16 (a candidate tree of more than 16 nodes; the chain and every base pass: one tile);
     // blockIdx.z = stream * nqt + query tile
@@ -271,9 +283,14 @@ k_attn_mfma(const bf16_t* __restrict__ kmat, const bf16_t* __restrict__ vtmat, c
         return;
     }
     TL_BEGIN
-    const int s = nqt > 1 ? (int)blockIdx.z / nqt : (int)blockIdx.z, r0 = ((int)blockIdx.z - s * nqt) * 16, rows = min(16, Mper - r0);
+    const int s = nqt > 1 ? (int)blockIdx.z / nqt : (int)blockIdx.z, r0 = ((int)blockIdx.z - s * nqt) * 16;
     // per-stream skip: the stream carried its hidden state, this base-pass row is not used (its K/V reads are saved)
     if (sskip && sskip[s]) return;
+    // merged-step schedule: the stream's rows of this pass are the dense rows row_s .. + cnt_s (k_step_begin); otherwise s * Mper .. + Mper
+    int row_s = s * Mper, cnt_s = Mper, pos_s = -1;
+    if (sinfo) { const int4 si = sinfo[s]; row_s = si.x; cnt_s = si.y; pos_s = si.z; }
+    if (r0 >= cnt_s) return;
+    const int rows = min(16, cnt_s - r0);
     typedef AttnLds<CROSS ? WM_XATTN_SPB_MAX : 1> Lds;
     Lds& A = *reinterpret_cast<Lds*>(smem_attn);
     float (&s_m)[4][16] = A.s_m; float (&s_l)[4][16] = A.s_l; int& s_last = A.s_last;
@@ -360,7 +377,7 @@ k_attn_mfma(const bf16_t* __restrict__ kmat, const bf16_t* __restrict__ vtmat, c
         if (aw && c < rows) {
 #pragma unroll
             for (int ds = 0; ds < 2; ++ds) {
-                const float4* qp = reinterpret_cast<const float4*>(qt + (s * Mper + c) * 64 + ds * 32 + g * 8);
+                const float4* qp = reinterpret_cast<const float4*>(qt + (s * Mper + c) * 64 + ds * 32 + g * 8);      // (fused variant: single-tile passes only)
                 qraw[ds][0] = qp[0]; qraw[ds][1] = qp[1];
             }
         }
@@ -368,23 +385,23 @@ k_attn_mfma(const bf16_t* __restrict__ kmat, const bf16_t* __restrict__ vtmat, c
 #pragma unroll
         for (int ds = 0; ds < 2; ++ds) {
             if (c < rows) {
-                const float4* qp = reinterpret_cast<const float4*>(q + (size_t)(s * Mper + r0 + c) * d + hd * 64 + ds * 32 + g * 8);
+                const float4* qp = reinterpret_cast<const float4*>(q + (size_t)(row_s + r0 + c) * d + hd * 64 + ds * 32 + g * 8);
                 qraw[ds][0] = qp[0]; qraw[ds][1] = qp[1];
             }
         }
     }
-    const int b0 = CROSS ? 0 : base[s];
+    const int b0 = CROSS ? 0 : (pos_s >= 0 ? pos_s : base[s]);
     if (done && *done) return;          // all streams finished: checked after the batch went out (off the critical path)
     // keys < limit are visible to query c; a candidate-tree node sees the history and (through `anc`) its ancestors' rows
     const unsigned long long anc = (!CROSS && anc_tab && c < rows) ? anc_tab[r0 + c] : 0ull;
     const int limit = CROSS ? S : ((!CROSS && anc_tab) ? min(b0, rows_alloc) : min(b0 + r0 + c + 1, rows_alloc));
-    int kend = CROSS ? min(S, kb + 64) : min(b0 + Mper, rows_alloc);
+    int kend = CROSS ? min(S, kb + 64) : min(b0 + cnt_s, rows_alloc);
     bf16x8_t qhi[2], qlo[2];
 #pragma unroll
     for (int ds = 0; ds < 2; ++ds) split_hilo8(qraw[ds][0], qraw[ds][1], qhi[ds], qlo[ds]);
     TL_PREP
     const int qr = threadIdx.x >> 4, ch = (threadIdx.x & 15) * 4;
-    const int row = s * Mper + r0 + qr;
+    const int row = row_s + r0 + qr;
     typedef unsigned long long u64;
     float M = -INFINITY, L = 0.f; float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 
@@ -542,10 +559,16 @@ __device__ __forceinline__ float proc_logit(float x, int n, int cur_len, const G
 
 __global__ void __launch_bounds__(256)
 k_select1(const float* __restrict__ logits, GenDev gp, const unsigned char* __restrict__ mask, const float* __restrict__ exppen,
-          const int* __restrict__ L, int rps, float* __restrict__ part1)
+          const int* __restrict__ L, int rps, float* __restrict__ part1, const int4* __restrict__ rowinfo = nullptr)
 {
     __shared__ float sv[4]; __shared__ int si[4]; __shared__ float sz[4];
-    const int row = blockIdx.y, sp = blockIdx.x, s = row / rps;
+    const int row = blockIdx.y, sp = blockIdx.x;
+    int s = row / rps;
+    if (rowinfo) {                          // merged-step schedule: dense rows; only a stream's verify rows are scored
+        const int4 ri = rowinfo[row];
+        if (ri.w != 2) return;
+        s = ri.x;
+    }
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int cur_len = L[s];
     const float* x = logits + (size_t)row * gp.Vpad;
@@ -583,10 +606,17 @@ k_select1(const float* __restrict__ logits, GenDev gp, const unsigned char* __re
 __global__ void __launch_bounds__(256)
 k_select2(const float* __restrict__ logits, GenDev gp, const unsigned char* __restrict__ mask, const float* __restrict__ exppen,
           const int* __restrict__ L, const int* __restrict__ cand, int rps, int out_row0, const float* __restrict__ part1,
-          float* __restrict__ part2, int* __restrict__ amax, float* __restrict__ pc, const TreeDev* __restrict__ tree)
+          float* __restrict__ part2, int* __restrict__ amax, float* __restrict__ pc, const TreeDev* __restrict__ tree,
+          const int4* __restrict__ rowinfo = nullptr)
 {
     __shared__ float sh[4];
-    const int row = blockIdx.y, sp = blockIdx.x, s = row / rps, i = row - s * rps;
+    const int row = blockIdx.y, sp = blockIdx.x;
+    int s = row / rps, i = row - s * rps;
+    if (rowinfo) {
+        const int4 ri = rowinfo[row];
+        if (ri.w != 2) return;
+        s = ri.x; i = ri.y;
+    }
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int cur_len = L[s];
     const float* x = logits + (size_t)row * gp.Vpad;
@@ -675,6 +705,35 @@ __global__ void k_set_cand(const int* __restrict__ amax, int* __restrict__ cand,
     if (e < n) cand[(e / rps) * WM_CAND_STRIDE + (e % rps)] = amax[e];
 }
 
+// merged-step schedule: what every stream contributes to this step's pass, as DENSE rows.  carry[s] (k_accept of the previous step /
+// iteration): 1 = the post-LN state of the stream's next base token is in hf_keep -> its K + 1 candidates are verified now (rows at L ..);
+// 0 = the stream accepted nothing: its next token ids[kvlen] needs the base pass first -> ONE row at position kvlen.
+// rowinfo[row] = {stream, index inside the stream, position of the stream's row 0, kind: 0 no row / 1 base row / 2 verify row} (.w doubles as
+// "row count class": the consumers need cnt = 1 or rps, derived from it), sinfo[s] = {first dense row, row count, position of row 0, mode},
+// steprows = {rows, 16-row tiles, passes that carried rows since wm_decode_begin}.  A finished stream contributes no rows.  One block;
+// streams <= 1024.
+__global__ void __launch_bounds__(256)
+k_step_begin(const int* __restrict__ carry, const int* __restrict__ L, const int* __restrict__ kvlen, const int* __restrict__ finished,
+             int4* __restrict__ rowinfo, int4* __restrict__ sinfo, int* __restrict__ steprows, int rps, int B, int Rmax)
+{
+    __shared__ int s_start[1025];
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int s = 0; s < B; ++s) { s_start[s] = acc; acc += finished[s] ? 0 : (carry[s] ? rps : 1); }
+        s_start[B] = acc;
+        steprows[0] = acc; steprows[1] = (acc + 15) >> 4;
+        if (acc > 0) steprows[2] += 1;          // passes that carried rows (wm_stats.schedule_steps)
+    }
+    __syncthreads();
+    const int nrows = s_start[B];
+    for (int s = threadIdx.x; s < B; s += blockDim.x) {
+        const int m = carry[s] ? 1 : 0, cnt = finished[s] ? 0 : (m ? rps : 1), pb = m ? L[s] : kvlen[s], r0 = s_start[s];
+        sinfo[s] = make_int4(r0, cnt, pb, m);
+        for (int r = 0; r < cnt; ++r) rowinfo[r0 + r] = make_int4(s, r, pb, m ? 2 : 1);
+    }
+    for (int row = nrows + threadIdx.x; row < Rmax; row += blockDim.x) rowinfo[row] = make_int4(0, 0, 0, 0);
+}
+
 // ---------------------------------------------------------------------------------------------
 // accept: one wavefront per stream.  Lane i (< K) evaluates candidate i+1; the leading-true count of
 // the wave ballot is the accept length a (medusa_utils.py:573-577 cumprod-sum for one candidate path).
@@ -685,21 +744,37 @@ __global__ void k_accept(GenDev gp, const int* __restrict__ cand, const int* __r
                          const float* __restrict__ part2, int* __restrict__ ids, int* __restrict__ L, int* __restrict__ kvlen,
                          int* __restrict__ finished, int* __restrict__ niter, long long* __restrict__ hist, int* __restrict__ done, int B,
                          int* __restrict__ carry, const float* __restrict__ hf, float* __restrict__ hf_keep, int d,
-                         int* __restrict__ hostflags, const float* __restrict__ hb, float* __restrict__ hb_keep)
+                         int* __restrict__ hostflags, const float* __restrict__ hb, float* __restrict__ hb_keep,
+                         const int4* __restrict__ sinfo = nullptr)
 {
     const int s = blockIdx.x, lane = threadIdx.x;
     if (finished[s]) return;
     const int K = gp.K, rps = K + 1;
+    const int row0 = sinfo ? sinfo[s].x : s * rps;            // merged-step schedule: the stream's first dense row of this pass
+    if (sinfo != nullptr && sinfo[s].w == 0) {
+        // merged-step schedule: this stream's one row was its base pass (token ids[kvlen] at position kvlen; its K / V row is in the cache):
+        // keep the post-LN state for the heads of the next step, nothing is verified or emitted
+        const float4* srcp = reinterpret_cast<const float4*>(hf + (size_t)row0 * d);
+        float4* dstp = reinterpret_cast<float4*>(hf_keep + (size_t)s * d);
+        for (int j = lane; j < (d >> 2); j += 64) dstp[j] = srcp[j];
+        if (hb) {
+            const float4* bs = reinterpret_cast<const float4*>(hb + (size_t)row0 * d);
+            float4* bd = reinterpret_cast<float4*>(hb_keep + (size_t)s * d);
+            for (int j = lane; j < (d >> 2); j += 64) bd[j] = bs[j];
+        }
+        if (lane == 0) { kvlen[s] = L[s]; carry[s] = 1; }
+        return;
+    }
     bool ok = false;
     if (lane < K) {
-        if (gp.accept_mode == WM_ACCEPT_GREEDY) ok = (cand[s * WM_CAND_STRIDE + lane + 1] == amax[s * rps + lane]);
+        if (gp.accept_mode == WM_ACCEPT_GREEDY) ok = (cand[s * WM_CAND_STRIDE + lane + 1] == amax[row0 + lane]);
         else {
-            const float* hp = part2 + (size_t)(s * rps + lane) * SEL_SP;
+            const float* hp = part2 + (size_t)(row0 + lane) * SEL_SP;
             float hsum = 0.f;
 #pragma unroll
             for (int k = 0; k < SEL_SP; ++k) hsum += hp[k];
             const float thr = fminf(gp.thr, gp.alpha * expf(hsum));            // H = -hsum
-            ok = pc[s * rps + lane] > thr;
+            ok = pc[row0 + lane] > thr;
         }
     }
     const unsigned long long m = __ballot(ok);
@@ -711,7 +786,7 @@ __global__ void k_accept(GenDev gp, const int* __restrict__ cand, const int* __r
     const int n_emit = (a == 0) ? 2 : a + 1;
     int tok = -1;
     if (lane < n_emit) {
-        tok = (a == 0 && lane == 1) ? amax[s * rps + 0] : cand[s * WM_CAND_STRIDE + lane];
+        tok = (a == 0 && lane == 1) ? amax[row0] : cand[s * WM_CAND_STRIDE + lane];
         if (Lcur + lane < gp.Tids) ids[(size_t)s * gp.Tids + Lcur + lane] = tok;
     }
     const bool hit_eos = __ballot(lane < n_emit && tok == gp.eos) != 0ull;
@@ -720,11 +795,11 @@ __global__ void k_accept(GenDev gp, const int* __restrict__ cand, const int* __r
     // save the row, and let the next (redundant) base pass skip its layers.  Bit-identical tokens, half the passes.
     const bool do_carry = carry != nullptr && a > 0;
     if (do_carry) {
-        const float4* srcp = reinterpret_cast<const float4*>(hf + (size_t)(s * rps + a) * d);
+        const float4* srcp = reinterpret_cast<const float4*>(hf + (size_t)(row0 + a) * d);
         float4* dstp = reinterpret_cast<float4*>(hf_keep + (size_t)s * d);
         for (int j = lane; j < (d >> 2); j += 64) dstp[j] = srcp[j];
         if (hb) {                  // Medusa-Block: the heads read the extra layer's output of that row (model.py:1414-1417)
-            const float4* bs = reinterpret_cast<const float4*>(hb + (size_t)(s * rps + a) * d);
+            const float4* bs = reinterpret_cast<const float4*>(hb + (size_t)(row0 + a) * d);
             float4* bd = reinterpret_cast<float4*>(hb_keep + (size_t)s * d);
             for (int j = lane; j < (d >> 2); j += 64) bd[j] = bs[j];
         }
@@ -953,7 +1028,7 @@ static inline int xattn_blocks_per_head(int NS, int heads_total)
 // host side
 // =============================================================================================
 static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0, int nb, int Mper, const int* base, bool kv_only,
-                     const int* sskip = nullptr, const DecLayerW* next = nullptr)
+                     const int* sskip = nullptr, const DecLayerW* next = nullptr, const int4* rowinfo = nullptr, const int4* sinfo = nullptr)
 {
     hipStream_t st = ctx->stream;
     const int d = ctx->d, H = ctx->H, K32 = d / 32, R = nb * Mper, F32 = ctx->ffn / 32;
@@ -975,7 +1050,7 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
     if (pf) g_pf_job = pf_for_gemm(w.out_w, f8, d / 16, K32, false);
     TL_SET(slot * 16 + 1 + 8192 * Mper);
     WM_HIP(launch_skinny_norm(st, WRef{w.qkv_w, w.qkv_s}, 3 * d / 16, K32, h, w.ln1_w, w.ln1_b, d, R, 1, 0, 1,
-                              EpQKVDec{ctx->qbuf, kc, vc, w.qkv_b, base, Mper, d, H, ctx->Tal, R}, ctx->xbuf, xpl));
+                              EpQKVDec{ctx->qbuf, kc, vc, w.qkv_b, base, Mper, d, H, ctx->Tal, R, rowinfo}, ctx->xbuf, xpl));
     if (kv_only) return WM_OK;
     // fused cross-attention query (FuseQ above): single-tile passes with bf16 weights whose projection plan has a compiled instance
     // OFF by default: measured 14.6 us for the fused launch against 5.6 (LN2 + cross-q) + 2.2 (boundary) + 6.5 (cross-attention)
@@ -1003,7 +1078,7 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
         const int zs = spf.n_jobs ? nz + (pf_round8(main_total) - main_total + (int)spf.n_jobs + H - 1) / H : nz;
         TL_SET(slot * 16 + 2 + 8192 * Mper);
         hipLaunchKernelGGL((k_attn_mfma<false, false, NoFuseQ>), dim3(1, H, zs), dim3(256), sizeof(AttnLds<1>), st, kc, vc, ctx->qbuf, base, sskip,
-                           Mper | (nz << 8), H | (1 << 8) | (nqt << 16), ctx->Tal, 0, g_skinny_done, K32, ctx->xbuf, xpl, nullptr, nullptr, nullptr, spf, NoFuseQ{}, ctx->cur_anc TL_PASS);
+                           Mper | (nz << 8), H | (1 << 8) | (nqt << 16), ctx->Tal, 0, g_skinny_done, K32, ctx->xbuf, xpl, nullptr, nullptr, nullptr, spf, NoFuseQ{}, ctx->cur_anc, sinfo TL_PASS);
         WM_HIP(hipGetLastError());
     }
     // 3. out_proj + residual
@@ -1042,7 +1117,7 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
                 WM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
                 hipLaunchKernelGGL(kern, dim3(xgrid, H, zs), dim3(64 * (KSv > 4 ? KSv : 4)), lds, st, kx, vx, ctx->qbuf, base, sskip, \
                                    Mper | (nz << 8), H | (ctx->NS << 8) | (nqt << 16), ctx->Spad, ctx->S, g_skinny_done, K32, ctx->xbuf, xpl, ctx->cml, ctx->co, ctx->ticket, xpf, \
-                                   FQ{ln, w.cq_w, w.cq_b}, nullptr TL_PASS);                                                         \
+                                   FQ{ln, w.cq_w, w.cq_b}, nullptr, (const int4*)nullptr TL_PASS);                                   \
             } while (0)
             if (cqp.nk == 8 && cqp.ksplit == 5) WM_XFUSE(8, 5);
             else if (cqp.nk == 8 && cqp.ksplit == 4) WM_XFUSE(8, 4);
@@ -1054,10 +1129,10 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
 #undef WM_XFUSE
         } else if (xattn_nt)
             hipLaunchKernelGGL((k_attn_mfma<true, true, NoFuseQ>), dim3(xgrid, H, zs), dim3(256), sizeof(AttnLds<WM_XATTN_SPB_MAX>), st, kx, vx, ctx->qbuf, base, sskip,
-                               Mper | (nz << 8), H | (ctx->NS << 8) | (nqt << 16), ctx->Spad, ctx->S, g_skinny_done, K32, ctx->xbuf, xpl, ctx->cml, ctx->co, ctx->ticket, xpf, NoFuseQ{}, nullptr TL_PASS);
+                               Mper | (nz << 8), H | (ctx->NS << 8) | (nqt << 16), ctx->Spad, ctx->S, g_skinny_done, K32, ctx->xbuf, xpl, ctx->cml, ctx->co, ctx->ticket, xpf, NoFuseQ{}, nullptr, sinfo TL_PASS);
         else
             hipLaunchKernelGGL((k_attn_mfma<true, false, NoFuseQ>), dim3(xgrid, H, zs), dim3(256), sizeof(AttnLds<WM_XATTN_SPB_MAX>), st, kx, vx, ctx->qbuf, base, sskip,
-                               Mper | (nz << 8), H | (ctx->NS << 8) | (nqt << 16), ctx->Spad, ctx->S, g_skinny_done, K32, ctx->xbuf, xpl, ctx->cml, ctx->co, ctx->ticket, xpf, NoFuseQ{}, nullptr TL_PASS);
+                               Mper | (nz << 8), H | (ctx->NS << 8) | (nqt << 16), ctx->Spad, ctx->S, g_skinny_done, K32, ctx->xbuf, xpl, ctx->cml, ctx->co, ctx->ticket, xpf, NoFuseQ{}, nullptr, sinfo TL_PASS);
         WM_HIP(hipGetLastError());
     }
     // 6. out_proj + residual
@@ -1085,9 +1160,14 @@ int wm_dec_stage_layers(wm_ctx* ctx, int b0, int nb, int Mper, int mode)
     hipStream_t st = ctx->stream;
     g_skinny_done = ctx->use_done ? ctx->done : nullptr;
     const int d = ctx->d, R = nb * Mper;
-    const int* base = (mode == 0 ? ctx->kvlen : ctx->L) + b0;
+    // mode 2 = merged step: per stream either its verify rows (as mode 1) or its one base row (k_step_begin: rowinfo / sinfo)
+    const int* base = (mode == 0 ? ctx->kvlen : ctx->L) + b0;          // mode 2: positions come from rowinfo / sinfo
     if (R > ctx->Rcap || Mper > ctx->Mmax) { ctx->err = "decode pass exceeds the row capacity of the context"; return WM_ERR_ARG; }
-    if (mode == 0)
+    if (mode == 2)
+        hipLaunchKernelGGL(k_embed, dim3(R), dim3(256), 0, st, ctx->h, ctx->tok_emb, ctx->dec_pos, base,
+                           ctx->cand + (size_t)b0 * WM_CAND_STRIDE, WM_CAND_STRIDE, 0, Mper, d, ctx->V, ctx->Tmax, (const int*)nullptr,
+                           ctx->rowinfo, ctx->ids, ctx->gp.Tids);
+    else if (mode == 0)
         hipLaunchKernelGGL(k_embed, dim3(R), dim3(256), 0, st, ctx->h, ctx->tok_emb, ctx->dec_pos, base,
                            ctx->ids + (size_t)b0 * ctx->gp.Tids, ctx->gp.Tids, 1, Mper, d, ctx->V, ctx->Tmax, nullptr);
     else
@@ -1100,7 +1180,8 @@ int wm_dec_stage_layers(wm_ctx* ctx, int b0, int nb, int Mper, int mode)
     // (the weights are streamed once for everybody) but its attention blocks exit, saving their K/V reads
     const int* sskip = (mode == 0 && Mper == 1 && ctx->dev_carry) ? ctx->carry + b0 : nullptr;
     for (int l = 0; l < ctx->cfg.dec_layers; ++l) {
-        int rc = dec_layer(ctx, ctx->dec[l], l, ctx->h, b0, nb, Mper, base, false, sskip, l + 1 < ctx->cfg.dec_layers ? &ctx->dec[l + 1] : nullptr);
+        int rc = dec_layer(ctx, ctx->dec[l], l, ctx->h, b0, nb, Mper, base, false, sskip, l + 1 < ctx->cfg.dec_layers ? &ctx->dec[l + 1] : nullptr,
+                           mode == 2 ? ctx->rowinfo : nullptr, mode == 2 ? ctx->sinfo : nullptr);
         if (rc) return rc;
     }
     return WM_OK;
@@ -1113,7 +1194,7 @@ int wm_dec_stage_final(wm_ctx* ctx, int b0, int nb, int Mper, int mode, int medu
 {
     hipStream_t st = ctx->stream;
     const int d = ctx->d, K32 = d / 32, R = nb * Mper;
-    const int* base = (mode == 0 ? ctx->kvlen : ctx->L) + b0;
+    const int* base = (mode == 0 ? ctx->kvlen : ctx->L) + b0;          // mode 2: positions come from rowinfo / sinfo
     float* hf = ctx->hf + (size_t)b0 * Mper * d;          // rows of this chunk; persists until the stream's next pass
     hipLaunchKernelGGL(k_rows_norm, dim3((R + 3) / 4), dim3(256), 0, st, ctx->h, 1, 0, ctx->dec_lnf_w, ctx->dec_lnf_b, 1,
                        hf, ctx->block ? ctx->hblk : nullptr, nullptr, (size_t)0, K32, 1, 0, d, R,
@@ -1126,7 +1207,8 @@ int wm_dec_stage_final(wm_ctx* ctx, int b0, int nb, int Mper, int mode, int medu
         const bool carrying = ctx->host_carry || ctx->dev_carry;
         const bool kv_only = !medusa && !carrying;
         const int* sskip = (mode == 0 && Mper == 1 && ctx->dev_carry) ? ctx->carry + b0 : nullptr;
-        int rc = dec_layer(ctx, ctx->dec[ctx->nkv - 1], ctx->nkv - 1, ctx->hblk, b0, nb, Mper, base, kv_only, sskip);
+        int rc = dec_layer(ctx, ctx->dec[ctx->nkv - 1], ctx->nkv - 1, ctx->hblk, b0, nb, Mper, base, kv_only, sskip, nullptr,
+                           mode == 2 ? ctx->rowinfo : nullptr, mode == 2 ? ctx->sinfo : nullptr);
         if (rc) return rc;
         if (sskip) {
             hipLaunchKernelGGL(k_rows_take_carried, dim3(R), dim3(256), 0, st, ctx->hblk + (size_t)b0 * d, ctx->hb_keep + (size_t)b0 * d,
@@ -1295,6 +1377,59 @@ int wm_dec_iter_rest(wm_ctx* ctx, int Mper_base)
                        ctx->kvlen, ctx->finished, ctx->niter, ctx->hist, ctx->done, B, (carry || ctx->dev_carry) ? ctx->carry : nullptr, ctx->hf,
                        carry ? ctx->hf : ctx->hf_keep, ctx->d, carry ? ctx->hostflags_dev : nullptr,
                        ctx->block ? ctx->hblk : nullptr, carry ? ctx->hblk : ctx->hb_keep);
+    WM_HIP(hipGetLastError());
+    return WM_OK;
+}
+
+// One STEP of the merged-step schedule (several streams, chain candidates, per-stream hidden-state carry; wm_engine.hip picks it).
+// The lock-step iteration above runs a base pass for every stream (the rows of carrying streams ride along) and then the verify pass:
+// two weight streams and two launch chains per iteration although only the streams that accepted nothing need the base pass.  Here
+// every stream contributes to ONE pass per step what it needs next: its K + 1 candidate rows (state carried: heads -> candidates ->
+// verify -> accept, exactly the iteration's second half) or its single base row (then its post-LN state is kept and it verifies in the
+// next step).  Per stream the arithmetic, the order of its passes and therefore its tokens are those of the lock-step schedule (and of a
+// single-stream run); only which other streams share a launch changes.  Reference loop: model.py:634-793 (one stream).
+int wm_dec_step(wm_ctx* ctx, int)
+{
+    hipStream_t st = ctx->stream;
+    const int B = ctx->Bdec, K = ctx->K, rps = K + 1;
+    const GenDev gp = ctx->gp;
+    g_skinny_done = ctx->use_done ? ctx->done : nullptr;
+    g_skinny_ntiles = nullptr;
+    if (B > 1024) { ctx->err = "merged-step schedule: more than 1024 streams"; return WM_ERR_ARG; }
+    hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(256), 0, st, ctx->carry, ctx->L, ctx->kvlen, ctx->finished, ctx->rowinfo, ctx->sinfo, ctx->steprows, rps, B, B * rps);
+    WM_HIP(hipGetLastError());
+    // (a2) heads + candidates from the kept states (streams in base mode: computed and ignored)
+    ctx->hf_cur = ctx->hf_keep;
+    float* hblk_rows = ctx->hblk;
+    if (ctx->block) ctx->hblk = ctx->hb_keep;                 // Medusa-Block: the heads read the kept block-layer outputs
+    int rc = wm_dec_stage_heads(ctx, B, 1, 0, 1);
+    ctx->hblk = hblk_rows;
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_select1, dim3(SEL_SP, B * rps), dim3(256), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen, ctx->L, rps, ctx->part1, (const int4*)nullptr);
+    WM_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_select_argmax, dim3((B * rps + 63) / 64), dim3(64), 0, st, ctx->part1, B * rps, 0, ctx->amax);
+    WM_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_set_cand, dim3((B * rps + 63) / 64), dim3(64), 0, st, ctx->amax, ctx->cand, rps, B * rps);
+    WM_HIP(hipGetLastError());
+    // (d) ONE pass over the dense rows: verify rows and base rows; the launches are sized for B * rps rows, token tiles beyond the step's
+    //     rows exit at once (g_skinny_ntiles)
+    g_skinny_ntiles = ctx->steprows + 1;
+    rc = wm_dec_stage_layers(ctx, 0, B, rps, 2);
+    if (rc == WM_OK) rc = wm_dec_stage_final(ctx, 0, B, rps, 2, 0);
+    if (rc == WM_OK) rc = wm_dec_stage_heads(ctx, B * rps, 1, 0, 0);
+    g_skinny_ntiles = nullptr;
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_select1, dim3(SEL_SP, B * rps), dim3(256), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen, ctx->L, rps, ctx->part1, (const int4*)ctx->rowinfo);
+    WM_HIP(hipGetLastError());
+    if (gp.accept_mode == WM_ACCEPT_TYPICAL)
+        hipLaunchKernelGGL(k_select2, dim3(SEL_SP, B * rps), dim3(256), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen, ctx->L,
+                           ctx->cand, rps, 0, ctx->part1, ctx->part2, ctx->amax, ctx->pc, (const TreeDev*)nullptr, (const int4*)ctx->rowinfo);
+    else
+        hipLaunchKernelGGL(k_select_argmax, dim3((B * rps + 63) / 64), dim3(64), 0, st, ctx->part1, B * rps, 0, ctx->amax);
+    WM_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_accept, dim3(B), dim3(64), 0, st, gp, ctx->cand, ctx->amax, ctx->pc, ctx->part2, ctx->ids, ctx->L,
+                       ctx->kvlen, ctx->finished, ctx->niter, ctx->hist, ctx->done, B, ctx->carry, ctx->hf, ctx->hf_keep, ctx->d,
+                       (int*)nullptr, ctx->block ? ctx->hblk : nullptr, ctx->hb_keep, (const int4*)ctx->sinfo);
     WM_HIP(hipGetLastError());
     return WM_OK;
 }

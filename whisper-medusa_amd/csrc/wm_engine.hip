@@ -34,7 +34,7 @@ extern "C" void wm_destroy(wm_ctx* ctx)
                     ctx->enc_out, ctx->kx, ctx->vx, ctx->kc, ctx->vc, ctx->h, ctx->hblk, ctx->hf, ctx->qbuf, ctx->xbuf, ctx->fbuf,
                     ctx->ybuf, ctx->cml, ctx->co, ctx->ticket, ctx->logits, ctx->amax, ctx->pc, ctx->part1, ctx->part2, ctx->ids, ctx->L, ctx->kvlen,
                     ctx->finished, ctx->cand, ctx->niter, ctx->hist, ctx->supmask, ctx->exppen, ctx->tap_tok, ctx->done,
-                    ctx->hf_keep, ctx->hb_keep, ctx->carry, ctx->rs_table, ctx->tree, ctx->sel_src, ctx->sel_n, ctx->sel_base, ctx->exn8, ctx->exs};
+                    ctx->hf_keep, ctx->hb_keep, ctx->carry, ctx->rowinfo, ctx->sinfo, ctx->steprows, ctx->rs_table, ctx->tree, ctx->sel_src, ctx->sel_n, ctx->sel_base, ctx->exn8, ctx->exs};
     for (void* b : bufs) if (b) hipFree(b);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
@@ -186,6 +186,7 @@ extern "C" int wm_create(const wm_config* cfg, const wm_weights* w, int device, 
     CREATE_HIP(dev_alloc(&ctx->hf_keep, B * d, st));
     CREATE_HIP(dev_alloc(&ctx->hb_keep, B * d, st));
     CREATE_HIP(dev_alloc(&ctx->carry, B, st));
+    CREATE_HIP(dev_alloc(&ctx->rowinfo, (size_t)ctx->Mmax * B, st)); CREATE_HIP(dev_alloc(&ctx->sinfo, B, st)); CREATE_HIP(dev_alloc(&ctx->steprows, 4, st));
     CREATE_HIP(dev_alloc(&ctx->sel_src, B * 16, st));
     CREATE_HIP(dev_alloc(&ctx->sel_n, B, st));
     CREATE_HIP(dev_alloc(&ctx->sel_base, B, st));
@@ -286,7 +287,10 @@ extern "C" int wm_decode_begin(wm_ctx* ctx, const wm_gen_params* gp, int B)
     ctx->fuse = std::getenv("WM_NO_CARRY") == nullptr;
     ctx->host_carry = ctx->fuse && B == 1 && !gp->vanilla;
     ctx->dev_carry = ctx->fuse && B > 1 && !gp->vanilla;
-    g.fuse = ctx->host_carry ? 1 : (ctx->dev_carry ? 2 : 0);
+    // several streams with the per-stream carry, chain candidates: the merged-step schedule (a stream that needs a base pass gets its one
+    // row inside the other streams' verify pass: wm_dec_step).  WM_NO_STEP=1: the lock-step iteration (base pass + verify pass for everybody).
+    ctx->step_flow = ctx->dev_carry && ctx->tn == 0 && std::getenv("WM_NO_STEP") == nullptr;
+    g.fuse = ctx->host_carry ? 1 : (ctx->dev_carry ? (ctx->step_flow ? 3 : 2) : 0);
     const bool same = ctx->graph && ctx->graph_B == B && std::memcmp(&g, &ctx->gp, sizeof(GenDev)) == 0;
     if (!same && ctx->graph) { hipGraphExecDestroy(ctx->graph); ctx->graph = nullptr; }
     if (!same && ctx->graph_base) { hipGraphExecDestroy(ctx->graph_base); ctx->graph_base = nullptr; }
@@ -310,6 +314,7 @@ extern "C" int wm_decode_begin(wm_ctx* ctx, const wm_gen_params* gp, int B)
     WM_HIP(hipMemsetAsync(ctx->hist, 0, 32 * sizeof(long long), st));
     WM_HIP(hipMemsetAsync(ctx->done, 0, 4 * sizeof(int), st));
     WM_HIP(hipMemsetAsync(ctx->carry, 0, ctx->maxB * sizeof(int), st));
+    WM_HIP(hipMemsetAsync(ctx->steprows, 0, 4 * sizeof(int), st));
     ctx->use_done = true;
     WM_HIP(hipMemcpyAsync(ctx->supmask, mask.data(), mask.size(), hipMemcpyHostToDevice, st));
     WM_HIP(hipMemcpyAsync(ctx->exppen, pen.data(), pen.size() * sizeof(float), hipMemcpyHostToDevice, st));
@@ -396,13 +401,14 @@ extern "C" int wm_decode_run(wm_ctx* ctx, int max_iters, int* n_unfinished)
                     if (rc) return rc;
                     ctx->first_done = true;
                 } else {
-                    if (use_graph && ctx->iters >= 2 && !ctx->graph) {   // shapes are warm: capture one steady-state iteration
-                        rc = capture_graph(ctx, &ctx->graph, wm_dec_iteration);
+                    int (*body)(wm_ctx*, int) = ctx->step_flow ? wm_dec_step : wm_dec_iteration;
+                    if (use_graph && ctx->iters >= 2 && !ctx->graph) {   // shapes are warm: capture one steady-state iteration / step
+                        rc = capture_graph(ctx, &ctx->graph, body);
                         if (rc) return rc;
                         ctx->graph_B = ctx->Bdec;
                     }
                     if (use_graph && ctx->graph) { WM_HIP(hipGraphLaunch(ctx->graph, st)); ctx->graph_replays++; }
-                    else { rc = wm_dec_iteration(ctx, 1); if (rc) return rc; }
+                    else { rc = body(ctx, 1); if (rc) return rc; }
                 }
                 ctx->iters++; done++;
             }
@@ -454,6 +460,11 @@ extern "C" int wm_get_stats(wm_ctx* ctx, wm_stats* out)
     out->tokens_emitted = h[16];
     out->ms_logmel = ctx->ms_logmel; out->ms_encode = ctx->ms_encode; out->ms_decode = ctx->ms_decode;
     out->graph_replays = ctx->graph_replays;
+    if (ctx->step_flow && ctx->steprows) {
+        int sr[4] = {0, 0, 0, 0};
+        WM_HIP(hipMemcpy(sr, ctx->steprows, sizeof(sr), hipMemcpyDeviceToHost));
+        out->schedule_steps = sr[2];
+    }
     return WM_OK;
 }
 

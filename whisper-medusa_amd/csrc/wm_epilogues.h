@@ -72,22 +72,30 @@ struct EpPackedAct {           // out_lo != nullptr: decoder path, value kept as
 struct EpQKVDec {              // K cache [s][h][pos][64]; V cache [s][h] as V^T MFMA fragments (vfrag_index)
     float* q; bf16_t* kc; bf16_t* vc; const float* bias; const int* base;
     int Mper, d, H, Tal, M;
+    const int4* rowinfo = nullptr; // merged-step schedule: dense rows, row m -> {stream, index inside the stream, position of its row 0, kind} (k_step_begin)
     __device__ __forceinline__ EpPre pre(int m, int n) const {
         EpPre p; p.b = make_float4(0.f, 0.f, 0.f, 0.f);
         p.a = *reinterpret_cast<const float4*>(bias + n);
-        p.i = base[min(m, M - 1) / Mper];                                    // rows >= M: the last row's stream (never stored)
+        if (rowinfo) {                                                        // one 16-byte load, requested with the rest of the launch's batch
+            const int4 ri = rowinfo[min(m, M - 1)];
+            p.i = ri.z; p.b.x = __int_as_float(ri.x); p.b.y = __int_as_float(ri.y); p.b.z = __int_as_float(ri.w == 2 ? Mper : ri.w);   // kind 0 / 1 / 2 -> 0 / 1 / Mper rows
+        } else {
+            const int sm = min(m, M - 1) / Mper;                              // rows >= M: the last row's stream (never stored)
+            p.i = base[sm];
+            p.b.x = __int_as_float(sm); p.b.y = __int_as_float(min(m, M - 1) - sm * Mper); p.b.z = __int_as_float(Mper);
+        }
         return p;
     }
     // NOTE: must be called by all 64 lanes of a wave together (the V branch exchanges values between lanes)
     __device__ __forceinline__ void fin(int m, int n, f32x4_t v, const EpPre& p) const {
-        const bool valid = m < M;
+        const bool inb = m < M;
         const float x0 = v[0] + p.a.x, x1 = v[1] + p.a.y, x2 = v[2] + p.a.z, x3 = v[3] + p.a.w;
         if (n < d) {                                   // n is wave-uniform up to the 16-feature tile: the branch is uniform
-            if (valid) *reinterpret_cast<float4*>(q + (size_t)m * d + n) = make_float4(x0 * 0.125f, x1 * 0.125f, x2 * 0.125f, x3 * 0.125f);
+            if (inb) *reinterpret_cast<float4*>(q + (size_t)m * d + n) = make_float4(x0 * 0.125f, x1 * 0.125f, x2 * 0.125f, x3 * 0.125f);
             return;
         }
-        const int mm = valid ? m : 0;
-        const int s = mm / Mper, r = mm - s * Mper;
+        const int s = __float_as_int(p.b.x), r = __float_as_int(p.b.y), cnt = __float_as_int(p.b.z);
+        const bool valid = inb && r < cnt;
         int pos = p.i + r; if (pos > Tal - 1) pos = Tal - 1;
         if (n < 2 * d) {
             const int c = n - d;
@@ -96,7 +104,7 @@ struct EpQKVDec {              // K cache [s][h][pos][64]; V cache [s][h] as V^T
         } else {
             const int c = n - 2 * d;
             // leader: position multiple of 4 whose next three rows exist, belong to the same stream and stay inside the cache
-            const bool lead = valid && (pos & 3) == 0 && (m & 15) <= 12 && m + 3 < M && (m + 3) / Mper == s && p.i + r + 3 <= Tal - 1;
+            const bool lead = valid && (pos & 3) == 0 && (m & 15) <= 12 && m + 3 < M && r + 3 < cnt && p.i + r + 3 <= Tal - 1;
             const int back = pos & 3;                  // my group's leader sits `back` lanes below me (if it is in my row group)
             const int lane = (int)(threadIdx.x & 63);
             const int src = lane - back;

@@ -100,6 +100,11 @@ struct wm_ctx {
     float *hb_keep = nullptr;                                               // Medusa-Block: carried block-layer output row per stream
     float *hf_cur = nullptr, *hf_keep = nullptr;                            // current chunk's rows; carried row per stream
     int* carry = nullptr;                                                   // [maxB] next base pass is redundant
+    // merged-step schedule (several streams, chain candidates; wm_decoder.hip wm_dec_step): per step and stream, written by k_step_begin
+    int4* rowinfo = nullptr;                                                // [Mmax * maxB] dense rows of the step's pass: {stream, index inside the stream, position of its row 0, kind 0 none / 1 base / 2 verify}
+    int4* sinfo = nullptr;                                                  // [maxB] {first dense row, row count, position of row 0, mode}
+    int* steprows = nullptr;                                                // [4] {dense rows of the pass, their 16-row tiles, 0, 0}
+    bool step_flow = false;
     // candidate tree (medusa_choices with top-k > 1); tn == 0: the chain
     int tn = 0, tp = 0;
     TreeDev tree_host{};
@@ -155,5 +160,6 @@ int wm_dec_pass(wm_ctx* ctx, int b0, int nb, int Mper, int mode, int medusa, int
 int wm_dec_iteration(wm_ctx* ctx, int Mper_base);   // one full iteration over all streams
 int wm_dec_prompt_prefix(wm_ctx* ctx, int P);       // K/V of a long prompt's leading chunks; returns the tokens left (<= 16), < 0 on error
 int wm_dec_iter_base(wm_ctx* ctx, int Mper_base);   // base pass layers + final LN
-int wm_dec_iter_rest(wm_ctx* ctx, int Mper_base);   // heads, candidates, verify pass, accept
+int wm_dec_iter_rest(wm_ctx* ctx, int Mper_base);
+int wm_dec_step(wm_ctx* ctx, int);   // heads, candidates, verify pass, accept
 int wm_dec_profile(wm_ctx* ctx, int kernel, int rows, int reps, float* ms, double* bytes);

@@ -410,9 +410,11 @@ k_skinny_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, in
 // (one wave per slice), so the operand bits equal those of a 16-row launch.
 template <int NK, class Ld>
 __global__ void __launch_bounds__(640)
-k_ln_tiles(Ld ld, int ksplit, bf16_t* __restrict__ xg, size_t plane, const int* __restrict__ done, int nmain, PfJob pf, int pf_sliced)
+k_ln_tiles(Ld ld, int ksplit, bf16_t* __restrict__ xg, size_t plane, const int* __restrict__ done, int nmain, PfJob pf, int pf_sliced,
+           const int* __restrict__ ntiles)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (ntiles && (int)blockIdx.x < nmain && (int)blockIdx.x >= *ntiles) return;       // no rows in this tile in this step
     // blocks beyond the token tiles: the launch has 2..22 blocks of work — the rest of the chip pulls the weight matrix of the GEMM that
     // follows towards the CUs that will read it (per consumer block / XCD for the two-tile kernel, whose block j runs on XCD j % 8; in
     // eighths for the token-tile kernels, where every XCD ends up reading the whole matrix and the point is the Infinity Cache)
@@ -462,12 +464,13 @@ k_ln_tiles(Ld ld, int ksplit, bf16_t* __restrict__ xg, size_t plane, const int* 
 template <int NKR, int RT, int TT, bool W8, class Ep>
 __global__ void WM_ROWS_BOUNDS
 k_rows_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int N16, int K32, int ksplit, const int* __restrict__ done,
-            const bf16_t* __restrict__ X, size_t plane, int MT, Ep ep)
+            const bf16_t* __restrict__ X, size_t plane, int MT, Ep ep, const int* __restrict__ ntiles)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // (checked first: moving the flag behind the first group of loads — a mid-loop exit — cost the 352-row launches ~3 us each, the
     //  compiler no longer overlapped the load groups across it: tests/microbench/r03_call4.sh)
     if (done && *done) return;
+    if (ntiles && (int)blockIdx.y * TT >= *ntiles) return;          // merged-step schedule: no rows in this token-tile group in this step
     const int lane = threadIdx.x & 63;
     const int ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rt0 = blockIdx.x * RT, mt0 = blockIdx.y * TT;
@@ -760,7 +763,7 @@ struct TileGemmCfg {
 template <int F, int TT, class Ep>
 __global__ void __launch_bounds__(512)
 k_tile_gemm(const bf16_t* __restrict__ W, int N16, int K32, int nk, const bf16_t* __restrict__ X, size_t plane, int MT,
-            int n_fb, int n_tg, const int* __restrict__ done, Ep ep)
+            int n_fb, int n_tg, const int* __restrict__ done, Ep ep, const int* __restrict__ ntiles)
 {
     typedef TileGemmCfg<F, TT> C;
     constexpr int TH = C::TH, LPW = C::LPW, R = C::R, STAGE = C::STAGE;
@@ -818,8 +821,8 @@ k_tile_gemm(const bf16_t* __restrict__ W, int N16, int K32, int nk, const bf16_t
 #pragma unroll
     for (int s = 0; s < R; ++s)
         if (s < NS) issue(s);
-    if (done && *done) {                       // every stream finished: nothing may stay in flight into a released LDS allocation
-        wm_wait_vmcnt<0>();
+    if ((done && *done) || (ntiles && mt0 >= *ntiles)) {   // every stream finished / no rows in this token group in this step: nothing may
+        wm_wait_vmcnt<0>();                                // stay in flight into a released LDS allocation
         return;
     }
 
@@ -899,6 +902,10 @@ k_tile_gemm(const bf16_t* __restrict__ W, int N16, int K32, int nk, const bf16_t
 
 // ---- host-side launch plan -------------------------------------------------------------------
 static thread_local const int* g_skinny_done = nullptr;     // device flag checked by every launch of this translation unit
+// merged-step schedule (wm_decoder.hip wm_dec_step): the pass's rows are dense and their number changes from step to step while the launches
+// (a captured graph) are sized for the maximum: device word = 16-row token tiles that hold rows in this step; the batched kernels' blocks
+// of tiles beyond it exit at once.  nullptr (every other pass): all tiles of the launch.
+static thread_local const int* g_skinny_ntiles = nullptr;
 struct SkinnyPlan { int ksplit, rt, nk, RT; };      // rt: row-tile groups per block (waves), RT: row tiles per wave (registers)
 
 // K-slices of at most 16 fragments (8 when the token operand is normalised in registers) and, if possible, >= 1024 waves.
@@ -1006,7 +1013,7 @@ static inline hipError_t launch_rows_gemm_w(hipStream_t st, WRef W, int N16, int
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(64 * p.ksplit), lds, st, W.w, W.scale, N16, K32, p.ksplit, g_skinny_done, X, plane, MT, ep);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * p.ksplit), lds, st, W.w, W.scale, N16, K32, p.ksplit, g_skinny_done, X, plane, MT, ep, g_skinny_ntiles);
     return hipGetLastError();
 }
 
@@ -1061,7 +1068,7 @@ static inline hipError_t launch_tile_gemm_ft(hipStream_t st, const bf16_t* W, in
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(n_fb * n_tg), dim3(512), lds, st, W, N16, K32, nk, X, plane, MT, n_fb, n_tg, g_skinny_done, ep);
+    hipLaunchKernelGGL(kern, dim3(n_fb * n_tg), dim3(512), lds, st, W, N16, K32, nk, X, plane, MT, n_fb, n_tg, g_skinny_done, ep, g_skinny_ntiles);
     return hipGetLastError();
 }
 
@@ -1177,8 +1184,8 @@ static inline hipError_t launch_skinny_norm_t(hipStream_t st, WRef W, int N16, i
         pf = PfJob{reinterpret_cast<const char*>(W.w), extra, job_bytes, (unsigned)(8 * ((slice + job_bytes - 1) / job_bytes)), wbytes};
     }
     if (pf.n_jobs) grid = pf_round8(MT) + (int)pf.n_jobs;
-    if (p.nk == 8) hipLaunchKernelGGL((k_ln_tiles<8, Ld>), dim3(grid), dim3(64 * p.ksplit), ld.lds_bytes(), st, ld, p.ksplit, xscr, plane, g_skinny_done, MT, pf, pf_sliced);
-    else if (p.nk == 4) hipLaunchKernelGGL((k_ln_tiles<4, Ld>), dim3(grid), dim3(64 * p.ksplit), ld.lds_bytes(), st, ld, p.ksplit, xscr, plane, g_skinny_done, MT, pf, pf_sliced);
+    if (p.nk == 8) hipLaunchKernelGGL((k_ln_tiles<8, Ld>), dim3(grid), dim3(64 * p.ksplit), ld.lds_bytes(), st, ld, p.ksplit, xscr, plane, g_skinny_done, MT, pf, pf_sliced, g_skinny_ntiles);
+    else if (p.nk == 4) hipLaunchKernelGGL((k_ln_tiles<4, Ld>), dim3(grid), dim3(64 * p.ksplit), ld.lds_bytes(), st, ld, p.ksplit, xscr, plane, g_skinny_done, MT, pf, pf_sliced, g_skinny_ntiles);
     else return hipErrorInvalidConfiguration;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

@@ -540,20 +540,27 @@ class WhisperMedusaModel:
             if streamer is not None:
                 streamer.put(torch.tensor([gp.prompt], dtype=torch.long))
 
+            K = self.config.medusa_num_heads
+
+            def over(b):
+                # stopped by a criterion, or finished by the engine's own rules (EOS emitted / length limits, model.py:774-793).  NOT "the
+                # stream emitted nothing": with several streams a step may be a stream's base pass (merged-step schedule), which emits nothing
+                if stop_len[b] is not None:
+                    return True
+                gen = cur[b][len(gp.prompt):]
+                return gp.eos_token_id in gen or len(cur[b]) >= gp.max_length or len(cur[b]) + K >= gp.hard_max_length
+
             def on_it(new):
-                live = False
                 for b in range(B):
                     if stop_len[b] is not None or not new[b]:
-                        continue                                            # stopped by a criterion / finished in the engine
+                        continue
                     cur[b].extend(new[b])
                     if streamer is not None:
                         streamer.put(torch.tensor(new[b], dtype=torch.long))
                     ids_b = torch.tensor([cur[b]], dtype=torch.long)
                     if host_crit and any(bool(torch.as_tensor(c(ids_b, None)).all()) for c in host_crit):
                         stop_len[b] = len(cur[b])
-                    else:
-                        live = True
-                return bool(host_crit) and not live                        # True: every stream is stopped or finished
+                return bool(host_crit) and all(over(b) for b in range(B))     # True ends the run (every stream stopped or finished)
 
             seqs = eng.decode(gp, B, on_iteration=on_it)
             seqs = [s_[: stop_len[b]] if stop_len[b] is not None else s_ for b, s_ in enumerate(seqs)]

@@ -46,7 +46,7 @@ class WmStats(C.Structure):
     _fields_ = [("iterations", C.c_int64), ("iterations_launched", C.c_int64), ("tokens_emitted", C.c_int64),
                 ("accept_hist", C.c_int64 * 16),
                 ("ms_logmel", C.c_float), ("ms_encode", C.c_float), ("ms_decode", C.c_float),
-                ("graph_replays", C.c_int32)]
+                ("graph_replays", C.c_int32), ("schedule_steps", C.c_int32)]
 
 
 EXPORTS = ["wm_create", "wm_destroy", "wm_last_error", "wm_abi_version", "wm_resample_len", "wm_resample", "wm_logmel", "wm_encode", "wm_set_encoder_output",
@@ -248,7 +248,7 @@ class Engine:
         return dict(iterations=s.iterations, iterations_launched=s.iterations_launched, tokens_emitted=s.tokens_emitted,
                     accept_hist=list(s.accept_hist)[: self.cfg.medusa_num_heads + 1],
                     ms_logmel=s.ms_logmel, ms_encode=s.ms_encode, ms_decode=s.ms_decode,
-                    graph_replays=s.graph_replays)
+                    graph_replays=s.graph_replays, schedule_steps=s.schedule_steps)
 
     def sync(self):
         self._check(self.lib.wm_sync(self.h), "wm_sync")

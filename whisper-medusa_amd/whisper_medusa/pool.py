@@ -40,8 +40,8 @@ def shard_bounds(n: int, parts: int) -> List[Tuple[int, int]]:
 def merge_stats(stats: Sequence[dict]) -> dict:
     """Whole-batch view of per-context statistics: counters add up, times are the slowest context's."""
     out = dict(stats[0])
-    for k in ("tokens_emitted", "iterations_launched", "graph_replays"):
-        out[k] = sum(s[k] for s in stats)
+    for k in ("tokens_emitted", "iterations_launched", "graph_replays", "schedule_steps"):
+        out[k] = sum(s.get(k, 0) for s in stats)
     out["iterations"] = max(s["iterations"] for s in stats)
     out["accept_hist"] = np.sum([np.asarray(s["accept_hist"]) for s in stats], axis=0).tolist()
     for k in ("ms_logmel", "ms_encode", "ms_decode"):
