@@ -1049,8 +1049,12 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
     // 1. LN1 + QKV; k rows / transposed v rows straight into the cache
     if (pf) g_pf_job = pf_for_gemm(w.out_w, f8, d / 16, K32, false);
     TL_SET(slot * 16 + 1 + 8192 * Mper);
-    WM_HIP(launch_skinny_norm(st, WRef{w.qkv_w, w.qkv_s}, 3 * d / 16, K32, h, w.ln1_w, w.ln1_b, d, R, 1, 0, 1,
-                              EpQKVDec{ctx->qbuf, kc, vc, w.qkv_b, base, Mper, d, H, ctx->Tal, R, rowinfo}, ctx->xbuf, xpl));
+    if (rowinfo)
+        WM_HIP(launch_skinny_norm(st, WRef{w.qkv_w, w.qkv_s}, 3 * d / 16, K32, h, w.ln1_w, w.ln1_b, d, R, 1, 0, 1,
+                                  EpQKVDecDense{ctx->qbuf, kc, vc, w.qkv_b, base, Mper, d, H, ctx->Tal, R, rowinfo}, ctx->xbuf, xpl));
+    else
+        WM_HIP(launch_skinny_norm(st, WRef{w.qkv_w, w.qkv_s}, 3 * d / 16, K32, h, w.ln1_w, w.ln1_b, d, R, 1, 0, 1,
+                                  EpQKVDec{ctx->qbuf, kc, vc, w.qkv_b, base, Mper, d, H, ctx->Tal, R}, ctx->xbuf, xpl));
     if (kv_only) return WM_OK;
     // fused cross-attention query (FuseQ above): single-tile passes with bf16 weights whose projection plan has a compiled instance
     // OFF by default: measured 14.6 us for the fused launch against 5.6 (LN2 + cross-q) + 2.2 (boundary) + 6.5 (cross-attention)

@@ -69,14 +69,17 @@ struct EpPackedAct {           // out_lo != nullptr: decoder path, value kept as
 // Decoder self-attention projections: q (scaled, fp32) to a row buffer, k/v rows (bf16) straight
 // into the contiguous KV cache at position base[stream] + r   (HF:modeling_whisper.py:288-318; the
 // reference's per-iteration cat-compaction, model.py:378-402, becomes "overwrite rows >= kv_len").
-struct EpQKVDec {              // K cache [s][h][pos][64]; V cache [s][h] as V^T MFMA fragments (vfrag_index)
+// DENSE (a type, not a run-time branch: a conditional load in pre() splits the launch's request batch — the one-stream QKV launch
+// measured 7.05 -> 7.76 us with an `if (rowinfo)` here): the merged-step schedule's dense rows, row m -> rowinfo[m] (k_step_begin).
+template <bool DENSE>
+struct EpQKVDecT {             // K cache [s][h][pos][64]; V cache [s][h] as V^T MFMA fragments (vfrag_index)
     float* q; bf16_t* kc; bf16_t* vc; const float* bias; const int* base;
     int Mper, d, H, Tal, M;
-    const int4* rowinfo = nullptr; // merged-step schedule: dense rows, row m -> {stream, index inside the stream, position of its row 0, kind} (k_step_begin)
+    const int4* rowinfo = nullptr; // DENSE: {stream, index inside the stream, position of its row 0, kind 0 none / 1 base / 2 verify}
     __device__ __forceinline__ EpPre pre(int m, int n) const {
         EpPre p; p.b = make_float4(0.f, 0.f, 0.f, 0.f);
         p.a = *reinterpret_cast<const float4*>(bias + n);
-        if (rowinfo) {                                                        // one 16-byte load, requested with the rest of the launch's batch
+        if constexpr (DENSE) {                                                // one 16-byte load, requested with the rest of the launch's batch
             const int4 ri = rowinfo[min(m, M - 1)];
             p.i = ri.z; p.b.x = __int_as_float(ri.x); p.b.y = __int_as_float(ri.y); p.b.z = __int_as_float(ri.w == 2 ? Mper : ri.w);   // kind 0 / 1 / 2 -> 0 / 1 / Mper rows
         } else {
@@ -120,6 +123,8 @@ struct EpQKVDec {              // K cache [s][h][pos][64]; V cache [s][h] as V^T
     }
     __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const { fin(m, n, v, pre(m, n)); }
 };
+typedef EpQKVDecT<false> EpQKVDec;
+typedef EpQKVDecT<true> EpQKVDecDense;
 
 // Medusa residual heads: y = x + SiLU(W x + b) (model.py:180-210) for head k = n / d, written as
 // packed bf16 row  m*row_mul + row_off + k  of the vocabulary-projection operand.
