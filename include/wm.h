@@ -158,7 +158,11 @@ int wm_set_encoder_output(wm_ctx* ctx, const float* hidden, int B);
 /* ---- F3..F14 the Medusa decode loop (replaces _medusa_greedy_search, model.py:404-835) ---- */
 int wm_decode_begin(wm_ctx* ctx, const wm_gen_params* gp, int B);
 /* Runs up to max_iters iterations (each = base pass + verify pass + accept), replayed from a
- * hipGraph after the first; returns the number of unfinished streams in *n_unfinished. */
+ * hipGraph after the first; returns the number of unfinished streams in *n_unfinished.
+ * Several streams with candidate chains run the merged-step schedule: max_iters then counts STEPS (one pass each:
+ * a stream whose last accept length was 0 spends one step on its base row and verifies in the next; the emitted
+ * tokens, accept histogram and per-stream iteration counts are those of the lock-step schedule).
+ * Environment: WM_NO_STEP=1 lock-step schedule, WM_NO_CARRY=1 no hidden-state carry, WM_NO_GRAPH=1 eager launches. */
 int wm_decode_run(wm_ctx* ctx, int max_iters, int* n_unfinished);
 /* ids (prompt + generated, post-EOS overwrite of model.py:798-810 applied) of one stream. */
 int wm_get_tokens(wm_ctx* ctx, int stream, int32_t* out /* HOST */, int cap, int* n);
