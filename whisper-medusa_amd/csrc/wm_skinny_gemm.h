@@ -462,7 +462,12 @@ k_ln_tiles(Ld ld, int ksplit, bf16_t* __restrict__ xg, size_t plane, const int* 
 #define WM_ROWS_G 4
 #endif
 template <int NKR, int RT, int TT, bool W8, class Ep>
-__global__ void WM_ROWS_BOUNDS
+__global__ void
+#ifdef WM_ROWS_TT4
+__launch_bounds__(TT >= 4 ? 320 : 640)          // the four-token-tile experiment runs 5 K-slice waves (K = 1280): 256 registers per lane
+#else
+WM_ROWS_BOUNDS
+#endif
 k_rows_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int N16, int K32, int ksplit, const int* __restrict__ done,
             const bf16_t* __restrict__ X, size_t plane, int MT, Ep ep, const int* __restrict__ ntiles)
 {
@@ -485,7 +490,7 @@ k_rows_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int 
     for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int j = 0; j < TT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    constexpr int G = WM_ROWS_G;
+    constexpr int G = TT >= 4 ? 2 : WM_ROWS_G;          // four token tiles: 24 fragments per two k-tiles next to 16 accumulator tiles
 #pragma unroll
     for (int kg = 0; kg < NKR; kg += G) {
         bf16x8_t a[RT][G], xh[TT][G], xl[TT][G];
@@ -1002,10 +1007,9 @@ static inline hipError_t launch_skinny(hipStream_t st, WRef W, int N16, int K32,
     return launch_skinny_w<false>(st, W, N16, K32, p, ld, ep);
 }
 
-template <int NKR, int RT, bool W8, class Ep>
+template <int NKR, int RT, bool W8, class Ep, int TT = 2>
 static inline hipError_t launch_rows_gemm_w(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p,
                                             const bf16_t* X, size_t plane, int MT, const Ep& ep) {
-    constexpr int TT = 2;
     const dim3 grid((N16 + RT - 1) / RT, (MT + TT - 1) / TT);
     const size_t lds = p.ksplit > 1 ? (size_t)RT * TT * p.ksplit * 1024 : 0;
     auto kern = k_rows_gemm<NKR, RT, TT, W8, Ep>;
@@ -1031,6 +1035,15 @@ static inline hipError_t launch_skinny_mt_nk(hipStream_t st, WRef W, int N16, in
     // weight row tiles per wave: as many as still leave >= 400 blocks (~1.5 per CU; swept 100..800 at 8 and 32 streams) (register blocking divides the L2 re-reads
     // of the token operand; with few token tiles the chip has to be filled by features instead).  Same results.
     const int groups = (MT + 1) / 2;
+#ifdef WM_ROWS_TT4
+    // experiment (build.py --variant tt4 -DWM_ROWS_TT4): the wide GEMMs (QKV, FC1) with FOUR token tiles per wave — 12 fragments per 32 MFMAs
+    // instead of 8 per 16, i.e. 25 % less L2 -> CU fill per MFMA, half the blocks
+    static const int tt4_min = skinny_env("WM_ROWS_TT4_MIN_BLOCKS", 350);
+    if (MT >= 8 && p.ksplit <= 5 && ((N16 + 3) / 4) * ((MT + 3) / 4) >= tt4_min) {
+        if (W.scale) return launch_rows_gemm_w<NKR, 4, true, Ep, 4>(st, W, N16, K32, p, X, plane, MT, ep);
+        return launch_rows_gemm_w<NKR, 4, false, Ep, 4>(st, W, N16, K32, p, X, plane, MT, ep);
+    }
+#endif
     if (((N16 + 3) / 4) * groups >= min_blocks) return launch_rows_gemm<NKR, 4>(st, W, N16, K32, p, X, plane, MT, ep);
     if (((N16 + 1) / 2) * groups >= min_blocks) return launch_rows_gemm<NKR, 2>(st, W, N16, K32, p, X, plane, MT, ep);
     return launch_rows_gemm<NKR, 1>(st, W, N16, K32, p, X, plane, MT, ep);
