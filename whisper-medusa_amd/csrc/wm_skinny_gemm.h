@@ -463,8 +463,10 @@ k_ln_tiles(Ld ld, int ksplit, bf16_t* __restrict__ xg, size_t plane, const int* 
 #endif
 template <int NKR, int RT, int TT, bool W8, class Ep>
 __global__ void
-#ifdef WM_ROWS_TT4
+#if defined(WM_ROWS_TT4)
 __launch_bounds__(TT >= 4 ? 320 : 640)          // the four-token-tile experiment runs 5 K-slice waves (K = 1280): 256 registers per lane
+#elif defined(WM_ROWS_PIPE)
+__launch_bounds__(NKR <= 8 ? 384 : 640)         // experiment: <= 6 K-slice waves of 8 k-tiles (checked at launch): 256 registers per lane
 #else
 WM_ROWS_BOUNDS
 #endif
@@ -472,10 +474,22 @@ k_rows_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int 
             const bf16_t* __restrict__ X, size_t plane, int MT, Ep ep, const int* __restrict__ ntiles)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#if defined(WM_ROWS_PIPE)
+    // Experiment (build.py --variant pipe -DWM_ROWS_PIPE), bf16 weights: the wave's K-slice as an explicit two-deep pipeline of two-k-tile
+    // groups.  The ISA of the plain form showed the scheduler trickling 2-3 fragment loads between MFMAs with vmcnt(1..2) waits (a few KB
+    // in flight per wave) behind five dependent scalar round trips (done / ntiles) in front of the first load.  Here: both groups'
+    // requests go out first, the two flags are read while they fly, then MFMA(group g) | requests(group g + 2) alternate, pinned with
+    // scheduling barriers; the waits are the compiler's counted ones.  Same arithmetic, same order.
+    constexpr bool kPipe = !W8 && (NKR <= 8 || RT <= 2);          // (16 k-tiles x 4 row tiles would spill under the 10-wave launch bound)
+#else
+    constexpr bool kPipe = false;
+#endif
     // (checked first: moving the flag behind the first group of loads — a mid-loop exit — cost the 352-row launches ~3 us each, the
     //  compiler no longer overlapped the load groups across it: tests/microbench/r03_call4.sh)
-    if (done && *done) return;
-    if (ntiles && (int)blockIdx.y * TT >= *ntiles) return;          // merged-step schedule: no rows in this token-tile group in this step
+    if constexpr (!kPipe) {
+        if (done && *done) return;
+        if (ntiles && (int)blockIdx.y * TT >= *ntiles) return;          // merged-step schedule: no rows in this token-tile group in this step
+    }
     const int lane = threadIdx.x & 63;
     const int ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rt0 = blockIdx.x * RT, mt0 = blockIdx.y * TT;
@@ -490,6 +504,39 @@ k_rows_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int 
     for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int j = 0; j < TT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if constexpr (kPipe) {
+        constexpr int G = 2, NG = NKR / G;
+        static_assert(NKR % G == 0, "K-slice is a multiple of two k-tiles");
+        bf16x8_t a[2][RT][G], xh[2][TT][G], xl[2][TT][G];
+#define WM_ROWS_LOAD(B, KG)                                                                                                   \
+        _Pragma("unroll") for (int u = 0; u < G; ++u) {                                                                      \
+            _Pragma("unroll") for (int j = 0; j < TT; ++j) {                                                                 \
+                xh[B][j][u] = ld_frag(xp[j] + (size_t)((KG) + u) * 512); xl[B][j][u] = ld_frag(xp[j] + plane + (size_t)((KG) + u) * 512); \
+            }                                                                                                                \
+            _Pragma("unroll") for (int i = 0; i < RT; ++i) a[B][i][u] = ld_wfrag<false, false>(W, wp[i] + (size_t)((KG) + u) * 512); \
+        }
+        WM_ROWS_LOAD(0, 0)
+        if constexpr (NG > 1) { WM_ROWS_LOAD(1, G) }
+        __builtin_amdgcn_sched_barrier(0);
+        if (done && *done) return;
+        if (ntiles && (int)blockIdx.y * TT >= *ntiles) return;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int b = g & 1;
+#pragma unroll
+            for (int u = 0; u < G; ++u)
+#pragma unroll
+                for (int i = 0; i < RT; ++i)
+#pragma unroll
+                    for (int j = 0; j < TT; ++j) { acc[i][j] = mfma16(a[b][i][u], xh[b][j][u], acc[i][j]); acc[i][j] = mfma16(a[b][i][u], xl[b][j][u], acc[i][j]); }
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 2 < NG) {
+                if (b == 0) { WM_ROWS_LOAD(0, (g + 2) * G) } else { WM_ROWS_LOAD(1, (g + 2) * G) }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef WM_ROWS_LOAD
+    } else {
     constexpr int G = TT >= 4 ? 2 : WM_ROWS_G;          // four token tiles: 24 fragments per two k-tiles next to 16 accumulator tiles
 #pragma unroll
     for (int kg = 0; kg < NKR; kg += G) {
@@ -508,6 +555,7 @@ k_rows_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int 
             for (int i = 0; i < RT; ++i)
 #pragma unroll
                 for (int j = 0; j < TT; ++j) { acc[i][j] = mfma16(a[i][u], xh[j][u], acc[i][j]); acc[i][j] = mfma16(a[i][u], xl[j][u], acc[i][j]); }
+    }
     }
     if (ksplit > 1) {
         float4* red = reinterpret_cast<float4*>(smem);
@@ -1013,6 +1061,9 @@ static inline hipError_t launch_rows_gemm_w(hipStream_t st, WRef W, int N16, int
     const dim3 grid((N16 + RT - 1) / RT, (MT + TT - 1) / TT);
     const size_t lds = p.ksplit > 1 ? (size_t)RT * TT * p.ksplit * 1024 : 0;
     auto kern = k_rows_gemm<NKR, RT, TT, W8, Ep>;
+#if defined(WM_ROWS_PIPE)
+    if (NKR <= 8 && p.ksplit > 6) return hipErrorInvalidConfiguration;          // launch bounds of the experiment
+#endif
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
