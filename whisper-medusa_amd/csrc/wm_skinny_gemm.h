@@ -491,8 +491,17 @@ k_rows_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int 
         if (ntiles && (int)blockIdx.y * TT >= *ntiles) return;          // merged-step schedule: no rows in this token-tile group in this step
     }
     const int lane = threadIdx.x & 63;
+#if defined(WM_ROWS_SHARE)
+    // Experiment (build.py --variant share -DWM_ROWS_SHARE): a block carries TWO feature groups (waves [0, ksplit) and [ksplit, 2 ksplit)) that
+    // read the same token fragments of the same K-slices at about the same time: the second read should hit the CU's L1 instead of the L2.
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fg = wave >= ksplit ? 1 : 0, nfg = (int)blockDim.x > 64 * ksplit ? 2 : 1;
+    const int ks = wave - fg * ksplit;
+    const int rt0 = ((int)blockIdx.x * nfg + fg) * RT, mt0 = blockIdx.y * TT;
+#else
     const int ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rt0 = blockIdx.x * RT, mt0 = blockIdx.y * TT;
+#endif
     const int kt0 = ks * NKR;
     size_t wp[RT]; const bf16_t* xp[TT];
 #pragma unroll
@@ -558,14 +567,20 @@ k_rows_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int 
     }
     }
     if (ksplit > 1) {
+#if defined(WM_ROWS_SHARE)
+        float4* red = reinterpret_cast<float4*>(smem) + (size_t)fg * RT * TT * ksplit * 64;
+        const int e0 = (int)threadIdx.x - fg * ksplit * 64, estep = ksplit * 64;
+#else
         float4* red = reinterpret_cast<float4*>(smem);
+        const int e0 = threadIdx.x, estep = blockDim.x;
+#endif
 #pragma unroll
         for (int i = 0; i < RT; ++i)
 #pragma unroll
             for (int j = 0; j < TT; ++j)
                 red[((i * TT + j) * ksplit + ks) * 64 + lane] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
         __syncthreads();
-        for (int e = threadIdx.x; e < RT * TT * 64; e += blockDim.x) {
+        for (int e = e0; e < RT * TT * 64; e += estep) {
             const int t = e >> 6, l2 = e & 63, i = t / TT, j = t - i * TT;
             f32x4_t sacc = {0.f, 0.f, 0.f, 0.f};
             for (int k2 = 0; k2 < ksplit; ++k2) {
@@ -1058,8 +1073,13 @@ static inline hipError_t launch_skinny(hipStream_t st, WRef W, int N16, int K32,
 template <int NKR, int RT, bool W8, class Ep, int TT = 2>
 static inline hipError_t launch_rows_gemm_w(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p,
                                             const bf16_t* X, size_t plane, int MT, const Ep& ep) {
-    const dim3 grid((N16 + RT - 1) / RT, (MT + TT - 1) / TT);
-    const size_t lds = p.ksplit > 1 ? (size_t)RT * TT * p.ksplit * 1024 : 0;
+#if defined(WM_ROWS_SHARE)
+    const int nfg = (p.ksplit > 1 && p.ksplit * 2 <= 10 && N16 >= 2 * RT) ? 2 : 1;
+#else
+    const int nfg = 1;
+#endif
+    const dim3 grid((N16 + RT * nfg - 1) / (RT * nfg), (MT + TT - 1) / TT);
+    const size_t lds = p.ksplit > 1 ? (size_t)RT * TT * p.ksplit * 1024 * nfg : 0;
     auto kern = k_rows_gemm<NKR, RT, TT, W8, Ep>;
 #if defined(WM_ROWS_PIPE)
     if (NKR <= 8 && p.ksplit > 6) return hipErrorInvalidConfiguration;          // launch bounds of the experiment
@@ -1068,7 +1088,7 @@ static inline hipError_t launch_rows_gemm_w(hipStream_t st, WRef W, int N16, int
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(64 * p.ksplit), lds, st, W.w, W.scale, N16, K32, p.ksplit, g_skinny_done, X, plane, MT, ep, g_skinny_ntiles);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * p.ksplit * nfg), lds, st, W.w, W.scale, N16, K32, p.ksplit, g_skinny_done, X, plane, MT, ep, g_skinny_ntiles);
     return hipGetLastError();
 }
 
