@@ -1,4 +1,5 @@
-"""In-kernel timeline of the single-stream decode chain (debug build libwm_tl.so, -DWM_TIMELINE).
+"""In-kernel timeline of the decode chain (debug build libwm_tl.so, -DWM_TIMELINE): one stream by default, `--batch 32` = the merged-step
+schedule's 352-row launches (k_rows_gemm records: cycles to "MFMAs issued", "K-slice partials exchanged", exit).
 
     python whisper-medusa_amd/build.py --timeline
     WM_LIB=whisper-medusa_amd/whisper_medusa/libwm_tl.so python tests/microbench/timeline.py --out gpurun_out/timeline_new
@@ -33,6 +34,7 @@ def main():
     ap.add_argument("--max-new", type=int, default=48)
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--cap", type=int, default=3_000_000)
+    ap.add_argument("--batch", type=int, default=1)
     args = ap.parse_args()
     import torch
     from whisper_medusa import MedusaConfig, WhisperMedusaModel, synth, ACCEPT_TYPICAL
@@ -44,19 +46,19 @@ def main():
     cfg = MedusaConfig.large_v2("base_head", K=10)
     cfg.decoder_layers = args.layers
     sd = synth.synth_state_dict(cfg, seed=0, device=str(dev), logit_std=4.5)
-    model = WhisperMedusaModel(cfg, sd, device=dev)
+    model = WhisperMedusaModel(cfg, sd, device=dev, max_batch=args.batch)
     eng = model.engine
     buf = torch.zeros(args.cap * REC.itemsize, dtype=torch.uint8, device=dev)
     idx = torch.zeros(4, dtype=torch.int32, device=dev)
     lib.wm_debug_timeline.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
     lib.wm_debug_timeline.restype = C.c_int32
-    wav = np.stack([synth.synth_clip(0, cfg.n_mel_frames * 160)])
+    wav = np.stack([synth.synth_clip(j, cfg.n_mel_frames * 160) for j in range(args.batch)])
     feats = model.extract_features(wav)
     gp = synth.bench_gen_params(cfg, max_new_tokens=args.max_new, accept_mode=ACCEPT_TYPICAL)
     eng.encode(feats)
-    eng.decode(gp, 1)                                        # warm: graphs captured
+    eng.decode(gp, args.batch)                               # warm: graphs captured
     assert lib.wm_debug_timeline(eng.h, C.c_void_p(buf.data_ptr()), C.c_void_p(idx.data_ptr()), args.cap) == 0
-    eng.decode(gp, 1)
+    eng.decode(gp, args.batch)
     st = eng.stats()
     torch.cuda.synchronize()
     n = int(idx[0].item())
@@ -75,7 +77,7 @@ def main():
         launches.append(dict(tag=int(r["tag"][0]), n=int(b - a), t0=int(r["rt0"].min()), t0_last=int(r["rt0"].max()),
                              t1_first=int(r["rt1"].min()), t1=int(r["rt1"].max()),
                              c_prep=float(r["c_prep"].mean()), c_mid=float(r["c_mid"].mean()), c_end=float(r["c_end"].mean()),
-                             c_end_max=float(r["c_end"].max())))
+                             c_end_max=float(r["c_end"].max()), blk=float(np.median((r["rt1"] - r["rt0"]).astype(np.float64))) * 0.01))
     TICK = 0.01                                               # 100 MHz realtime counter -> microseconds
     rows = {}
     for i, L in enumerate(launches):
@@ -85,20 +87,20 @@ def main():
         else:
             key = (STEP.get(tag % 16, str(tag % 16)), tag >> 13)
         gap = (L["t0"] - launches[i - 1]["t1"]) * TICK if i > 0 else 0.0
-        d = rows.setdefault(key, dict(n=0, dur=[], gap=[], spread=[], prep=[], mid=[], end=[], blocks=[], endmax=[]))
+        d = rows.setdefault(key, dict(n=0, dur=[], gap=[], spread=[], prep=[], mid=[], end=[], blocks=[], endmax=[], blk=[]))
         d["n"] += 1
         d["dur"].append((L["t1"] - L["t0"]) * TICK); d["gap"].append(gap); d["spread"].append((L["t0_last"] - L["t0"]) * TICK)
         d["prep"].append(L["c_prep"]); d["mid"].append(L["c_mid"]); d["end"].append(L["c_end"]); d["blocks"].append(L["n"])
-        d["endmax"].append(L["c_end_max"])
+        d["endmax"].append(L["c_end_max"]); d["blk"].append(L["blk"])
     lines = [f"{n} block records over {st['iterations']} Medusa iterations; {st['ms_decode'] / max(st['iterations'], 1):.3f} ms / iteration with probes",
              "", "times in microseconds (100 MHz realtime counter, 10 ns resolution), phases in shader cycles (mean over blocks)", "",
-             "| kernel | rows/stream | launches | blocks | gap before (median) | entry spread | first entry -> last exit | cycles: operands ready | products done | exit (mean) | exit (max) |",
-             "|---|---|---|---|---|---|---|---|---|---|---|"]
+             "| kernel | rows/stream | launches | blocks | gap before (median) | entry spread | first entry -> last exit | block entry -> exit (median) | cycles: operands ready | products done | exit (mean) | exit (max) |",
+             "|---|---|---|---|---|---|---|---|---|---|---|---|"]
     tot = {}
     for key in sorted(rows, key=lambda k: (k[1], list(STEP.values()).index(k[0]) if k[0] in STEP.values() else 99)):
         d = rows[key]
         med = lambda v: float(np.median(v))
-        lines.append(f"| {key[0]} | {key[1]} | {d['n']} | {int(med(d['blocks']))} | {med(d['gap']):.2f} | {med(d['spread']):.2f} | {med(d['dur']):.2f} | "
+        lines.append(f"| {key[0]} | {key[1]} | {d['n']} | {int(med(d['blocks']))} | {med(d['gap']):.2f} | {med(d['spread']):.2f} | {med(d['dur']):.2f} | {med(d['blk']):.2f} | "
                      f"{med(d['prep']):.0f} | {med(d['mid']):.0f} | {med(d['end']):.0f} | {med(d['endmax']):.0f} |")
         tot.setdefault(key[1], [0.0, 0.0])
         if key[0] in STEP.values():

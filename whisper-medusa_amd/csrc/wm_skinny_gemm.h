@@ -471,9 +471,10 @@ __launch_bounds__(NKR <= 8 ? 384 : 640)         // experiment: <= 6 K-slice wave
 WM_ROWS_BOUNDS
 #endif
 k_rows_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int N16, int K32, int ksplit, const int* __restrict__ done,
-            const bf16_t* __restrict__ X, size_t plane, int MT, Ep ep, const int* __restrict__ ntiles)
+            const bf16_t* __restrict__ X, size_t plane, int MT, Ep ep, const int* __restrict__ ntiles TL_ARG)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    TL_BEGIN
 #if defined(WM_ROWS_PIPE)
     // Experiment (build.py --variant pipe -DWM_ROWS_PIPE), bf16 weights: the wave's K-slice as an explicit two-deep pipeline of two-k-tile
     // groups.  The ISA of the plain form showed the scheduler trickling 2-3 fragment loads between MFMAs with vmcnt(1..2) waits (a few KB
@@ -566,6 +567,7 @@ k_rows_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int 
                 for (int j = 0; j < TT; ++j) { acc[i][j] = mfma16(a[i][u], xh[j][u], acc[i][j]); acc[i][j] = mfma16(a[i][u], xl[j][u], acc[i][j]); }
     }
     }
+    TL_PREP          // timeline build: the wave's MFMAs have issued
     if (ksplit > 1) {
 #if defined(WM_ROWS_SHARE)
         float4* red = reinterpret_cast<float4*>(smem) + (size_t)fg * RT * TT * ksplit * 64;
@@ -580,6 +582,7 @@ k_rows_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int 
             for (int j = 0; j < TT; ++j)
                 red[((i * TT + j) * ksplit + ks) * 64 + lane] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
         __syncthreads();
+        TL_MID       // timeline build: K-slice partials exchanged
         for (int e = e0; e < RT * TT * 64; e += estep) {
             const int t = e >> 6, l2 = e & 63, i = t / TT, j = t - i * TT;
             f32x4_t sacc = {0.f, 0.f, 0.f, 0.f};
@@ -613,6 +616,7 @@ k_rows_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int 
                     ep.fin((mt0 + j) * 16 + (lane & 15), (rt0 + i) * 16 + 4 * (lane >> 4), acc[i][j], pre[i][j]);
                 }
     }
+    TL_END
 }
 
 // ---- 17..32 token rows (two token tiles): the weight-streaming kernel with a second token tile ---------------------
@@ -1088,7 +1092,7 @@ static inline hipError_t launch_rows_gemm_w(hipStream_t st, WRef W, int N16, int
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(64 * p.ksplit * nfg), lds, st, W.w, W.scale, N16, K32, p.ksplit, g_skinny_done, X, plane, MT, ep, g_skinny_ntiles);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * p.ksplit * nfg), lds, st, W.w, W.scale, N16, K32, p.ksplit, g_skinny_done, X, plane, MT, ep, g_skinny_ntiles TL_PASS);
     return hipGetLastError();
 }
 
