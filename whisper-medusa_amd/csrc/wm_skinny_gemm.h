@@ -68,6 +68,25 @@ struct TlProbe {
 #define TL_SET(t) ((void)0)
 #endif
 
+// ---- experiment (build.py --variant lntail -DWM_LN_TAIL): LayerNorm in the tail of the producing GEMM --------------------------------
+// profiles/r04_timeline_b32.md: a merged step spends 28 % of a decoder layer in the three k_ln_tiles launches and their boundaries.
+// With a tail job riding on the residual GEMM (out-proj -> LN2, cross-out -> LN3), the LAST block to finish a token-tile group — a ticket
+// per group, release / acquire fences at agent scope around it, no block ever waits — runs the k_ln_tiles code for the group's rows and
+// writes the packed hi / lo operand; the consumer's LayerNorm launch is skipped.  Same LdNormT arithmetic on the same residual rows:
+// bit-identical.  Off in the product build: not yet measured.
+struct LnTail {
+    const float* h; const float* gamma; const float* beta; bf16_t* xg; size_t plane; int d, K32, M; int* ticket;
+};
+#ifdef WM_LN_TAIL
+static thread_local LnTail g_ln_tail = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr};      // host: rides on the next rows-GEMM launch
+static thread_local const float* g_ln_tail_done = nullptr;                 // host: gamma of the LayerNorm the last launch's tail produced
+#define LNT_ARG , LnTail tail
+#define LNT_PASS(t) , t
+#else
+#define LNT_ARG
+#define LNT_PASS(t)
+#endif
+
 // ---- weight fragments: raw load now, widen later (an fp8 fragment must not be converted before the batch is in flight) ----
 template <bool W8> struct WRaw { typedef u32x4_t type; };
 template <> struct WRaw<true> { typedef u32x2_t type; };
@@ -471,7 +490,7 @@ __launch_bounds__(NKR <= 8 ? 384 : 640)         // experiment: <= 6 K-slice wave
 WM_ROWS_BOUNDS
 #endif
 k_rows_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int N16, int K32, int ksplit, const int* __restrict__ done,
-            const bf16_t* __restrict__ X, size_t plane, int MT, Ep ep, const int* __restrict__ ntiles TL_ARG)
+            const bf16_t* __restrict__ X, size_t plane, int MT, Ep ep, const int* __restrict__ ntiles LNT_ARG TL_ARG)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     TL_BEGIN
@@ -616,6 +635,47 @@ k_rows_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int 
                     ep.fin((mt0 + j) * 16 + (lane & 15), (rt0 + i) * 16 + 4 * (lane >> 4), acc[i][j], pre[i][j]);
                 }
     }
+#ifdef WM_LN_TAIL
+    if (tail.xg != nullptr && ksplit > 1) {
+        __shared__ int s_tail_last;
+        __threadfence();                                   // release: this block's residual rows are visible at agent scope
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int t = __hip_atomic_fetch_add(tail.ticket + blockIdx.y, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = (t == (int)gridDim.x - 1);
+            if (last) __hip_atomic_store(tail.ticket + blockIdx.y, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // re-arm for the next launch / replay
+            s_tail_last = last;
+        }
+        __syncthreads();
+        if (s_tail_last) {
+            __threadfence();                               // acquire: the other blocks' rows
+            constexpr int NKL = 8;
+            const LdNorm ln{tail.h, tail.gamma, tail.beta, tail.d, tail.K32, tail.M, 1, 0};
+            const int ksl = tail.K32 / NKL;                // K-slices of the LayerNorm = waves per tile (launch: blockDim == 64 ksl or 128 ksl)
+            const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+            const bool two = (int)blockDim.x >= 128 * ksl; // two tile groups side by side (TT == 2), else one after the other
+            const int grp = two ? (wv >= ksl ? 1 : 0) : 0, ksn = wv - grp * ksl;
+            typename LdNorm::template Regs<NKL> xr;
+#pragma unroll
+            for (int jj = 0; jj < TT; ++jj) {
+                if (two && jj > 0) break;
+                const int j = two ? grp : jj, tile = min(mt0 + j, MT - 1);
+                if (jj == 0) { ln.template issue<NKL>(xr, smem, ksn * NKL, lane, tile * 16, true, true); ln.template stage<NKL>(xr, smem); }
+                else ln.template issue<NKL>(xr, smem, ksn * NKL, lane, tile * 16, true, false);
+                ln.template stats<NKL>(xr, smem, ksn, ksl, true, lane, j & 1);
+                bf16_t* dst = tail.xg + (size_t)tile * tail.K32 * 512;
+#pragma unroll
+                for (int u = 0; u < NKL; ++u) {
+                    bf16x8_t bh, bl;
+                    ln.template frag<NKL>(xr, smem, u, ksn * NKL + u, lane, bh, bl);
+                    const size_t o = ((size_t)(ksn * NKL + u) * 64 + lane) * 8;
+                    *reinterpret_cast<uint4*>(dst + o) = __builtin_bit_cast(uint4, bh);
+                    *reinterpret_cast<uint4*>(dst + tail.plane + o) = __builtin_bit_cast(uint4, bl);
+                }
+            }
+        }
+    }
+#endif
     TL_END
 }
 
@@ -1092,7 +1152,26 @@ static inline hipError_t launch_rows_gemm_w(hipStream_t st, WRef W, int N16, int
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
+#ifdef WM_LN_TAIL
+    LnTail tail = g_ln_tail;
+    g_ln_tail = LnTail{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr};
+    g_ln_tail_done = nullptr;
+    {
+        const int ksl = tail.xg ? tail.K32 / 8 : 0;
+        const bool ok = tail.xg && TT == 2 && nfg == 1 && p.ksplit > 1 && tail.K32 % 8 == 0 && tail.K32 * 32 == tail.d &&
+                        (p.ksplit == ksl || p.ksplit == 2 * ksl) && tail.K32 * 16 <= 2 * 64 * p.ksplit;      // gamma | beta: two float4 per thread
+        if (!ok) tail.xg = nullptr;
+    }
+    size_t lds_t = lds;
+    if (tail.xg) { lds_t = std::max(lds, (size_t)(2 * tail.d * sizeof(float) + 2048)); g_ln_tail_done = tail.gamma; }
+    if (lds_t > 64 * 1024 && lds_t != lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(64 * p.ksplit * nfg), lds_t, st, W.w, W.scale, N16, K32, p.ksplit, g_skinny_done, X, plane, MT, ep, g_skinny_ntiles LNT_PASS(tail) TL_PASS);
+#else
     hipLaunchKernelGGL(kern, grid, dim3(64 * p.ksplit * nfg), lds, st, W.w, W.scale, N16, K32, p.ksplit, g_skinny_done, X, plane, MT, ep, g_skinny_ntiles TL_PASS);
+#endif
     return hipGetLastError();
 }
 
@@ -1208,6 +1287,11 @@ static inline hipError_t launch_skinny2(hipStream_t st, WRef W, int N16, int K32
 template <class Ep>
 static inline hipError_t launch_skinny_mt(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p,
                                           const bf16_t* X, size_t plane, int MT, int R, const Ep& ep) {
+#ifdef WM_LN_TAIL
+    const bool rows_kernel = !use_tile_gemm(N16, K32, MT, W.scale != nullptr, p.nk) &&
+                             !(MT == 2 && skinny_env("WM_SKINNY2", 1) && p.ksplit * p.rt <= 10 && p.ksplit * p.nk == K32);
+    if (!rows_kernel) { g_ln_tail = LnTail{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr}; g_ln_tail_done = nullptr; }
+#endif
     // the LDS-ring tile kernel (same accumulation order, bit-identical results)
     if (use_tile_gemm(N16, K32, MT, W.scale != nullptr, p.nk))
         return launch_tile_gemm(st, W.w, N16, K32, p.nk, X, plane, MT, ep);
@@ -1254,6 +1338,14 @@ static inline hipError_t launch_skinny_norm_t(hipStream_t st, WRef W, int N16, i
         }
         return hipGetLastError();
     }
+#ifdef WM_LN_TAIL
+    if (Ld::do_norm && g_ln_tail_done != nullptr && g_ln_tail_done == ld.gamma) {      // the producing GEMM's tail wrote this operand
+        g_ln_tail_done = nullptr;
+        g_ln_pf_extra = nullptr;
+        return launch_skinny_mt(st, W, N16, K32, p, xscr, plane, MT, R, ep);
+    }
+    g_ln_tail_done = nullptr;
+#endif
     // weight prefetch riding on the LayerNorm launch (token-tile path with bf16 weights only; WM_LN_PREFETCH=0 turns it off)
     const int ln_pf = skinny_env("WM_LN_PREFETCH", 1);
     PfJob pf{nullptr, nullptr, 0u, 0u, 0ull};
