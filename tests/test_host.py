@@ -394,6 +394,27 @@ def test_dynamic_stopping_criteria_run_on_the_host_after_every_iteration():
     m.generate(feats, language="en", stopping_criteria=[crit2])
     assert eng.iters == 2
 
+    # merged-step schedule (several streams): a step can be a stream's base pass and emit nothing for it — that is neither "finished" nor
+    # a reason to ask the criteria again for that stream
+    class StepEng(Eng):
+        def decode(self, gp, B, on_iteration=None, **kw):
+            seqs = [list(gp.prompt) for _ in range(B)]
+            for it in range(6):
+                new = [([] if (b == 0 and it % 2 == 1) else [10 * it + b]) for b in range(B)]       # stream 0 idles on odd steps
+                for b in range(B):
+                    seqs[b] += new[b]
+                if on_iteration is not None and on_iteration(new) is True:
+                    break
+            self.iters = it + 1
+            return seqs
+
+    m._engine = eng2 = StepEng(cfg, [])
+    crit3 = StopOn(41)                                             # stream 1 emits 41 in step 4; stream 0 (0, 20, 40) never stops
+    out = m.generate(feats, language="en", stopping_criteria=[crit3])
+    assert eng2.iters == 6                                         # the idle steps of stream 0 did not end the run
+    assert out[0, P:].tolist()[:3] == [0, 20, 40] and out[1, P:].tolist()[:5] == [1, 11, 21, 31, 41]
+    assert crit3.asked == 3 + 5                                    # asked once per step in which the stream emitted something
+
 
 def test_generate_output_object_mirrors_the_reference_model_output():
     from whisper_medusa.api import GenerateEncoderDecoderOutput
