@@ -43,6 +43,26 @@ def test_executed_bytes_price_what_the_carry_really_runs():
     assert p["w_vanilla"] == p["w_verify"]                       # Linear: the verify pass and a vanilla step both run one head
 
 
+def test_merged_step_schedule_is_priced_per_step():
+    """Several streams on the merged-step schedule (wm_stats.schedule_steps > 0): every step is ONE pass — the weights once, each stream's
+    K/V once — and bench.py prices an iteration as steps-per-iteration of those.  With a share p0 of iterations that accept nothing, an
+    iteration is 1 + p0 steps: the K/V reads equal the lock-step schedule's (whose base pass skips the attention of carried streams), the
+    weights stream 1 + p0 times instead of twice — the schedule's gain is the base pass's launch chain, not bytes."""
+    b = _bench()
+    lin = MedusaConfig.large_v2("base_head", K=10)
+    p = b.decode_iter_bytes(lin, 32, 64, parts=True)
+    kv = p["cross_kv_per_stream_pass"] + p["self_kv_per_stream_pass"]
+    one_step = b.executed_bytes(lin, 32, 64, False, 0.0, 0.0)
+    assert abs(one_step - (p["w_verify"] + 32 * kv)) < 64.0
+    lock_step = b.executed_bytes(lin, 32, 64, False, 1.0, 0.45)
+    assert abs((lock_step - 1.45 * one_step) - (p["w_base"] - 0.45 * p["w_verify"])) < 4096.0
+    import json
+    import os
+    line = json.loads(open(os.path.join(os.path.dirname(__file__), "..", "profiles", "r04_bench_default.json")).read().strip().splitlines()[-1])
+    leg = next(c for c in line["configs"] if c["config"].startswith("configs[1] shape at 32 streams"))
+    assert leg["merged_steps_per_iteration"] and 1.0 < leg["merged_steps_per_iteration"] < 2.0 and leg["parity_checked"] is True
+
+
 def test_prefill_flops_match_the_survey_figure():
     b = _bench()
     lin = MedusaConfig.large_v2("base_head", K=10)
