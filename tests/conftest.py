@@ -18,8 +18,44 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
+# The driver's `pytest tests -m gpu` has a 1200 s limit (GPUTEST_r04.json: killed there after ~83 of 171 tests).  Three rules keep the
+# default GPU set far below it:
+#   * tests whose cost is host-CPU oracle time at large-v2 (the live fp32-pinned tables, the 8-stream 39-node tree) carry the `slow`
+#     marker and run only with WM_SLOW=1 (`WM_SLOW=1 python -m pytest tests -m "gpu and slow"`); their default-set counterparts compare
+#     against ids minted offline (tests/golden/fp32_pinned_runs.npz, oracle/make_fp32_golden.py);
+#   * the cheap kernel-level parity files run first, tests/test_gpu_large.py last: an overrun would cut the least;
+#   * the oracle runs on a bounded number of host threads (WM_ORACLE_THREADS, default 16): its passes are chains of small ops, and on the
+#     GPU box's many cores the default thread pool made them several times slower than on an 8-core container (measured).
+# tests/test_host.py::test_recorded_gpu_suite_duration_fits_the_driver_limit reads the durations the last whole-suite run recorded.
+GPU_FILE_ORDER = ["test_gpu_parity.py", "test_gpu_tree.py", "test_gpu_features.py", "test_bench_dist.py", "test_gpu_large.py"]
+_DURATIONS = {}
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: minutes of host-CPU oracle time; runs only with WM_SLOW=1")
+    try:
+        import torch
+        n = int(os.environ.get("WM_ORACLE_THREADS", "16"))
+        if n > 0:
+            torch.set_num_threads(min(n, os.cpu_count() or n))
+    except Exception:  # noqa: BLE001
+        pass
+
+
+def pytest_collection_modifyitems(config, items):
+    if os.environ.get("WM_SLOW", "0") in ("", "0"):
+        skip = pytest.mark.skip(reason="slow: set WM_SLOW=1")
+        for it in items:
+            if "slow" in it.keywords:
+                it.add_marker(skip)
+    rank = {f: i for i, f in enumerate(GPU_FILE_ORDER)}
+    items.sort(key=lambda it: rank.get(os.path.basename(str(it.fspath)), -1))      # stable: CPU files first, in their own order
+
+
+def pytest_runtest_logreport(report):
+    if report.when in ("setup", "call", "teardown"):
+        _DURATIONS[report.nodeid] = _DURATIONS.get(report.nodeid, 0.0) + report.duration
 
 
 @pytest.fixture(scope="session")
@@ -38,9 +74,35 @@ def gpu(built_lib):
     return torch.device("cuda", 0)
 
 
+def _write_durations(terminalreporter):
+    """Per-test wall time (setup + call + teardown) of a GPU session -> gpurun_out/gpu_suite_durations.json (+ tests/ when the run was
+    the whole `-m gpu` set): the record the host-side budget test reads."""
+    import json
+    gpu_ids = {k: round(v, 2) for k, v in _DURATIONS.items() if "test_gpu_" in k or "test_bench_dist" in k}
+    if len(gpu_ids) < 20:
+        return
+    passed = len(terminalreporter.stats.get("passed", []))
+    failed = len(terminalreporter.stats.get("failed", [])) + len(terminalreporter.stats.get("error", []))
+    rep = {"total_s": round(sum(_DURATIONS.values()), 1), "tests": len(_DURATIONS), "passed": passed, "failed": failed,
+           "slow_included": os.environ.get("WM_SLOW", "0") not in ("", "0"), "oracle_threads": os.environ.get("WM_ORACLE_THREADS", "16"),
+           "durations": dict(sorted(gpu_ids.items(), key=lambda kv: -kv[1]))}
+    for d in (os.path.join(ROOT, "gpurun_out"),):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "gpu_suite_durations.json"), "w") as f:
+                    json.dump(rep, f, indent=1)
+            except OSError:
+                pass
+    terminalreporter.write_line(f"gpu suite: {rep['tests']} tests, {rep['total_s']} s in tests (slow set {'in' if rep['slow_included'] else 'ex'}cluded)")
+
+
 def pytest_terminal_summary(terminalreporter, exitstatus, config):
     """One line of parity evidence per session + tests/parity_report.json (ties followed must be counted,
     agreement numbers asserted AND visible in the driver's log)."""
+    try:
+        _write_durations(terminalreporter)
+    except Exception:  # noqa: BLE001
+        pass
     try:
         import json
         import helpers

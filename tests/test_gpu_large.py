@@ -19,7 +19,9 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def large(gpu):
     cfg = MedusaConfig.large_v2("base_head", K=10)
-    sd = synth.synth_state_dict(cfg, seed=0, device=str(gpu), logit_std=4.5)      # bench.py's checkpoint: mixed accept lengths
+    # bench.py's checkpoint recipe (mixed accept lengths), drawn from the CPU generator: the SAME weights oracle/make_fp32_golden.py minted
+    # tests/golden/fp32_pinned_runs.npz on (~30 s of host time once per module; the GPU generator's stream is not reproducible offline)
+    sd = synth.synth_state_dict(cfg, seed=0, device="cpu", logit_std=4.5)
     model = WhisperMedusaModel(cfg, sd, device=gpu, max_batch=12)
     wav = np.stack([synth.synth_clip(i) for i in range(2)])
     feats = model.extract_features(wav)
@@ -88,15 +90,15 @@ def test_large_prompt_pass_against_oracle(large):
     d = (z - ref).abs()
     print('large prompt pass: max|d|', float(d.max()), 'mean|d|', float(d.mean()), 'ref max', float(ref.abs().max()))
     # tolerance, stated as what it is (north_star says "logits within 1e-3"; that holds RELATIVE to the logit scale, not in
-    # absolute terms): <= 2e-3 of the scale at the worst element, <= 2e-4 of it on average.  Round 1 measured max 5.5e-3 /
-    # mean 7e-4 absolute at scale 8.2; with bench.py's checkpoint (scale ~27) ~2.7e-2 / ~3e-3.  Cause: the cross K/V cache is
+    # absolute terms): <= 1e-3 of the scale at the worst element, <= 2e-4 of it on average (round 4 measured 6.3e-4 / 8.8e-5 of a
+    # scale of 25: 1.57e-2 / 2.2e-3 absolute, about one fp16 ulp at that magnitude).  Cause: the cross K/V cache is
     # stored in bf16 by contract, and a value whose fp32 sum lands within summation-order noise of a bf16 rounding boundary
     # is stored one bf16 ulp apart by oracle and engine.
     scale = float(ref.abs().max())
     from helpers import record_table
     record_table("large-v2 prompt pass, all 11 heads: engine logits vs bf16-contract oracle", max_abs_diff=round(float(d.max()), 5),
                  mean_abs_diff=round(float(d.mean()), 6), logit_scale=round(scale, 3), max_rel_to_scale=round(float(d.max()) / scale, 6))
-    assert d.max() <= 2e-3 * scale and d.mean() <= 2e-4 * scale, (float(d.max()), float(d.mean()), scale)
+    assert d.max() <= 1e-3 * scale and d.mean() <= 2e-4 * scale, (float(d.max()), float(d.mean()), scale)
     assert (z[:, -1].argmax(-1) == ref[:, -1].argmax(-1)).all()
 
 
@@ -218,59 +220,63 @@ def test_large_end_to_end_audio_to_tokens(large, large_oracle):
     assert large_oracle.decode(enc_e, gp).ids == got
 
 
-_FP32_ENC = {}
+def _print_fp32_table(capsys, name, rows):
+    agree, total = sum(r[1] for r in rows), sum(r[2] for r in rows)
+    with capsys.disabled():
+        print(f"\n{name}:")
+        for i, f, ngen, margin, pc in rows:
+            print(f"  clip {i}: {f:2d} / {ngen} generated ids agree before the first divergence; top-2 logit margin there {margin:.4f}")
+        print(f"  total {agree} / {total} = {agree / max(total, 1):.3f}")
+    return agree, total
 
 
 @pytest.mark.parametrize("mode", [ACCEPT_GREEDY, ACCEPT_TYPICAL])
 def test_large_token_agreement_with_the_pinned_fp32_oracle(large, mode, capsys):
-    """The cross-mode table of tests/test_gpu_parity.py at large-v2: engine (bf16 contract) against the oracle
-    in the mode PINNED to the reference (sim="fp32"), audio -> tokens with nothing shared but checkpoint and waveform: 8 clips,
-    48 new tokens, first-divergence index and the oracle's top-2 margin there.  The fp32 oracle runs its own
-    log-mel and its own fp32 encoder on the host cores (~7 s per clip, computed once per clip for both modes) and its own decode
-    loop (~14 s per clip and mode)."""
-    from oracle.whisper_medusa_oracle import Oracle
-    from helpers import record_table
+    """The cross-mode table at the BASELINE shape: engine (bf16 contract) against the oracle in the mode PINNED to the reference
+    (sim="fp32"), audio -> tokens with nothing shared but checkpoint and waveform: 8 clips x 48 new tokens per mode.  The fp32 side — its own
+    log-mel, its own fp32 encoder, its own decode loop — was minted offline by oracle/make_fp32_golden.py on the same CPU-seeded checkpoint
+    and the same clips (tests/golden/fp32_pinned_runs.npz; the table refuses another checkpoint); this test runs the engine and compares.
+    (Round 4 ran the oracle live here: 708 s of host time on the GPU box, and the driver's run was killed at its 1200 s limit.  The live form
+    is test_large_fp32_table_live, behind the `slow` marker.)"""
+    from helpers import record_table, fp32_golden, fp32_agreement_rows
     cfg, sd, model, _ = large
     eng = model.engine
-    orc32 = Oracle(cfg, _cpu_sd(sd), sim="fp32")
+    g = fp32_golden("large", sd)
+    seed, clip0, N, NEW = (int(x) for x in g["large_meta"])
     n = cfg.n_mel_frames * 160
-    N, NEW = 8, 48
-    wavs = [synth.synth_clip(300 + i, n) for i in range(N)]
+    wavs = [synth.synth_clip(clip0 + i, n) for i in range(N)]
     gp = synth.bench_gen_params(cfg, max_new_tokens=NEW, accept_mode=mode)
     eng.encode(model.extract_features(np.stack(wavs)))
     got = eng.decode(gp, N)
-    P = len(gp.prompt)
-    rows, agree, total = [], 0, 0
-    for i in range(N):
-        if i not in _FP32_ENC:                              # the fp32 encoder pass of a clip serves both acceptance modes
-            from oracle.whisper_medusa_oracle import log_mel
-            _FP32_ENC[i] = orc32.encode(torch.from_numpy(log_mel(wavs[i], cfg.num_mel_bins, n)))
-        ref = orc32.decode(_FP32_ENC[i], gp, trace=True)
-        f = next((j for j, (a, b) in enumerate(zip(got[i], ref.ids)) if a != b), min(len(got[i]), len(ref.ids)))
-        ngen = len(ref.ids) - P
-        agree += f - P; total += ngen
-        margin = float("nan")
-        if f < len(ref.ids):
-            pos = P
-            for t in ref.trace:
-                if pos + len(t["emit"]) > f:
-                    top2 = torch.topk(t["v"][0], 2).values
-                    margin = float(top2[0] - top2[1])
-                    break
-                pos += len(t["emit"])
-        rows.append((i, f - P, ngen, margin))
+    rows = fp32_agreement_rows(g, "large", mode, got)
     name = f"fp32-pinned end-to-end large-v2 {'typical' if mode == ACCEPT_TYPICAL else 'exact-match'}"
-    with capsys.disabled():
-        print(f"\n{name}:")
-        for i, f, ngen, margin in rows:
-            print(f"  clip {i}: {f:2d} / {ngen} generated ids agree before the first divergence; top-2 logit margin there {margin:.4f}")
-        print(f"  total {agree} / {total} = {agree / max(total, 1):.3f}")
-    record_table(name, agree=agree, total=total, frac=round(agree / max(total, 1), 3),
+    agree, total = _print_fp32_table(capsys, name, rows)
+    record_table(name, agree=agree, total=total, frac=round(agree / max(total, 1), 3), oracle="offline (tests/golden/fp32_pinned_runs.npz)",
                  first_divergence=[r[1] for r in rows], top2_margin=[None if r[3] != r[3] else round(r[3], 4) for r in rows])
-    assert all(f >= 1 for _, f, _, _ in rows)                # never on the first token
-    # measured on MI355X: round 3 (4 clips x 16 tokens) 86 / 86 (exact-match) and 95 / 95 (typical); round 4 at 8 clips x 48 tokens see
-    # tests/parity_report.json.  Floor: a divergence on a chaotic random-weight run loses the rest of that clip, so the floor is per table
+    assert all(r[1] >= 1 for r in rows)                      # never on the first token
+    # measured on MI355X: round 3 (4 clips x 16 tokens) 86 / 86 and 95 / 95; round 4 (8 clips x 48 tokens, GPU-seeded checkpoint, live oracle)
+    # 387 / 387 and 425 / 425.  Floor: a divergence on a chaotic random-weight run loses the rest of that clip, so the floor is per table
     assert agree >= 0.80 * total, (agree, total)
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("mode", [ACCEPT_GREEDY, ACCEPT_TYPICAL])
+def test_large_fp32_table_live(large, mode, capsys):
+    """The same table with the fp32 oracle run LIVE on the host cores of the GPU box (minutes: WM_SLOW=1), and the offline table checked
+    against it id for id — the golden file cannot drift from the oracle unnoticed."""
+    from oracle.whisper_medusa_oracle import Oracle, log_mel
+    from helpers import fp32_golden
+    cfg, sd, model, _ = large
+    g = fp32_golden("large", sd)
+    seed, clip0, N, NEW = (int(x) for x in g["large_meta"])
+    orc32 = Oracle(cfg, _cpu_sd(sd), sim="fp32")
+    n = cfg.n_mel_frames * 160
+    gp = synth.bench_gen_params(cfg, max_new_tokens=NEW, accept_mode=mode)
+    m = "typical" if mode == ACCEPT_TYPICAL else "greedy"
+    for i in range(N):
+        wav = synth.synth_clip(clip0 + i, n)
+        ref = orc32.decode(orc32.encode(torch.from_numpy(log_mel(wav, cfg.num_mel_bins, n))), gp)
+        assert ref.ids == [int(t) for t in g[f"large_{m}_ids"][i][: int(g[f"large_{m}_len"][i])]], i
 
 
 @pytest.fixture(scope="module")
@@ -307,12 +313,12 @@ def test_large_block_decode_loop_matches_the_oracle(large_block):
     prompt = synth.default_prompt(cfg)
     z = eng.forward_logits([prompt], 0, False)[:, 0]
     r = orc.decoder_pass(orc.new_state(enc[4]), prompt, 0, disable_medusa=False)
-    # logit tolerance, stated as what it is: with the checkpoint of bench.py (logit scale ~27) the worst element differs by
-    # ~1e-3 of the scale (2.7e-2 absolute), the mean by ~1e-4 of it — the bf16 K/V-cache and encoder-output rounding points
+    # logit tolerance, stated as what it is: with the checkpoint of bench.py (logit scale ~25) the worst element differs by
+    # < 1e-3 of the scale, the mean by ~1e-4 of it — the bf16 K/V-cache and encoder-output rounding points
     # are shared, but fp32 sums are ordered differently, so single values near a bf16 rounding boundary land on the other side
     scale = float(r.abs().max())
     print("large block prompt pass: max|d|", float((z - r).abs().max()), "mean|d|", float((z - r).abs().mean()), "scale", scale)
-    assert (z - r).abs().max() <= 2e-3 * scale and (z - r).abs().mean() <= 2e-4 * scale
+    assert (z - r).abs().max() <= 1e-3 * scale and (z - r).abs().mean() <= 2e-4 * scale
 
 
 def test_large_block_thirty_two_streams_match_the_oracle(large_block):
@@ -336,7 +342,9 @@ def test_large_block_thirty_two_streams_match_the_oracle(large_block):
         print(f"large block B=32 stream {s_}: accept lengths {accepts}")
 
 
-def test_large_candidate_tree_of_39_nodes_matches_the_oracle(gpu):
+@pytest.mark.parametrize("runs", [pytest.param(((1, 0),), id="one-stream"),
+                                  pytest.param(((3, 1), (8, 5)), id="three-and-eight-streams", marks=pytest.mark.slow)])
+def test_large_candidate_tree_of_39_nodes_matches_the_oracle(gpu, runs):
     """The shipped shape with a real candidate tree: large-v2, K = 10, medusa_choices = [1, 2, 2, 1 x 8] — top-2 on
     the first two heads, 39 nodes in three 16-row query tiles, 4 paths.  One stream, stream 1 of a 3-stream batch and stream 5 of an 8-stream batch (312 verify rows) against
     oracle.decode_tree (pinned to the reference's buffers / candidates / posterior by tests/test_tree_golden.py) on the engine's
@@ -353,7 +361,7 @@ def test_large_candidate_tree_of_39_nodes_matches_the_oracle(gpu):
     wav = np.stack([synth.synth_clip(500 + i, n) for i in range(8)])
     feats = model.extract_features(wav)
     gp = synth.bench_gen_params(cfg, max_new_tokens=24, accept_mode=ACCEPT_TYPICAL)
-    for B, pick in ((1, 0), (3, 1), (8, 5)):
+    for B, pick in runs:
         eng.encode(feats[:B].contiguous())
         enc = eng.encoder_output(B)
         got = eng.decode(gp, B)[pick]

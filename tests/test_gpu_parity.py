@@ -532,53 +532,54 @@ def test_token_agreement_with_the_pinned_fp32_oracle_end_to_end(gpu, mode, capsy
     """Cross-mode evidence: audio -> tokens on the engine (bf16 parameters and KV cache, bf16 encoder
     operands, hi/lo decoder operands: DESIGN.md §2) against the PINNED oracle mode — sim="fp32", the one reproduced from the
     reference's own code in tests/test_oracle_golden.py — running its OWN log-mel and encoder, on 16 clips of tiny.en shape.
-    Nothing is shared between the two sides but the checkpoint and the waveform.  Reports, per clip, how many generated ids
-    agree before the first divergence and the oracle's decision margins at that point; asserts floors on the agreement.
+    Nothing is shared between the two sides but the checkpoint and the waveform.  The oracle's side was minted offline
+    (oracle/make_fp32_golden.py -> tests/golden/fp32_pinned_runs.npz, same CPU-seeded checkpoint, same clips; the live form is
+    test_tiny_fp32_table_live behind the `slow` marker).  Reports, per clip, how many generated ids agree before the first
+    divergence and the oracle's decision margins at that point; asserts floors on the agreement.
     (The bf16-contract oracle fed with the engine's encoder output agrees bit-exactly: test_decode_tokens_bit_exact.)"""
+    from helpers import record_table, fp32_golden, fp32_agreement_rows
     cfg = MedusaConfig.tiny_en(K=4)
     sd = synth.synth_state_dict(cfg, seed=0)
-    N = 16
+    g = fp32_golden("tiny", sd)
+    seed, clip0, N, NEW = (int(x) for x in g["tiny_meta"])
     model = WhisperMedusaModel(cfg, sd, device=gpu, max_batch=N)
-    orc32 = Oracle(cfg, sd, sim="fp32")
     n = cfg.n_mel_frames * 160
-    wavs = [synth.synth_clip(200 + i, n) for i in range(N)]
-    gp = golden_gen_params(cfg, mode, 32)
-    feats = model.extract_features(wavs)
-    model.engine.encode(feats)
+    wavs = [synth.synth_clip(clip0 + i, n) for i in range(N)]
+    gp = golden_gen_params(cfg, mode, NEW)
+    model.engine.encode(model.extract_features(wavs))
     got = model.engine.decode(gp, N)
-    P = len(gp.prompt)
-    rows, agree, total = [], 0, 0
-    for i in range(N):
-        ref = orc32.transcribe(wavs[i], gp, trace=True)
-        f = _first_div(got[i], ref.ids)
-        ngen = len(ref.ids) - P
-        agree += f - P; total += ngen
-        margin = ""
-        if f < len(ref.ids):
-            # the oracle iteration that emitted the first differing id: its closest accept/reject call and its top-2 margin
-            pos, it = P, None
-            for t in ref.trace:
-                if pos + len(t["emit"]) > f:
-                    it = t
-                    break
-                pos += len(t["emit"])
-            if it is not None:
-                top2 = torch.topk(it["v"][0], 2).values
-                m_acc = float((it["p_c"] - it["thr"]).abs().min()) if "p_c" in it else float("nan")
-                margin = f"top-2 logit margin {float(top2[0] - top2[1]):.4f}, min |p_c - thr| {m_acc:.5f}"
-        rows.append((i, f - P, ngen, margin))
+    rows = fp32_agreement_rows(g, "tiny", mode, got)
+    agree, total = sum(r[1] for r in rows), sum(r[2] for r in rows)
     with capsys.disabled():
         print(f"\nengine (bf16 contract) vs pinned fp32 oracle, end to end, tiny.en K=4, mode {'typical' if mode == ACCEPT_TYPICAL else 'exact-match'}:")
-        for i, f, ngen, margin in rows:
+        for i, f, ngen, mg, pc in rows:
+            margin = "" if f == ngen else f"top-2 logit margin {mg:.4f}, min |p_c - thr| {pc:.5f}"
             print(f"  clip {i:2d}: {f:2d} / {ngen} generated ids agree before the first divergence  {margin}")
         print(f"  total {agree} / {total} = {agree / max(total, 1):.3f}")
-    full = sum(1 for _, f, ngen, _ in rows if f == ngen)
+    full = sum(1 for r in rows if r[1] == r[2])
     # floors (measured values are printed above and recorded in DESIGN.md §2): the two sides never disagree on the first token,
     # and a clear majority of the generated ids is reproduced although no rounding point is shared
-    from helpers import record_table
     record_table(f"fp32-pinned end-to-end tiny.en {'typical' if mode == ACCEPT_TYPICAL else 'exact-match'}",
-                 agree=agree, total=total, frac=round(agree / max(total, 1), 3), clips_fully_equal=full, clips=N)
-    assert all(f >= 1 for _, f, _, _ in rows)
+                 agree=agree, total=total, frac=round(agree / max(total, 1), 3), clips_fully_equal=full, clips=N,
+                 oracle="offline (tests/golden/fp32_pinned_runs.npz)")
+    assert all(r[1] >= 1 for r in rows)
     # measured in round 2 on MI355X: 491 / 512 (exact-match) and 496 / 516 (typical) = 0.96; floor = measured - 5 %
     assert agree >= 0.91 * total, (agree, total, full)
     model.engine.close()
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("mode", [ACCEPT_GREEDY, ACCEPT_TYPICAL])
+def test_tiny_fp32_table_live(mode):
+    """The offline table against the fp32 oracle run live (WM_SLOW=1): id for id."""
+    from helpers import fp32_golden
+    cfg = MedusaConfig.tiny_en(K=4)
+    sd = synth.synth_state_dict(cfg, seed=0)
+    g = fp32_golden("tiny", sd)
+    seed, clip0, N, NEW = (int(x) for x in g["tiny_meta"])
+    orc32 = Oracle(cfg, sd, sim="fp32")
+    gp = golden_gen_params(cfg, mode, NEW)
+    m = "typical" if mode == ACCEPT_TYPICAL else "greedy"
+    for i in range(N):
+        ref = orc32.transcribe(synth.synth_clip(clip0 + i, cfg.n_mel_frames * 160), gp)
+        assert ref.ids == [int(t) for t in g[f"tiny_{m}_ids"][i][: int(g[f"tiny_{m}_len"][i])]], i

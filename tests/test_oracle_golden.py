@@ -203,3 +203,27 @@ def test_long_prompt_runs_match_reference(tag, heads, seed):
         gp.max_length = min(len(gp.prompt) + 24, cfg.max_target_positions)
         r = orc.decode(enc, gp)
         assert r.ids == runs[f"{tag}_{plen}_ids"].tolist() and r.accept_lengths == runs[f"{tag}_{plen}_accepts"].tolist(), (tag, plen)
+
+
+def test_offline_fp32_tables_match_the_live_oracle():
+    """tests/golden/fp32_pinned_runs.npz (oracle/make_fp32_golden.py: the pinned fp32 mode run audio -> tokens offline, compared with the
+    engine on the GPU box) cannot drift from the oracle: three tiny.en clips re-run live here in both acceptance modes, id for id, and the
+    large-v2 table's bookkeeping (8 clips x 48 new tokens, emitted ids per iteration sum to the ids stored) checked."""
+    from helpers import fp32_golden
+    cfg = MedusaConfig.tiny_en(K=4)
+    sd = synth.synth_state_dict(cfg, seed=0)
+    g = fp32_golden("tiny", sd)
+    seed, clip0, N, NEW = (int(x) for x in g["tiny_meta"])
+    orc = Oracle(cfg, sd, sim="fp32")
+    for mode, m in ((ACCEPT_GREEDY, "greedy"), (ACCEPT_TYPICAL, "typical")):
+        gp = golden_gen_params(cfg, mode, NEW)
+        for i in (0, 7, 15):
+            ref = orc.transcribe(synth.synth_clip(clip0 + i, cfg.n_mel_frames * 160), gp)
+            assert ref.ids == [int(t) for t in g[f"tiny_{m}_ids"][i][: int(g[f"tiny_{m}_len"][i])]], (m, i)
+    assert [int(x) for x in g["large_meta"]] == [0, 300, 8, 48]
+    for m in ("greedy", "typical"):
+        P = int(g[f"large_{m}_prompt_len"])
+        for i in range(8):
+            n = int(g[f"large_{m}_len"][i])
+            assert n - P >= 48 - 10 and int(g[f"large_{m}_emit"][i].sum()) == n - P
+            assert (g[f"large_{m}_ids"][i][:n] >= 0).all() and (g[f"large_{m}_ids"][i][n:] == -1).all()
