@@ -9,7 +9,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-CSRC = os.path.join(HERE, "csrc")
+CSRC = os.environ.get("WM_CSRC", os.path.join(HERE, "csrc"))      # WM_CSRC: a patched copy of csrc/ (A/B variants of tests/microbench)
 OUT_DIR = os.path.join(HERE, "whisper_medusa")
 LIB = os.path.join(OUT_DIR, "libwm.so")
 SOURCES = ["wm_engine.hip", "wm_decoder.hip", "wm_encoder.hip"]

@@ -1088,9 +1088,6 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
     // 3. out_proj + residual
     if (pf) g_pf_job = pf_for_gemm(w.cq_w, f8, d / 16, K32, true);
     TL_SET(slot * 16 + 3 + 8192 * Mper);
-#ifdef WM_LN_TAIL
-    if (R > 32 && !fuse_cq) g_ln_tail = LnTail{h, w.ln2_w, w.ln2_b, ctx->xbuf, xpl, d, K32, R, ctx->ln_ticket};      // LN2 in the tail of this GEMM
-#endif
     WM_HIP(launch_skinny_rows(st, WRef{w.out_w, w.out_s}, d / 16, K32, R, ctx->xbuf, xpl, EpResidual{h, w.out_b, d, R}));
     // 4. LN2 + cross-attention q (its own launch unless fused into 5.)
     if (!fuse_cq) {
@@ -1145,9 +1142,6 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
     // 6. out_proj + residual
     if (pf) g_pf_job = pf_for_gemm(w.fc1_w, f8, ctx->ffn / 16, K32, true);
     TL_SET(slot * 16 + 6 + 8192 * Mper);
-#ifdef WM_LN_TAIL
-    if (R > 32) g_ln_tail = LnTail{h, w.ln3_w, w.ln3_b, ctx->xbuf, xpl, d, K32, R, ctx->ln_ticket};                   // LN3 in the tail of this GEMM
-#endif
     WM_HIP(launch_skinny_rows(st, WRef{w.cout_w, w.cout_s}, d / 16, K32, R, ctx->xbuf, xpl, EpResidual{h, w.cout_b, d, R}));
     // 7. LN3 + fc1 + GELU
     if (pf) g_pf_job = pf_for_gemm(w.fc2_w, f8, d / 16, F32, false);

@@ -32,7 +32,7 @@ extern "C" void wm_destroy(wm_ctx* ctx)
     if (ctx->hostflags) hipHostFree(ctx->hostflags);
     void* bufs[] = {ctx->feats_own, ctx->clipmax, ctx->A1, ctx->a1, ctx->A2, ctx->eh, ctx->exn, ctx->eq, ctx->ek, ctx->evt, ctx->eff,
                     ctx->enc_out, ctx->kx, ctx->vx, ctx->kc, ctx->vc, ctx->h, ctx->hblk, ctx->hf, ctx->qbuf, ctx->xbuf, ctx->fbuf,
-                    ctx->ybuf, ctx->cml, ctx->co, ctx->ticket, ctx->ln_ticket, ctx->logits, ctx->amax, ctx->pc, ctx->part1, ctx->part2, ctx->ids, ctx->L, ctx->kvlen,
+                    ctx->ybuf, ctx->cml, ctx->co, ctx->ticket, ctx->logits, ctx->amax, ctx->pc, ctx->part1, ctx->part2, ctx->ids, ctx->L, ctx->kvlen,
                     ctx->finished, ctx->cand, ctx->niter, ctx->hist, ctx->supmask, ctx->exppen, ctx->tap_tok, ctx->done,
                     ctx->hf_keep, ctx->hb_keep, ctx->carry, ctx->rowinfo, ctx->sinfo, ctx->steprows, ctx->rs_table, ctx->tree, ctx->sel_src, ctx->sel_n, ctx->sel_base, ctx->exn8, ctx->exs};
     for (void* b : bufs) if (b) hipFree(b);
@@ -201,7 +201,6 @@ extern "C" int wm_create(const wm_config* cfg, const wm_weights* w, int device, 
     CREATE_HIP(dev_alloc(&ctx->cml, RW * H * ctx->NS * 2, st));
     CREATE_HIP(dev_alloc(&ctx->co, RW * H * ctx->NS * 64, st));
     CREATE_HIP(dev_alloc(&ctx->ticket, B * 32 * (WM_TREE_MAX_NODES / 16), st));
-    CREATE_HIP(dev_alloc(&ctx->ln_ticket, 256, st));
     CREATE_HIP(dev_alloc(&ctx->logits, RW * ctx->Vpad, st));
     CREATE_HIP(dev_alloc(&ctx->amax, B * WM_TREE_MAX_NODES, st));
     CREATE_HIP(dev_alloc(&ctx->pc, B * WM_TREE_MAX_NODES, st));

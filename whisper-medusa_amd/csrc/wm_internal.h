@@ -120,7 +120,6 @@ struct wm_ctx {
     bf16_t *xbuf = nullptr, *fbuf = nullptr, *ybuf = nullptr;
     float *cml = nullptr, *co = nullptr;   // cross-attention partials
     int* ticket = nullptr;                 // [16 streams][H] arrival tickets of the cross-attention key splits
-    int* ln_ticket = nullptr;              // [256] arrival tickets per token-tile group (LayerNorm-in-the-tail experiment, -DWM_LN_TAIL)
     float* logits = nullptr;               // [32][Vpad]
     int* amax = nullptr; float *pc = nullptr;                   // select outputs, [maxB*16]
     float *part1 = nullptr, *part2 = nullptr;                   // select slice partials [16][SEL_SP][4] / [maxB*16][SEL_SP]

@@ -68,25 +68,6 @@ struct TlProbe {
 #define TL_SET(t) ((void)0)
 #endif
 
-// ---- experiment (build.py --variant lntail -DWM_LN_TAIL): LayerNorm in the tail of the producing GEMM --------------------------------
-// profiles/r04_timeline_b32.md: a merged step spends 28 % of a decoder layer in the three k_ln_tiles launches and their boundaries.
-// With a tail job riding on the residual GEMM (out-proj -> LN2, cross-out -> LN3), the LAST block to finish a token-tile group — a ticket
-// per group, release / acquire fences at agent scope around it, no block ever waits — runs the k_ln_tiles code for the group's rows and
-// writes the packed hi / lo operand; the consumer's LayerNorm launch is skipped.  Same LdNormT arithmetic on the same residual rows:
-// bit-identical.  Off in the product build: not yet measured.
-struct LnTail {
-    const float* h; const float* gamma; const float* beta; bf16_t* xg; size_t plane; int d, K32, M; int* ticket;
-};
-#ifdef WM_LN_TAIL
-static thread_local LnTail g_ln_tail = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr};      // host: rides on the next rows-GEMM launch
-static thread_local const float* g_ln_tail_done = nullptr;                 // host: gamma of the LayerNorm the last launch's tail produced
-#define LNT_ARG , LnTail tail
-#define LNT_PASS(t) , t
-#else
-#define LNT_ARG
-#define LNT_PASS(t)
-#endif
-
 // ---- weight fragments: raw load now, widen later (an fp8 fragment must not be converted before the batch is in flight) ----
 template <bool W8> struct WRaw { typedef u32x4_t type; };
 template <> struct WRaw<true> { typedef u32x2_t type; };
@@ -470,58 +451,24 @@ k_ln_tiles(Ld ld, int ksplit, bf16_t* __restrict__ xg, size_t plane, const int* 
 // traffic of the operand re-reads by RT resp. TT); blockIdx.y walks the token-tile groups, so the chip is filled
 // by tokens as well as by features and the weights are re-read from L2 / Infinity Cache, not HBM.  Per output the
 // accumulation order is the 16-row kernel's (k ascending, hi then lo; K-slices summed in order): bit-identical.
-// Build-time experiment knobs (tests/microbench, `build.py --variant`): WM_ROWS_MINW = minimum waves per SIMD the register allocation of
-// k_rows_gemm must allow (5 -> <= 96 VGPRs: two 10-wave blocks, or four 5-wave blocks, per CU), WM_ROWS_G = k-tiles per load group.
-#ifdef WM_ROWS_MINW
-#define WM_ROWS_BOUNDS __launch_bounds__(640, WM_ROWS_MINW)
-#else
-#define WM_ROWS_BOUNDS __launch_bounds__(640)
-#endif
-#ifndef WM_ROWS_G
-#define WM_ROWS_G 4
-#endif
+// (Round 4's measured-negative variants of this kernel — four token tiles per wave, an explicit two-deep request pipeline, two feature
+// groups per block sharing token fragments through the L1, a 96-register budget — are kept as tests/microbench/r04_rows_variants.patch;
+// round 5's LDS-shared token tiles with register-direct weights (k_rows_lds) and the LayerNorm in the producing GEMM's tail with a
+// write-through hand-off as tests/microbench/r05_rows_lds_ln_tail.patch: measured, profiles/r05_rows_lds.md.)
 template <int NKR, int RT, int TT, bool W8, class Ep>
-__global__ void
-#if defined(WM_ROWS_TT4)
-__launch_bounds__(TT >= 4 ? 320 : 640)          // the four-token-tile experiment runs 5 K-slice waves (K = 1280): 256 registers per lane
-#elif defined(WM_ROWS_PIPE)
-__launch_bounds__(NKR <= 8 ? 384 : 640)         // experiment: <= 6 K-slice waves of 8 k-tiles (checked at launch): 256 registers per lane
-#else
-WM_ROWS_BOUNDS
-#endif
+__global__ void __launch_bounds__(640)
 k_rows_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int N16, int K32, int ksplit, const int* __restrict__ done,
-            const bf16_t* __restrict__ X, size_t plane, int MT, Ep ep, const int* __restrict__ ntiles LNT_ARG TL_ARG)
+            const bf16_t* __restrict__ X, size_t plane, int MT, Ep ep, const int* __restrict__ ntiles TL_ARG)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     TL_BEGIN
-#if defined(WM_ROWS_PIPE)
-    // Experiment (build.py --variant pipe -DWM_ROWS_PIPE), bf16 weights: the wave's K-slice as an explicit two-deep pipeline of two-k-tile
-    // groups.  The ISA of the plain form showed the scheduler trickling 2-3 fragment loads between MFMAs with vmcnt(1..2) waits (a few KB
-    // in flight per wave) behind five dependent scalar round trips (done / ntiles) in front of the first load.  Here: both groups'
-    // requests go out first, the two flags are read while they fly, then MFMA(group g) | requests(group g + 2) alternate, pinned with
-    // scheduling barriers; the waits are the compiler's counted ones.  Same arithmetic, same order.
-    constexpr bool kPipe = !W8 && (NKR <= 8 || RT <= 2);          // (16 k-tiles x 4 row tiles would spill under the 10-wave launch bound)
-#else
-    constexpr bool kPipe = false;
-#endif
     // (checked first: moving the flag behind the first group of loads — a mid-loop exit — cost the 352-row launches ~3 us each, the
     //  compiler no longer overlapped the load groups across it: tests/microbench/r03_call4.sh)
-    if constexpr (!kPipe) {
-        if (done && *done) return;
-        if (ntiles && (int)blockIdx.y * TT >= *ntiles) return;          // merged-step schedule: no rows in this token-tile group in this step
-    }
+    if (done && *done) return;
+    if (ntiles && (int)blockIdx.y * TT >= *ntiles) return;          // merged-step schedule: no rows in this token-tile group in this step
     const int lane = threadIdx.x & 63;
-#if defined(WM_ROWS_SHARE)
-    // Experiment (build.py --variant share -DWM_ROWS_SHARE): a block carries TWO feature groups (waves [0, ksplit) and [ksplit, 2 ksplit)) that
-    // read the same token fragments of the same K-slices at about the same time: the second read should hit the CU's L1 instead of the L2.
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int fg = wave >= ksplit ? 1 : 0, nfg = (int)blockDim.x > 64 * ksplit ? 2 : 1;
-    const int ks = wave - fg * ksplit;
-    const int rt0 = ((int)blockIdx.x * nfg + fg) * RT, mt0 = blockIdx.y * TT;
-#else
     const int ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rt0 = blockIdx.x * RT, mt0 = blockIdx.y * TT;
-#endif
     const int kt0 = ks * NKR;
     size_t wp[RT]; const bf16_t* xp[TT];
 #pragma unroll
@@ -533,40 +480,7 @@ k_rows_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int 
     for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int j = 0; j < TT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    if constexpr (kPipe) {
-        constexpr int G = 2, NG = NKR / G;
-        static_assert(NKR % G == 0, "K-slice is a multiple of two k-tiles");
-        bf16x8_t a[2][RT][G], xh[2][TT][G], xl[2][TT][G];
-#define WM_ROWS_LOAD(B, KG)                                                                                                   \
-        _Pragma("unroll") for (int u = 0; u < G; ++u) {                                                                      \
-            _Pragma("unroll") for (int j = 0; j < TT; ++j) {                                                                 \
-                xh[B][j][u] = ld_frag(xp[j] + (size_t)((KG) + u) * 512); xl[B][j][u] = ld_frag(xp[j] + plane + (size_t)((KG) + u) * 512); \
-            }                                                                                                                \
-            _Pragma("unroll") for (int i = 0; i < RT; ++i) a[B][i][u] = ld_wfrag<false, false>(W, wp[i] + (size_t)((KG) + u) * 512); \
-        }
-        WM_ROWS_LOAD(0, 0)
-        if constexpr (NG > 1) { WM_ROWS_LOAD(1, G) }
-        __builtin_amdgcn_sched_barrier(0);
-        if (done && *done) return;
-        if (ntiles && (int)blockIdx.y * TT >= *ntiles) return;
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const int b = g & 1;
-#pragma unroll
-            for (int u = 0; u < G; ++u)
-#pragma unroll
-                for (int i = 0; i < RT; ++i)
-#pragma unroll
-                    for (int j = 0; j < TT; ++j) { acc[i][j] = mfma16(a[b][i][u], xh[b][j][u], acc[i][j]); acc[i][j] = mfma16(a[b][i][u], xl[b][j][u], acc[i][j]); }
-            __builtin_amdgcn_sched_barrier(0);
-            if (g + 2 < NG) {
-                if (b == 0) { WM_ROWS_LOAD(0, (g + 2) * G) } else { WM_ROWS_LOAD(1, (g + 2) * G) }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#undef WM_ROWS_LOAD
-    } else {
-    constexpr int G = TT >= 4 ? 2 : WM_ROWS_G;          // four token tiles: 24 fragments per two k-tiles next to 16 accumulator tiles
+    constexpr int G = 4;          // k-tiles per load group
 #pragma unroll
     for (int kg = 0; kg < NKR; kg += G) {
         bf16x8_t a[RT][G], xh[TT][G], xl[TT][G];
@@ -585,16 +499,10 @@ k_rows_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int 
 #pragma unroll
                 for (int j = 0; j < TT; ++j) { acc[i][j] = mfma16(a[i][u], xh[j][u], acc[i][j]); acc[i][j] = mfma16(a[i][u], xl[j][u], acc[i][j]); }
     }
-    }
     TL_PREP          // timeline build: the wave's MFMAs have issued
     if (ksplit > 1) {
-#if defined(WM_ROWS_SHARE)
-        float4* red = reinterpret_cast<float4*>(smem) + (size_t)fg * RT * TT * ksplit * 64;
-        const int e0 = (int)threadIdx.x - fg * ksplit * 64, estep = ksplit * 64;
-#else
         float4* red = reinterpret_cast<float4*>(smem);
         const int e0 = threadIdx.x, estep = blockDim.x;
-#endif
 #pragma unroll
         for (int i = 0; i < RT; ++i)
 #pragma unroll
@@ -635,47 +543,6 @@ k_rows_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int 
                     ep.fin((mt0 + j) * 16 + (lane & 15), (rt0 + i) * 16 + 4 * (lane >> 4), acc[i][j], pre[i][j]);
                 }
     }
-#ifdef WM_LN_TAIL
-    if (tail.xg != nullptr && ksplit > 1) {
-        __shared__ int s_tail_last;
-        __threadfence();                                   // release: this block's residual rows are visible at agent scope
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const int t = __hip_atomic_fetch_add(tail.ticket + blockIdx.y, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = (t == (int)gridDim.x - 1);
-            if (last) __hip_atomic_store(tail.ticket + blockIdx.y, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // re-arm for the next launch / replay
-            s_tail_last = last;
-        }
-        __syncthreads();
-        if (s_tail_last) {
-            __threadfence();                               // acquire: the other blocks' rows
-            constexpr int NKL = 8;
-            const LdNorm ln{tail.h, tail.gamma, tail.beta, tail.d, tail.K32, tail.M, 1, 0};
-            const int ksl = tail.K32 / NKL;                // K-slices of the LayerNorm = waves per tile (launch: blockDim == 64 ksl or 128 ksl)
-            const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-            const bool two = (int)blockDim.x >= 128 * ksl; // two tile groups side by side (TT == 2), else one after the other
-            const int grp = two ? (wv >= ksl ? 1 : 0) : 0, ksn = wv - grp * ksl;
-            typename LdNorm::template Regs<NKL> xr;
-#pragma unroll
-            for (int jj = 0; jj < TT; ++jj) {
-                if (two && jj > 0) break;
-                const int j = two ? grp : jj, tile = min(mt0 + j, MT - 1);
-                if (jj == 0) { ln.template issue<NKL>(xr, smem, ksn * NKL, lane, tile * 16, true, true); ln.template stage<NKL>(xr, smem); }
-                else ln.template issue<NKL>(xr, smem, ksn * NKL, lane, tile * 16, true, false);
-                ln.template stats<NKL>(xr, smem, ksn, ksl, true, lane, j & 1);
-                bf16_t* dst = tail.xg + (size_t)tile * tail.K32 * 512;
-#pragma unroll
-                for (int u = 0; u < NKL; ++u) {
-                    bf16x8_t bh, bl;
-                    ln.template frag<NKL>(xr, smem, u, ksn * NKL + u, lane, bh, bl);
-                    const size_t o = ((size_t)(ksn * NKL + u) * 64 + lane) * 8;
-                    *reinterpret_cast<uint4*>(dst + o) = __builtin_bit_cast(uint4, bh);
-                    *reinterpret_cast<uint4*>(dst + tail.plane + o) = __builtin_bit_cast(uint4, bl);
-                }
-            }
-        }
-    }
-#endif
     TL_END
 }
 
@@ -1137,41 +1004,14 @@ static inline hipError_t launch_skinny(hipStream_t st, WRef W, int N16, int K32,
 template <int NKR, int RT, bool W8, class Ep, int TT = 2>
 static inline hipError_t launch_rows_gemm_w(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p,
                                             const bf16_t* X, size_t plane, int MT, const Ep& ep) {
-#if defined(WM_ROWS_SHARE)
-    const int nfg = (p.ksplit > 1 && p.ksplit * 2 <= 10 && N16 >= 2 * RT) ? 2 : 1;
-#else
-    const int nfg = 1;
-#endif
-    const dim3 grid((N16 + RT * nfg - 1) / (RT * nfg), (MT + TT - 1) / TT);
-    const size_t lds = p.ksplit > 1 ? (size_t)RT * TT * p.ksplit * 1024 * nfg : 0;
+    const dim3 grid((N16 + RT - 1) / RT, (MT + TT - 1) / TT);
+    const size_t lds = p.ksplit > 1 ? (size_t)RT * TT * p.ksplit * 1024 : 0;
     auto kern = k_rows_gemm<NKR, RT, TT, W8, Ep>;
-#if defined(WM_ROWS_PIPE)
-    if (NKR <= 8 && p.ksplit > 6) return hipErrorInvalidConfiguration;          // launch bounds of the experiment
-#endif
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-#ifdef WM_LN_TAIL
-    LnTail tail = g_ln_tail;
-    g_ln_tail = LnTail{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr};
-    g_ln_tail_done = nullptr;
-    {
-        const int ksl = tail.xg ? tail.K32 / 8 : 0;
-        const bool ok = tail.xg && TT == 2 && nfg == 1 && p.ksplit > 1 && tail.K32 % 8 == 0 && tail.K32 * 32 == tail.d &&
-                        (p.ksplit == ksl || p.ksplit == 2 * ksl) && tail.K32 * 16 <= 2 * 64 * p.ksplit;      // gamma | beta: two float4 per thread
-        if (!ok) tail.xg = nullptr;
-    }
-    size_t lds_t = lds;
-    if (tail.xg) { lds_t = std::max(lds, (size_t)(2 * tail.d * sizeof(float) + 2048)); g_ln_tail_done = tail.gamma; }
-    if (lds_t > 64 * 1024 && lds_t != lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(kern, grid, dim3(64 * p.ksplit * nfg), lds_t, st, W.w, W.scale, N16, K32, p.ksplit, g_skinny_done, X, plane, MT, ep, g_skinny_ntiles LNT_PASS(tail) TL_PASS);
-#else
-    hipLaunchKernelGGL(kern, grid, dim3(64 * p.ksplit * nfg), lds, st, W.w, W.scale, N16, K32, p.ksplit, g_skinny_done, X, plane, MT, ep, g_skinny_ntiles TL_PASS);
-#endif
+    hipLaunchKernelGGL(kern, grid, dim3(64 * p.ksplit), lds, st, W.w, W.scale, N16, K32, p.ksplit, g_skinny_done, X, plane, MT, ep, g_skinny_ntiles TL_PASS);
     return hipGetLastError();
 }
 
@@ -1189,15 +1029,6 @@ static inline hipError_t launch_skinny_mt_nk(hipStream_t st, WRef W, int N16, in
     // weight row tiles per wave: as many as still leave >= 400 blocks (~1.5 per CU; swept 100..800 at 8 and 32 streams) (register blocking divides the L2 re-reads
     // of the token operand; with few token tiles the chip has to be filled by features instead).  Same results.
     const int groups = (MT + 1) / 2;
-#ifdef WM_ROWS_TT4
-    // experiment (build.py --variant tt4 -DWM_ROWS_TT4): the wide GEMMs (QKV, FC1) with FOUR token tiles per wave — 12 fragments per 32 MFMAs
-    // instead of 8 per 16, i.e. 25 % less L2 -> CU fill per MFMA, half the blocks
-    static const int tt4_min = skinny_env("WM_ROWS_TT4_MIN_BLOCKS", 350);
-    if (MT >= 8 && p.ksplit <= 5 && ((N16 + 3) / 4) * ((MT + 3) / 4) >= tt4_min) {
-        if (W.scale) return launch_rows_gemm_w<NKR, 4, true, Ep, 4>(st, W, N16, K32, p, X, plane, MT, ep);
-        return launch_rows_gemm_w<NKR, 4, false, Ep, 4>(st, W, N16, K32, p, X, plane, MT, ep);
-    }
-#endif
     if (((N16 + 3) / 4) * groups >= min_blocks) return launch_rows_gemm<NKR, 4>(st, W, N16, K32, p, X, plane, MT, ep);
     if (((N16 + 1) / 2) * groups >= min_blocks) return launch_rows_gemm<NKR, 2>(st, W, N16, K32, p, X, plane, MT, ep);
     return launch_rows_gemm<NKR, 1>(st, W, N16, K32, p, X, plane, MT, ep);
@@ -1287,11 +1118,6 @@ static inline hipError_t launch_skinny2(hipStream_t st, WRef W, int N16, int K32
 template <class Ep>
 static inline hipError_t launch_skinny_mt(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p,
                                           const bf16_t* X, size_t plane, int MT, int R, const Ep& ep) {
-#ifdef WM_LN_TAIL
-    const bool rows_kernel = !use_tile_gemm(N16, K32, MT, W.scale != nullptr, p.nk) &&
-                             !(MT == 2 && skinny_env("WM_SKINNY2", 1) && p.ksplit * p.rt <= 10 && p.ksplit * p.nk == K32);
-    if (!rows_kernel) { g_ln_tail = LnTail{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr}; g_ln_tail_done = nullptr; }
-#endif
     // the LDS-ring tile kernel (same accumulation order, bit-identical results)
     if (use_tile_gemm(N16, K32, MT, W.scale != nullptr, p.nk))
         return launch_tile_gemm(st, W.w, N16, K32, p.nk, X, plane, MT, ep);
@@ -1338,14 +1164,6 @@ static inline hipError_t launch_skinny_norm_t(hipStream_t st, WRef W, int N16, i
         }
         return hipGetLastError();
     }
-#ifdef WM_LN_TAIL
-    if (Ld::do_norm && g_ln_tail_done != nullptr && g_ln_tail_done == ld.gamma) {      // the producing GEMM's tail wrote this operand
-        g_ln_tail_done = nullptr;
-        g_ln_pf_extra = nullptr;
-        return launch_skinny_mt(st, W, N16, K32, p, xscr, plane, MT, R, ep);
-    }
-    g_ln_tail_done = nullptr;
-#endif
     // weight prefetch riding on the LayerNorm launch (token-tile path with bf16 weights only; WM_LN_PREFETCH=0 turns it off)
     const int ln_pf = skinny_env("WM_LN_PREFETCH", 1);
     PfJob pf{nullptr, nullptr, 0u, 0u, 0ull};
