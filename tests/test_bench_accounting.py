@@ -2,6 +2,8 @@
 import importlib.util
 import os
 
+import pytest
+
 from helpers import ROOT, MedusaConfig
 
 
@@ -56,10 +58,21 @@ def test_merged_step_schedule_is_priced_per_step():
     assert abs(one_step - (p["w_verify"] + 32 * kv)) < 64.0
     lock_step = b.executed_bytes(lin, 32, 64, False, 1.0, 0.45)
     assert abs((lock_step - 1.45 * one_step) - (p["w_base"] - 0.45 * p["w_verify"])) < 4096.0
+
+
+def test_newest_committed_bench_line_reports_the_merged_step_legs():
+    """The newest profiles/rNN_bench_default.json (a measurement artefact: absent or renamed, this check is skipped — the accounting itself
+    is tested above on synthetic numbers) carries the 32-stream legs with steps-per-iteration between 1 and 2 and a parity check."""
+    import glob
     import json
-    import os
-    line = json.loads(open(os.path.join(os.path.dirname(__file__), "..", "profiles", "r04_bench_default.json")).read().strip().splitlines()[-1])
-    leg = next(c for c in line["configs"] if c["config"].startswith("configs[1] shape at 32 streams"))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_default.json")))
+    if not files:
+        pytest.skip("no committed bench line")
+    line = json.loads(open(files[-1]).read().strip().splitlines()[-1])
+    legs = [c for c in line.get("configs", []) if str(c.get("config", "")).startswith("configs[1] shape at 32 streams")]
+    if not legs:
+        pytest.skip("the newest bench line has no 32-stream leg")
+    leg = legs[0]
     assert leg["merged_steps_per_iteration"] and 1.0 < leg["merged_steps_per_iteration"] < 2.0 and leg["parity_checked"] is True
 
 

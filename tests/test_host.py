@@ -702,3 +702,18 @@ def test_from_pretrained_resolves_hub_names_through_huggingface_hub(tmp_path, mo
     assert WhisperMedusaModel.from_pretrained(str(ckpt)).config.d_model == cfg.d_model and calls == []
     with pytest.raises(OSError, match="neither a checkpoint directory nor a hub repository"):
         WhisperMedusaModel.from_pretrained("aiola/whisper-medusa-linear-libri", local_files_only=True)
+
+
+def test_recorded_gpu_suite_duration_fits_the_driver_limit():
+    """The driver runs `pytest tests -m gpu` under a 1200 s limit; round 4's suite had grown to 1460-1564 s and was killed there
+    (GPUTEST_r04.json).  tests/gpu_suite_durations.json is the per-test record (setup + call + teardown) conftest.py wrote on the last
+    whole-suite run on an MI355X box (`tests/microbench/r05_call2.sh`): it must cover the whole default set, be green, and stay below 900 s
+    in total — with no single test above 120 s, so that one slow box cannot eat the margin."""
+    import json
+    rec = json.load(open(os.path.join(ROOT, "tests", "gpu_suite_durations.json")))
+    assert rec["failed"] == 0 and rec["passed"] >= 150 and not rec["slow_included"], {k: v for k, v in rec.items() if k != "durations"}
+    assert rec["total_s"] <= 900.0, rec["total_s"]
+    worst = max(rec["durations"].items(), key=lambda kv: kv[1])
+    assert worst[1] <= 120.0, worst
+    files = {k.split("::")[0] for k in rec["durations"]}
+    assert {"tests/test_gpu_parity.py", "tests/test_gpu_tree.py", "tests/test_gpu_features.py", "tests/test_gpu_large.py", "tests/test_bench_dist.py"} <= files

@@ -1064,7 +1064,8 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
     static const bool fuse_env = [] { const char* v = std::getenv("WM_FUSE_CQ"); return v && std::atoi(v) != 0; }();
     const SkinnyPlan cqp = skinny_plan(d / 16, K32, true);
     const bool fuse_shape = (cqp.nk == 8 && cqp.ksplit >= 1 && cqp.ksplit <= 5) || (cqp.nk == 4 && (cqp.ksplit == 1 || cqp.ksplit == 3));
-    const bool fuse_cq = fuse_env && R <= 16 && !f8 && fuse_shape && H * 4 == d / 16;       // single tile: nqt == 1
+    // (not under the merged-step schedule's dense rows: the fused instance reads q at stream * Mper + row)
+    const bool fuse_cq = fuse_env && R <= 16 && !f8 && fuse_shape && H * 4 == d / 16 && rowinfo == nullptr;       // single tile: nqt == 1
     const PfJob kvjob = (pf && nqt == 1 && ctx->NS % xgrid == 0 && ctx->Spad == ctx->NS * 256)
         ? PfJob{reinterpret_cast<const char*>(kx), reinterpret_cast<const char*>(vx), (unsigned)(ctx->NS / xgrid) * 256 * 128,
                 (unsigned)(xgrid * H * nb), (unsigned long long)H * nb * ctx->Spad * 128}

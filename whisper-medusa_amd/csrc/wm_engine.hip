@@ -462,7 +462,8 @@ extern "C" int wm_get_stats(wm_ctx* ctx, wm_stats* out)
     out->graph_replays = ctx->graph_replays;
     if (ctx->step_flow && ctx->steprows) {
         int sr[4] = {0, 0, 0, 0};
-        WM_HIP(hipMemcpy(sr, ctx->steprows, sizeof(sr), hipMemcpyDeviceToHost));
+        WM_HIP(hipMemcpyAsync(sr, ctx->steprows, sizeof(sr), hipMemcpyDeviceToHost, ctx->stream));       // on the context's stream like every other read
+        WM_HIP(hipStreamSynchronize(ctx->stream));
         out->schedule_steps = sr[2];
     }
     return WM_OK;
@@ -522,6 +523,7 @@ extern "C" int wm_forward_logits(wm_ctx* ctx, int B, const int32_t* tokens, int 
     GenDev g = ctx->gp;
     g.K = K; g.V = V; g.Vpad = ctx->Vpad; g.Tids = Tids; g.vanilla = 0;
     ctx->gp = g; ctx->began = false; ctx->use_done = false; ctx->host_carry = false; ctx->dev_carry = false;
+    ctx->step_flow = false;                 // (wm_get_stats must not report the previous decode's schedule_steps for this pass)
     if (ctx->graph) { hipGraphExecDestroy(ctx->graph); ctx->graph = nullptr; }
     if (ctx->graph_base) { hipGraphExecDestroy(ctx->graph_base); ctx->graph_base = nullptr; }
     std::vector<float> rowbuf((size_t)nout * ctx->Vpad);

@@ -55,7 +55,7 @@ class EngineEncoderOutput:
         if self._t is None:
             if getattr(self._engine, "_enc_stamp", None) is not self._wm_stamp:
                 raise RuntimeError("this encoder pass is no longer resident in the engine")
-            self._t = self._engine.encoder_output(self._batch)
+            self._t = self._engine.encoder_output_cached(self._batch)
         return self._t
 
     def __getitem__(self, i):
@@ -750,7 +750,8 @@ class WhisperMedusaModel:
           returned ``past_key_values`` is an ``EngineKVCache`` handle saying how many positions are cached, and a following call that
           passes it back appends its tokens behind them (``get_seq_length()`` like HF's cache classes).  ``decoder_position_ids``
           override the start position as in the reference;
-        * ``return_dict=False`` gives the reference's tuple ``(logits, past_key_values, encoder_last_hidden_state)``;
+        * ``return_dict=False`` gives the reference's tuple ``(logits, past_key_values, encoder_last_hidden_state)`` (``use_cache=None``
+          counts as True, HF's ``config.use_cache`` default); the hidden state is copied from the device once per encoder pass;
         * masks, ``decoder_inputs_embeds``, attentions / hidden states and ``labels`` (training) are not part of the engine: they raise.
 
         ``logits`` are ``[K+1 (1 with disable_medusa), B, T, V]``.  The engine evaluates 16 positions per pass: longer inputs go
@@ -806,7 +807,9 @@ class WhisperMedusaModel:
             logits = eng.forward_logits(toks, pos0, dm)
         else:
             logits = torch.cat([eng.forward_logits([row[c: c + 16] for row in toks], pos0 + c, dm) for c in range(0, T, 16)], dim=2)
-        want_cache = bool(use_cache) or past_key_values is not None
+        # use_cache=None means config.use_cache = True, as in HF (the reference's tuple is (logits, past_key_values, encoder state))
+        want_cache = (use_cache is None) or bool(use_cache) or past_key_values is not None
+        # the handle carries the stamp the pass just set (engine.forward_logits): older handles — positions now overwritten — are refused
         pkv = EngineKVCache(id(eng), eng._enc_stamp, eng._kv_stamp, B, pos0 + T) if want_cache else None
         if enc_ref is None:
             enc_ref = EngineEncoderOutput(eng, B, eng._enc_stamp)

@@ -259,6 +259,14 @@ class Engine:
         self._check(self.lib.wm_get_encoder_output(self.h, B, out.ctypes.data_as(C.POINTER(C.c_float))), "wm_get_encoder_output")
         return torch.from_numpy(out)
 
+    def encoder_output_cached(self, B: int) -> torch.Tensor:
+        """The resident encoder pass's hidden state, fetched from the device once per encoder pass (api.forward's tuple return hands it
+        out on every call of a per-token loop: one D2H copy of [B, n_ctx, d] per pass, not per token)."""
+        c = getattr(self, "_enc_host", None)
+        if c is None or c[0] is not self._enc_stamp or c[1] != B:
+            self._enc_host = (self._enc_stamp, B, self.encoder_output(B))
+        return self._enc_host[2]
+
     def cross_kv(self, kv_layer: int, stream: int, head: int):
         S = self.cfg.max_source_positions
         k = np.empty((S, 64), dtype=np.float32); v = np.empty((S, 64), dtype=np.float32)
@@ -271,6 +279,9 @@ class Engine:
         flat = _i32arr([t for row in tokens for t in row])
         n_out = 1 if disable_medusa else self.cfg.medusa_num_heads + 1
         out = np.empty((n_out, B, T, self.cfg.vocab_size), dtype=np.float32)
+        # the pass overwrites cache rows pos0 .. pos0 + T: every EngineKVCache handle issued so far goes stale (api.forward hands the
+        # caller a fresh one carrying the new stamp) — a later pass at a smaller position can no longer be followed by an old handle
+        self._kv_stamp = object()
         self._check(self.lib.wm_forward_logits(self.h, B, flat, T, pos0, 1 if disable_medusa else 0,
                                                out.ctypes.data_as(C.POINTER(C.c_float))), "wm_forward_logits")
         return torch.from_numpy(out)
