@@ -63,13 +63,39 @@ def executed_bytes(cfg, B, mean_len, dec_fp8, p_base_pass, p_base_attn):
     return p["w_verify"] + B * kv + p_base_pass * p["w_base"] + p_base_attn * B * kv
 
 
-def prefill_flops(cfg):
-    """Algorithmic FLOPs of the encoder + cross-KV projection for one 30 s clip."""
+def prefill_flops(cfg, parts=False):
+    """Algorithmic FLOPs of the encoder + cross-KV projection for one 30 s clip.
+    ``parts``: (flops of the GEMMs the fp8 configuration runs on the fp8 MFMA — the LayerNorm-fed QKV and FC1 of every encoder layer and
+    the cross-K/V projection —, flops that stay bf16 there: out-proj, FC2, attention, convolutions)."""
     d, f, S, L = cfg.d_model, cfg.encoder_ffn_dim, cfg.max_source_positions, cfg.encoder_layers
     per_layer = 4 * 2 * S * d * d + 2 * 2 * S * S * d + 2 * 2 * S * d * f
     conv = 2 * (2 * S) * d * 3 * cfg.num_mel_bins + 2 * S * d * 3 * d
     cross = cfg.n_kv_layers * 2 * 2 * S * d * d
+    if parts:
+        f8 = L * (3 * 2 * S * d * d + 2 * S * d * f) + cross
+        return f8, L * per_layer + conv + cross - f8
     return L * per_layer + conv + cross
+
+
+MFMA_PEAK_BF16, MFMA_PEAK_FP8 = 2.5e15, 5.0e15          # dense, BASELINE.md §2 (AMD's headline figures include 2:1 sparsity)
+
+
+def prefill_roofline(cfg, clips, ms, fp8):
+    """Prefill priced against the matrix-core peak.  bf16: 2.5 PFLOP/s.  The fp8 configuration runs 7 / 12 of its GEMM flops on the fp8 MFMA
+    (peak 5 PFLOP/s): its floor is flops_fp8 / 5e15 + flops_bf16 / 2.5e15 and `frac` is floor / measured; the same time against the bf16
+    peak alone is kept as `frac_vs_bf16_peak` (the number earlier rounds reported for this leg)."""
+    flops = prefill_flops(cfg) * clips
+    t = ms * 1e-3
+    out = {"bound": "mfma", "tflops_per_clip": round(prefill_flops(cfg) / 1e12, 3), "achieved": round(flops / t / 1e12, 1), "unit": "TFLOP/s"}
+    if fp8:
+        f8, bf = prefill_flops(cfg, parts=True)
+        floor = clips * (f8 / MFMA_PEAK_FP8 + bf / MFMA_PEAK_BF16)
+        out.update({"peak": round(flops / floor / 1e12, 1), "peak_note": "blended: fp8 share of the flops at 5 PFLOP/s, the rest at 2.5 PFLOP/s",
+                    "fp8_flop_share": round(f8 / (f8 + bf), 4), "frac": round(floor / t, 4),
+                    "frac_vs_bf16_peak": round(flops / t / MFMA_PEAK_BF16, 4)})
+    else:
+        out.update({"peak": MFMA_PEAK_BF16 / 1e12, "frac": round(flops / t / MFMA_PEAK_BF16, 4)})
+    return out
 
 
 DECODE_SOURCES = ("wm_common.h", "wm_decoder.hip", "wm_engine.hip", "wm_epilogues.h", "wm_internal.h", "wm_skinny_gemm.h")
@@ -97,12 +123,22 @@ def cpu_baseline_leg(cfg, sd, eng, gp, wav0, engine_ids, n_iters, fp8, full_budg
     (the whole 128-token budget with --cpu-full).  Parity: the oracle in the engine's numeric contract (sim="bf16"), fed with
     the engine's encoder output, must emit exactly the engine's token ids for those iterations."""
     from oracle.whisper_medusa_oracle import Oracle, log_mel
-    ncore = min(os.cpu_count() or 1, 64)
-    torch.set_num_threads(ncore)
     sd_cpu = {k: v.float().cpu() for k, v in sd.items()}
     orc = Oracle(cfg, sd_cpu, sim="fp32", dec_fp8=fp8, enc_fp8=fp8)             # the reference's default dtype
     n = cfg.n_mel_frames * 160
     wav = wav0.cpu().numpy()
+    # The host thread count is calibrated, not assumed: the decode loop is a chain of small ops and skinny GEMVs, and on the GPU box's 256
+    # hardware threads torch's default pool (128) and the 64 threads of earlier rounds are ~3x SLOWER than 16 (profiles/r05_oracle_threads.log).
+    # The baseline is the best of {8, 16, 32, 64} threads on two decode iterations; `cores` reports the count used for the decode sample.
+    enc0 = eng.encoder_output(1)[0]
+    cand = [c for c in (8, 16, 32, 64) if c <= (os.cpu_count() or 1)] or [os.cpu_count() or 1]
+    calib = {}
+    for c in cand:
+        torch.set_num_threads(c)
+        orc.decode(enc0, gp, max_iters=1)
+        t = time.perf_counter(); orc.decode(enc0, gp, max_iters=2); calib[c] = time.perf_counter() - t
+    ncore = min(calib, key=calib.get)
+    torch.set_num_threads(ncore)
 
     def timed(fn, reps=3):
         fn()                                                         # warm-up
@@ -124,6 +160,7 @@ def cpu_baseline_leg(cfg, sd, eng, gp, wav0, engine_ids, n_iters, fp8, full_budg
     agree32 = next((i for i, (a, b) in enumerate(zip(engine_ids, r.ids)) if a != b), min(len(engine_ids), len(r.ids))) - len(gp.prompt)
     audio_s = 30.0 * cfg.max_source_positions / 1500.0
     return {"value": round(ntok / t_dec, 3), "unit": "tokens/s", "cores": ncore, "kind": "port",
+            "threads_calibration_s": {str(k): round(v, 3) for k, v in calib.items()},
             "sample": f"oracle (PyTorch CPU fp32 restatement of the reference loop) on clip 0, 1 warm-up + 3 runs, median: log-mel "
                       f"{t_mel:.2f} s, encoder {t_enc:.2f} s, decode (cross-KV projection + {r.n_iters} Medusa iterations = {ntok} tokens, "
                       f"from the GPU encoder output) {t_dec:.2f} s",
@@ -166,7 +203,7 @@ def leg_parity(cfg, sd, eng, gp, fp8, iters=8):
     """Stream 0 of the leg's LAST decoded batch against the oracle in the engine's numeric contract, fed with the engine's encoder
     output, for the first `iters` Medusa iterations (the checker, never the thing measured)."""
     from oracle.whisper_medusa_oracle import Oracle
-    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
     orc = Oracle(cfg, {k: v.float().cpu() for k, v in sd.items()}, sim="bf16", dec_fp8=fp8, enc_fp8=fp8)
     enc = eng.encoder_output(1)[0]
     ref = orc.decode(enc, gp, max_iters=iters)
@@ -175,7 +212,7 @@ def leg_parity(cfg, sd, eng, gp, fp8, iters=8):
     return {"parity_checked": bool(got[:n] == ref.ids), "parity_tokens_compared": n - len(gp.prompt), "parity_iterations": ref.n_iters}
 
 
-def extra_config(name, heads, B, fp8, dev, logit_std, max_new, steps=2):
+def extra_config(name, heads, B, fp8, dev, logit_std, max_new, steps=4):
     """One more BASELINE.json config measured in the same process (B streams, one context): whole-step tokens/s, decode
     iteration time, vanilla anchor, roofline fractions, and a parity check of stream 0 against the oracle."""
     from whisper_medusa import MedusaConfig, WhisperMedusaModel, ACCEPT_TYPICAL, synth, weights
@@ -221,7 +258,8 @@ def extra_config(name, heads, B, fp8, dev, logit_std, max_new, steps=2):
            "roofline_frac_hbm": round(bytes_iter / (t_iter * 1e-3) / 8e12, 4),
            "merged_steps_per_iteration": round(sched / max(it, 1), 3) if sched else None,
            "prefill_tflops": round(prefill_flops(cfg) * B / (ms_enc / steps * 1e-3) / 1e12, 1),
-           "prefill_frac_mfma": round(prefill_flops(cfg) * B / (ms_enc / steps * 1e-3) / 2.5e15, 4)}
+           "prefill": prefill_roofline(cfg, B, ms_enc / steps, fp8)}
+    out["prefill_frac_mfma"] = out["prefill"]["frac"]        # fp8 leg: against the blended fp8 / bf16 peak (prefill_roofline)
     out.update(parity)
     eng.close()
     del model, blob
@@ -282,6 +320,8 @@ def main():
     t0 = time.time()
     blob, offs = wd.broadcast_blob(blob, offs, device=dev)
     torch.cuda.synchronize()
+    # (tests/test_bench_dist.py stretches the one-time set-up phase to show that it lies outside the timed region)
+    time.sleep(float(os.environ.get("WM_BENCH_TEST_SETUP_DELAY_S", "0") or 0))
     t_bcast = time.time() - t0
     model = WhisperMedusaModel.from_blob(cfg, blob, offs, max_batch=B, dec_weight_fp8=args.fp8_weights, enc_fp8=args.fp8_weights)
     eng = model.engine
@@ -353,7 +393,7 @@ def main():
 
     # HBM traffic per iteration from the PMC pass (profiles/): only if that pass was taken on THESE kernels (sha over csrc/)
     traffic = None; traffic_src = None
-    tname = next((n for n in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", n))), "r04_pmc_traffic.json")
+    tname = next((n for n in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", n))), "r05_pmc_traffic.json")
     tpath = os.path.join(ROOT, "profiles", tname)
     if args.model == "large-v2" and B == 1 and args.heads == "linear" and not args.fp8_weights and os.path.exists(tpath):
         tj = json.load(open(tpath))
@@ -417,10 +457,7 @@ def main():
                      "vanilla_step": None if vanilla_ms_step is None else
                                      {"bytes": round(van_bytes), "ms": round(vanilla_ms_step, 4),
                                       "frac": round(van_bytes / (vanilla_ms_step * 1e-3) / 8e12, 4)},
-                     "prefill": {"bound": "mfma", "tflops_per_clip": round(prefill_flops(cfg) / 1e12, 3),
-                                 "achieved": round(prefill_flops(cfg) * B / (ms_enc / args.steps * 1e-3) / 1e12, 1),
-                                 "peak": 2500.0, "unit": "TFLOP/s",
-                                 "frac": round(prefill_flops(cfg) * B / (ms_enc / args.steps * 1e-3) / 2.5e15, 4)},
+                     "prefill": prefill_roofline(cfg, B, ms_enc / args.steps, args.fp8_weights),
                      "layer_gemms": None if gemm_ms is None else
                                     {"rows": gemm_rows, "ms": round(gemm_ms, 5), "bytes": round(gemm_bytes),
                                      "achieved_gbs": round(gemm_bytes / (gemm_ms * 1e-3) / 1e9, 1)}},
