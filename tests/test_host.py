@@ -632,7 +632,14 @@ def test_forward_keyword_surface_follows_the_reference():
     class Eng(_FakeEngine):
         def forward_logits(self, tokens, pos0, disable_medusa):
             self.calls.append(("forward_logits", len(tokens), len(tokens[0]), pos0))
+            self._kv_stamp = object()                              # as Engine.forward_logits: the pass overwrites cache rows, older handles go stale
             return torch.zeros(1 if disable_medusa else cfg.medusa_num_heads + 1, len(tokens), len(tokens[0]), 8)
+
+        def encoder_output_cached(self, B):                        # as Engine: one device fetch per encoder pass
+            c = getattr(self, "_enc_host", None)
+            if c is None or c[0] is not self._enc_stamp or c[1] != B:
+                self._enc_host = (self._enc_stamp, B, self.encoder_output(B))
+            return self._enc_host[2]
 
         def set_encoder_output(self, hidden):
             self.calls.append(("set_encoder_output", tuple(hidden.shape))); self._B = hidden.shape[0]; self._enc_stamp = object()
@@ -657,10 +664,18 @@ def test_forward_keyword_surface_follows_the_reference():
     assert o2.encoder_last_hidden_state.shape == (2, cfg.max_source_positions, cfg.d_model) and o2.encoder_outputs[0] is o2.encoder_last_hidden_state
     assert [c[0] for c in eng.calls] == ["forward_logits", "encoder_output"]
     # a foreign tensor (or HF-style tuple) replaces the encoder pass through the engine, and invalidates older cache handles
-    eng.calls.clear()
     hid = torch.zeros(2, cfg.max_source_positions, cfg.d_model)
+    # an OLDER handle of the same chain is stale once a later pass has run (its positions were overwritten): refused, not silently appended to
+    with pytest.raises(ValueError, match="reused the cache since"):
+        m.forward(encoder_outputs=o1.encoder_outputs, decoder_input_ids=ids[:, :1], past_key_values=o1.past_key_values)
+    eng.calls.clear()
+    # use_cache=None counts as True (HF: config.use_cache): the tuple is (logits, past_key_values, encoder_last_hidden_state) as in the reference
     o3 = m.forward(encoder_outputs=(hid,), decoder_input_ids=ids, return_dict=False)
-    assert [c[0] for c in eng.calls] == ["set_encoder_output", "forward_logits", "encoder_output"] and isinstance(o3, tuple) and len(o3) == 2
+    assert [c[0] for c in eng.calls] == ["set_encoder_output", "forward_logits", "encoder_output"] and isinstance(o3, tuple) and len(o3) == 3
+    assert isinstance(o3[1], EngineKVCache) and o3[1].get_seq_length() == 3
+    o3b = m.forward(decoder_input_ids=ids[:, :1], past_key_values=o3[1], return_dict=False)      # per-token loop: the hidden state is NOT fetched again
+    assert [c[0] for c in eng.calls] == ["set_encoder_output", "forward_logits", "encoder_output", "forward_logits"] and o3b[2] is o3[2]
+    assert len(m.forward(decoder_input_ids=ids, use_cache=False, return_dict=False)) == 2
     with pytest.raises(ValueError, match="another engine, encoder pass"):
         m.forward(decoder_input_ids=ids[:, :1], past_key_values=o2.past_key_values)
     o4 = m.forward(decoder_input_ids=ids, use_cache=True, return_dict=False)
@@ -717,3 +732,82 @@ def test_recorded_gpu_suite_duration_fits_the_driver_limit():
     assert worst[1] <= 120.0, worst
     files = {k.split("::")[0] for k in rec["durations"]}
     assert {"tests/test_gpu_parity.py", "tests/test_gpu_tree.py", "tests/test_gpu_features.py", "tests/test_gpu_large.py", "tests/test_bench_dist.py"} <= files
+
+
+def test_checkpoint_written_by_hf_modules_round_trips_through_the_loader(tmp_path):
+    """The day real weights appear (`aiola/whisper-medusa-linear-libri`, reference README.md:29-32; loader model.py:265-291) the loader
+    meets a directory written by HF code, not by `synth`: `config.json` = `WhisperConfig.to_dict()` of the base model + the Medusa fields
+    (reference utils/config_and_args.py:17-62, dozens of keys this engine ignores), `model.safetensors` = the module tree's state dict with
+    torch's own key names and HF's TIED `proj_out.weight` dropped by the safetensors writer.  This test builds exactly that with the real
+    `transformers` classes (a small random-init Whisper) and a module tree shaped like the reference's (model.py:212-256:
+    `whisper_model`, `medusa_heads.{k}.0.linear`), then: from_pretrained -> packed blob (matrices unpacked and compared with the HF
+    parameters) -> save_pretrained -> identical tensors back."""
+    import json
+    transformers = pytest.importorskip("transformers")
+    from safetensors.torch import save_model
+    from whisper_medusa import WhisperMedusaModel
+    K, d = 3, 128
+    hf_cfg = transformers.WhisperConfig(d_model=d, encoder_layers=2, decoder_layers=2, encoder_attention_heads=2, decoder_attention_heads=2,
+                                        encoder_ffn_dim=4 * d, decoder_ffn_dim=4 * d, vocab_size=1031, num_mel_bins=80, max_source_positions=96,
+                                        max_target_positions=64, eos_token_id=1028, pad_token_id=1028, decoder_start_token_id=1029,
+                                        suppress_tokens=[3, 5], begin_suppress_tokens=[7, 1028], max_length=64)
+    torch.manual_seed(5)
+    whisper = transformers.WhisperForConditionalGeneration(hf_cfg)
+
+    class ResBlock(torch.nn.Module):                    # MedusaResBlock, model.py:180-210
+        def __init__(self):
+            super().__init__()
+            self.linear = torch.nn.Linear(d, d)
+
+    class Ref(torch.nn.Module):                         # the reference's module tree, model.py:212-256 (Medusa-Linear: K + 1 residual heads)
+        def __init__(self):
+            super().__init__()
+            self.whisper_model = whisper
+            self.medusa_heads = torch.nn.ModuleList([torch.nn.Sequential(ResBlock()) for _ in range(K + 1)])
+
+    ref = Ref()
+    names = dict(ref.state_dict())
+    assert "whisper_model.proj_out.weight" in names and "medusa_heads.3.0.linear.bias" in names
+    assert names["whisper_model.proj_out.weight"].data_ptr() == names["whisper_model.model.decoder.embed_tokens.weight"].data_ptr()   # tied
+    ck = tmp_path / "ckpt"
+    ck.mkdir()
+    save_model(ref, str(ck / "model.safetensors"))      # what HF's save_pretrained does with shared tensors: one name survives
+    cfg_json = dict(hf_cfg.to_dict(), architectures=["WhisperMedusaModel"], medusa_num_heads=K, medusa_num_layers=1, medusa_hidden_size=d,
+                    whisper_model_name="openai/whisper-large-v2", medusa_choices=[1] * (K + 1), medusa_heads_type="base_head",
+                    medusa_loss_on_original=False, medusa_kl_loss=False, medusa_kl_weight=0, output_whisper_original=False)
+    json.dump(cfg_json, open(ck / "config.json", "w"))
+    m = WhisperMedusaModel.from_pretrained(str(ck))
+    cfg = m.config
+    assert (cfg.d_model, cfg.decoder_layers, cfg.vocab_size, cfg.medusa_num_heads, cfg.max_source_positions, cfg.eos_token_id) == (d, 2, 1031, K, 96, 1028)
+    assert cfg.suppress_tokens == [3, 5] and cfg.begin_suppress_tokens == [7, 1028]
+    from safetensors.torch import load_file, save_file
+    raw = load_file(str(ck / "model.safetensors"))
+    emb_k, proj_k = "whisper_model.model.decoder.embed_tokens.weight", "whisper_model.proj_out.weight"
+    assert (proj_k in raw) != (emb_k in raw)                                     # exactly one name of the tied pair is on disk
+    # the other writer's choice: the same checkpoint with the surviving name swapped must load to the same blob
+    alt = tmp_path / "ckpt_alt"
+    alt.mkdir()
+    kept, other = (emb_k, proj_k) if emb_k in raw else (proj_k, emb_k)
+    save_file({(other if k == kept else k): v.contiguous() for k, v in raw.items()}, str(alt / "model.safetensors"))
+    json.dump(cfg_json, open(alt / "config.json", "w"))
+    b_alt, _ = weights.build_blob(cfg, WhisperMedusaModel.from_pretrained(str(alt))._sd, device="cpu")
+    blob, offs = weights.build_blob(cfg, m._sd, device="cpu")
+    assert len(offs) == weights.n_table_entries(cfg) and torch.equal(blob, b_alt)
+    # spot checks against the HF parameters: the fused q|k|v matrix of decoder layer 1 and the tied vocabulary matrix, both as packed bf16
+    K32 = d // 32
+    base = 19 + 12 * cfg.encoder_layers + 18 * 1                      # canonical order (weights.canonical_tensors): decoder layer 1's first entry (ln1 gamma)
+    qkv_off = int(offs[base + 2])
+    qkv = torch.cat([names[f"whisper_model.model.decoder.layers.1.self_attn.{p}_proj.weight"] for p in "qkv"], 0).detach()
+    got = weights.unpack_matrix(blob[qkv_off: qkv_off + qkv.numel() * 2].view(torch.bfloat16), 3 * d, d)
+    assert torch.equal(got, qkv.to(torch.bfloat16))
+    vpad = (cfg.vocab_size + 127) // 128 * 128
+    voc = weights.unpack_matrix(blob[int(offs[11]): int(offs[11]) + vpad * d * 2].view(torch.bfloat16), vpad, d)
+    assert torch.equal(voc[: cfg.vocab_size], names["whisper_model.proj_out.weight"].detach().to(torch.bfloat16)) and not voc[cfg.vocab_size:].any()
+    out = tmp_path / "resaved"
+    m.save_pretrained(str(out))
+    back = weights.load_state_dict_from_dir(str(out))
+    assert "whisper_model.proj_out.weight" not in back
+    for k, v in back.items():
+        assert torch.equal(v, names[k].detach()), k
+    assert set(back) == set(names) - {"whisper_model.proj_out.weight"}
+    assert WhisperMedusaModel.from_pretrained(str(out)).config.to_dict() == cfg.to_dict()

@@ -195,8 +195,17 @@ def load_state_dict_from_dir(path: str) -> Dict[str, torch.Tensor]:
         from safetensors.torch import load_file
         for f in files:
             sd.update(load_file(f))
-        return sd
+        return resolve_tied_embeddings(sd)
     binf = os.path.join(path, "pytorch_model.bin")
     if os.path.exists(binf):
-        return torch.load(binf, map_location="cpu", weights_only=True)
+        return resolve_tied_embeddings(torch.load(binf, map_location="cpu", weights_only=True))
     raise OSError(f"no model.safetensors / pytorch_model.bin under {path}")
+
+
+def resolve_tied_embeddings(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """HF ties ``proj_out.weight`` to the decoder's ``embed_tokens.weight`` and a safetensors writer keeps ONE of the two names
+    (transformers keeps embed_tokens; ``safetensors.torch.save_model`` keeps whichever sorts first).  Whichever survived serves both."""
+    emb, proj = "whisper_model.model.decoder.embed_tokens.weight", "whisper_model.proj_out.weight"
+    if emb not in sd and proj in sd:
+        sd[emb] = sd[proj]
+    return sd
