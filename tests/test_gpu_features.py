@@ -217,3 +217,43 @@ def test_forward_with_encoder_outputs_and_cache_handles(gpu):
         m8.forward(encoder_outputs=(hid[:1],), decoder_input_ids=ids[:1])
     m8.engine.close()
     model.engine.close()
+
+
+@pytest.mark.parametrize("heads", ["base_head", "medusa_block"])
+def test_arbitrary_logits_processors_match_the_fused_loop(gpu, heads):
+    """generate(logits_processor=[any Python callable]) (reference model.py:1106-1116 hands any list to HF): the host path — the
+    reference's loop structure with every decoder pass on the engine (wm_forward_logits) and processors / candidates / posterior in
+    torch — must emit the tokens of the fused device loop: with a processor that changes nothing, and with a token ban that the fused loop
+    expresses as its static suppress list.  tiny.en shape, two clips, both acceptance modes."""
+    from transformers.generation.logits_process import LogitsProcessor, LogitsProcessorList
+    cfg = MedusaConfig.tiny_en(heads, K=4)
+    sd = synth.synth_state_dict(cfg, seed=4)
+    model = WhisperMedusaModel(cfg, sd, device=gpu, max_batch=2)
+    n = cfg.n_mel_frames * 160
+    feats = model.extract_features(np.stack([synth.synth_clip(30 + i, n) for i in range(2)]))
+
+    class Identity(LogitsProcessor):
+        calls = 0
+        def __call__(self, input_ids, scores):
+            Identity.calls += 1
+            return scores
+
+    class Ban(LogitsProcessor):
+        def __init__(self, toks): self.toks = list(toks)
+        def __call__(self, input_ids, scores):
+            scores = scores.clone(); scores[:, self.toks] = -float("inf"); return scores
+
+    kw = dict(max_new_tokens=28, exponential_decay_length_penalty=(6, 1.3))
+    for temperature in (None, 0.0):
+        fused = model.generate(feats, temperature=temperature, **kw)
+        st_fused = dict(model.last_stats)
+        host = model.generate(feats, temperature=temperature, logits_processor=LogitsProcessorList([Identity()]), **kw)
+        assert model.last_stats["host_processors"] == 1 and Identity.calls >= 4
+        assert host.tolist() == fused.tolist(), (heads, temperature)
+        assert model.last_stats["accept_hist"][: cfg.medusa_num_heads + 1] == st_fused["accept_hist"][: cfg.medusa_num_heads + 1]
+    P = len(model._last_prompt)
+    ban = sorted(set(fused[0, P:].tolist()) - {cfg.eos_token_id, cfg.pad_token_id})[:3]
+    want = model.generate(feats, suppress_tokens=sorted(set(cfg.suppress_tokens or []) | set(ban)), **kw)
+    got = model.generate(feats, logits_processor=[Ban(ban)], **kw)
+    assert got.tolist() == want.tolist() and not set(ban) & set(got[:, P:].flatten().tolist())
+    model.engine.close()

@@ -325,7 +325,7 @@ def test_automatic_micro_batch_policy():
 
 def test_hf_processors_and_criteria_are_lowered_into_generation_params():
     """generate(logits_processor=..., stopping_criteria=...) (reference model.py:1106-1124 hands them to HF): the static ones are
-    folded into wm_gen_params, built here with the REAL transformers classes; anything dynamic is refused."""
+    folded into wm_gen_params, built here with the REAL transformers classes; anything dynamic is kept for the host."""
     from transformers.generation.logits_process import (LogitsProcessorList, SuppressTokensLogitsProcessor, TemperatureLogitsWarper,
                                                         SuppressTokensAtBeginLogitsProcessor, ExponentialDecayLengthPenalty)
     from transformers.generation.stopping_criteria import StoppingCriteriaList, MaxLengthCriteria, MaxTimeCriteria
@@ -347,8 +347,9 @@ def test_hf_processors_and_criteria_are_lowered_into_generation_params():
     # a penalty whose start lies inside the prompt cannot be expressed (negative relative start = off in wm_gen_params): refuse, do not drop it
     with pytest.raises(NotImplementedError, match="regulation_start"):
         lower_processors(gp2, [ExponentialDecayLengthPenalty((2, 1.25), big.eos_token_id, 0)], None)
-    with pytest.raises(NotImplementedError, match="TemperatureLogitsWarper"):
-        lower_processors(gp, [TemperatureLogitsWarper(0.7)], None)
+    # any other processor is a Python callable on the logits: kept for the host path (generate() then runs the loop pass by pass), not refused
+    g_t = lower_processors(m._gen_params("en", None, None, 64, None, None, False, None, None, None, None, None), [TemperatureLogitsWarper(0.7)], None)
+    assert [type(p_).__name__ for p_ in g_t._host_processors] == ["TemperatureLogitsWarper"]
     # a criterion that is not a static rule goes to the host list (asked after every iteration), it does not raise
     g3 = lower_processors(m._gen_params("en", None, None, 64, None, None, False, None, None, None, None, None), None, [MaxTimeCriteria(1.0)])
     assert [type(c).__name__ for c in g3._host_criteria] == ["MaxTimeCriteria"]
@@ -811,3 +812,81 @@ def test_checkpoint_written_by_hf_modules_round_trips_through_the_loader(tmp_pat
         assert torch.equal(v, names[k].detach()), k
     assert set(back) == set(names) - {"whisper_model.proj_out.weight"}
     assert WhisperMedusaModel.from_pretrained(str(out)).config.to_dict() == cfg.to_dict()
+
+
+def test_arbitrary_logits_processors_run_the_reference_loop_on_the_host():
+    """generate(logits_processor=[any callable]) — the reference hands the list to HF and calls it on the base / Medusa logits and on the
+    verify logits (model.py:1106-1116, :653-665, :689-694).  The engine path for that (api._decode_host_processors) runs the loop on the
+    host with every decoder pass on the engine.  Here the engine is a test double whose passes are the ORACLE's decoder passes (same
+    cache semantics: K/V rows appended at the pass's position): with a processor that changes nothing the ids must equal oracle.decode's
+    (both acceptance modes, with and without EOS, Linear and Block), and a processor that bans tokens must equal the static suppress list."""
+    from transformers.generation.logits_process import LogitsProcessor, LogitsProcessorList
+    from oracle.whisper_medusa_oracle import Oracle
+    from whisper_medusa import WhisperMedusaModel
+    from helpers import golden_gen_params, ACCEPT_TYPICAL, ACCEPT_GREEDY
+
+    class OracleEngine:
+        def __init__(self, orc, encs):
+            self.orc, self.encs, self.calls, self._B, self._enc_stamp, self._kv_stamp = orc, encs, [], None, object(), object()
+
+        def encode(self, feats):
+            self.calls.append(("encode", feats.shape[0])); self.st = self.orc.new_state(self.encs[int(feats[0, 0, 0])]); self._B = 1
+
+        def forward_logits(self, tokens, pos0, disable_medusa):
+            assert len(tokens) == 1 and len(tokens[0]) <= 16
+            self.calls.append(("forward_logits", len(tokens[0]), pos0, disable_medusa))
+            self.st["kv_len"] = pos0
+            return self.orc.decoder_pass(self.st, list(tokens[0]), pos0, disable_medusa)[:, None]          # [n_out, 1, T, V]
+
+    class Identity(LogitsProcessor):
+        def __init__(self): self.lens = []
+        def __call__(self, input_ids, scores):
+            self.lens.append((input_ids.shape, scores.shape)); return scores
+
+    class Ban(LogitsProcessor):
+        def __init__(self, toks): self.toks = toks
+        def __call__(self, input_ids, scores):
+            scores = scores.clone(); scores[:, self.toks] = -float("inf"); return scores
+
+    for heads, seed in (("base_head", 11), ("medusa_block", 13)):
+        cfg = MedusaConfig.micro(K=4, heads_type=heads)
+        sd = synth.synth_state_dict(cfg, seed=seed)
+        orc = Oracle(cfg, sd, sim="fp32")
+        g = torch.Generator().manual_seed(3)
+        encs = [torch.randn(cfg.max_source_positions, cfg.d_model, generator=g) for _ in range(2)]
+        m = WhisperMedusaModel(cfg, {})
+        m._engine = eng = OracleEngine(orc, encs)
+        m._max_batch = 2
+        feats = torch.zeros(2, cfg.num_mel_bins, cfg.n_mel_frames); feats[1] = 1.0          # the double reads the clip index from the features
+        for mode in (ACCEPT_TYPICAL, ACCEPT_GREEDY):
+            for eos_free in (True, False):
+                gp = golden_gen_params(cfg, mode, 40, suppress_eos=eos_free)
+                ident = Identity()
+                kw = dict(max_new_tokens=40, exponential_decay_length_penalty=gp.exp_decay, suppress_tokens=gp.suppress_tokens,
+                          begin_suppress_tokens=gp.begin_suppress_tokens, temperature=0.0 if mode == ACCEPT_GREEDY else None)
+                out = m.generate(feats, logits_processor=LogitsProcessorList([ident]), **kw)
+                for b in range(2):
+                    ref = orc.decode(encs[b], gp)
+                    got = out[b].tolist()
+                    want = ref.ids[: ref.ids.index(gp.eos_token_id, len(gp.prompt)) + 1] if gp.eos_token_id in ref.ids[len(gp.prompt):] else ref.ids
+                    assert got[: len(want)] == want and all(t == gp.pad_token_id for t in got[len(want):]), (heads, mode, eos_free, b)
+                # every call saw input_ids [1, L] and rows [K + 1, V]: base + Medusa logits, then the K + 1 verify rows, same L (model.py:653-694)
+                assert all(i[0] == 1 and s_[0] == cfg.medusa_num_heads + 1 and s_[1] == cfg.vocab_size for i, s_ in ident.lens)
+                assert ident.lens[0][0][1] == len(gp.prompt) and ident.lens[1][0][1] == len(gp.prompt)
+                assert m.last_stats["host_processors"] == 1 and m.last_stats["iterations"] >= 2
+        # a banning processor == the same ids in the static suppress list (which the fused loop would use)
+        gp = golden_gen_params(cfg, ACCEPT_TYPICAL, 32)
+        ref = orc.decode(encs[0], gp)
+        extra = sorted(set(ref.ids[len(gp.prompt):]))[:3]                       # tokens the unconstrained run emits
+        gp_b = golden_gen_params(cfg, ACCEPT_TYPICAL, 32)
+        gp_b.suppress_tokens = sorted(set(gp_b.suppress_tokens) | set(extra))
+        want = orc.decode(encs[0], gp_b).ids
+        out = m.generate(feats[:1], logits_processor=[Ban(extra)], max_new_tokens=32, exponential_decay_length_penalty=gp.exp_decay,
+                         suppress_tokens=gp.suppress_tokens, begin_suppress_tokens=gp.begin_suppress_tokens)
+        assert out[0].tolist()[: len(want)] == want and not set(extra) & set(out[0].tolist()[len(gp.prompt):])
+    # trees and the vanilla anchor are not part of this path
+    tcfg = MedusaConfig.micro(K=3, medusa_choices=[1, 2, 2, 1])
+    mt = WhisperMedusaModel(tcfg, {})
+    mt._engine = OracleEngine(None, [])
+    with pytest.raises(NotImplementedError, match="candidate tree"):
+        mt.generate(torch.zeros(1, tcfg.num_mel_bins, tcfg.n_mel_frames), logits_processor=[Identity()])

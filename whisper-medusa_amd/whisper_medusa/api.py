@@ -125,9 +125,9 @@ def _as_int_list(x) -> List[int]:
 
 def lower_processors(gp: GenParams, logits_processor, stopping_criteria) -> GenParams:
     """Fold caller-supplied HF processors / criteria into the generation parameters.  A custom processor replaces the default of
-    its type (HF's merge rule); a logits processor that is not a static mask / penalty raises NotImplementedError (the logits never
-    leave the device inside an iteration); a stopping criterion that is not a static length / EOS rule is kept for the host
-    (``gp._host_criteria``) and evaluated after every iteration."""
+    its type (HF's merge rule); a logits processor that is not a static mask / penalty is kept for the host (``gp._host_processors``:
+    generate() then runs the loop with the logits copied out after every pass — the slow path, the reference's own); a stopping
+    criterion that is not a static length / EOS rule is kept for the host (``gp._host_criteria``) and evaluated after every iteration."""
     P = len(gp.prompt)
     for proc in (logits_processor or []):
         name = type(proc).__name__
@@ -148,7 +148,12 @@ def lower_processors(gp: GenParams, logits_processor, stopping_criteria) -> GenP
                                           f"decoder prompt ({P} tokens): build it with input_ids_seq_length = the prompt length")
             gp.exp_decay = (start, float(proc.regulation_factor))
         else:
-            raise NotImplementedError(f"logits processor {name} is not supported by the HIP engine (supported: {', '.join(_LOWERABLE_PROCESSORS)})")
+            # any other processor is a Python callable on the logits (the reference hands the list to HF, model.py:1106-1116): it runs on
+            # the host between the engine's passes (WhisperMedusaModel._decode_host_processors: the reference's own loop structure,
+            # one stream at a time, logits copied out after every pass).  Order as in HF: the defaults above first, custom ones after.
+            host = getattr(gp, "_host_processors", None) or []
+            host.append(proc)
+            gp._host_processors = host
     for crit in (stopping_criteria or []):
         name = type(crit).__name__
         if name == "MaxLengthCriteria":
@@ -512,7 +517,8 @@ class WhisperMedusaModel:
             gp = lower_processors(gp, logits_processor, stopping_criteria)
         self._last_prompt = list(gp.prompt)
         feats = input_features.to(self.device, torch.float32).contiguous()
-        n_ctx = self._micro_batches_for(B) if (kwargs.get("streamer") is None and not getattr(gp, "_host_criteria", None)) else 1
+        n_ctx = self._micro_batches_for(B) if (kwargs.get("streamer") is None and not getattr(gp, "_host_criteria", None)
+                                               and not getattr(gp, "_host_processors", None)) else 1
         # language detection has just encoded exactly this batch on the model's own engine: decoding there saves the pool's second
         # encoder pass over the same clips (the automatic policy's gain at 2-3 clips is smaller than an encoder pass)
         if self._micro_batches is None and kwargs.get("_encoded_batch") == B and getattr(self._engine, "_B", None) == B:
@@ -523,14 +529,17 @@ class WhisperMedusaModel:
             self.last_stats = pool.last_stats
             return self._outputs(seqs, gp, return_dict_in_generate, return_segments)
         eng = self.engine
-        # language detection just encoded exactly these clips on this engine (one language group, same order): its encoder output and
-        # cross-K/V are still resident — decode from them instead of running the encoder a second time
-        if not (kwargs.get("_encoded_batch") == B and getattr(eng, "_B", None) == B):
-            eng.encode(feats)                                               # F1 + F2
         streamer = kwargs.get("streamer")
         host_crit = getattr(gp, "_host_criteria", None)
         if streamer is not None and B != 1:
             raise ValueError("streamer only supports batch size 1")        # HF streamers are batch-1
+        if getattr(gp, "_host_processors", None):
+            seqs = self._decode_host_processors(feats, gp, streamer, host_crit)
+            return self._outputs(seqs, gp, return_dict_in_generate, return_segments)
+        # language detection just encoded exactly these clips on this engine (one language group, same order): its encoder output and
+        # cross-K/V are still resident — decode from them instead of running the encoder a second time
+        if not (kwargs.get("_encoded_batch") == B and getattr(eng, "_B", None) == B):
+            eng.encode(feats)                                               # F1 + F2
         if streamer is not None or host_crit:
             # one iteration per engine call: the streamer gets the tokens of every iteration (model.py:1034-1035 prompt, :758-759
             # tokens, :795-796 end); stopping criteria that are not static length / EOS rules are asked after every iteration with
@@ -570,6 +579,102 @@ class WhisperMedusaModel:
             seqs = eng.decode(gp, B)                                        # F3..F14
         self.last_stats = eng.stats()
         return self._outputs(seqs, gp, return_dict_in_generate, return_segments)
+
+    # ---- arbitrary logits processors: the reference's loop with the passes on the engine --------------------------------------------
+    @staticmethod
+    def _static_processors(scores: torch.Tensor, cur_len: int, gp: GenParams) -> torch.Tensor:
+        """The processors the engine fuses into its select kernels, in torch, for the host path: HF's ExponentialDecayLengthPenalty,
+        SuppressTokensAtBeginLogitsProcessor, SuppressTokensLogitsProcessor on rows ``scores [R, V]``; every row sees the same
+        ``cur_len = input_ids.shape[-1]`` (model.py:653-665, :689-694)."""
+        s_ = scores.clone()
+        if gp.exp_decay is not None:
+            start = int(gp.exp_decay[0]) + len(gp.prompt)
+            if cur_len > start:
+                e = gp.eos_token_id
+                s_[:, e] = s_[:, e] + s_[:, e].abs() * (pow(float(gp.exp_decay[1]), cur_len - start) - 1.0)
+        if gp.begin_suppress_tokens and cur_len == gp.begin_index:
+            s_[:, list(gp.begin_suppress_tokens)] = -float("inf")
+        if gp.suppress_tokens:
+            s_[:, list(gp.suppress_tokens)] = -float("inf")
+        return s_
+
+    @staticmethod
+    def _accept_length(v: torch.Tensor, cand: torch.Tensor, gp: GenParams) -> int:
+        """evaluate_posterior for one candidate chain (medusa_utils.py:526-588): exact match at temperature 0 (:547-560), typical
+        acceptance otherwise (:562-577: p_c > min(threshold, alpha exp(-H)), H = -sum p log(p + 1e-5)); the number of leading accepts."""
+        if gp.accept_mode == ACCEPT_GREEDY or not gp.temperature:
+            ok = cand[1:] == torch.argmax(v[:-1], dim=-1)
+        else:
+            p = torch.softmax(v[:-1] / gp.temperature, dim=-1)
+            p_c = torch.gather(p, -1, cand[1:].unsqueeze(-1)).squeeze(-1)
+            H = -torch.sum(p * torch.log(p + 1e-5), dim=-1)
+            ok = p_c > torch.minimum(torch.full_like(H, gp.posterior_threshold), torch.exp(-H) * gp.posterior_alpha)
+        return int(torch.cumprod(ok.int(), dim=0).sum().item())
+
+    def _decode_host_processors(self, feats: torch.Tensor, gp: GenParams, streamer=None, host_crit=None) -> List[List[int]]:
+        """generate() with logits processors that are arbitrary Python callables (the reference hands ANY list to HF's machinery,
+        model.py:1106-1116, and calls it on the base / Medusa logits and on the verify logits, :653-665, :689-694).  The engine's fused
+        loop never lets logits leave the device, so this path runs the reference's loop structure (model.py:634-793) on the host, one
+        stream at a time (the reference asserts batch 1), with every decoder pass on the engine (`wm_forward_logits`: K/V rows appended
+        to the contiguous cache at the pass's position; rejected rows are overwritten by the next pass) and everything that touches
+        logits — the static processors, the caller's processors, arg-max candidates, the posterior — in torch.  Same tokens as the fused
+        loop wherever the caller's processors are pure functions of (ids, logits); orders of magnitude slower: it exists for API
+        completeness, not for throughput.  Candidate chains only."""
+        cfg, eng = self.config, self.engine
+        if cfg.is_tree:
+            raise NotImplementedError("custom logits processors with a candidate tree (medusa_choices with top-k > 1) are not supported")
+        if gp.vanilla:
+            raise NotImplementedError("custom logits processors with vanilla=True are not supported")
+        procs = list(gp._host_processors)
+        K, P, eos = cfg.medusa_num_heads, len(gp.prompt), gp.eos_token_id
+
+        def run(ids_t: torch.Tensor, scores: torch.Tensor) -> torch.Tensor:
+            out = self._static_processors(scores, ids_t.shape[-1], gp)
+            for pr in procs:
+                out = pr(ids_t, out)
+            return out
+
+        def engine_pass(tokens: List[int], pos0: int, disable_medusa: bool) -> torch.Tensor:       # [n_out, T, V]
+            if len(tokens) <= 16:
+                return eng.forward_logits([tokens], pos0, disable_medusa)[:, 0]
+            return torch.cat([eng.forward_logits([tokens[c: c + 16]], pos0 + c, disable_medusa)[:, 0] for c in range(0, len(tokens), 16)], dim=1)
+
+        seqs: List[List[int]] = []
+        n_iter = n_tok = 0
+        hist = [0] * (K + 1)
+        for b in range(feats.shape[0]):
+            eng.encode(feats[b: b + 1].contiguous())
+            ids, kv = list(gp.prompt), 0
+            if streamer is not None:
+                streamer.put(torch.tensor([gp.prompt], dtype=torch.long))
+            while True:
+                L = len(ids)
+                ids_t = torch.tensor([ids], dtype=torch.long)
+                z = engine_pass(ids[kv:L], kv, False)[:, -1]                     # base + Medusa logits of the last position  [K+1, V]
+                cand = torch.argmax(run(ids_t, z), dim=-1)                        # generate_candidates, top-1 chain (medusa_utils.py:446-458)
+                v = run(ids_t, engine_pass(cand.tolist(), L, True)[0])            # verify pass (medusa_utils.py:494-521), same input_ids
+                a = self._accept_length(v, cand, gp)
+                if a == 0:
+                    emit = [int(cand[0]), int(torch.argmax(v[0]))]               # model.py:710-713, medusa_utils.py:636-641
+                    kv = L + 1
+                else:
+                    emit = [int(t) for t in cand[: a + 1]]
+                    kv = L + a
+                ids += emit
+                hist[a] += 1; n_iter += 1; n_tok += len(emit)
+                if streamer is not None:
+                    streamer.put(torch.tensor(emit, dtype=torch.long))
+                stop = bool(host_crit) and any(bool(torch.as_tensor(c(torch.tensor([ids], dtype=torch.long), None)).all()) for c in host_crit)
+                if stop or eos in emit or len(ids) >= gp.max_length or len(ids) + K >= gp.hard_max_length:     # model.py:774-793
+                    break
+            if eos in ids[P:]:                                                    # post-EOS overwrite, model.py:798-810
+                j = ids.index(eos, P)
+                ids = ids[: j + 1] + [eos] * (len(ids) - j - 1)
+            seqs.append(ids)
+            if streamer is not None:
+                streamer.end()
+        self.last_stats = dict(iterations=n_iter, iterations_launched=n_iter, tokens_emitted=n_tok, accept_hist=hist, host_processors=len(procs))
+        return seqs
 
     def _outputs(self, seqs, gp, return_dict_in_generate, return_segments):
         """Default: the padded LongTensor.  ``return_dict_in_generate`` / ``return_segments``: the reference's dict form
