@@ -689,6 +689,7 @@ def test_forward_keyword_surface_follows_the_reference():
     for kw in ("decoder_attention_mask", "head_mask", "decoder_inputs_embeds"):
         with pytest.raises(NotImplementedError, match=kw):
             m.forward(decoder_input_ids=ids, **{kw: torch.zeros(1)})
+    assert m.forward(decoder_input_ids=ids, decoder_attention_mask=torch.ones_like(ids)).logits is not None     # a mask that masks nothing is fine
     with pytest.raises(NotImplementedError, match="labels"):
         m.forward(decoder_input_ids=ids, labels=ids)
 

@@ -865,6 +865,12 @@ class WhisperMedusaModel:
             raise ValueError("decoder_input_ids is required")
         if labels is not None or kwargs.get("labels") is not None:
             raise NotImplementedError("training (labels / loss) is out of scope for the inference engine")
+        if decoder_attention_mask is not None:
+            # a mask that masks nothing is what HF's own generate() passes along; anything else would need per-position masking in the
+            # engine's causal attention (not built: the reference's loop never produces one)
+            if not bool(torch.as_tensor(decoder_attention_mask).bool().all()):
+                raise NotImplementedError("forward(decoder_attention_mask=...) with masked positions is not supported by the HIP engine")
+            decoder_attention_mask = None
         for name, v in (("decoder_attention_mask", decoder_attention_mask), ("head_mask", head_mask), ("decoder_head_mask", decoder_head_mask),
                         ("cross_attn_head_mask", cross_attn_head_mask), ("decoder_inputs_embeds", decoder_inputs_embeds)):
             if v is not None:
