@@ -21,8 +21,10 @@ eng = model.engine
 ARMS = [("k_rows_gemm", dict(WM_ROWS_LDS="0")), ("k_rows_lds auto", dict(WM_ROWS_LDS="1"))]
 for nw, ft in ((4, 1), (5, 1), (8, 1), (4, 2), (6, 2), (8, 2)):
     ARMS.append((f"k_rows_lds NW={nw} FT={ft}", dict(WM_ROWS_LDS="1", WM_RL_NW=str(nw), WM_RL_FT=str(ft))))
+if "--short" in sys.argv:          # counter passes: the shipped kernel and the planned shapes only, 352 rows
+    ARMS = ARMS[:2]
 KEYS = ("WM_ROWS_LDS", "WM_RL_NW", "WM_RL_FT")
-for rows in (352, 176):
+for rows in ((352,) if "--short" in sys.argv else (352, 176)):
     for tag, env in (ARMS if rows == 352 else ARMS[:2]):
         for k in KEYS:
             os.environ.pop(k, None)

@@ -6,7 +6,7 @@ import sqlite3
 import sys
 
 c = sqlite3.connect(sys.argv[1])
-pat = re.compile(sys.argv[3] if len(sys.argv) > 3 else r"k_gemm|k_flash|k_rows_gemm|k_skinny|k_attn|k_ln_tiles")
+pat = re.compile(sys.argv[3] if len(sys.argv) > 3 else r"k_gemm|k_flash|k_rows_gemm|k_rows_lds|k_skinny|k_attn|k_ln_tiles")
 rows = c.execute("select name, counter_name, sum(counter_value), count(distinct dispatch_id) from pmc_events group by name, counter_name").fetchall()
 agg = {}
 for n, cn, v, k in rows:
