@@ -18,14 +18,15 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
-# The driver's `pytest tests -m gpu` has a 1200 s limit (GPUTEST_r04.json: killed there after ~83 of 171 tests).  Three rules keep the
-# default GPU set far below it:
-#   * tests whose cost is host-CPU oracle time at large-v2 (the live fp32-pinned tables, the 8-stream 39-node tree) carry the `slow`
-#     marker and run only with WM_SLOW=1 (`WM_SLOW=1 python -m pytest tests -m "gpu and slow"`); their default-set counterparts compare
-#     against ids minted offline (tests/golden/fp32_pinned_runs.npz, oracle/make_fp32_golden.py);
-#   * the cheap kernel-level parity files run first, tests/test_gpu_large.py last: an overrun would cut the least;
+# The driver's `pytest tests -m gpu` has a 1200 s limit (GPUTEST_r04.json: killed there after ~83 of 171 tests; the suite had grown to
+# 1564 s).  What keeps the GPU set far below it now (round 5: 176 tests in ~300 s on an MI355X box):
 #   * the oracle runs on a bounded number of host threads (WM_ORACLE_THREADS, default 16): its passes are chains of small ops, and on the
-#     GPU box's many cores the default thread pool made them several times slower than on an 8-core container (measured).
+#     GPU box's 256 hardware threads torch's default pool (128) made them 3-12x slower than 16 threads (profiles/r05_oracle_threads.log:
+#     6 iterations 8.8 s at 64 threads, 2.8 s at 16) — the 8-clip fp32-pinned large-v2 tables fell from 708 s to 140 s;
+#   * the fp32-pinned tables also exist against ids minted offline (tests/golden/fp32_pinned_runs.npz, oracle/make_fp32_golden.py):
+#     seconds on the box; the live tables check the golden file against the oracle run on the box, id for id;
+#   * the cheap kernel-level parity files run first, tests/test_gpu_large.py last: an overrun would cut the least;
+#   * a `slow` marker exists for tests that cost minutes of host-CPU oracle time (skipped unless WM_SLOW=1); none carries it at present.
 # tests/test_host.py::test_recorded_gpu_suite_duration_fits_the_driver_limit reads the durations the last whole-suite run recorded.
 GPU_FILE_ORDER = ["test_gpu_parity.py", "test_gpu_tree.py", "test_gpu_features.py", "test_bench_dist.py", "test_gpu_large.py"]
 _DURATIONS = {}

@@ -236,8 +236,8 @@ def test_large_token_agreement_with_the_pinned_fp32_oracle(large, mode, capsys):
     (sim="fp32"), audio -> tokens with nothing shared but checkpoint and waveform: 8 clips x 48 new tokens per mode.  The fp32 side — its own
     log-mel, its own fp32 encoder, its own decode loop — was minted offline by oracle/make_fp32_golden.py on the same CPU-seeded checkpoint
     and the same clips (tests/golden/fp32_pinned_runs.npz; the table refuses another checkpoint); this test runs the engine and compares.
-    (Round 4 ran the oracle live here: 708 s of host time on the GPU box, and the driver's run was killed at its 1200 s limit.  The live form
-    is test_large_fp32_table_live, behind the `slow` marker.)"""
+    (Round 4 ran the oracle live here with torch's default thread pool: 708 s of host time on the GPU box, and the driver's run was killed at
+    its 1200 s limit.  The live form is test_large_fp32_table_live below: 140 s with the bounded thread pool of tests/conftest.py.)"""
     from helpers import record_table, fp32_golden, fp32_agreement_rows
     cfg, sd, model, _ = large
     eng = model.engine
@@ -259,11 +259,10 @@ def test_large_token_agreement_with_the_pinned_fp32_oracle(large, mode, capsys):
     assert agree >= 0.80 * total, (agree, total)
 
 
-@pytest.mark.slow
 @pytest.mark.parametrize("mode", [ACCEPT_GREEDY, ACCEPT_TYPICAL])
 def test_large_fp32_table_live(large, mode, capsys):
-    """The same table with the fp32 oracle run LIVE on the host cores of the GPU box (minutes: WM_SLOW=1), and the offline table checked
-    against it id for id — the golden file cannot drift from the oracle unnoticed."""
+    """The same table with the fp32 oracle run LIVE on the host cores of the GPU box (~70 s per mode on 16 threads), and the offline table
+    checked against it id for id — the golden file cannot drift from the oracle unnoticed."""
     from oracle.whisper_medusa_oracle import Oracle, log_mel
     from helpers import fp32_golden
     cfg, sd, model, _ = large
@@ -349,7 +348,7 @@ def test_large_block_thirty_two_streams_match_the_oracle(large_block):
 
 
 @pytest.mark.parametrize("runs", [pytest.param(((1, 0),), id="one-stream"),
-                                  pytest.param(((3, 1), (8, 5)), id="three-and-eight-streams", marks=pytest.mark.slow)])
+                                  pytest.param(((3, 1), (8, 5)), id="three-and-eight-streams")])
 def test_large_candidate_tree_of_39_nodes_matches_the_oracle(gpu, runs):
     """The shipped shape with a real candidate tree: large-v2, K = 10, medusa_choices = [1, 2, 2, 1 x 8] — top-2 on
     the first two heads, 39 nodes in three 16-row query tiles, 4 paths.  One stream, stream 1 of a 3-stream batch and stream 5 of an 8-stream batch (312 verify rows) against

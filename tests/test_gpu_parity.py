@@ -534,7 +534,7 @@ def test_token_agreement_with_the_pinned_fp32_oracle_end_to_end(gpu, mode, capsy
     reference's own code in tests/test_oracle_golden.py — running its OWN log-mel and encoder, on 16 clips of tiny.en shape.
     Nothing is shared between the two sides but the checkpoint and the waveform.  The oracle's side was minted offline
     (oracle/make_fp32_golden.py -> tests/golden/fp32_pinned_runs.npz, same CPU-seeded checkpoint, same clips; the live form is
-    test_tiny_fp32_table_live behind the `slow` marker).  Reports, per clip, how many generated ids agree before the first
+    test_tiny_fp32_table_live below).  Reports, per clip, how many generated ids agree before the first
     divergence and the oracle's decision margins at that point; asserts floors on the agreement.
     (The bf16-contract oracle fed with the engine's encoder output agrees bit-exactly: test_decode_tokens_bit_exact.)"""
     from helpers import record_table, fp32_golden, fp32_agreement_rows
@@ -568,10 +568,9 @@ def test_token_agreement_with_the_pinned_fp32_oracle_end_to_end(gpu, mode, capsy
     model.engine.close()
 
 
-@pytest.mark.slow
 @pytest.mark.parametrize("mode", [ACCEPT_GREEDY, ACCEPT_TYPICAL])
 def test_tiny_fp32_table_live(mode):
-    """The offline table against the fp32 oracle run live (WM_SLOW=1): id for id."""
+    """The offline table against the fp32 oracle run live on the box's host cores: id for id."""
     from helpers import fp32_golden
     cfg = MedusaConfig.tiny_en(K=4)
     sd = synth.synth_state_dict(cfg, seed=0)

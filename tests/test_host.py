@@ -728,7 +728,7 @@ def test_recorded_gpu_suite_duration_fits_the_driver_limit():
     in total — with no single test above 120 s, so that one slow box cannot eat the margin."""
     import json
     rec = json.load(open(os.path.join(ROOT, "tests", "gpu_suite_durations.json")))
-    assert rec["failed"] == 0 and rec["passed"] >= 150 and not rec["slow_included"], {k: v for k, v in rec.items() if k != "durations"}
+    assert rec["failed"] == 0 and rec["passed"] >= 170, {k: v for k, v in rec.items() if k != "durations"}
     assert rec["total_s"] <= 900.0, rec["total_s"]
     worst = max(rec["durations"].items(), key=lambda kv: kv[1])
     assert worst[1] <= 120.0, worst
