@@ -251,7 +251,24 @@ def test_arbitrary_logits_processors_match_the_fused_loop(gpu, heads):
         assert model.last_stats["host_processors"] == 1 and Identity.calls >= 4
         assert host.tolist() == fused.tolist(), (heads, temperature)
         assert model.last_stats["accept_hist"][: cfg.medusa_num_heads + 1] == st_fused["accept_hist"][: cfg.medusa_num_heads + 1]
-    P = len(model._last_prompt)
+    # a long decoder prompt (prompt_ids conditioning: 21 + 2 tokens, more than one 16-row pass) and a host-side stopping criterion on top
+    from transformers.generation.stopping_criteria import StoppingCriteria
+    pid = torch.tensor([cfg.prev_sot_token_id if cfg.prev_sot_token_id < cfg.vocab_size else 9] + list(range(100, 120)))
+    fused_p = model.generate(feats[:1], prompt_ids=pid, **kw)
+    host_p = model.generate(feats[:1], prompt_ids=pid, logits_processor=[Identity()], **kw)
+    assert host_p.tolist() == fused_p.tolist() and len(model._last_prompt) == 21 + len(synth.default_prompt(cfg))
+
+    class StopAfter(StoppingCriteria):
+        def __init__(self, n): self.n = n
+        def __call__(self, input_ids, scores, **kw_):
+            return torch.tensor([input_ids.shape[-1] >= self.n])
+
+    Pp = len(model._last_prompt)
+    cut = model.generate(feats[:1], prompt_ids=pid, logits_processor=[Identity()], stopping_criteria=[StopAfter(Pp + 6)], **kw)
+    n_cut = cut.shape[1]                                             # one stream: the tensor is exactly its sequence
+    assert n_cut <= fused_p.shape[1] and cut[0].tolist() == fused_p[0, :n_cut].tolist()
+    assert (Pp + 6 <= n_cut < Pp + 6 + cfg.medusa_num_heads + 1) or cfg.eos_token_id in cut[0, Pp:].tolist()     # stopped at the first iteration that reached the length
+    P = len(synth.default_prompt(cfg))
     ban = sorted(set(fused[0, P:].tolist()) - {cfg.eos_token_id, cfg.pad_token_id})[:3]
     want = model.generate(feats, suppress_tokens=sorted(set(cfg.suppress_tokens or []) | set(ban)), **kw)
     got = model.generate(feats, logits_processor=[Ban(ban)], **kw)
