@@ -546,111 +546,6 @@ k_rows_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int 
     TL_END
 }
 
-// ---- more than 32 token rows, LayerNorm in the GEMM's own prologue (round 5) --------------------------------------------------------------
-// The batched LayerNorm-fed GEMMs (LN1 + QKV, LN2 + cross-q, LN3 + FC1) ran as k_ln_tiles (2..22 blocks of work between two kernel
-// boundaries: 96 launches = 12-15 % of a 32-stream step) + k_rows_gemm.  Hand-offs inside a launch cost more than the launch (this round's
-// LayerNorm-in-the-producer's-tail measurement); what costs no hand-off at all is the CONSUMER normalising the rows it reads: a block of
-// k_rows_gemm already reads the complete K range of its two token tiles — one K-slice per wave — i.e. exactly the slicing of k_ln_tiles.
-// Here each wave loads its slice of the two tiles' fp32 residual rows (4 bytes per element: the bytes of the hi + lo planes it would have
-// read), the block exchanges the per-row statistics through LDS with the LdNormT code (same slices, same order: bit-identical operands),
-// every wave normalises its fragments in registers and multiplies.  The normalisation is repeated by every feature block (N16 / RT of them):
-// VALU work that hides under the L2-bound operand traffic of these launches (k_skinny2_norm, the two-tile form of the 32-row passes, is
-// latency-bound instead and loses).  Accumulation order = k_rows_gemm's = the 16-row kernel's.
-template <int NKR, int RT, bool W8, class Ld, class Ep>
-__global__ void __launch_bounds__(320)
-k_rows_norm_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int N16, int K32, int ksplit, const int* __restrict__ done,
-                 Ld ld, int MT, Ep ep, const int* __restrict__ ntiles)
-{
-    constexpr int TT = 2, G = 4;
-    static_assert(NKR % G == 0, "K-slice is a multiple of 4 k-tiles");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (done && *done) return;
-    if (ntiles && (int)blockIdx.y * TT >= *ntiles) return;          // merged-step schedule: no rows in this token-tile group in this step
-    const int lane = threadIdx.x & 63;
-    const int ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int rt0 = blockIdx.x * RT, mt0 = blockIdx.y * TT;
-    const int kt0 = ks * NKR;
-    // the launch's request batch: LayerNorm parameters, both tiles' rows (rows beyond the pass re-read its last row: LdNormT::issue), then the
-    // first group of weight fragments
-    typename Ld::template Regs<NKR> x0, x1;
-    ld.template issue<NKR>(x0, smem, kt0, lane, mt0 * 16);
-    ld.template issue<NKR>(x1, smem, kt0, lane, min(mt0 + 1, MT - 1) * 16, true, false);
-    size_t wp[RT];
-#pragma unroll
-    for (int i = 0; i < RT; ++i) wp[i] = ((size_t)min(rt0 + i, N16 - 1) * K32 + kt0) * 512 + lane * 8;
-    bf16x8_t a[RT][G];
-#pragma unroll
-    for (int u = 0; u < G; ++u)
-#pragma unroll
-        for (int i = 0; i < RT; ++i) a[i][u] = ld_wfrag<W8, false>(W, wp[i] + (size_t)u * 512);
-    ld.template stage<NKR>(x0, smem);
-    ld.template stats<NKR>(x0, smem, ks, ksplit, true, lane, 0);
-    ld.template stats<NKR>(x1, smem, ks, ksplit, true, lane, 1);
-    f32x4_t acc[RT][TT];
-#pragma unroll
-    for (int i = 0; i < RT; ++i)
-#pragma unroll
-        for (int j = 0; j < TT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kg = 0; kg < NKR; kg += G) {
-        bf16x8_t an[RT][G];
-        if (kg + G < NKR) {
-#pragma unroll
-            for (int u = 0; u < G; ++u)
-#pragma unroll
-                for (int i = 0; i < RT; ++i) an[i][u] = ld_wfrag<W8, false>(W, wp[i] + (size_t)(kg + G + u) * 512);
-        }
-#pragma unroll
-        for (int u = 0; u < G; ++u) {
-            bf16x8_t h0, l0, h1, l1;
-            ld.template frag<NKR>(x0, smem, kg + u, kt0 + kg + u, lane, h0, l0);
-            ld.template frag<NKR>(x1, smem, kg + u, kt0 + kg + u, lane, h1, l1);
-#pragma unroll
-            for (int i = 0; i < RT; ++i) {
-                acc[i][0] = mfma16(a[i][u], h0, acc[i][0]); acc[i][0] = mfma16(a[i][u], l0, acc[i][0]);
-                acc[i][1] = mfma16(a[i][u], h1, acc[i][1]); acc[i][1] = mfma16(a[i][u], l1, acc[i][1]);
-            }
-        }
-        if (kg + G < NKR) {
-#pragma unroll
-            for (int u = 0; u < G; ++u)
-#pragma unroll
-                for (int i = 0; i < RT; ++i) a[i][u] = an[i][u];
-        }
-    }
-    // K-slice partials through LDS, summed in slice order (k_rows_gemm's reduce), behind the LayerNorm staging area
-    float4* red = reinterpret_cast<float4*>(smem + ld.lds_bytes());
-    if (ksplit > 1) {
-#pragma unroll
-        for (int i = 0; i < RT; ++i)
-#pragma unroll
-            for (int j = 0; j < TT; ++j)
-                red[((i * TT + j) * ksplit + ks) * 64 + lane] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-        __syncthreads();
-        for (int e = threadIdx.x; e < RT * TT * 64; e += blockDim.x) {
-            const int t = e >> 6, l2 = e & 63, i = t / TT, j = t - i * TT;
-            f32x4_t sacc = {0.f, 0.f, 0.f, 0.f};
-            for (int k2 = 0; k2 < ksplit; ++k2) {
-                const float4 p = red[(t * ksplit + k2) * 64 + l2];
-                sacc[0] += p.x; sacc[1] += p.y; sacc[2] += p.z; sacc[3] += p.w;
-            }
-            if (rt0 + i < N16 && mt0 + j < MT) {
-                if constexpr (W8) sacc = scale4(sacc, wscale, (rt0 + i) * 16 + 4 * (l2 >> 4));
-                ep.store4((mt0 + j) * 16 + (l2 & 15), (rt0 + i) * 16 + 4 * (l2 >> 4), sacc);
-            }
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < RT; ++i)
-#pragma unroll
-            for (int j = 0; j < TT; ++j)
-                if (rt0 + i < N16 && mt0 + j < MT) {
-                    if constexpr (W8) acc[i][j] = scale4(acc[i][j], wscale, (rt0 + i) * 16 + 4 * (lane >> 4));
-                    ep.store4((mt0 + j) * 16 + (lane & 15), (rt0 + i) * 16 + 4 * (lane >> 4), acc[i][j]);
-                }
-    }
-}
-
 // ---- 17..32 token rows (two token tiles): the weight-streaming kernel with a second token tile ---------------------
 // The base pass of up to 32 streams (and every vanilla step) is still a weight-streaming problem: 3-13 MB of weights against
 // <= 64 KB of token operand.  Same organisation as k_skinny_gemm — the wave's whole K-slice of the weight stream, both token
@@ -1005,9 +900,6 @@ k_tile_gemm(const bf16_t* __restrict__ W, int N16, int K32, int nk, const bf16_t
 }
 
 // ---- host-side launch plan -------------------------------------------------------------------
-#ifndef WM_ROWS_NORM_DEFAULT
-#define WM_ROWS_NORM_DEFAULT 0          // k_rows_norm_gemm (LayerNorm in the batched GEMM's prologue): WM_ROWS_NORM overrides
-#endif
 static thread_local const int* g_skinny_done = nullptr;     // device flag checked by every launch of this translation unit
 // merged-step schedule (wm_decoder.hip wm_dec_step): the pass's rows are dense and their number changes from step to step while the launches
 // (a captured graph) are sized for the maximum: device word = 16-row token tiles that hold rows in this step; the batched kernels' blocks
@@ -1271,32 +1163,6 @@ static inline hipError_t launch_skinny_norm_t(hipStream_t st, WRef W, int N16, i
             else hipLaunchKernelGGL((k_skinny2_norm<4, false, Ld, Ep>), dim3(grid), dim3(threads), lds, st, W.w, W.scale, N16, K32, p.ksplit, p.rt, magic, g_skinny_done, ld, ep);
         }
         return hipGetLastError();
-    }
-    // three or more token tiles: the LayerNorm in the GEMM's own prologue (k_rows_norm_gemm; WM_ROWS_NORM=0: LayerNorm launch + k_rows_gemm).
-    // Same RT rule as launch_skinny_mt_nk; blocks of <= 5 K-slice waves (320 threads: both tiles' fp32 rows live in registers).
-    if (MT >= 3 && skinny_env("WM_ROWS_NORM", WM_ROWS_NORM_DEFAULT) && p.ksplit <= 5 && p.ksplit * p.nk == K32 && (p.nk == 8 || p.nk == 4) &&
-        !use_tile_gemm(N16, K32, MT, W.scale != nullptr, p.nk)) {
-        g_ln_pf_extra = nullptr;
-        static const int min_blocks = skinny_env("WM_ROWS_GEMM_MIN_BLOCKS", 400);
-        const int groups = (MT + 1) / 2;
-        const int RT = (((N16 + 3) / 4) * groups >= min_blocks) ? 4 : ((((N16 + 1) / 2) * groups >= min_blocks) ? 2 : 1);
-        const dim3 grid((N16 + RT - 1) / RT, groups);
-        const size_t lds = (size_t)ld.lds_bytes() + (p.ksplit > 1 ? (size_t)RT * 2 * p.ksplit * 1024 : 0);
-#define WM_RNG(NKv, RTv, W8v)                                                                                                  \
-        do {                                                                                                                  \
-            auto kern = k_rows_norm_gemm<NKv, RTv, W8v, Ld, Ep>;                                                              \
-            if (lds > 64 * 1024) { hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e_ != hipSuccess) return e_; } \
-            hipLaunchKernelGGL(kern, grid, dim3(64 * p.ksplit), lds, st, W.w, W.scale, N16, K32, p.ksplit, g_skinny_done, ld, MT, ep, g_skinny_ntiles); \
-            return hipGetLastError();                                                                                          \
-        } while (0)
-        if (W.scale) {
-            if (p.nk == 8) { if (RT == 4) WM_RNG(8, 4, true); if (RT == 2) WM_RNG(8, 2, true); WM_RNG(8, 1, true); }
-            if (RT == 4) WM_RNG(4, 4, true); if (RT == 2) WM_RNG(4, 2, true); WM_RNG(4, 1, true);
-        } else {
-            if (p.nk == 8) { if (RT == 4) WM_RNG(8, 4, false); if (RT == 2) WM_RNG(8, 2, false); WM_RNG(8, 1, false); }
-            if (RT == 4) WM_RNG(4, 4, false); if (RT == 2) WM_RNG(4, 2, false); WM_RNG(4, 1, false);
-        }
-#undef WM_RNG
     }
     // weight prefetch riding on the LayerNorm launch (token-tile path with bf16 weights only; WM_LN_PREFETCH=0 turns it off)
     const int ln_pf = skinny_env("WM_LN_PREFETCH", 1);
