@@ -70,6 +70,48 @@ def test_wav_decode_matches_torchaudio_normalisation(tmp_path):
         assert sr == 8000 and np.allclose(v[0], want, atol=0)
 
 
+def test_wav_decode_agrees_with_scipys_reader_on_every_sample_format(tmp_path):
+    """read_wav against an independent decoder (scipy.io.wavfile) on the formats torchaudio.load reads: PCM 8 / 16 / 32 bit, IEEE float 32 /
+    64 (format tag 3, which the standard library's `wave` refuses), mono and stereo; plus a hand-built WAVE_FORMAT_EXTENSIBLE header
+    (tag 0xFFFE with the PCM sub-format GUID: what multi-channel / high-resolution writers emit) and a file with an odd-sized extra chunk
+    in front of the data."""
+    from scipy.io import wavfile
+    rng = np.random.default_rng(3)
+    for dt, scale in ((np.uint8, None), (np.int16, 32768.0), (np.int32, 2147483648.0), (np.float32, 1.0), (np.float64, 1.0)):
+        for ch in (1, 2):
+            if dt == np.uint8:
+                a = rng.integers(0, 256, size=(777, ch), dtype=np.uint8)
+                want = (a.astype(np.float32) - 128.0) / 128.0
+            elif np.issubdtype(dt, np.integer):
+                a = rng.integers(np.iinfo(dt).min, np.iinfo(dt).max, size=(777, ch), dtype=dt)
+                want = (a.astype(np.float64) / scale).astype(np.float32)
+            else:
+                a = rng.uniform(-1, 1, size=(777, ch)).astype(dt)
+                want = a.astype(np.float32)
+            q = tmp_path / f"s_{np.dtype(dt).name}_{ch}.wav"
+            wavfile.write(str(q), 22050, a if ch == 2 else a[:, 0])
+            sr_s, back = wavfile.read(str(q))                       # the independent reader sees what we wrote
+            assert sr_s == 22050 and np.array_equal(np.atleast_2d(back.T).T.reshape(777, ch), a)
+            v, sr = read_wav(q)
+            assert sr == 22050 and v.shape == (ch, 777) and v.dtype == np.float32 and np.array_equal(v, want.T), (dt, ch)
+    # WAVE_FORMAT_EXTENSIBLE, 24-bit PCM in 3-byte containers, stereo, with a 'LIST' chunk of odd size before 'data'
+    samples = [-(1 << 23), 1 << 22, 12345, -54321]                 # L R L R
+    data = b"".join(struct.pack("<i", s_)[:3] for s_ in samples)
+    guid_pcm = struct.pack("<H", 1) + bytes.fromhex("000000001000800000aa00389b71")
+    fmt = struct.pack("<HHIIHH", 0xFFFE, 2, 48000, 48000 * 6, 6, 24) + struct.pack("<HHI", 22, 24, 3) + guid_pcm
+    lst = b"LIST" + struct.pack("<I", 5) + b"abcde" + b"\x00"
+    body = b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt + lst + b"data" + struct.pack("<I", len(data)) + data
+    q = tmp_path / "ext.wav"
+    q.write_bytes(b"RIFF" + struct.pack("<I", len(body)) + body)
+    v, sr = read_wav(q)
+    assert sr == 48000 and v.shape == (2, 2) and np.allclose(v, [[-1.0, 12345 / (1 << 23)], [0.5, -54321 / (1 << 23)]], atol=0)
+    with pytest.raises(ValueError, match="format tag"):
+        bad = bytearray(q.read_bytes()); bad[20:22] = struct.pack("<H", 85)      # MPEG layer 3 in a WAV container
+        (tmp_path / "mp3.wav").write_bytes(bytes(bad)); read_wav(tmp_path / "mp3.wav")
+    with pytest.raises(ValueError, match="RIFF"):
+        (tmp_path / "x.wav").write_bytes(b"fLaC" + bytes(40)); read_wav(tmp_path / "x.wav")
+
+
 def test_resample_len_helper_of_the_c_abi(built_lib):
     lib = ctypes.CDLL(built_lib)
     lib.wm_resample_len.argtypes = [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32]
