@@ -5,6 +5,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r05c7; mkdir -p $O
+export WM_LIB=$R/whisper-medusa_amd/whisper_medusa/libwm_enctiles.so   # tests/microbench/r05_build_enc_tiles.sh (at the time of the call these knobs were in the product library)
 echo "== timing"
 timeout 400 python tests/microbench/r05_enc_balance.py --out $O/r05_enc_balance.json 2>&1 | grep -v "^$" | tail -30
 echo "== kernel trace, one clip"

@@ -895,12 +895,12 @@ def test_arbitrary_logits_processors_run_the_reference_loop_on_the_host():
 
 def test_measured_negative_kernels_kept_as_patches_still_apply():
     """Kernels that were built, measured slower and taken out of the product live on as patches against the product sources
-    (tests/microbench/*.patch: round 4's k_rows_gemm variants, round 5's k_rows_lds + LayerNorm tail and k_rows_norm_gemm; profiles/ holds the
+    (tests/microbench/*.patch: round 4's k_rows_gemm variants, round 5's k_rows_lds + LayerNorm tail, k_rows_norm_gemm and the few-clip encoder tiles; profiles/ holds the
     measurements).  They must keep applying, or the A/B cannot be repeated (`tests/microbench/r05_build_rowslds.sh`)."""
     import shutil
     import subprocess
     if shutil.which("git") is None or not os.path.isdir(os.path.join(ROOT, ".git")):
         pytest.skip("needs the git work tree")
-    for name in ("r04_rows_variants.patch", "r05_rows_lds_ln_tail.patch", "r05_rows_norm_gemm.patch"):
+    for name in ("r04_rows_variants.patch", "r05_rows_lds_ln_tail.patch", "r05_rows_norm_gemm.patch", "r05_enc_few_clip_tiles.patch"):
         r = subprocess.run(["git", "apply", "--check", os.path.join("tests", "microbench", name)], cwd=ROOT, capture_output=True, text=True)
         assert r.returncode == 0, (name, r.stderr[-400:])

@@ -50,14 +50,9 @@ __device__ __forceinline__ void ring_barrier()
 // 64-row block per CU at most: KS = 2 doubles the waves per CU and halves the dependent K loop (FC2: 80 -> 40 steps).
 // Everywhere else two resident blocks x 2 stages measured faster than one block x 3-4 stages
 // (tests/microbench/enc_sweep.sh: occupancy beats ring depth).
-// XS = K-split over BLOCKS (round 5; one clip, N = d: FC2): block (split, tn, tm) walks the split-th part of K.  Split 0 runs the
-// epilogue as usual (h = (h + bias) + p_0), split s > 0 stores its fp32 partial tile to part[s - 1][m][n] and the NEXT LayerNorm launch
-// adds it to the residual row it reads anyway (k_enc_ln_rows) — a reduce at a launch boundary that exists already: no ticket, no fence,
-// deterministic.  What it buys: 128 x 128 tiles x 2 splits are the same 240 blocks as 64 x 128 tiles, but a CU pulls
-// (128 + 128) x K / 2 operand elements through its L2 -> LDS path instead of (64 + 128) x K: a third less on the path that bounds these GEMMs.
-template <int BM, int NST, int KS, class Ep, int XS = 1>
+template <int BM, int NST, int KS, class Ep>
 __global__ void __launch_bounds__(256 * KS)
-k_gemm_tiled(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32, int tiles_m, int tiles_n, Ep ep, float* __restrict__ part, int part_ld, long part_stride)
+k_gemm_tiled(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32, int tiles_m, int tiles_n, Ep ep)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_all[];
     constexpr int XB = BM / 16 * 2;            // X fragments per stage (m-tiles x 2 k-tiles)
@@ -72,14 +67,12 @@ k_gemm_tiled(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32
     char* smem = smem_all + grp * (NST * STAGE);
     // XCD-aware remap: consecutive tiles of one weight panel stay on one XCD's L2
     int bid = blockIdx.x;
-    const int nwg = tiles_m * tiles_n * XS;
+    const int nwg = tiles_m * tiles_n;
     if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
-    const int split = XS > 1 ? bid / (tiles_m * tiles_n) : 0;         // split-major: an XCD's blocks share one K range
-    if (XS > 1) bid -= split * (tiles_m * tiles_n);
     const int tn = bid / tiles_m, tm = bid - tn * tiles_m;
 
-    const int nkt = (K32 >> 1) / (KS * XS);    // k-steps of this group (the launcher checks divisibility)
-    const int k0 = (split * KS + grp) * nkt;
+    const int nkt = (K32 >> 1) / KS;           // k-steps of this group (the launcher checks divisibility)
+    const int k0 = grp * nkt;
     const bf16_t* xg = X + (size_t)tm * (BM / 16) * K32 * 512 + lane * 8;
     const bf16_t* wg = W + (size_t)tn * 8 * K32 * 512 + lane * 8;
 
@@ -156,17 +149,6 @@ k_gemm_tiled(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32
     }
 
     const int m0 = tm * BM + wm * (BM / 2) + (lane & 15), n0 = tn * GT_BN + wn * 64 + 4 * (lane >> 4);
-    if constexpr (XS > 1) {
-        if (split > 0) {                       // fp32 partial tile, row-major like the residual stream
-            float* pp = part + (size_t)(split - 1) * part_stride + (size_t)m0 * part_ld + n0;
-#pragma unroll
-            for (int j = 0; j < MJ; ++j)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    *reinterpret_cast<float4*>(pp + (size_t)j * 16 * part_ld + i * 16) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-            return;
-        }
-    }
     ep_tiles<4, MJ>(ep, m0, n0, acc);
 }
 
@@ -180,27 +162,7 @@ static inline hipError_t launch_gemm_tiled_bm(hipStream_t st, const bf16_t* X, c
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256 * KS), lds, st, X, W, K32, tiles_m, tiles_n, ep, (float*)nullptr, 0, 0L);
-    return hipGetLastError();
-}
-
-// Residual GEMM with the K loop split over two blocks per 128 x 128 tile (k_gemm_tiled<.., XS = 2>): returns true when the split form
-// was launched — the caller then hands `part` to the next LayerNorm launch, which folds it into the residual stream.
-static inline bool gemm_resid_split_applies(int Mrows, int N, int K32)
-{
-    const int mode = [] { const char* v = std::getenv("WM_ENC_XSPLIT"); return v ? std::atoi(v) : 1; }();       // read per launch (A/B inside one process)
-    if (!mode || Mrows % 128 || N % GT_BN || K32 % 4) return false;
-    const int tiles = (Mrows / 128) * (N / GT_BN);
-    return tiles * 2 <= 256 && (K32 >> 1) / 2 >= 8 && (mode == 2 || (K32 >> 1) >= 40);     // mode 2: the K = d GEMM (out-proj) too
-}
-static inline hipError_t launch_gemm_resid_split(hipStream_t st, const bf16_t* X, const bf16_t* W, int Mrows, int N, int K32, const EpResidual& ep, float* part)
-{
-    const int tiles_m = Mrows / 128, tiles_n = N / GT_BN;
-    constexpr int NST = 4, lds = NST * (128 / 16 * 2 + 16) * 1024;
-    auto kern = k_gemm_tiled<128, NST, 1, EpResidual, 2>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n * 2), dim3(256), lds, st, X, W, K32, tiles_m, tiles_n, ep, part, N, (long)Mrows * N);
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256 * KS), lds, st, X, W, K32, tiles_m, tiles_n, ep);
     return hipGetLastError();
 }
 
@@ -590,17 +552,6 @@ static inline hipError_t launch_gemm_tiled(hipStream_t st, const bf16_t* X, cons
     if (blocks128 < bm64_below) {
         if (small_ks == 2 && (K32 >> 1) % 2 == 0 && (K32 >> 1) >= 8) return launch_gemm_tiled_bm<64, 3, 2>(st, X, W, Mrows, N, K32, ep);
         return launch_gemm_tiled_bm<64, 4, 1>(st, X, W, Mrows, N, K32, ep);
-    }
-    // One balanced round of taller tiles (round 5).  These GEMMs are bound by what ONE CU pulls through its L2 -> LDS path (~50 GB/s with
-    // the ~100 KB in flight that fit the LDS): with 128-row tiles the one-clip QKV GEMM is 360 blocks and FC1 480 on 256 CUs — the CUs
-    // that hold two blocks need twice as long as the others.  192 (QKV) / 256 (FC1) rows make both 240 equal blocks: rounds x (BM + 128)
-    // operand rows per CU falls from 512 to 320 / 384.  Same k order, one accumulator per output: bit-identical to the 128-row tiles.
-    const int balance = [] { const char* v = std::getenv("WM_ENC_BALANCE"); return v ? std::atoi(v) : 1; }();     // read per launch (A/B inside one process)
-    if (balance) {
-        auto cost = [&](int bm) { if (Mrows % bm) return 1 << 30; const int t = (Mrows / bm) * (N / GT_BN); return ((t + 255) / 256) * (bm + GT_BN); };
-        const int c128 = cost(128), c192 = cost(192), c256 = cost(256);
-        if (c192 * 5 <= c128 * 4 && c192 <= c256) return launch_gemm_tiled_bm<192, 3, 1>(st, X, W, Mrows, N, K32, ep);
-        if (c256 * 5 <= c128 * 4) return launch_gemm_tiled_bm<256, 3, 1>(st, X, W, Mrows, N, K32, ep);
     }
     // experiment knob (off): 256-token tiles — a wave owns 128 tokens x 64 features (8 x 4 MFMA tiles, 128 accumulator
     // registers), a quarter fewer LDS reads per MFMA, but one wave per SIMD: measured 511 vs 591 TFLOP/s at 32 clips
@@ -1177,38 +1128,21 @@ k_enc_ln(const float* __restrict__ src, const float* __restrict__ gamma, const f
 // One wave per row (the form of rounds 1-2): with one or two clips the 16-row-group kernel is only 96-192 blocks of serial phases
 // (10.3 us per launch against 6.8 for this one, profiles/r03_kernel_trace_bench_b1.md); its scattered 16-byte stores do not matter at
 // that size.  Same two-pass statistics, another summation order (big-batch and few-clip encoder outputs are not bit-identical anyway).
-// PART: the preceding residual GEMM ran with its K loop split over two blocks (k_gemm_tiled<.., XS = 2>): the row in `src` lacks the
-// second split's partial sums, which lie in `part`; they are added here and the completed row is written back to the residual stream.
-template <bool PART>
 __global__ void __launch_bounds__(256)
-k_enc_ln_rows(float* __restrict__ src, const float* __restrict__ gamma, const float* __restrict__ beta,
-              bf16_t* __restrict__ out_p, int K32, int d, int M, const float* __restrict__ part)
+k_enc_ln_rows(const float* __restrict__ src, const float* __restrict__ gamma, const float* __restrict__ beta,
+              bf16_t* __restrict__ out_p, int K32, int d, int M)
 {
     const int lane = threadIdx.x & 63;
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
     const int nv = d >> 2;
-    float4* sp = reinterpret_cast<float4*>(src + (size_t)m * d);
+    const float4* sp = reinterpret_cast<const float4*>(src + (size_t)m * d);
     float4 v[8], gv[8], bv[8];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int j = lane + 64 * i;
         v[i] = (j < nv) ? sp[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    if constexpr (PART) {
-        const float4* pp = reinterpret_cast<const float4*>(part + (size_t)m * d);
-        float4 pv[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int j = lane + 64 * i;
-            pv[i] = (j < nv) ? pp[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            v[i].x += pv[i].x; v[i].y += pv[i].y; v[i].z += pv[i].z; v[i].w += pv[i].w;
-            if (lane + 64 * i < nv) sp[lane + 64 * i] = v[i];
-        }
     }
     // gamma / beta requested with the row (one batch): loaded inside the output loop, every iteration's parameter loads put an
     // s_waitcnt vmcnt(0) in front of its store, which also waits for the previous iteration's store — 5 dependent round trips per row
@@ -1242,12 +1176,10 @@ k_enc_ln_rows(float* __restrict__ src, const float* __restrict__ gamma, const fl
     }
 }
 
-// part != nullptr: the residual rows still lack the partial sums of the split residual GEMM in front of this launch (launch_gemm_resid_split)
-static inline void launch_enc_ln(hipStream_t st, float* src, const float* gamma, const float* beta, bf16_t* out_p, int K32, int d, int M, const float* part = nullptr)
+static inline void launch_enc_ln(hipStream_t st, const float* src, const float* gamma, const float* beta, bf16_t* out_p, int K32, int d, int M)
 {
     static const int rows_below = [] { const char* v = std::getenv("WM_ENC_LN_ROWS_BELOW"); return v ? std::atoi(v) : 256; }();   // 16-row groups
-    if (part) { hipLaunchKernelGGL(k_enc_ln_rows<true>, dim3((M + 3) / 4), dim3(256), 0, st, src, gamma, beta, out_p, K32, d, M, part); return; }
-    if (M / 16 < rows_below) { hipLaunchKernelGGL(k_enc_ln_rows<false>, dim3((M + 3) / 4), dim3(256), 0, st, src, gamma, beta, out_p, K32, d, M, (const float*)nullptr); return; }
+    if (M / 16 < rows_below) { hipLaunchKernelGGL(k_enc_ln_rows, dim3((M + 3) / 4), dim3(256), 0, st, src, gamma, beta, out_p, K32, d, M); return; }
     if (K32 <= 40) hipLaunchKernelGGL(k_enc_ln<10>, dim3(M / 16), dim3(256), 0, st, src, gamma, beta, out_p, K32, d, M);
     else hipLaunchKernelGGL(k_enc_ln<16>, dim3(M / 16), dim3(256), 0, st, src, gamma, beta, out_p, K32, d, M);     // d <= 2048 (wm_create)
 }
@@ -1625,9 +1557,6 @@ int wm_enc_encode(wm_ctx* ctx, const float* feats, int B)
         WM_HIP(hipGetLastError());
         WM_HIP(launch_gemm_tiled(st, ctx->A2, ctx->conv2_w, M, d, K32c, EpConv2{ctx->eh, ctx->conv2_b, ctx->enc_pos, S, Spad, d}));
     }
-    // residual GEMMs with the K loop split over two blocks (few clips, bf16 path): the partial of the second split waits in ctx->epart
-    // until the next LayerNorm launch folds it into the residual stream
-    const float* pend = nullptr;
     for (int l = 0; l < ctx->cfg.enc_layers; ++l) {
         const EncLayerW& w = ctx->enc[l];
         if (f8) {
@@ -1636,8 +1565,7 @@ int wm_enc_encode(wm_ctx* ctx, const float* feats, int B)
             WM_HIP(launch_gemm_f8(st, ctx->exn8, w.qkv_w8, M, 3 * d, (K32 + 3) / 4,
                                   EpScaled<EpQKVEnc>{EpQKVEnc{ctx->eq, ctx->ek, ctx->evt, w.qkv_b, Spad, H, d}, ctx->exs, w.qkv_ws}));
         } else {
-            launch_enc_ln(st, ctx->eh, w.ln1_w, w.ln1_b, ctx->exn, K32, d, M, pend);
-            pend = nullptr;
+            launch_enc_ln(st, ctx->eh, w.ln1_w, w.ln1_b, ctx->exn, K32, d, M);
             WM_HIP(hipGetLastError());
             WM_HIP(launch_gemm_tiled(st, ctx->exn, w.qkv_w, M, 3 * d, K32, EpQKVEnc{ctx->eq, ctx->ek, ctx->evt, w.qkv_b, Spad, H, d}));
         }
@@ -1658,27 +1586,18 @@ int wm_enc_encode(wm_ctx* ctx, const float* feats, int B)
         else
             hipLaunchKernelGGL(k_flash_enc<2>, dim3(Spad / 128, H, B), dim3(256), 3 * 16 * 1024, st, ctx->eq, ctx->ek, ctx->evt, ctx->exn, S, Spad, H, K32);
         WM_HIP(hipGetLastError());
-        if (!f8 && ctx->epart && (size_t)M * d <= ctx->epart_n && gemm_resid_split_applies(M, d, K32)) {
-            WM_HIP(launch_gemm_resid_split(st, ctx->exn, w.out_w, M, d, K32, EpResidual{ctx->eh, w.out_b, d, M}, ctx->epart));
-            pend = ctx->epart;
-        } else
-            WM_HIP(launch_gemm_tiled(st, ctx->exn, w.out_w, M, d, K32, EpResidual{ctx->eh, w.out_b, d, M}));
+        WM_HIP(launch_gemm_tiled(st, ctx->exn, w.out_w, M, d, K32, EpResidual{ctx->eh, w.out_b, d, M}));
         if (f8) {
             hipLaunchKernelGGL(k_enc_ln_f8<false>, dim3((M + 3) / 4), dim3(256), 0, st, ctx->eh, w.ln2_w, w.ln2_b, ctx->exn8, ctx->exs, nullptr, K32, d, M);
             WM_HIP(hipGetLastError());
             WM_HIP(launch_gemm_f8(st, ctx->exn8, w.fc1_w8, M, ffn, (K32 + 3) / 4,
                                   EpScaled<EpPackedAct<2>>{EpPackedAct<2>{ctx->eff, nullptr, w.fc1_b, ffn / 32, M}, ctx->exs, w.fc1_ws}));
         } else {
-            launch_enc_ln(st, ctx->eh, w.ln2_w, w.ln2_b, ctx->exn, K32, d, M, pend);
-            pend = nullptr;
+            launch_enc_ln(st, ctx->eh, w.ln2_w, w.ln2_b, ctx->exn, K32, d, M);
             WM_HIP(hipGetLastError());
             WM_HIP(launch_gemm_tiled(st, ctx->exn, w.fc1_w, M, ffn, K32, EpPackedAct<2>{ctx->eff, nullptr, w.fc1_b, ffn / 32, M}));
         }
-        if (!f8 && ctx->epart && (size_t)M * d <= ctx->epart_n && gemm_resid_split_applies(M, d, ffn / 32)) {
-            WM_HIP(launch_gemm_resid_split(st, ctx->eff, w.fc2_w, M, d, ffn / 32, EpResidual{ctx->eh, w.fc2_b, d, M}, ctx->epart));
-            pend = ctx->epart;
-        } else
-            WM_HIP(launch_gemm_tiled(st, ctx->eff, w.fc2_w, M, d, ffn / 32, EpResidual{ctx->eh, w.fc2_b, d, M}));
+        WM_HIP(launch_gemm_tiled(st, ctx->eff, w.fc2_w, M, d, ffn / 32, EpResidual{ctx->eh, w.fc2_b, d, M}));
     }
     // cross K/V of every decoder layer (+ the Medusa block) in one GEMM
     if (f8) {
@@ -1688,7 +1607,7 @@ int wm_enc_encode(wm_ctx* ctx, const float* feats, int B)
         WM_HIP(launch_gemm_f8(st, ctx->exn8, ctx->ckv_w8, M, ctx->nkv * 2 * d, (K32 + 3) / 4,
                               EpScaled<EpCrossKV>{EpCrossKV{ctx->kx, ctx->vx, ctx->ckv_b, Spad, H, d, B}, ctx->exs, ctx->ckv_ws}));
     } else {
-        launch_enc_ln(st, ctx->eh, ctx->enc_lnf_w, ctx->enc_lnf_b, ctx->enc_out, K32, d, M, pend);
+        launch_enc_ln(st, ctx->eh, ctx->enc_lnf_w, ctx->enc_lnf_b, ctx->enc_out, K32, d, M);
         WM_HIP(hipGetLastError());
         WM_HIP(launch_gemm_tiled(st, ctx->enc_out, ctx->ckv_w, M, ctx->nkv * 2 * d, K32,
                                  EpCrossKV{ctx->kx, ctx->vx, ctx->ckv_b, Spad, H, d, B}));

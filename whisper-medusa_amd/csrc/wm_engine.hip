@@ -30,7 +30,7 @@ extern "C" void wm_destroy(wm_ctx* ctx)
     if (ctx->graph) hipGraphExecDestroy(ctx->graph);
     if (ctx->graph_base) hipGraphExecDestroy(ctx->graph_base);
     if (ctx->hostflags) hipHostFree(ctx->hostflags);
-    void* bufs[] = {ctx->feats_own, ctx->clipmax, ctx->A1, ctx->a1, ctx->A2, ctx->eh, ctx->exn, ctx->eq, ctx->ek, ctx->evt, ctx->eff, ctx->epart,
+    void* bufs[] = {ctx->feats_own, ctx->clipmax, ctx->A1, ctx->a1, ctx->A2, ctx->eh, ctx->exn, ctx->eq, ctx->ek, ctx->evt, ctx->eff,
                     ctx->enc_out, ctx->kx, ctx->vx, ctx->kc, ctx->vc, ctx->h, ctx->hblk, ctx->hf, ctx->qbuf, ctx->xbuf, ctx->fbuf,
                     ctx->ybuf, ctx->cml, ctx->co, ctx->ticket, ctx->logits, ctx->amax, ctx->pc, ctx->part1, ctx->part2, ctx->ids, ctx->L, ctx->kvlen,
                     ctx->finished, ctx->cand, ctx->niter, ctx->hist, ctx->supmask, ctx->exppen, ctx->tap_tok, ctx->done,
@@ -173,8 +173,6 @@ extern "C" int wm_create(const wm_config* cfg, const wm_weights* w, int device, 
     CREATE_HIP(dev_alloc(&ctx->ek, Menc * d, st));
     CREATE_HIP(dev_alloc(&ctx->evt, Menc * d, st));
     CREATE_HIP(dev_alloc(&ctx->eff, Menc * ctx->ffn, st));
-    ctx->epart_n = std::min(Menc * d, (size_t)128 * 128 * 128);      // split residual GEMMs run with <= 128 tiles of 128 x 128
-    CREATE_HIP(dev_alloc(&ctx->epart, ctx->epart_n, st));
     CREATE_HIP(dev_alloc(&ctx->enc_out, Menc * d, st));
     CREATE_HIP(dev_alloc(&ctx->kx, (size_t)ctx->nkv * Menc * d, st));
     CREATE_HIP(dev_alloc(&ctx->vx, (size_t)ctx->nkv * Menc * d, st));

@@ -83,8 +83,6 @@ struct wm_ctx {
     bf16_t* exn = nullptr;            // packed [B*Spad][d]
     bf16_t *eq = nullptr, *ek = nullptr, *evt = nullptr;   // [B][H][Spad][64] / vt [B][H][64][Spad]
     bf16_t* eff = nullptr;            // packed [B*Spad][ffn]
-    float* epart = nullptr;           // [<= 128 tiles x 128 rows][d] fp32: partial sums of the second K-split of a split residual GEMM (few clips)
-    size_t epart_n = 0;               // its size in floats
     bf16_t* enc_out = nullptr;        // packed [B*Spad][d]
     int K1pad = 0;
     bool enc_f8 = false;              // fp8 MFMA encoder path
