@@ -904,3 +904,51 @@ def test_measured_negative_kernels_kept_as_patches_still_apply():
     for name in ("r04_rows_variants.patch", "r05_rows_lds_ln_tail.patch", "r05_rows_norm_gemm.patch", "r05_enc_few_clip_tiles.patch"):
         r = subprocess.run(["git", "apply", "--check", os.path.join("tests", "microbench", name)], cwd=ROOT, capture_output=True, text=True)
         assert r.returncode == 0, (name, r.stderr[-400:])
+
+
+def test_generate_reads_a_passed_generation_config_and_explicit_arguments_win():
+    """generate(generation_config=...) — the reference hands it to HF's _prepare_generation_config (model.py:936-943): a copy of the
+    passed config updated by the call's explicit arguments.  The fields this path reads (length budget, language / task, suppress
+    lists, length penalty, acceptance thresholds, return_dict_in_generate, the not-supported switches) follow that rule."""
+    from transformers import GenerationConfig
+    from whisper_medusa import WhisperMedusaModel
+    cfg = MedusaConfig.micro(K=4)
+    cfg.is_multilingual = True
+    cfg.vocab_size = 51865
+    cfg.lang_to_id = {"<|en|>": 50259, "<|de|>": 50261}
+    cfg.task_to_id = {"transcribe": 50359, "translate": 50358}
+    m = WhisperMedusaModel(cfg, {})
+    m._max_batch = 1
+    feats = torch.zeros(1, cfg.num_mel_bins, cfg.n_mel_frames)
+    seen = []
+
+    class Eng(_FakeEngine):
+        def decode(self, gp, B, **kw):
+            seen.append(gp)
+            return super().decode(gp, B, **kw)
+
+    m._engine = Eng(cfg, [50259])
+    gc = GenerationConfig(max_new_tokens=9, language="de", task="translate", suppress_tokens=[3, 4], begin_suppress_tokens=[5],
+                          exponential_decay_length_penalty=(6, 1.25), return_dict_in_generate=True)
+    gc.posterior_threshold, gc.posterior_alpha = 0.2, 0.4           # MedusaGenerationConfig fields (medusa_utils.py:12-40)
+    out = m.generate(feats, generation_config=gc)
+    gp = seen[-1]
+    assert gp.prompt[1:3] == [50261, 50358] and gp.max_length == len(gp.prompt) + 9
+    assert list(gp.suppress_tokens) == [3, 4] and list(gp.begin_suppress_tokens) == [5] and tuple(gp.exp_decay) == (6, 1.25)
+    assert (gp.posterior_threshold, gp.posterior_alpha) == (0.2, 0.4) and hasattr(out, "sequences")
+    # explicit arguments of the call win over the config
+    out = m.generate(feats, generation_config=gc, max_new_tokens=5, language="en", task="transcribe", suppress_tokens=[8],
+                     posterior_alpha=0.1, return_dict_in_generate=False)
+    gp = seen[-1]
+    assert gp.prompt[1:3] == [50259, 50359] and gp.max_length == len(gp.prompt) + 5 and list(gp.suppress_tokens) == [8]
+    assert gp.posterior_alpha == 0.1 and gp.posterior_threshold == 0.2 and torch.is_tensor(out)
+    # without a config nothing changes: the model's own defaults
+    m.generate(feats, language="en")
+    assert seen[-1].max_length == min(cfg.max_length, cfg.max_target_positions) and list(seen[-1].suppress_tokens) == list(cfg.suppress_tokens or [])
+    # the switches the reference raises for are read from the config too
+    for field, exc in (("return_timestamps", NotImplementedError), ("do_sample", NotImplementedError), ("num_beams", Exception)):
+        bad = GenerationConfig(**{field: 4 if field == "num_beams" else True})
+        with pytest.raises(exc):
+            m.generate(feats, generation_config=bad, language="en")
+    with pytest.raises(NotImplementedError):
+        m.generate(feats, language="en", do_sample=True)

@@ -478,6 +478,27 @@ class WhisperMedusaModel:
                  force_unique_generate_call: Optional[bool] = None, **kwargs):
         """Same signature as the reference (model.py:1419-1449).  Returns ``LongTensor [B, T]`` holding the
         prompt + generated ids, right-padded with ``pad_token_id`` (model.py:1747-1762)."""
+        if generation_config is not None:
+            # HF semantics (model.py:936-943 -> GenerationMixin._prepare_generation_config): a copy of the passed config, updated by every
+            # explicit argument of this call — an explicit argument wins, the config fills what the call leaves open.  Only the fields this
+            # path reads are consulted; sampling has no Medusa path in the reference either (model.py:1128-1156).
+            gc = generation_config
+
+            def pick(name, cur):
+                return cur if cur is not None else getattr(gc, name, None)
+            return_timestamps = pick("return_timestamps", return_timestamps)
+            task, language = pick("task", task), pick("language", language)
+            no_speech_threshold = pick("no_speech_threshold", no_speech_threshold)
+            return_token_timestamps = pick("return_token_timestamps", return_token_timestamps)
+            return_dict_in_generate = pick("return_dict_in_generate", return_dict_in_generate)
+            for name in ("max_new_tokens", "max_length", "num_beams", "suppress_tokens", "begin_suppress_tokens",
+                         "exponential_decay_length_penalty", "posterior_threshold", "posterior_alpha"):
+                if kwargs.get(name) is None and getattr(gc, name, None) is not None:
+                    kwargs[name] = getattr(gc, name)
+            if kwargs.get("do_sample") is None and getattr(gc, "do_sample", False):
+                kwargs["do_sample"] = True
+        if kwargs.get("do_sample"):
+            raise NotImplementedError("sampling (do_sample=True) is not supported with medusa")      # model.py:1128-1156: no Medusa branch
         if return_timestamps:
             raise NotImplementedError("return_timestamps is not supported with medusa for now")   # model.py:1171-1175
         if no_speech_threshold is not None:
