@@ -901,7 +901,8 @@ def test_measured_negative_kernels_kept_as_patches_still_apply():
     import subprocess
     if shutil.which("git") is None or not os.path.isdir(os.path.join(ROOT, ".git")):
         pytest.skip("needs the git work tree")
-    for name in ("r04_rows_variants.patch", "r05_rows_lds_ln_tail.patch", "r05_rows_norm_gemm.patch", "r05_enc_few_clip_tiles.patch"):
+    for name in ("r04_rows_variants.patch", "r05_rows_lds_ln_tail.patch", "r05_rows_norm_gemm.patch", "r05_enc_few_clip_tiles.patch",
+                 "r05_small_operand_prefetch.patch"):
         r = subprocess.run(["git", "apply", "--check", os.path.join("tests", "microbench", name)], cwd=ROOT, capture_output=True, text=True)
         assert r.returncode == 0, (name, r.stderr[-400:])
 

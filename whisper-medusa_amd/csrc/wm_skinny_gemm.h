@@ -217,7 +217,13 @@ struct LdNormT {
     // `rows`: false for waves that only help staging gamma / beta (the fused cross-attention kernel has more waves than K-slices)
     template <int NB>
     __device__ __forceinline__ void issue(Regs<NB>& r, char* smem, int kt0, int lane, int row0 = 0, bool rows = true, bool dma = true) const {
-        const int rr = lane & 15, g8 = (lane >> 4) * 8;
+        issue_w<NB, false>(r, smem, kt0, lane, row0, rows, dma, 0, 15);
+    }
+    // WIN: [rlo, rhi] = the rows of the tile this block works on (k_ln_tiles with row sub-blocks); lanes of other rows read the nearest row of
+    // the window again — the same addresses as that row's lanes, no extra traffic, no exec-masked load — and their results are not stored
+    template <int NB, bool WIN>
+    __device__ __forceinline__ void issue_w(Regs<NB>& r, char* smem, int kt0, int lane, int row0, bool rows, bool dma, int rlo, int rhi) const {
+        const int rr = WIN ? min(max(lane & 15, rlo), rhi) : (lane & 15), g8 = (lane >> 4) * 8;
         // rows >= M: the last row again (LdPacked::issue: no exec-masked loads); `rows` is wave-uniform
         const float* hrow = h + (size_t)(min(row0 + rr, M - 1) * row_mul + row_off) * d + (size_t)kt0 * 32 + g8;
         r.ngb = dma ? 1 : 0;                                          // (a literal at every call site)
@@ -408,13 +414,20 @@ k_skinny_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, in
 // ---- batched path (token rows R > 16) ----------------------------------------------------------
 // LayerNorm of all row tiles to global packed hi/lo planes: the SAME code as the fused loader with the same K-slicing
 // (one wave per slice), so the operand bits equal those of a 16-row launch.
+// Row sub-blocks (round 5): a 16-row tile is worked on by `sub` blocks of 16 / sub rows each (nmain = tiles x sub).  The launch has 2..22 tiles
+// and part of its time is what ONE CU needs to pull a tile's 80 KB of fp32 rows in and push 80 KB of hi / lo fragments out (~55 GB/s per CU: 1.5 us
+// each way); a row's statistics and normalisation involve no other row, so half tiles on two CUs move half the bytes each.  Every wave still
+// runs the full-tile instruction stream — lanes outside the block's row window re-read a row of the window and do not store —, so the operand
+// bits are those of the whole-tile form.  Measured at 32 streams (profiles/r05_ln_row_subblocks.md): 1 / 2 / 4 / 8 blocks per tile = 7.87 / 7.72 /
+// 7.74 / 7.91 ms per Medusa iteration, vanilla step 3.70 -> 3.63 ms; the launch stays a ~5 us latency structure, so 2 is the default.
 template <int NK, class Ld>
 __global__ void __launch_bounds__(640)
 k_ln_tiles(Ld ld, int ksplit, bf16_t* __restrict__ xg, size_t plane, const int* __restrict__ done, int nmain, PfJob pf, int pf_sliced,
-           const int* __restrict__ ntiles)
+           const int* __restrict__ ntiles, int sub)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (ntiles && (int)blockIdx.x < nmain && (int)blockIdx.x >= *ntiles) return;       // no rows in this tile in this step
+    const int tile = (int)blockIdx.x / sub;
+    if (ntiles && (int)blockIdx.x < nmain && tile >= *ntiles) return;       // no rows in this tile in this step
     // blocks beyond the token tiles: the launch has 2..22 blocks of work — the rest of the chip pulls the weight matrix of the GEMM that
     // follows towards the CUs that will read it (per consumer block / XCD for the two-tile kernel, whose block j runs on XCD j % 8; in
     // eighths for the token-tile kernels, where every XCD ends up reading the whole matrix and the point is the Infinity Cache)
@@ -429,20 +442,24 @@ k_ln_tiles(Ld ld, int ksplit, bf16_t* __restrict__ xg, size_t plane, const int* 
     const int ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int kt0 = ks * NK;
     typename Ld::template Regs<NK> xr;
-    ld.template issue<NK>(xr, smem, kt0, lane, blockIdx.x * 16);
+    const int nrow = 16 / sub, rlo = ((int)blockIdx.x - tile * sub) * nrow, rhi = rlo + nrow - 1;
+    ld.template issue_w<NK, true>(xr, smem, kt0, lane, tile * 16, true, true, rlo, rhi);
     ld.template stage<NK>(xr, smem);
     // `done` (every stream finished) is looked at once the loads are in flight: as the first instruction it is a dependent scalar
     // round trip (~1 us) in front of every launch of the chain.  No LDS-DMA may be outstanding when the block leaves.
     if (done && *done) return;
     ld.template stats<NK>(xr, smem, ks, ksplit, true, lane);
-    bf16_t* dst = xg + (size_t)blockIdx.x * ld.K32 * 512;
+    bf16_t* dst = xg + (size_t)tile * ld.K32 * 512;
+    const bool mine = (lane & 15) >= rlo && (lane & 15) <= rhi;
 #pragma unroll
     for (int u = 0; u < NK; ++u) {
         bf16x8_t bh, bl;
         ld.template frag<NK>(xr, smem, u, kt0 + u, lane, bh, bl);
         const size_t o = ((size_t)(kt0 + u) * 64 + lane) * 8;
-        *reinterpret_cast<uint4*>(dst + o) = __builtin_bit_cast(uint4, bh);
-        *reinterpret_cast<uint4*>(dst + plane + o) = __builtin_bit_cast(uint4, bl);
+        if (mine) {
+            *reinterpret_cast<uint4*>(dst + o) = __builtin_bit_cast(uint4, bh);
+            *reinterpret_cast<uint4*>(dst + plane + o) = __builtin_bit_cast(uint4, bl);
+        }
     }
 }
 
@@ -1181,9 +1198,14 @@ static inline hipError_t launch_skinny_norm_t(hipStream_t st, WRef W, int N16, i
         const unsigned job_bytes = 64 * 1024;
         pf = PfJob{reinterpret_cast<const char*>(W.w), extra, job_bytes, (unsigned)(8 * ((slice + job_bytes - 1) / job_bytes)), wbytes};
     }
-    if (pf.n_jobs) grid = pf_round8(MT) + (int)pf.n_jobs;
-    if (p.nk == 8) hipLaunchKernelGGL((k_ln_tiles<8, Ld>), dim3(grid), dim3(64 * p.ksplit), ld.lds_bytes(), st, ld, p.ksplit, xscr, plane, g_skinny_done, MT, pf, pf_sliced, g_skinny_ntiles);
-    else if (p.nk == 4) hipLaunchKernelGGL((k_ln_tiles<4, Ld>), dim3(grid), dim3(64 * p.ksplit), ld.lds_bytes(), st, ld, p.ksplit, xscr, plane, g_skinny_done, MT, pf, pf_sliced, g_skinny_ntiles);
+    // row sub-blocks per token tile (WM_LN_SUB = 1 / 2 / 4 / 8; 1 = the whole-tile form of rounds 1-4)
+    int sub = skinny_env("WM_LN_SUB", 2);
+    if (sub != 1 && sub != 2 && sub != 4 && sub != 8) sub = 1;
+    const int nmain = MT * sub;
+    grid = nmain;
+    if (pf.n_jobs) grid = pf_round8(nmain) + (int)pf.n_jobs;
+    if (p.nk == 8) hipLaunchKernelGGL((k_ln_tiles<8, Ld>), dim3(grid), dim3(64 * p.ksplit), ld.lds_bytes(), st, ld, p.ksplit, xscr, plane, g_skinny_done, nmain, pf, pf_sliced, g_skinny_ntiles, sub);
+    else if (p.nk == 4) hipLaunchKernelGGL((k_ln_tiles<4, Ld>), dim3(grid), dim3(64 * p.ksplit), ld.lds_bytes(), st, ld, p.ksplit, xscr, plane, g_skinny_done, nmain, pf, pf_sliced, g_skinny_ntiles, sub);
     else return hipErrorInvalidConfiguration;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
