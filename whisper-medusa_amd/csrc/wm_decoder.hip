@@ -264,22 +264,26 @@ struct NoFuseQ { static constexpr bool kOn = false; static constexpr int NK = 1,
 template <bool CROSS, bool NT, class FQ>
 __global__ void __launch_bounds__(FQ::kOn ? (FQ::KS > 4 ? 64 * FQ::KS : 256) : 256)
 k_attn_mfma(const bf16_t* __restrict__ kmat, const bf16_t* __restrict__ vtmat, const float* __restrict__ q,
-            const int* __restrict__ base, const int* __restrict__ sskip, int mper_nbz, int h_ns, int rows_alloc, int S,
+            const int4* __restrict__ sinfo, const int* __restrict__ sskip, int mper_nbz, int h_ns, int rows_alloc, int S,
             // ---- the 14 dwords above are preloaded into SGPRs (-amdgpu-kernarg-preload-count=16 = kernarg pointer + 14 dwords):
             // everything a block needs to put its K/V and q loads on the wire.  What follows is fetched from the kernarg
             // segment (a dependent scalar load, ~1 us on a cold launch: the in-kernel timeline showed the attention launches
             // entering 1.3 us later than the GEMMs, whose early arguments already sat in the preloaded range) and is first
-            // touched after those loads are in flight.
+            // touched after those loads are in flight.  Round 5: `sinfo` (read BEFORE the loads: a stream without rows in this step leaves) took
+            // the preloaded slot of `base` (the cache length, first needed after the loads) — its pointer was a kernarg load and its entry a
+            // second dependent one in front of every K/V request of a merged step —, and gx, a HIDDEN kernel argument (one more
+            // scalar round trip before the first request of every cross-attention launch), rides in bits 24-31 of h_ns.
             const int* __restrict__ done, int K32, bf16_t* __restrict__ xout, size_t xplane, float* __restrict__ ml, float* __restrict__ po,
-            int* __restrict__ ticket, PfJob pf, FQ fq, const unsigned long long* __restrict__ anc_tab, const int4* __restrict__ sinfo TL_ARG)
+            int* __restrict__ ticket, PfJob pf, FQ fq, const unsigned long long* __restrict__ anc_tab, const int* __restrict__ base TL_ARG)
 {
     // Mper query rows per stream as nqt tiles of <= 16 (a candidate tree of more than 16 nodes; the chain and every base pass: one tile);
     // blockIdx.z = stream * nqt + query tile
-    const int Mper = mper_nbz & 0xff, nbz = mper_nbz >> 8, H = h_ns & 0xff, NS = (h_ns >> 8) & 0xff, nqt = max(h_ns >> 16, 1);
+    const int Mper = mper_nbz & 0xff, nbz = mper_nbz >> 8, H = h_ns & 0xff, NS = (h_ns >> 8) & 0xff, nqt = max((h_ns >> 16) & 0xff, 1);
+    const int gx = (h_ns >> 24) & 0xff;             // == gx
     extern __shared__ __attribute__((aligned(16))) char smem_attn[];
     if ((int)blockIdx.z >= nbz) {          // prefetch-only blocks (extra z slices): wm_skinny_gemm.h, PfJob
-        const int main_total = gridDim.x * gridDim.y * nbz;
-        pf_block(pf, main_total + (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * (blockIdx.z - nbz))) - pf_round8(main_total));
+        const int main_total = gx * gridDim.y * nbz;
+        pf_block(pf, main_total + (int)(blockIdx.x + gx * (blockIdx.y + gridDim.y * (blockIdx.z - nbz))) - pf_round8(main_total));
         return;
     }
     TL_BEGIN
@@ -298,10 +302,10 @@ k_attn_mfma(const bf16_t* __restrict__ kmat, const bf16_t* __restrict__ vtmat, c
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
     const bool aw = w < 4;                  // the four attention waves (the fused variant may carry more waves for its LayerNorm)
     const int hd = blockIdx.y, d = H * 64;
-    // CROSS: the block walks key splits [sp0, sp1); with gridDim.x == NS that is one split per block (single stream:
+    // CROSS: the block walks key splits [sp0, sp1); with gx == NS that is one split per block (single stream:
     // all CUs busy), with fewer blocks per (stream, head) each walks several (large batches: fewer partial hand-offs).
     // The arithmetic per split and the merge order over splits do not depend on the grouping: bit-identical outputs.
-    const int spb = CROSS ? (NS + gridDim.x - 1) / gridDim.x : 1;
+    const int spb = CROSS ? (NS + gx - 1) / gx : 1;
     const int sp0 = CROSS ? blockIdx.x * spb : 0, sp1 = CROSS ? min(NS, sp0 + spb) : 1;
 
     const bf16_t* kp = kmat + ((size_t)s * H + hd) * rows_alloc * 64;
@@ -451,7 +455,7 @@ k_attn_mfma(const bf16_t* __restrict__ kmat, const bf16_t* __restrict__ vtmat, c
             // publish it: relaxed agent-scope atomics (write-through sc1), see the hand-off note below
             *reinterpret_cast<float4*>(&s_part[sp - sp0][qr][ch]) = acc;
             if (ch == 0) { s_part[sp - sp0][qr][64] = M; s_part[sp - sp0][qr][65] = L; }
-            if (gridDim.x > 1) {
+            if (gx > 1) {
                 u64* pd = reinterpret_cast<u64*>(po + (((size_t)row * H + hd) * NS + sp) * 64 + ch);
                 __hip_atomic_store(pd, ((u64)__float_as_uint(acc.y) << 32) | __float_as_uint(acc.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(pd + 1, ((u64)__float_as_uint(acc.w) << 32) | __float_as_uint(acc.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -476,12 +480,12 @@ k_attn_mfma(const bf16_t* __restrict__ kmat, const bf16_t* __restrict__ vtmat, c
     // Hand-off in the "8-byte agent-scope atomics on both sides" form (cdna_hip_programming.md G16): payload
     // stores are relaxed agent-scope atomics (write-through sc1), every storing wave drains vmcnt, one lane takes
     // a relaxed ticket; the last arriver reads the other partials with relaxed agent-scope atomic loads (L1 bypass).
-    if (gridDim.x > 1) {
+    if (gx > 1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
             const int t = __hip_atomic_fetch_add(ticket + blockIdx.z * H + hd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = (t == (int)gridDim.x - 1);
+            const int last = (t == gx - 1);
             if (last) __hip_atomic_store(ticket + blockIdx.z * H + hd, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch / replay
             s_last = last;
         }
@@ -491,7 +495,7 @@ k_attn_mfma(const bf16_t* __restrict__ kmat, const bf16_t* __restrict__ vtmat, c
     if (qr < rows) {
         // merge the NS partials in split order (the same arithmetic whether they come from LDS or from other blocks)
         float ms[WM_XATTN_NS_MAX], ls[WM_XATTN_NS_MAX]; float4 ov[WM_XATTN_NS_MAX];
-        if (gridDim.x > 1) {
+        if (gx > 1) {
             // every partial (this block's own included: they were published above) is fetched in ONE batch of relaxed
             // agent-scope loads (L1 bypass) — one memory round trip for the last-arriving block instead of one per split
             const u64* mlp = reinterpret_cast<const u64*>(ml + ((size_t)row * H + hd) * NS * 2);
@@ -1082,8 +1086,8 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
         const int main_total = H * nz;
         const int zs = spf.n_jobs ? nz + (pf_round8(main_total) - main_total + (int)spf.n_jobs + H - 1) / H : nz;
         TL_SET(slot * 16 + 2 + 8192 * Mper);
-        hipLaunchKernelGGL((k_attn_mfma<false, false, NoFuseQ>), dim3(1, H, zs), dim3(256), sizeof(AttnLds<1>), st, kc, vc, ctx->qbuf, base, sskip,
-                           Mper | (nz << 8), H | (1 << 8) | (nqt << 16), ctx->Tal, 0, g_skinny_done, K32, ctx->xbuf, xpl, nullptr, nullptr, nullptr, spf, NoFuseQ{}, ctx->cur_anc, sinfo TL_PASS);
+        hipLaunchKernelGGL((k_attn_mfma<false, false, NoFuseQ>), dim3(1, H, zs), dim3(256), sizeof(AttnLds<1>), st, kc, vc, ctx->qbuf, sinfo, sskip,
+                           Mper | (nz << 8), H | (1 << 8) | (nqt << 16) | (1 << 24), ctx->Tal, 0, g_skinny_done, K32, ctx->xbuf, xpl, nullptr, nullptr, nullptr, spf, NoFuseQ{}, ctx->cur_anc, base TL_PASS);
         WM_HIP(hipGetLastError());
     }
     // 3. out_proj + residual
@@ -1120,9 +1124,9 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
                 const size_t lds = (fragb > sizeof(LdsT) ? fragb : ((sizeof(LdsT) + 15) & ~(size_t)15)) + ln.lds_bytes() + 16 * 64 * sizeof(float); \
                 auto kern = k_attn_mfma<true, true, FQ>;                                                                      \
                 WM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-                hipLaunchKernelGGL(kern, dim3(xgrid, H, zs), dim3(64 * (KSv > 4 ? KSv : 4)), lds, st, kx, vx, ctx->qbuf, base, sskip, \
-                                   Mper | (nz << 8), H | (ctx->NS << 8) | (nqt << 16), ctx->Spad, ctx->S, g_skinny_done, K32, ctx->xbuf, xpl, ctx->cml, ctx->co, ctx->ticket, xpf, \
-                                   FQ{ln, w.cq_w, w.cq_b}, nullptr, (const int4*)nullptr TL_PASS);                                   \
+                hipLaunchKernelGGL(kern, dim3(xgrid, H, zs), dim3(64 * (KSv > 4 ? KSv : 4)), lds, st, kx, vx, ctx->qbuf, (const int4*)nullptr, sskip, \
+                                   Mper | (nz << 8), H | (ctx->NS << 8) | (nqt << 16) | (xgrid << 24), ctx->Spad, ctx->S, g_skinny_done, K32, ctx->xbuf, xpl, ctx->cml, ctx->co, ctx->ticket, xpf, \
+                                   FQ{ln, w.cq_w, w.cq_b}, nullptr, base TL_PASS);                                                    \
             } while (0)
             if (cqp.nk == 8 && cqp.ksplit == 5) WM_XFUSE(8, 5);
             else if (cqp.nk == 8 && cqp.ksplit == 4) WM_XFUSE(8, 4);
@@ -1133,11 +1137,11 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
             else WM_XFUSE(4, 1);
 #undef WM_XFUSE
         } else if (xattn_nt)
-            hipLaunchKernelGGL((k_attn_mfma<true, true, NoFuseQ>), dim3(xgrid, H, zs), dim3(256), sizeof(AttnLds<WM_XATTN_SPB_MAX>), st, kx, vx, ctx->qbuf, base, sskip,
-                               Mper | (nz << 8), H | (ctx->NS << 8) | (nqt << 16), ctx->Spad, ctx->S, g_skinny_done, K32, ctx->xbuf, xpl, ctx->cml, ctx->co, ctx->ticket, xpf, NoFuseQ{}, nullptr, sinfo TL_PASS);
+            hipLaunchKernelGGL((k_attn_mfma<true, true, NoFuseQ>), dim3(xgrid, H, zs), dim3(256), sizeof(AttnLds<WM_XATTN_SPB_MAX>), st, kx, vx, ctx->qbuf, sinfo, sskip,
+                               Mper | (nz << 8), H | (ctx->NS << 8) | (nqt << 16) | (xgrid << 24), ctx->Spad, ctx->S, g_skinny_done, K32, ctx->xbuf, xpl, ctx->cml, ctx->co, ctx->ticket, xpf, NoFuseQ{}, nullptr, base TL_PASS);
         else
-            hipLaunchKernelGGL((k_attn_mfma<true, false, NoFuseQ>), dim3(xgrid, H, zs), dim3(256), sizeof(AttnLds<WM_XATTN_SPB_MAX>), st, kx, vx, ctx->qbuf, base, sskip,
-                               Mper | (nz << 8), H | (ctx->NS << 8) | (nqt << 16), ctx->Spad, ctx->S, g_skinny_done, K32, ctx->xbuf, xpl, ctx->cml, ctx->co, ctx->ticket, xpf, NoFuseQ{}, nullptr, sinfo TL_PASS);
+            hipLaunchKernelGGL((k_attn_mfma<true, false, NoFuseQ>), dim3(xgrid, H, zs), dim3(256), sizeof(AttnLds<WM_XATTN_SPB_MAX>), st, kx, vx, ctx->qbuf, sinfo, sskip,
+                               Mper | (nz << 8), H | (ctx->NS << 8) | (nqt << 16) | (xgrid << 24), ctx->Spad, ctx->S, g_skinny_done, K32, ctx->xbuf, xpl, ctx->cml, ctx->co, ctx->ticket, xpf, NoFuseQ{}, nullptr, base TL_PASS);
         WM_HIP(hipGetLastError());
     }
     // 6. out_proj + residual

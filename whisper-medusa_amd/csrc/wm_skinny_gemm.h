@@ -163,9 +163,19 @@ __device__ __forceinline__ void pf_block_sliced(const PfJob& pf, int job)
 }
 
 // ---- token operand: packed hi/lo planes in global memory (written by the previous kernel's epilogue) ------------
+// Kernel-argument form of a loader (round 5): three pointers and two ints passed as SCALAR kernel arguments right behind W, so that the kernarg
+// preload (the first 16 dwords) covers everything the launch's request batch needs.  A loader passed as a struct is never preloaded (LLVM
+// preloads scalar arguments only): the ISA of rounds 2-4 had an s_load + s_waitcnt lgkmcnt(0) — a scalar-memory round trip — between the first
+// four weight requests and the rest of the batch in the plain launches, and in front of EVERY request in the LayerNorm-fused ones.
+struct LdArgs { const void* a; const void* b; const void* c; int i0, i1; };
 struct LdPacked {
     const bf16_t* X; int K32; size_t plane; int M;           // lo plane at X + plane; rows >= M are not read
     static constexpr bool kNorm = false;
+    LdArgs pack() const { return LdArgs{X, reinterpret_cast<const void*>(plane), nullptr, M, 0}; }
+    bool packs() const { return true; }
+    __device__ __forceinline__ static LdPacked make(const void* a, const void* b, const void*, int i0, int, int K32_) {
+        return LdPacked{reinterpret_cast<const bf16_t*>(a), K32_, reinterpret_cast<size_t>(b), i0};
+    }
     template <int NB> struct Regs { bf16x8_t h[NB], l[NB]; };
     __host__ __device__ int lds_bytes() const { return 0; }
     // Lanes of rows >= M read row M - 1 again (the same 16 bytes as that row's lane: no extra traffic) instead of being switched off: an
@@ -200,9 +210,16 @@ struct LdNormT {
     int d, K32, M, row_mul, row_off;
     static constexpr bool kNorm = true;
     static constexpr bool do_norm = NORM;
+    // (M < 65536 rows, row_mul < 256, row_off < 128 — prompt chunks of <= 16 tokens, candidate trees of <= 64 nodes: the launchers check packs())
+    LdArgs pack() const { return LdArgs{h, gamma, beta, d, M | (row_mul << 16) | (row_off << 24)}; }
+    bool packs() const { return M >= 0 && M < 65536 && row_mul >= 0 && row_mul < 256 && row_off >= 0 && row_off < 128; }
+    __device__ __forceinline__ static LdNormT make(const void* a, const void* b, const void* c, int i0, int i1, int K32_) {
+        return LdNormT{reinterpret_cast<const float*>(a), reinterpret_cast<const float*>(b), reinterpret_cast<const float*>(c),
+                       i0, K32_, i1 & 65535, (i1 >> 16) & 255, i1 >> 24};
+    }
     // gb: the thread's share of gamma | beta on its way to LDS.  A block has >= 64 K32 / NB threads (one wave per K-slice of NB k-tiles, times
     // the row-tile groups), gamma | beta are d / 2 = 16 K32 float4: ceil(NB / 4) per thread always suffice.
-    template <int NB> struct Regs { float4 v0[NB], v1[NB]; float mean, rstd; float4 gb[(NB + 3) / 4]; int ngb; };
+    template <int NB> struct Regs { float4 v0[NB], v1[NB]; float mean, rstd; float4 gb[(NB + 3) / 4]; int ngb; int nthr; };
     __host__ __device__ int lds_bytes() const { return 2 * d * (int)sizeof(float) + 2048; }   // gamma, beta, statistics
 
     // Order of the requests: gamma / beta FIRST (ordinary loads into registers, written to LDS in stats()), the token rows after them; the
@@ -216,13 +233,15 @@ struct LdNormT {
     // registers, which made the compiler copy a loaded value inside the masked region: a full s_waitcnt in the MIDDLE of the request batch.
     // `rows`: false for waves that only help staging gamma / beta (the fused cross-attention kernel has more waves than K-slices)
     template <int NB>
-    __device__ __forceinline__ void issue(Regs<NB>& r, char* smem, int kt0, int lane, int row0 = 0, bool rows = true, bool dma = true) const {
-        issue_w<NB, false>(r, smem, kt0, lane, row0, rows, dma, 0, 15);
+    // nthr: the block's thread count when the caller has it in a register (k_skinny_gemm: from its preloaded plan word); 0 = blockDim.x, which
+    // is a hidden kernel argument — a scalar load and its wait in front of the first request of the launch
+    __device__ __forceinline__ void issue(Regs<NB>& r, char* smem, int kt0, int lane, int row0 = 0, bool rows = true, bool dma = true, int nthr = 0) const {
+        issue_w<NB, false>(r, smem, kt0, lane, row0, rows, dma, 0, 15, nthr);
     }
     // WIN: [rlo, rhi] = the rows of the tile this block works on (k_ln_tiles with row sub-blocks); lanes of other rows read the nearest row of
     // the window again — the same addresses as that row's lanes, no extra traffic, no exec-masked load — and their results are not stored
     template <int NB, bool WIN>
-    __device__ __forceinline__ void issue_w(Regs<NB>& r, char* smem, int kt0, int lane, int row0, bool rows, bool dma, int rlo, int rhi) const {
+    __device__ __forceinline__ void issue_w(Regs<NB>& r, char* smem, int kt0, int lane, int row0, bool rows, bool dma, int rlo, int rhi, int nthr_ = 0) const {
         const int rr = WIN ? min(max(lane & 15, rlo), rhi) : (lane & 15), g8 = (lane >> 4) * 8;
         // rows >= M: the last row again (LdPacked::issue: no exec-masked loads); `rows` is wave-uniform
         const float* hrow = h + (size_t)(min(row0 + rr, M - 1) * row_mul + row_off) * d + (size_t)kt0 * 32 + g8;
@@ -231,7 +250,8 @@ struct LdNormT {
             if (dma) {
                 // always ceil(NB / 4) float4 per thread, indices clamped (a thread beyond the end re-reads the last float4 and re-writes
                 // its LDS slot): no branch and no run-time count in the request batch — a conditional load here went through scratch
-                const int nf4 = d >> 1, nthr = blockDim.x;            // float4 of gamma | beta; d % 4 == 0
+                const int nf4 = d >> 1, nthr = nthr_ ? nthr_ : (int)blockDim.x;            // float4 of gamma | beta; d % 4 == 0
+                r.nthr = nthr;
 #pragma unroll
                 for (int i = 0; i < (NB + 3) / 4; ++i) {
                     const int f = min((int)threadIdx.x + i * nthr, nf4 - 1);
@@ -256,7 +276,7 @@ struct LdNormT {
     __device__ __forceinline__ void stage(const Regs<NB>& r, char* smem) const {
         if constexpr (NORM) {
             if (r.ngb) {
-                const int nf4 = d >> 1, nthr = blockDim.x;
+                const int nf4 = d >> 1, nthr = r.nthr;
 #pragma unroll
                 for (int i = 0; i < (NB + 3) / 4; ++i) reinterpret_cast<float4*>(smem)[min((int)threadIdx.x + i * nthr, nf4 - 1)] = r.gb[i];
             }
@@ -311,11 +331,14 @@ typedef LdNormT<false> LdIdent;
 // tile per block would put more blocks than CUs on the chip).  RT > 1 needs ksplit >= RT.
 template <int NK, int RT, bool W8, class Ld, class Ep>
 __global__ void __launch_bounds__(640)
-k_skinny_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int N16, int K32, int ksplit, int rt_per_wg, int ks_magic,
-              int nmain, const int* __restrict__ done, Ld ld, Ep ep, PfJob pf TL_ARG)
+k_skinny_gemm(const bf16_t* __restrict__ W, const void* __restrict__ la, const void* __restrict__ lb, const void* __restrict__ lc, int li0, int li1,
+              int N16, int K32, int plan, int nmain, const float* __restrict__ wscale, const int* __restrict__ done, Ep ep, PfJob pf TL_ARG)
 {
+    // W .. wscale are 16 dwords: all of them arrive in SGPRs with the wave (kernarg preload); plan = ksplit | rt_per_wg << 8 | ks_magic << 16
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if ((int)blockIdx.x >= nmain) { pf_block(pf, (int)blockIdx.x - pf_round8(nmain)); return; }      // prefetch-only blocks
+    const Ld ld = Ld::make(la, lb, lc, li0, li1, K32);
+    const int ksplit = plan & 255, rt_per_wg = (plan >> 8) & 255, ks_magic = plan >> 16;
     TL_BEGIN
     constexpr int XB = (NK > 8 && !Ld::kNorm) ? NK / 2 : NK;
     const int lane = threadIdx.x & 63;
@@ -330,7 +353,7 @@ k_skinny_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, in
     typename WRaw<W8>::type a[RT][NK];
     typename Ld::template Regs<XB> xr;
     if constexpr (Ld::kNorm) {
-        ld.template issue<XB>(xr, smem, kt0, lane);
+        ld.template issue<XB>(xr, smem, kt0, lane, 0, true, true, 64 * ksplit * rt_per_wg);
     }
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
@@ -346,6 +369,10 @@ k_skinny_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, in
     const int tf = (ksplit > 1) ? blockIdx.x * rt_per_wg * RT + wave : tile0;
     const int em = lane & 15, en = tf * 16 + 4 * (lane >> 4);
     const bool edo = ((ksplit > 1) ? (wave < rt_per_wg * RT) : true) && tf < N16;
+    // (the epilogue's fields are the only kernel arguments of the batch that are not preloaded: their s_load goes out at the top of the main path.
+    // A sched_barrier here — to keep their s_waitcnt out of the batch — sinks that s_load below the barrier as well, the epilogue operands are
+    // then requested a scalar round trip later, and since the LAST request's arrival ends a launch of this chain, the iteration took 2.64 instead
+    // of 2.52 ms: measured, profiles/r05_kernarg_preload.md)
     {   // every wave requests them (a wave that finishes nothing: the last tile's; a few hundred bytes): no branch in the request batch
         const int enc = min(tf, N16 - 1) * 16 + 4 * (lane >> 4);
         pre = ep.pre(em, enc);
@@ -422,10 +449,14 @@ k_skinny_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, in
 // 7.74 / 7.91 ms per Medusa iteration, vanilla step 3.70 -> 3.63 ms; the launch stays a ~5 us latency structure, so 2 is the default.
 template <int NK, class Ld>
 __global__ void __launch_bounds__(640)
-k_ln_tiles(Ld ld, int ksplit, bf16_t* __restrict__ xg, size_t plane, const int* __restrict__ done, int nmain, PfJob pf, int pf_sliced,
-           const int* __restrict__ ntiles, int sub)
+k_ln_tiles(const void* __restrict__ la, const void* __restrict__ lb, const void* __restrict__ lc, int li0, int li1, int K32, int ks_sub, int nmain,
+           const int* __restrict__ ntiles, bf16_t* __restrict__ xg, size_t plane, const int* __restrict__ done, PfJob pf, int pf_sliced)
 {
+    // la .. ntiles are 13 dwords, preloaded with the wave (LdArgs; as a struct in front, the loader kept EVERY argument of this launch out of the
+    // preload: two scalar round trips — arguments, then *ntiles — in front of the first request); ks_sub = ksplit | sub << 8
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Ld ld = Ld::make(la, lb, lc, li0, li1, K32);
+    const int ksplit = ks_sub & 255, sub = ks_sub >> 8;
     const int tile = (int)blockIdx.x / sub;
     if (ntiles && (int)blockIdx.x < nmain && tile >= *ntiles) return;       // no rows in this tile in this step
     // blocks beyond the token tiles: the launch has 2..22 blocks of work — the rest of the chip pulls the weight matrix of the GEMM that
@@ -443,7 +474,7 @@ k_ln_tiles(Ld ld, int ksplit, bf16_t* __restrict__ xg, size_t plane, const int* 
     const int kt0 = ks * NK;
     typename Ld::template Regs<NK> xr;
     const int nrow = 16 / sub, rlo = ((int)blockIdx.x - tile * sub) * nrow, rhi = rlo + nrow - 1;
-    ld.template issue_w<NK, true>(xr, smem, kt0, lane, tile * 16, true, true, rlo, rhi);
+    ld.template issue_w<NK, true>(xr, smem, kt0, lane, tile * 16, true, true, rlo, rhi, 64 * ksplit);
     ld.template stage<NK>(xr, smem);
     // `done` (every stream finished) is looked at once the loads are in flight: as the first instruction it is a dependent scalar
     // round trip (~1 us) in front of every launch of the chain.  No LDS-DMA may be outstanding when the block leaves.
@@ -474,9 +505,10 @@ k_ln_tiles(Ld ld, int ksplit, bf16_t* __restrict__ xg, size_t plane, const int* 
 // write-through hand-off as tests/microbench/r05_rows_lds_ln_tail.patch: measured, profiles/r05_rows_lds.md.)
 template <int NKR, int RT, int TT, bool W8, class Ep>
 __global__ void __launch_bounds__(640)
-k_rows_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int N16, int K32, int ksplit, const int* __restrict__ done,
-            const bf16_t* __restrict__ X, size_t plane, int MT, Ep ep, const int* __restrict__ ntiles TL_ARG)
+k_rows_gemm(const bf16_t* __restrict__ W, const bf16_t* __restrict__ X, size_t plane, const int* __restrict__ done, const int* __restrict__ ntiles,
+            int N16, int K32, int ksplit, int MT, const float* __restrict__ wscale, Ep ep TL_ARG)
 {
+    // W .. MT are 14 dwords: preloaded (ntiles used to follow the epilogue struct: its pointer, then *ntiles — two scalar round trips at entry)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     TL_BEGIN
     // (checked first: moving the flag behind the first group of loads — a mid-loop exit — cost the 352-row launches ~3 us each, the
@@ -571,10 +603,13 @@ k_rows_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int 
 // against 7 us for the single-tile launch.)  Same plan, same accumulation order: bit-identical to single-stream runs.
 template <int NK, bool W8, class Ep>
 __global__ void __launch_bounds__(640)
-k_skinny2_gemm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, int N16, int K32, int ksplit, int rt_per_wg, int ks_magic,
-               const int* __restrict__ done, const bf16_t* __restrict__ X, size_t plane, int M, Ep ep)
+k_skinny2_gemm(const bf16_t* __restrict__ W, const bf16_t* __restrict__ X, size_t plane, const int* __restrict__ done, int N16, int K32, int plan, int M,
+               const float* __restrict__ wscale, Ep ep)
 {
+    // W .. M are 12 dwords: preloaded (plane and M used to lie behind the 14th dword: the token requests waited for a scalar load);
+    // plan = ksplit | rt_per_wg << 8 | ks_magic << 16
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int ksplit = plan & 255, rt_per_wg = (plan >> 8) & 255, ks_magic = plan >> 16;
     // token fragments held at a time: 4 k-tiles x 2 token tiles x hi/lo = 64 registers next to the wave's NK weight fragments (a block
     // of 10 waves leaves 168 registers per lane); the next round is requested as soon as the MFMAs of this one have issued
     constexpr int XB = 4;
@@ -985,7 +1020,10 @@ static inline hipError_t launch_skinny_nk_rt(hipStream_t st, WRef W, int N16, in
     const PfJob pf = g_pf_job;
     g_pf_job = PfJob{nullptr, nullptr, 0u, 0u, 0ull};
     const int grid_all = pf.n_jobs ? pf_round8(grid) + (int)pf.n_jobs : grid;
-    hipLaunchKernelGGL(kern, dim3(grid_all), dim3(threads), lds, st, W.w, W.scale, N16, K32, p.ksplit, p.rt, magic, grid, g_skinny_done, ld, ep, pf TL_PASS);
+    const LdArgs la = ld.pack();
+    if (p.ksplit > 255 || p.rt > 255 || magic > 32767 || !ld.packs()) return hipErrorInvalidConfiguration;
+    hipLaunchKernelGGL(kern, dim3(grid_all), dim3(threads), lds, st, W.w, la.a, la.b, la.c, la.i0, la.i1, N16, K32, p.ksplit | (p.rt << 8) | (magic << 16), grid,
+                       W.scale, g_skinny_done, ep, pf TL_PASS);
     return hipGetLastError();
 }
 // the bytes block j of the skinny GEMM (W, N16, K32, loader kind) reads: one prefetch job per consumer block
@@ -1028,7 +1066,7 @@ static inline hipError_t launch_rows_gemm_w(hipStream_t st, WRef W, int N16, int
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(64 * p.ksplit), lds, st, W.w, W.scale, N16, K32, p.ksplit, g_skinny_done, X, plane, MT, ep, g_skinny_ntiles TL_PASS);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * p.ksplit), lds, st, W.w, X, plane, g_skinny_done, g_skinny_ntiles, N16, K32, p.ksplit, MT, W.scale, ep TL_PASS);
     return hipGetLastError();
 }
 
@@ -1112,8 +1150,8 @@ static inline hipError_t launch_skinny2_nk(hipStream_t st, WRef W, int N16, int 
     const int grid = (N16 + p.rt - 1) / p.rt, threads = 64 * p.ksplit * p.rt;
     const size_t lds = p.ksplit > 1 ? (size_t)p.rt * 2 * p.ksplit * 1024 : 0;
     const int magic = (256 + p.ksplit - 1) / p.ksplit;
-    hipLaunchKernelGGL((k_skinny2_gemm<NK, W8, Ep>), dim3(grid), dim3(threads), lds, st, W.w, W.scale, N16, K32, p.ksplit, p.rt, magic, g_skinny_done,
-                       X, plane, R, ep);
+    hipLaunchKernelGGL((k_skinny2_gemm<NK, W8, Ep>), dim3(grid), dim3(threads), lds, st, W.w, X, plane, g_skinny_done, N16, K32, p.ksplit | (p.rt << 8) | (magic << 16), R,
+                       W.scale, ep);
     return hipGetLastError();
 }
 template <bool W8, class Ep>
@@ -1204,8 +1242,12 @@ static inline hipError_t launch_skinny_norm_t(hipStream_t st, WRef W, int N16, i
     const int nmain = MT * sub;
     grid = nmain;
     if (pf.n_jobs) grid = pf_round8(nmain) + (int)pf.n_jobs;
-    if (p.nk == 8) hipLaunchKernelGGL((k_ln_tiles<8, Ld>), dim3(grid), dim3(64 * p.ksplit), ld.lds_bytes(), st, ld, p.ksplit, xscr, plane, g_skinny_done, nmain, pf, pf_sliced, g_skinny_ntiles, sub);
-    else if (p.nk == 4) hipLaunchKernelGGL((k_ln_tiles<4, Ld>), dim3(grid), dim3(64 * p.ksplit), ld.lds_bytes(), st, ld, p.ksplit, xscr, plane, g_skinny_done, nmain, pf, pf_sliced, g_skinny_ntiles, sub);
+    const LdArgs la = ld.pack();
+    if (!ld.packs() || p.ksplit > 255) return hipErrorInvalidConfiguration;
+    if (p.nk == 8) hipLaunchKernelGGL((k_ln_tiles<8, Ld>), dim3(grid), dim3(64 * p.ksplit), ld.lds_bytes(), st, la.a, la.b, la.c, la.i0, la.i1, K32, p.ksplit | (sub << 8), nmain,
+                                      g_skinny_ntiles, xscr, plane, g_skinny_done, pf, pf_sliced);
+    else if (p.nk == 4) hipLaunchKernelGGL((k_ln_tiles<4, Ld>), dim3(grid), dim3(64 * p.ksplit), ld.lds_bytes(), st, la.a, la.b, la.c, la.i0, la.i1, K32, p.ksplit | (sub << 8), nmain,
+                                           g_skinny_ntiles, xscr, plane, g_skinny_done, pf, pf_sliced);
     else return hipErrorInvalidConfiguration;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
