@@ -1,11 +1,11 @@
 #!/bin/bash
-# round 5, GPU call 15: preloaded scalar arguments in the batched kernels too (k_ln_tiles, k_rows_gemm, k_skinny2_gemm) — new library against the
+# round 5, GPU calls 15-16: preloaded scalar arguments in the batched kernels too (k_ln_tiles, k_rows_gemm, k_skinny2_gemm) — new library against the
 # committed one (libwm_base.so), 32 streams and one stream, interleaved; bit-exactness tests of the batched paths
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=$GRAFT_REPO_ROOT/gpurun_out/r05c15; mkdir -p $O
 L=$GRAFT_REPO_ROOT/whisper-medusa_amd/whisper_medusa
 timeout 500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_large.py -m gpu -q -p no:cacheprovider -x -k "merged_step or batch or streams or micro_batches or wide or bit_exact or carry or logits" 2>&1 | tail -3
-for rep in 1 2; do
+for rep in 1 2 3; do
 for arm in base new; do
   unset WM_LIB
   if [ $arm = base ]; then export WM_LIB=$L/libwm_base.so; fi

@@ -235,13 +235,17 @@ struct LdNormT {
     template <int NB>
     // nthr: the block's thread count when the caller has it in a register (k_skinny_gemm: from its preloaded plan word); 0 = blockDim.x, which
     // is a hidden kernel argument — a scalar load and its wait in front of the first request of the launch
-    __device__ __forceinline__ void issue(Regs<NB>& r, char* smem, int kt0, int lane, int row0 = 0, bool rows = true, bool dma = true, int nthr = 0) const {
-        issue_w<NB, false>(r, smem, kt0, lane, row0, rows, dma, 0, 15, nthr);
+    __device__ __forceinline__ void issue(Regs<NB>& r, char* smem, int kt0, int lane, int row0 = 0, bool rows = true, bool dma = true) const {
+        issue_w<NB, false, false>(r, smem, kt0, lane, row0, rows, dma, 0, 15, 0);
+    }
+    template <int NB>          // the caller knows the block's thread count (a run-time test "nthr ? nthr : blockDim.x" keeps the hidden-argument load in the code)
+    __device__ __forceinline__ void issue_n(Regs<NB>& r, char* smem, int kt0, int lane, int nthr) const {
+        issue_w<NB, false, true>(r, smem, kt0, lane, 0, true, true, 0, 15, nthr);
     }
     // WIN: [rlo, rhi] = the rows of the tile this block works on (k_ln_tiles with row sub-blocks); lanes of other rows read the nearest row of
     // the window again — the same addresses as that row's lanes, no extra traffic, no exec-masked load — and their results are not stored
-    template <int NB, bool WIN>
-    __device__ __forceinline__ void issue_w(Regs<NB>& r, char* smem, int kt0, int lane, int row0, bool rows, bool dma, int rlo, int rhi, int nthr_ = 0) const {
+    template <int NB, bool WIN, bool NTHR>
+    __device__ __forceinline__ void issue_w(Regs<NB>& r, char* smem, int kt0, int lane, int row0, bool rows, bool dma, int rlo, int rhi, int nthr_) const {
         const int rr = WIN ? min(max(lane & 15, rlo), rhi) : (lane & 15), g8 = (lane >> 4) * 8;
         // rows >= M: the last row again (LdPacked::issue: no exec-masked loads); `rows` is wave-uniform
         const float* hrow = h + (size_t)(min(row0 + rr, M - 1) * row_mul + row_off) * d + (size_t)kt0 * 32 + g8;
@@ -250,7 +254,7 @@ struct LdNormT {
             if (dma) {
                 // always ceil(NB / 4) float4 per thread, indices clamped (a thread beyond the end re-reads the last float4 and re-writes
                 // its LDS slot): no branch and no run-time count in the request batch — a conditional load here went through scratch
-                const int nf4 = d >> 1, nthr = nthr_ ? nthr_ : (int)blockDim.x;            // float4 of gamma | beta; d % 4 == 0
+                const int nf4 = d >> 1, nthr = NTHR ? nthr_ : (int)blockDim.x;            // float4 of gamma | beta; d % 4 == 0
                 r.nthr = nthr;
 #pragma unroll
                 for (int i = 0; i < (NB + 3) / 4; ++i) {
@@ -353,7 +357,7 @@ k_skinny_gemm(const bf16_t* __restrict__ W, const void* __restrict__ la, const v
     typename WRaw<W8>::type a[RT][NK];
     typename Ld::template Regs<XB> xr;
     if constexpr (Ld::kNorm) {
-        ld.template issue<XB>(xr, smem, kt0, lane, 0, true, true, 64 * ksplit * rt_per_wg);
+        ld.template issue_n<XB>(xr, smem, kt0, lane, 64 * ksplit * rt_per_wg);
     }
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
@@ -458,7 +462,6 @@ k_ln_tiles(const void* __restrict__ la, const void* __restrict__ lb, const void*
     const Ld ld = Ld::make(la, lb, lc, li0, li1, K32);
     const int ksplit = ks_sub & 255, sub = ks_sub >> 8;
     const int tile = (int)blockIdx.x / sub;
-    if (ntiles && (int)blockIdx.x < nmain && tile >= *ntiles) return;       // no rows in this tile in this step
     // blocks beyond the token tiles: the launch has 2..22 blocks of work — the rest of the chip pulls the weight matrix of the GEMM that
     // follows towards the CUs that will read it (per consumer block / XCD for the two-tile kernel, whose block j runs on XCD j % 8; in
     // eighths for the token-tile kernels, where every XCD ends up reading the whole matrix and the point is the Infinity Cache)
@@ -474,14 +477,20 @@ k_ln_tiles(const void* __restrict__ la, const void* __restrict__ lb, const void*
     const int kt0 = ks * NK;
     typename Ld::template Regs<NK> xr;
     const int nrow = 16 / sub, rlo = ((int)blockIdx.x - tile * sub) * nrow, rhi = rlo + nrow - 1;
-    ld.template issue_w<NK, true>(xr, smem, kt0, lane, tile * 16, true, true, rlo, rhi, 64 * ksplit);
+    ld.template issue_w<NK, true, true>(xr, smem, kt0, lane, tile * 16, true, true, rlo, rhi, 64 * ksplit);
     ld.template stage<NK>(xr, smem);
-    // `done` (every stream finished) is looked at once the loads are in flight: as the first instruction it is a dependent scalar
-    // round trip (~1 us) in front of every launch of the chain.  No LDS-DMA may be outstanding when the block leaves.
-    if (done && *done) return;
+    // `done` (every stream finished) and the step's tile count (merged-step schedule: no rows in this tile in this step) only decide whether
+    // the block STORES: as tests in front of the requests they were dependent scalar round trips heading every launch of the chain, and as an
+    // early exit behind the requests the compiler sank the row loads below the exit's branch (ISA) — the same round trips again.  A block
+    // without rows normalises whatever lies in its tile of the scratch (sized for the full pass) and stores nothing.
+    const int* dp = done ? done : reinterpret_cast<const int*>(la);
+    const int* np = ntiles ? ntiles : reinterpret_cast<const int*>(la);
+    int dv = *dp, nv = *np;
+    asm volatile("" : "+s"(dv), "+s"(nv));           // requested HERE, behind the row requests and under their latency (left alone, the two s_loads sink to the stores)
     ld.template stats<NK>(xr, smem, ks, ksplit, true, lane);
     bf16_t* dst = xg + (size_t)tile * ld.K32 * 512;
-    const bool mine = (lane & 15) >= rlo && (lane & 15) <= rhi;
+    const bool live = !((done && dv) || (ntiles && tile >= nv));
+    const bool mine = live && (lane & 15) >= rlo && (lane & 15) <= rhi;
 #pragma unroll
     for (int u = 0; u < NK; ++u) {
         bf16x8_t bh, bl;
@@ -513,8 +522,13 @@ k_rows_gemm(const bf16_t* __restrict__ W, const bf16_t* __restrict__ X, size_t p
     TL_BEGIN
     // (checked first: moving the flag behind the first group of loads — a mid-loop exit — cost the 352-row launches ~3 us each, the
     //  compiler no longer overlapped the load groups across it: tests/microbench/r03_call4.sh)
-    if (done && *done) return;
-    if (ntiles && (int)blockIdx.y * TT >= *ntiles) return;          // merged-step schedule: no rows in this token-tile group in this step
+    {   // both flags are requested before either is waited for (address select instead of a null test: a branch would serialise the two scalar loads)
+        const int* dp = done ? done : reinterpret_cast<const int*>(W);
+        const int* np = ntiles ? ntiles : reinterpret_cast<const int*>(W);
+        int dv = *dp, nv = *np;
+        asm volatile("" : "+s"(dv), "+s"(nv));            // both values exist here: the two s_loads go out together, one wait
+        if ((done && dv) || (ntiles && (int)blockIdx.y * TT >= nv)) return;          // merged-step schedule: no rows in this token-tile group in this step
+    }
     const int lane = threadIdx.x & 63;
     const int ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rt0 = blockIdx.x * RT, mt0 = blockIdx.y * TT;
