@@ -1,11 +1,11 @@
 #!/bin/bash
-# round 5, closing measurement call of the second session (sources with the preloaded kernel arguments and the LayerNorm row sub-blocks): HBM traffic counters
+# round 5, closing measurement call of the second session, run twice: r05final2 on commit c7f95a7, r05final3 on the final sources (with the preloaded kernel arguments and the LayerNorm row sub-blocks): HBM traffic counters
 # (with / without the in-launch prefetch blocks), kernel traces at 1 and 32 streams, matrix-pipe busy at 32 streams, the whole GPU suite as the driver runs it,
 # smoke(), the default bench line
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r05final2; mkdir -p $O
+O=$R/gpurun_out/r05final3; mkdir -p $O
 cd /tmp
 echo "== pmc fetch b1, no prefetch blocks"
 WM_PREFETCH=0 timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pmc2 -o pmc2 -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vanilla --no-extra-configs > $O/pmc2.log 2>&1; echo rc $?
