@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5, GPU calls 15-16: preloaded scalar arguments in the batched kernels too (k_ln_tiles, k_rows_gemm, k_skinny2_gemm) — new library against the
+# round 5, GPU calls 15, 16, 19: preloaded scalar arguments in the batched kernels too (k_ln_tiles, k_rows_gemm, k_skinny2_gemm) — new library against the
 # committed one (libwm_base.so), 32 streams and one stream, interleaved; bit-exactness tests of the batched paths
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=$GRAFT_REPO_ROOT/gpurun_out/r05c15; mkdir -p $O
