@@ -338,7 +338,9 @@ __global__ void __launch_bounds__(640)
 k_skinny_gemm(const bf16_t* __restrict__ W, const void* __restrict__ la, const void* __restrict__ lb, const void* __restrict__ lc, int li0, int li1,
               int N16, int K32, int plan, int nmain, const float* __restrict__ wscale, const int* __restrict__ done, Ep ep, PfJob pf TL_ARG)
 {
-    // W .. wscale are 16 dwords: all of them arrive in SGPRs with the wave (kernarg preload); plan = ksplit | rt_per_wg << 8 | ks_magic << 16
+    // W .. nmain are 14 dwords: exactly what the kernarg preload delivers in SGPRs with the wave (-amdgpu-kernarg-preload-count=16 = the kernarg
+    // pointer + 14 dwords); wscale, done and the structs behind them are s_loaded at the top of the main path and consumed after the request batch.
+    // plan = ksplit | rt_per_wg << 8 | ks_magic << 16
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if ((int)blockIdx.x >= nmain) { pf_block(pf, (int)blockIdx.x - pf_round8(nmain)); return; }      // prefetch-only blocks
     const Ld ld = Ld::make(la, lb, lc, li0, li1, K32);
