@@ -129,14 +129,19 @@ def cpu_baseline_leg(cfg, sd, eng, gp, wav0, engine_ids, n_iters, fp8, full_budg
     wav = wav0.cpu().numpy()
     # The host thread count is calibrated, not assumed: the decode loop is a chain of small ops and skinny GEMVs, and on the GPU box's 256
     # hardware threads torch's default pool (128) and the 64 threads of earlier rounds are ~3x SLOWER than 16 (profiles/r05_oracle_threads.log).
-    # The baseline is the best of {8, 16, 32, 64} threads on two decode iterations; `cores` reports the count used for the decode sample.
+    # The baseline is the best of {8, 16, 32, 64} threads: per count one warm-up iteration, then the median of three 2-iteration samples (a
+    # single sample moved the pick between runs).  `cores` = the box's hardware threads (os.cpu_count()), `threads_used` = the pool of the sample.
     enc0 = eng.encoder_output(1)[0]
-    cand = [c for c in (8, 16, 32, 64) if c <= (os.cpu_count() or 1)] or [os.cpu_count() or 1]
+    hw = os.cpu_count() or 1
+    cand = [c for c in (8, 16, 32, 64) if c <= hw] or [hw]
     calib = {}
     for c in cand:
         torch.set_num_threads(c)
         orc.decode(enc0, gp, max_iters=1)
-        t = time.perf_counter(); orc.decode(enc0, gp, max_iters=2); calib[c] = time.perf_counter() - t
+        ts = []
+        for _ in range(3):
+            t = time.perf_counter(); orc.decode(enc0, gp, max_iters=2); ts.append(time.perf_counter() - t)
+        calib[c] = median(ts)
     ncore = min(calib, key=calib.get)
     torch.set_num_threads(ncore)
 
@@ -159,7 +164,7 @@ def cpu_baseline_leg(cfg, sd, eng, gp, wav0, engine_ids, n_iters, fp8, full_budg
     first = next((i for i, (a, b) in enumerate(zip(engine_ids, r16.ids)) if a != b), min(len(engine_ids), len(r16.ids)))
     agree32 = next((i for i, (a, b) in enumerate(zip(engine_ids, r.ids)) if a != b), min(len(engine_ids), len(r.ids))) - len(gp.prompt)
     audio_s = 30.0 * cfg.max_source_positions / 1500.0
-    return {"value": round(ntok / t_dec, 3), "unit": "tokens/s", "cores": ncore, "kind": "port",
+    return {"value": round(ntok / t_dec, 3), "unit": "tokens/s", "cores": hw, "threads_used": ncore, "kind": "port",
             "threads_calibration_s": {str(k): round(v, 3) for k, v in calib.items()},
             "sample": f"oracle (PyTorch CPU fp32 restatement of the reference loop) on clip 0, 1 warm-up + 3 runs, median: log-mel "
                       f"{t_mel:.2f} s, encoder {t_enc:.2f} s, decode (cross-KV projection + {r.n_iters} Medusa iterations = {ntok} tokens, "
@@ -172,7 +177,7 @@ def cpu_baseline_leg(cfg, sd, eng, gp, wav0, engine_ids, n_iters, fp8, full_budg
             "fp32_oracle_agrees_for_tokens": agree32}
 
 
-def acceptance_sensitivity(eng, cfg, gp_base, B, max_new, fp8=False):
+def acceptance_sensitivity(eng, cfg, gp_base, B, max_new, fp8=False, accepts=None, vanilla_tps=None):
     """Decode-only tokens/s with the accept length of every iteration FORCED to a (wm.h force_accept): the cost side of the
     headline, independent of what the random-init heads happen to accept.  a = 0 is the floor (2 tokens, 2 passes per iteration).
     Each row also carries the HBM fraction of what that iteration executes: a = 0 runs both passes (SURVEY §8d's bytes), a >= 1 at one
@@ -180,13 +185,14 @@ def acceptance_sensitivity(eng, cfg, gp_base, B, max_new, fp8=False):
     import copy
     out = {}
     mean_len = len(gp_base.prompt) + max_new / 2
-    for a in (0, 1, 2, 3, 5, cfg.medusa_num_heads):
+    for a in (accepts or (0, 1, 2, 3, 5, cfg.medusa_num_heads)):
         g = copy.copy(gp_base); g.force_accept = a
         eng.decode(g, B)
         st = eng.stats()
         ms_it = st["ms_decode"] / max(st["iterations"], 1)
         nbytes = executed_bytes(cfg, B, mean_len, fp8, 1.0 if (a == 0 or B > 1) else 0.0, 1.0 if a == 0 else 0.0)
         passes = "verify + base" if a == 0 else ("verify only" if B == 1 else "verify + base weights (attention of carried streams skipped)")
+        spi = None
         if st.get("schedule_steps", 0) > 0:      # merged-step schedule: one pass per step, an accept length of 0 costs the stream a second step
             spi = st["schedule_steps"] / max(st["iterations"], 1)
             nbytes = spi * executed_bytes(cfg, B, mean_len, fp8, 0.0, 0.0)
@@ -196,6 +202,10 @@ def acceptance_sensitivity(eng, cfg, gp_base, B, max_new, fp8=False):
                          "tokens_per_iteration": round(st["tokens_emitted"] / max(st["iterations"], 1) / B, 3),
                          "passes": passes,
                          "bytes_executed": round(nbytes), "frac_hbm_executed": round(nbytes / (ms_it * 1e-3) / 8e12, 4)}
+        if spi is not None:
+            out[f"a={a}"]["steps_per_iteration"] = round(spi, 3)
+        if vanilla_tps:        # the leg's Medusa / vanilla ratio AT this accept length (the cost side, whatever the random-init heads accept)
+            out[f"a={a}"]["medusa_over_vanilla"] = round(out[f"a={a}"]["tokens_per_sec"] / vanilla_tps, 3)
     return out
 
 
@@ -212,7 +222,7 @@ def leg_parity(cfg, sd, eng, gp, fp8, iters=8):
     return {"parity_checked": bool(got[:n] == ref.ids), "parity_tokens_compared": n - len(gp.prompt), "parity_iterations": ref.n_iters}
 
 
-def extra_config(name, heads, B, fp8, dev, logit_std, max_new, steps=4):
+def extra_config(name, heads, B, fp8, dev, logit_std, max_new, steps=8):
     """One more BASELINE.json config measured in the same process (B streams, one context): whole-step tokens/s, decode
     iteration time, vanilla anchor, roofline fractions, and a parity check of stream 0 against the oracle."""
     from whisper_medusa import MedusaConfig, WhisperMedusaModel, ACCEPT_TYPICAL, synth, weights
@@ -261,6 +271,13 @@ def extra_config(name, heads, B, fp8, dev, logit_std, max_new, steps=4):
            "prefill": prefill_roofline(cfg, B, ms_enc / steps, fp8)}
     out["prefill_frac_mfma"] = out["prefill"]["frac"]        # fp8 leg: against the blended fp8 / bf16 peak (prefill_roofline)
     out.update(parity)
+    if B > 1:
+        # the ratio at a STATED acceptance (the reference's x1.5 implies ~3 tokens per iteration, /root/reference/README.md:34-35): forced accept
+        # lengths 0..3 on this leg's encoder state — ms per iteration, merged steps per iteration, Medusa / vanilla at that accept length
+        try:
+            out["acceptance_sensitivity"] = acceptance_sensitivity(eng, cfg, gp, B, max_new, fp8, accepts=(0, 1, 2, 3), vanilla_tps=van)
+        except Exception as e:  # noqa: BLE001
+            out["acceptance_sensitivity"] = {"failed": repr(e)}
     eng.close()
     del model, blob
     torch.cuda.empty_cache()
@@ -289,6 +306,7 @@ def main():
                     help="skip the vanilla-greedy anchor (PMC passes: only Medusa iterations in the counter totals)")
     ap.add_argument("--cpu-iters", type=int, default=8, help="Medusa iterations of the CPU-baseline decode sample")
     ap.add_argument("--cpu-full", action="store_true", help="CPU baseline decodes the whole max-new budget (minutes)")
+    ap.add_argument("--test-setup-delay-s", type=float, default=0.0, help=argparse.SUPPRESS)     # test harness only (tests/test_bench_dist.py)
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the BASELINE configs[2] (Block, 32 streams) and configs[4] (fp8, 32 streams) legs and the sensitivity rows")
     args = ap.parse_args()
@@ -320,8 +338,8 @@ def main():
     t0 = time.time()
     blob, offs = wd.broadcast_blob(blob, offs, device=dev)
     torch.cuda.synchronize()
-    # (tests/test_bench_dist.py stretches the one-time set-up phase to show that it lies outside the timed region)
-    time.sleep(float(os.environ.get("WM_BENCH_TEST_SETUP_DELAY_S", "0") or 0))
+    if args.test_setup_delay_s > 0:      # tests/test_bench_dist.py stretches the one-time set-up phase to show that it lies outside the timed region
+        time.sleep(args.test_setup_delay_s)
     t_bcast = time.time() - t0
     model = WhisperMedusaModel.from_blob(cfg, blob, offs, max_batch=B, dec_weight_fp8=args.fp8_weights, enc_fp8=args.fp8_weights)
     eng = model.engine

@@ -41,10 +41,10 @@ def test_bench_two_ranks_at_thirty_two_streams_per_rank(gpu):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     # the weight-broadcast phase is stretched by 4 s on every rank: were it inside the timed region, each of the 2 steps would cost >= 2 s
-    env = dict(os.environ, WM_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", WM_BENCH_TEST_SETUP_DELAY_S="4")
+    env = dict(os.environ, WM_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--model", "tiny.en",
-           "--batch", "32", "--max-new", "24", "--no-cpu-baseline", "--no-extra-configs"]
+           "--batch", "32", "--max-new", "24", "--no-cpu-baseline", "--no-extra-configs", "--test-setup-delay-s", "4"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -871,9 +871,14 @@ def test_arbitrary_logits_processors_run_the_reference_loop_on_the_host():
                     got = out[b].tolist()
                     want = ref.ids[: ref.ids.index(gp.eos_token_id, len(gp.prompt)) + 1] if gp.eos_token_id in ref.ids[len(gp.prompt):] else ref.ids
                     assert got[: len(want)] == want and all(t == gp.pad_token_id for t in got[len(want):]), (heads, mode, eos_free, b)
-                # every call saw input_ids [1, L] and rows [K + 1, V]: base + Medusa logits, then the K + 1 verify rows, same L (model.py:653-694)
-                assert all(i[0] == 1 and s_[0] == cfg.medusa_num_heads + 1 and s_[1] == cfg.vocab_size for i, s_ in ident.lens)
-                assert ident.lens[0][0][1] == len(gp.prompt) and ident.lens[1][0][1] == len(gp.prompt)
+                # per iteration three calls like the reference's (model.py:653-655 base row, :656-665 the K Medusa rows, :689-694 the K + 1 verify
+                # rows), every one with input_ids [1, L] of the SAME pre-update length L
+                Kh = cfg.medusa_num_heads
+                assert len(ident.lens) % 3 == 0
+                for j in range(0, len(ident.lens), 3):
+                    (i0, s0), (i1, s1), (i2, s2) = ident.lens[j: j + 3]
+                    assert i0 == i1 == i2 and i0[0] == 1 and (s0, s1, s2) == ((1, cfg.vocab_size), (Kh, cfg.vocab_size), (Kh + 1, cfg.vocab_size))
+                assert ident.lens[0][0][1] == len(gp.prompt)
                 assert m.last_stats["host_processors"] == 1 and m.last_stats["iterations"] >= 2
         # a banning processor == the same ids in the static suppress list (which the fused loop would use)
         gp = golden_gen_params(cfg, ACCEPT_TYPICAL, 32)
@@ -953,3 +958,10 @@ def test_generate_reads_a_passed_generation_config_and_explicit_arguments_win():
             m.generate(feats, generation_config=bad, language="en")
     with pytest.raises(NotImplementedError):
         m.generate(feats, language="en", do_sample=True)
+    # fields HF would apply and this path does not read are named in a warning, not dropped silently; the model's own values are no request
+    import warnings
+    with pytest.warns(UserWarning, match="temperature, eos_token_id"):
+        m.generate(feats, generation_config=GenerationConfig(max_new_tokens=3, temperature=0.7, eos_token_id=7), language="en")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        m.generate(feats, generation_config=GenerationConfig(max_new_tokens=3, suppress_tokens=[3], eos_token_id=cfg.eos_token_id), language="en")

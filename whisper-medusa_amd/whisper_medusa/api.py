@@ -497,6 +497,22 @@ class WhisperMedusaModel:
                     kwargs[name] = getattr(gc, name)
             if kwargs.get("do_sample") is None and getattr(gc, "do_sample", False):
                 kwargs["do_sample"] = True
+            # fields HF's _prepare_generation_config would apply and this path does not read: say so instead of ignoring them silently
+            # (a value equal to the model's own generation config, or to HF's default, is not a request)
+            own = getattr(self, "generation_config", None)
+            ignored = []
+            for name, dflt in (("temperature", 1.0), ("eos_token_id", None), ("pad_token_id", None), ("forced_decoder_ids", None),
+                               ("top_k", 50), ("top_p", 1.0), ("repetition_penalty", 1.0), ("no_repeat_ngram_size", 0),
+                               ("length_penalty", 1.0), ("bad_words_ids", None), ("min_length", 0), ("min_new_tokens", None)):
+                v = getattr(gc, name, None)
+                if v is None or v == dflt or (own is not None and v == getattr(own, name, None)):
+                    continue
+                ignored.append(name)
+            if ignored:
+                import warnings
+                warnings.warn("generate(generation_config=...): the Medusa path does not honour " + ", ".join(ignored) +
+                              " from a passed config (see INTEGRATION.md, 'generation_config fields'); pass processors / criteria explicitly",
+                              UserWarning, stacklevel=2)
         if kwargs.get("do_sample"):
             raise NotImplementedError("sampling (do_sample=True) is not supported with medusa")      # model.py:1128-1156: no Medusa branch
         if return_timestamps:
@@ -672,7 +688,12 @@ class WhisperMedusaModel:
                 L = len(ids)
                 ids_t = torch.tensor([ids], dtype=torch.long)
                 z = engine_pass(ids[kv:L], kv, False)[:, -1]                     # base + Medusa logits of the last position  [K+1, V]
-                cand = torch.argmax(run(ids_t, z), dim=-1)                        # generate_candidates, top-1 chain (medusa_utils.py:446-458)
+                # two calls like the reference (model.py:653-655 base rows, :656-665 Medusa rows): a processor that indexes rows by batch
+                # (HF RepetitionPenalty / NoRepeatNGram gather on row 0 of input_ids) then touches the base row in one call and the first
+                # Medusa head's row in the other, as there.  (Only the LAST position is processed: on the first iteration the reference hands
+                # over all P prompt positions x heads and consumes the last, medusa_utils.py:446-449.)
+                zp = torch.cat([run(ids_t, z[:1]), run(ids_t, z[1:])], dim=0) if z.shape[0] > 1 else run(ids_t, z)
+                cand = torch.argmax(zp, dim=-1)                                   # generate_candidates, top-1 chain (medusa_utils.py:446-458)
                 v = run(ids_t, engine_pass(cand.tolist(), L, True)[0])            # verify pass (medusa_utils.py:494-521), same input_ids
                 a = self._accept_length(v, cand, gp)
                 if a == 0:
