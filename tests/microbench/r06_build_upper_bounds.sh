@@ -5,7 +5,7 @@
 #   libwm_nolonoln.so both
 # Numerically meaningless; only the time counts.  Loaded through WM_LIB; never by the product.
 set -e
-R=$(cd "$(dirname "$0")/../.." && pwd)
+R=$(cd "$(dirname "$0")/../.." && pwd)     # run from a checkout of the commit tests/microbench/PATCHES.json names for the patch
 T=$(mktemp -d)
 mkdir -p $T/whisper-medusa_amd $T/include
 cp -r $R/whisper-medusa_amd/csrc $T/whisper-medusa_amd/csrc

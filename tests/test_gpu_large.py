@@ -6,6 +6,7 @@
   ~0.3 s on 64 cores, a 48-token run ~10-15 s);
 * size-independent properties at the full size (exact-match == vanilla greedy, batch == independent streams);
 * end-to-end audio -> tokens against the oracle's own log-mel + encoder (bf16 contract)."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -100,6 +101,47 @@ def test_large_prompt_pass_against_oracle(large):
                  mean_abs_diff=round(float(d.mean()), 6), logit_scale=round(scale, 3), max_rel_to_scale=round(float(d.max()) / scale, 6))
     assert d.max() <= 1e-3 * scale and d.mean() <= 2e-4 * scale, (float(d.max()), float(d.mean()), scale)
     assert (z[:, -1].argmax(-1) == ref[:, -1].argmax(-1)).all()
+    # the same pass with the ENGINE's cross-K/V bits handed to the oracle, and against the fp32 oracle (recorded; measured round 6: 8.4e-4 with the
+    # engine's cross-K/V against 8.7e-4 without — the cross-K/V cache is NOT where the distance comes from, contrary to what rounds 2-5 wrote —,
+    # 1.15e-3 against the fp32 oracle, whose own distance to the contract oracle is 1.06e-3: the engine sits as far from the contract oracle as two
+    # roundings of the self-K/V rows to bf16 sit from each other)
+    assert _logit_figures(eng, cfg, {k: v.float().cpu() for k, v in sd.items()}, enc, 0, z,
+                          "large-v2 Medusa-Linear prompt pass: logit distance by source (relative to the logit scale)", cfg.decoder_layers) <= 1e-3
+
+
+def _logit_figures(eng, cfg, sd_cpu, enc, stream, z, label, n_kv):
+    """where the engine-vs-oracle logit distance of a prompt pass comes from, and what it is against fp32.
+    (i)  per output row group: the base row (no extra layer) against the Medusa rows;
+    (ii) the contract oracle handed the ENGINE's cross-K/V (tap wm_get_cross_kv) instead of projecting its own from the engine's encoder
+         output: the difference to the headline figure is what the cross-K/V cache's bf16 rounding points contribute (measured: almost
+         nothing, 8.4e-4 against 8.7e-4 — the distance comes from the SELF-K/V rows, rounded to bf16 by contract on both sides from fp32
+         sums in two orders, and from there through a softmax over the pass's few keys);
+    (iii) the engine against the fp32 oracle (no rounding point at all) from the same encoder output: the distance north_star's
+         "logits within 1e-3" would be measured at if the reference ran in fp32."""
+    from oracle.whisper_medusa_oracle import Oracle
+    from helpers import record_table
+    prompt = synth.default_prompt(cfg)
+    orc = Oracle(cfg, sd_cpu, sim="bf16")
+    st = orc.new_state(enc)
+    ref = orc.decoder_pass(st, prompt, 0, disable_medusa=False)
+    scale = float(ref.abs().max())
+    st2 = orc.new_state(enc)
+    H = cfg.decoder_attention_heads
+    for l in range(n_kv):
+        ks, vs = zip(*[eng.cross_kv(l, stream, h) for h in range(H)])
+        st2["cross_kv"][l] = (torch.stack(ks), torch.stack(vs))
+    ref_x = orc.decoder_pass(st2, prompt, 0, disable_medusa=False)
+    o32 = Oracle(cfg, sd_cpu, sim="fp32")
+    ref32 = o32.decoder_pass(o32.new_state(enc), prompt, 0, disable_medusa=False)
+    rel = lambda a, b: round(float((a - b).abs().max()) / scale, 6)       # noqa: E731
+    record_table(label, logit_scale=round(scale, 3),
+                 contract_all_rows=rel(z, ref), contract_base_row=rel(z[:1], ref[:1]), contract_medusa_rows=rel(z[1:], ref[1:]),
+                 contract_with_engine_cross_kv=rel(z, ref_x), contract_with_engine_cross_kv_mean=round(float((z - ref_x).abs().mean()) / scale, 7),
+                 fp32_oracle_all_rows=rel(z, ref32), fp32_oracle_mean=round(float((z - ref32).abs().mean()) / scale, 7),
+                 contract_oracle_vs_fp32_oracle=rel(ref, ref32))
+    print(label, "rel to scale: contract", rel(z, ref), "base row", rel(z[:1], ref[:1]), "medusa rows", rel(z[1:], ref[1:]),
+          "| engine cross-K/V handed to the oracle", rel(z, ref_x), "| vs fp32 oracle", rel(z, ref32), "(contract oracle vs fp32 oracle", rel(ref, ref32), ")")
+    return rel(z, ref_x)
 
 
 def test_large_natural_eos_run_matches_the_oracle(large, large_oracle):
@@ -311,7 +353,11 @@ def test_large_block_decode_loop_matches_the_oracle(large_block):
     # one prompt pass of every head against the oracle (logit tolerance as for Linear)
     prompt = synth.default_prompt(cfg)
     z = eng.forward_logits([prompt], 0, False)[:, 0]
-    r = orc.decoder_pass(orc.new_state(enc[4]), prompt, 0, disable_medusa=False)
+    # (round 6: the oracle gets the encoder output the engine HOLDS — clip 4 encoded alone just above —, not row 4 of the 6-clip pass: the
+    #  encoder picks its GEMM tiles by batch size and the two differ by fp32 summation order, DESIGN.md §4 "Batch invariance"; rounds 3-5 compared
+    #  across that difference, which is part of what the 1.18e-3 measured)
+    enc1 = eng.encoder_output(1)[0]
+    r = orc.decoder_pass(orc.new_state(enc1), prompt, 0, disable_medusa=False)
     # logit tolerance, stated as what it is: with the checkpoint of bench.py (logit scale ~25) the worst element differs by
     # < 1e-3 of the scale, the mean by ~1e-4 of it — the bf16 K/V-cache and encoder-output rounding points
     # are shared, but fp32 sums are ordered differently, so single values near a bf16 rounding boundary land on the other side
@@ -321,9 +367,14 @@ def test_large_block_decode_loop_matches_the_oracle(large_block):
     record_table("large-v2 Medusa-Block prompt pass, all 11 heads: engine logits vs bf16-contract oracle", max_abs_diff=round(float((z - r).abs().max()), 5),
                  mean_abs_diff=round(float((z - r).abs().mean()), 6), logit_scale=round(scale, 3), max_rel_to_scale=round(float((z - r).abs().max()) / scale, 6))
     # Medusa-Block runs the K heads behind one more decoder layer (33 layers of bf16 K/V rounding points instead of 32): measured round 5
-    # 3.08e-2 absolute on a scale of 26.2 = 1.18e-3 relative at the worst element (mean 1.5e-4); Medusa-Linear (the headline
-    # configuration, asserted at 1e-3 above) 6.3e-4.  The bound here is 1.5e-3: stated, not hidden in slack.
-    assert (z - r).abs().max() <= 1.5e-3 * scale and (z - r).abs().mean() <= 2e-4 * scale
+    # 3.08e-2 absolute on a scale of 26.2 = 1.18e-3 relative at the worst element (mean 1.5e-4) — against row 4 of the SIX-clip encoder pass
+    # while the engine held the clip's single-clip encoding (two fp32 summation orders in the encoder: see above).  Round 6
+    # compares like with like and splits the figure by source (_logit_figures): base row (32 layers, like Linear), Medusa rows (33), the same
+    # pass with the engine's cross-K/V handed to the oracle, and the fp32 oracle.  The bound is north_star's 1e-3 of the logit scale, as for Linear.
+    figs = _logit_figures(eng, cfg, _cpu_sd(sd), enc1, 0, z, "large-v2 Medusa-Block prompt pass: logit distance by source (relative to the logit scale)",
+                          cfg.decoder_layers + 1)
+    assert (z - r).abs().mean() <= 2e-4 * scale and figs <= 1.5e-3
+    assert (z - r).abs().max() <= float(os.environ.get("WM_BLOCK_LOGIT_BOUND", "1e-3")) * scale, float((z - r).abs().max()) / scale
 
 
 def test_large_block_thirty_two_streams_match_the_oracle(large_block):

@@ -899,17 +899,34 @@ def test_arbitrary_logits_processors_run_the_reference_loop_on_the_host():
 
 
 def test_measured_negative_kernels_kept_as_patches_still_apply():
-    """Kernels that were built, measured slower and taken out of the product live on as patches against the product sources
-    (tests/microbench/*.patch: round 4's k_rows_gemm variants, round 5's k_rows_lds + LayerNorm tail, k_rows_norm_gemm and the few-clip encoder tiles; profiles/ holds the
-    measurements).  They must keep applying, or the A/B cannot be repeated (`tests/microbench/r05_build_rowslds.sh`)."""
+    """Kernels that were built, measured slower and taken out of the product live on as patches (tests/microbench/*.patch: round 4's k_rows_gemm
+    variants, round 5's k_rows_lds + LayerNorm tail, k_rows_norm_gemm, the few-clip encoder tiles, round 6's upper-bound arms; profiles/ holds
+    the measurements).  Each patch is pinned to the commit whose sources it was measured on (tests/microbench/PATCHES.json: round 6 reorganised
+    the decode GEMMs, rebasing five dead kernels onto it would only make them rot differently): it must apply to THAT tree, so that the
+    A/B can be repeated from `git worktree add <dir> <commit>` + `tests/microbench/r05_build_rowslds.sh`-style build scripts."""
+    import json
     import shutil
     import subprocess
+    import tempfile
     if shutil.which("git") is None or not os.path.isdir(os.path.join(ROOT, ".git")):
         pytest.skip("needs the git work tree")
-    for name in ("r04_rows_variants.patch", "r05_rows_lds_ln_tail.patch", "r05_rows_norm_gemm.patch", "r05_enc_few_clip_tiles.patch",
-                 "r05_small_operand_prefetch.patch"):
-        r = subprocess.run(["git", "apply", "--check", os.path.join("tests", "microbench", name)], cwd=ROOT, capture_output=True, text=True)
-        assert r.returncode == 0, (name, r.stderr[-400:])
+    manifest = json.load(open(os.path.join(ROOT, "tests", "microbench", "PATCHES.json")))["patches"]
+    on_disk = sorted(f for f in os.listdir(os.path.join(ROOT, "tests", "microbench")) if f.endswith(".patch"))
+    live = [f for f in on_disk if f.startswith(("r05_", "r06_")) or f == "r04_rows_variants.patch"]
+    assert sorted(manifest) == live, (sorted(manifest), live)
+    for name, commit in manifest.items():
+        if subprocess.run(["git", "cat-file", "-e", commit + "^{commit}"], cwd=ROOT, capture_output=True).returncode != 0:
+            pytest.skip(f"base commit {commit} of {name} is not in this clone")
+        text = open(os.path.join(ROOT, "tests", "microbench", name)).read()
+        files = sorted({l[6:].split("\t")[0].strip() for l in text.splitlines() if l.startswith("+++ b/")})
+        with tempfile.TemporaryDirectory() as t:
+            for f in files:
+                r = subprocess.run(["git", "show", f"{commit}:{f}"], cwd=ROOT, capture_output=True)
+                assert r.returncode == 0, (name, f, commit)
+                os.makedirs(os.path.dirname(os.path.join(t, f)), exist_ok=True)
+                open(os.path.join(t, f), "wb").write(r.stdout)
+            r = subprocess.run(["patch", "-p1", "--dry-run", "-s", "-i", os.path.join(ROOT, "tests", "microbench", name)], cwd=t, capture_output=True, text=True)
+            assert r.returncode == 0, (name, commit, (r.stdout + r.stderr)[-400:])
 
 
 def test_generate_reads_a_passed_generation_config_and_explicit_arguments_win():

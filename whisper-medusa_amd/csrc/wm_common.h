@@ -199,3 +199,41 @@ __device__ __forceinline__ void st_hilo4(bf16_t* hi, bf16_t* lo, float4 y)
     b.y = pack_bf2(y.z - __uint_as_float(a.y << 16), y.w - __uint_as_float(a.y & 0xffff0000u));
     *reinterpret_cast<uint2*>(lo) = b;
 }
+
+// ---- LayerNorm folded into the GEMM it feeds (round 6) -------------------------------------------------------------------------
+//   W LN(x) + b  =  rstd * ( W (gamma o x)  -  mean * c )  +  b',      c[n] = sum_k W[n][k] gamma[k],   b'[n] = b[n] + sum_k W[n][k] beta[k]
+// (exact algebra: HF LayerNorm, modeling_whisper.py:416-505 pre-LN layers).  The launch that PRODUCES the residual row x (out-proj / FC2 epilogue,
+// embed, final LayerNorm for the Medusa-Block layer) also writes the operand gamma o x as packed hi / lo planes and, per (row, 16-feature tile),
+// the partial (sum x, sum x^2); the consuming GEMM is then a plain packed-operand GEMM whose block sums the row's partials in a FIXED order
+// (groups of 8 tiles in tile order, then the groups in order: the same in the 16-row, two-tile and token-tile kernels => a B-stream run stays
+// bit-identical to B single-stream runs) and applies mean / rstd to the accumulator.  No LayerNorm launch (three per decoder layer in a batched
+// pass), no statistics -> barrier -> normalise prologue in the single-stream launches.  c and b' are computed once in wm_create (fp64 sums).
+// Partial table layout: stats[tile][row] (float2; row stride `ld` = row capacity, a multiple of 16): a finishing wave stores 16 rows x 8 B = one
+// 128-B line per tile.
+struct FoldIn {
+    const float2* stats; const float* c; int T16; int ld; float inv_d;
+};
+
+// the thread's share of a block's row statistics: partial group `grp` (tiles 8 grp .. 8 grp + 7, summed in order) of row `row`
+struct FoldPart { float2 v[8]; };
+__device__ __forceinline__ void fold_part_load(FoldPart& fp, const FoldIn& f, int row, int grp) {
+    const float2* p = f.stats + (size_t)(grp * 8) * f.ld + row;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fp.v[j] = p[(size_t)j * f.ld];
+}
+__device__ __forceinline__ float2 fold_part_sum(const FoldPart& fp) {
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s += fp.v[j].x; q += fp.v[j].y; }
+    return make_float2(s, q);
+}
+// mean / rstd of a row from its G group partials in LDS (part[grp * nrows + r]), summed in group order
+__device__ __forceinline__ float2 fold_row_stat(const float2* part, int r, int nrows, int G, float inv_d) {
+    float s = 0.f, q = 0.f;
+    for (int g2 = 0; g2 < G; ++g2) { const float2 p = part[g2 * nrows + r]; s += p.x; q += p.y; }
+    const float mean = s * inv_d;
+    return make_float2(mean, rsqrtf(fmaxf(q * inv_d - mean * mean, 0.f) + 1e-5f));
+}
+__device__ __forceinline__ f32x4_t fold_apply(f32x4_t v, float2 mr, float4 c) {
+    return f32x4_t{mr.y * (v[0] - mr.x * c.x), mr.y * (v[1] - mr.x * c.y), mr.y * (v[2] - mr.x * c.z), mr.y * (v[3] - mr.x * c.w)};
+}

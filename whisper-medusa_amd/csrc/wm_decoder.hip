@@ -16,7 +16,10 @@
 __global__ void k_embed(float* __restrict__ h, const bf16_t* __restrict__ tok_emb, const float* __restrict__ pos_emb,
                         const int* __restrict__ base, const int* __restrict__ tok_src, int tok_stride, int use_base_off,
                         int Mper, int d, int V, int Tmax, const int* __restrict__ depth,
-                        const int4* __restrict__ rowinfo = nullptr, const int* __restrict__ ids = nullptr, int ids_stride = 0)
+                        const int4* __restrict__ rowinfo = nullptr, const int* __restrict__ ids = nullptr, int ids_stride = 0,
+                        // LayerNorm fold (wm_common.h): operand gamma o h of layer 0's QKV GEMM + the row's statistics partials
+                        const float* __restrict__ gnext = nullptr, bf16_t* __restrict__ xo = nullptr, size_t xplane = 0,
+                        float2* __restrict__ stats = nullptr, int sld = 0)
 {
     const int row = blockIdx.x;
     int s = row / Mper, r = row - s * Mper;
@@ -38,9 +41,18 @@ __global__ void k_embed(float* __restrict__ h, const bf16_t* __restrict__ tok_em
     for (int j = threadIdx.x * 4; j < d; j += blockDim.x * 4) {
         const uint2 t = *reinterpret_cast<const uint2*>(te + j);
         const float4 p = *reinterpret_cast<const float4*>(pe + j);
-        *reinterpret_cast<float4*>(h + (size_t)row * d + j) =
-            make_float4(bf2f((bf16_t)(t.x & 0xffff)) + p.x, bf2f((bf16_t)(t.x >> 16)) + p.y,
-                        bf2f((bf16_t)(t.y & 0xffff)) + p.z, bf2f((bf16_t)(t.y >> 16)) + p.w);
+        const float4 y = make_float4(bf2f((bf16_t)(t.x & 0xffff)) + p.x, bf2f((bf16_t)(t.x >> 16)) + p.y,
+                                     bf2f((bf16_t)(t.y & 0xffff)) + p.z, bf2f((bf16_t)(t.y >> 16)) + p.w);
+        *reinterpret_cast<float4*>(h + (size_t)row * d + j) = y;
+        if (gnext) {            // (kernel-uniform; a 16-feature tile = 4 adjacent lanes, all inside the loop together: d % 16 == 0)
+            const float4 g = *reinterpret_cast<const float4*>(gnext + j);
+            const size_t o = packed_index(row, j, d >> 5);
+            st_hilo4(xo + o, xo + xplane + o, make_float4(y.x * g.x, y.y * g.y, y.z * g.z, y.w * g.w));
+            float sm = (y.x + y.y) + (y.z + y.w), q = (y.x * y.x + y.y * y.y) + (y.z * y.z + y.w * y.w);
+            sm += __shfl_xor(sm, 1, 64); q += __shfl_xor(q, 1, 64);
+            sm += __shfl_xor(sm, 2, 64); q += __shfl_xor(q, 2, 64);
+            if ((j & 15) == 0) stats[(size_t)(j >> 4) * sld + row] = make_float2(sm, q);
+        }
     }
 }
 
@@ -51,7 +63,10 @@ __global__ void k_embed(float* __restrict__ h, const bf16_t* __restrict__ tok_em
 __global__ void k_rows_norm(const float* __restrict__ src, int src_mul, int src_off, const float* __restrict__ gamma,
                             const float* __restrict__ beta, int do_norm, float* __restrict__ out_a, float* __restrict__ out_b,
                             bf16_t* __restrict__ out_p, size_t p_plane, int K32, int p_mul, int p_off, int d, int M,
-                            const int* __restrict__ carry, const float* __restrict__ hf_keep)
+                            const int* __restrict__ carry, const float* __restrict__ hf_keep,
+                            // LayerNorm fold (Medusa-Block: the extra layer's LN1 reads the rows written to out_b): operand gamma o y + partials
+                            const float* __restrict__ gnext = nullptr, bf16_t* __restrict__ xo = nullptr, size_t xplane = 0,
+                            float2* __restrict__ stats = nullptr, int sld = 0)
 {
     const int lane = threadIdx.x & 63;
     const int m = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -95,6 +110,15 @@ __global__ void k_rows_norm(const float* __restrict__ src, int src_mul, int src_
             }
             if (out_a) reinterpret_cast<float4*>(out_a + (size_t)m * d)[j] = y;
             if (out_b) reinterpret_cast<float4*>(out_b + (size_t)m * d)[j] = y;
+            if (gnext) {        // (kernel-uniform; features 4 j .. 4 j + 3: a 16-feature tile = 4 adjacent lanes, all of them below nv: d % 16 == 0)
+                const float4 g = reinterpret_cast<const float4*>(gnext)[j];
+                const size_t o = packed_index(m, j * 4, K32);
+                st_hilo4(xo + o, xo + xplane + o, make_float4(y.x * g.x, y.y * g.y, y.z * g.z, y.w * g.w));
+                float sm = (y.x + y.y) + (y.z + y.w), q2 = (y.x * y.x + y.y * y.y) + (y.z * y.z + y.w * y.w);
+                sm += __shfl_xor(sm, 1, 64); q2 += __shfl_xor(q2, 1, 64);
+                sm += __shfl_xor(sm, 2, 64); q2 += __shfl_xor(q2, 2, 64);
+                if ((j & 3) == 0) stats[(size_t)(j >> 2) * sld + m] = make_float2(sm, q2);
+            }
             if (out_p) {
                 const size_t o = packed_index(m * p_mul + p_off, j * 4, K32);
                 st_hilo4(out_p + o, out_p + p_plane + o, y);
@@ -1050,10 +1074,26 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
     const int nz = nb * nqt;                     // (stream, query tile) pairs = z-blocks of the attention launches
     const int xheads = sskip ? std::max(1, H * nb / skip_div) : H * nz;
     const int xgrid = xattn_blocks_per_head(ctx->NS, xheads);
+    // LayerNorm fold (round 6, wm_common.h): the three LayerNorm-fed GEMMs read the operand gamma o h (ctx->xn) and the rows' statistics
+    // partials (ctx->lnstats) that the launch producing h wrote (embed / final LayerNorm for LN1 of the first layer, FC2 of the layer below,
+    // out-proj for LN2, cross-out for LN3) and apply mean / rstd to their accumulators: no LayerNorm launch, no statistics prologue.
+    const bool fold = ctx->ln_fold;
+    const FoldIn fin_base{ctx->lnstats, nullptr, d / 16, ctx->Rcap, 1.0f / (float)d};
+    auto fold_in = [&](const float* c) { FoldIn f = fin_base; f.c = c; return f; };
+    auto res_fold = [&](const float* bias, const float* gnext) {
+        EpResidualFold e{h, bias, d, R}; e.gnext = gnext; e.xo = ctx->xn; e.xplane = xpl; e.stats = ctx->lnstats; e.K32 = K32; e.sld = ctx->Rcap;
+        return e;
+    };
     // 1. LN1 + QKV; k rows / transposed v rows straight into the cache
     if (pf) g_pf_job = pf_for_gemm(w.out_w, f8, d / 16, K32, false);
     TL_SET(slot * 16 + 1 + 8192 * Mper);
-    if (rowinfo)
+    if (fold && rowinfo)
+        WM_HIP(launch_skinny_fold(st, WRef{w.qkv_w, w.qkv_s}, 3 * d / 16, K32, R, ctx->xn, xpl, fold_in(w.qkv_c),
+                                  EpQKVDecDense{ctx->qbuf, kc, vc, w.qkv_bf, base, Mper, d, H, ctx->Tal, R, rowinfo}));
+    else if (fold)
+        WM_HIP(launch_skinny_fold(st, WRef{w.qkv_w, w.qkv_s}, 3 * d / 16, K32, R, ctx->xn, xpl, fold_in(w.qkv_c),
+                                  EpQKVDec{ctx->qbuf, kc, vc, w.qkv_bf, base, Mper, d, H, ctx->Tal, R}));
+    else if (rowinfo)
         WM_HIP(launch_skinny_norm(st, WRef{w.qkv_w, w.qkv_s}, 3 * d / 16, K32, h, w.ln1_w, w.ln1_b, d, R, 1, 0, 1,
                                   EpQKVDecDense{ctx->qbuf, kc, vc, w.qkv_b, base, Mper, d, H, ctx->Tal, R, rowinfo}, ctx->xbuf, xpl));
     else
@@ -1069,7 +1109,7 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
     const SkinnyPlan cqp = skinny_plan(d / 16, K32, true);
     const bool fuse_shape = (cqp.nk == 8 && cqp.ksplit >= 1 && cqp.ksplit <= 5) || (cqp.nk == 4 && (cqp.ksplit == 1 || cqp.ksplit == 3));
     // (not under the merged-step schedule's dense rows: the fused instance reads q at stream * Mper + row)
-    const bool fuse_cq = fuse_env && R <= 16 && !f8 && fuse_shape && H * 4 == d / 16 && rowinfo == nullptr;       // single tile: nqt == 1
+    const bool fuse_cq = fuse_env && !fold && R <= 16 && !f8 && fuse_shape && H * 4 == d / 16 && rowinfo == nullptr;       // single tile: nqt == 1
     const PfJob kvjob = (pf && nqt == 1 && ctx->NS % xgrid == 0 && ctx->Spad == ctx->NS * 256)
         ? PfJob{reinterpret_cast<const char*>(kx), reinterpret_cast<const char*>(vx), (unsigned)(ctx->NS / xgrid) * 256 * 128,
                 (unsigned)(xgrid * H * nb), (unsigned long long)H * nb * ctx->Spad * 128}
@@ -1093,13 +1133,22 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
     // 3. out_proj + residual
     if (pf) g_pf_job = pf_for_gemm(w.cq_w, f8, d / 16, K32, true);
     TL_SET(slot * 16 + 3 + 8192 * Mper);
-    WM_HIP(launch_skinny_rows(st, WRef{w.out_w, w.out_s}, d / 16, K32, R, ctx->xbuf, xpl, EpResidual{h, w.out_b, d, R}));
+    // batched passes with the LayerNorm folded: no LayerNorm launch is left to pull the next GEMM's weights towards the chip, the launch that
+    // produces the residual rows carries that job (wm_skinny_gemm.h pf_set_batched); WM_PREFETCH=0 turns it off with the others
+    const bool pfb = fold && ctx->prefetch && R > 16;
+    const int MTp = (R + 15) / 16;
+    if (pfb) pf_set_batched(w.cq_w, nullptr, f8, d / 16, K32, MTp);
+    if (fold) WM_HIP(launch_skinny_rows(st, WRef{w.out_w, w.out_s}, d / 16, K32, R, ctx->xbuf, xpl, res_fold(w.out_b, w.ln2_w)));
+    else WM_HIP(launch_skinny_rows(st, WRef{w.out_w, w.out_s}, d / 16, K32, R, ctx->xbuf, xpl, EpResidual{h, w.out_b, d, R}));
     // 4. LN2 + cross-attention q (its own launch unless fused into 5.)
     if (!fuse_cq) {
         if (pf) g_pf_job = kvjob;
         TL_SET(slot * 16 + 4 + 8192 * Mper);
-        WM_HIP(launch_skinny_norm(st, WRef{w.cq_w, w.cq_s}, d / 16, K32, h, w.ln2_w, w.ln2_b, d, R, 1, 0, 1, EpF32{ctx->qbuf, w.cq_b, d, R, 0.125f},
-                                  ctx->xbuf, xpl));
+        if (fold)
+            WM_HIP(launch_skinny_fold(st, WRef{w.cq_w, w.cq_s}, d / 16, K32, R, ctx->xn, xpl, fold_in(w.cq_c), EpF32{ctx->qbuf, w.cq_bf, d, R, 0.125f}));
+        else
+            WM_HIP(launch_skinny_norm(st, WRef{w.cq_w, w.cq_s}, d / 16, K32, h, w.ln2_w, w.ln2_b, d, R, 1, 0, 1, EpF32{ctx->qbuf, w.cq_b, d, R, 0.125f},
+                                      ctx->xbuf, xpl));
     }
     // 5. cross-attention over the encoder K/V, 256 keys per block
     // a base pass with per-stream carry skips the blocks of carrying streams (about half of them at the measured acceptance
@@ -1147,17 +1196,66 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
     // 6. out_proj + residual
     if (pf) g_pf_job = pf_for_gemm(w.fc1_w, f8, ctx->ffn / 16, K32, true);
     TL_SET(slot * 16 + 6 + 8192 * Mper);
-    WM_HIP(launch_skinny_rows(st, WRef{w.cout_w, w.cout_s}, d / 16, K32, R, ctx->xbuf, xpl, EpResidual{h, w.cout_b, d, R}));
+    if (pfb) pf_set_batched(w.fc1_w, nullptr, f8, ctx->ffn / 16, K32, MTp);
+    if (fold) WM_HIP(launch_skinny_rows(st, WRef{w.cout_w, w.cout_s}, d / 16, K32, R, ctx->xbuf, xpl, res_fold(w.cout_b, w.ln3_w)));
+    else WM_HIP(launch_skinny_rows(st, WRef{w.cout_w, w.cout_s}, d / 16, K32, R, ctx->xbuf, xpl, EpResidual{h, w.cout_b, d, R}));
     // 7. LN3 + fc1 + GELU
     if (pf) g_pf_job = pf_for_gemm(w.fc2_w, f8, d / 16, F32, false);
-    if (ctx->prefetch && R > 16) g_ln_pf_extra = w.fc2_w;     // batched passes: the LayerNorm launch pulls FC1 and FC2 (same size)
+    if (ctx->prefetch && R > 16 && !fold) g_ln_pf_extra = w.fc2_w;     // batched passes: the LayerNorm launch pulls FC1 and FC2 (same size)
     TL_SET(slot * 16 + 7 + 8192 * Mper);
-    WM_HIP(launch_skinny_norm(st, WRef{w.fc1_w, w.fc1_s}, ctx->ffn / 16, K32, h, w.ln3_w, w.ln3_b, d, R, 1, 0, 1,
-                              EpPackedAct<1>{ctx->fbuf, ctx->fbuf + fpl, w.fc1_b, F32, R}, ctx->xbuf, xpl));
-    // 8. fc2 + residual
+    if (pfb) pf_set_batched(w.fc2_w, nullptr, f8, d / 16, F32, MTp);
+    if (fold)
+        WM_HIP(launch_skinny_fold(st, WRef{w.fc1_w, w.fc1_s}, ctx->ffn / 16, K32, R, ctx->xn, xpl, fold_in(w.fc1_c),
+                                  EpPackedAct<1>{ctx->fbuf, ctx->fbuf + fpl, w.fc1_bf, F32, R}));
+    else
+        WM_HIP(launch_skinny_norm(st, WRef{w.fc1_w, w.fc1_s}, ctx->ffn / 16, K32, h, w.ln3_w, w.ln3_b, d, R, 1, 0, 1,
+                                  EpPackedAct<1>{ctx->fbuf, ctx->fbuf + fpl, w.fc1_b, F32, R}, ctx->xbuf, xpl));
+    if (pfb && next) pf_set_batched(next->qkv_w, nullptr, f8, 3 * d / 16, K32, MTp);
+    // 8. fc2 + residual (fold: + the operand of the NEXT layer's LN1 + QKV; the last layer's rows go to the final LayerNorm launch instead)
     if (pf && next) g_pf_job = pf_for_gemm(next->qkv_w, f8, 3 * d / 16, K32, true);
     TL_SET(slot * 16 + 8 + 8192 * Mper);
-    WM_HIP(launch_skinny_rows(st, WRef{w.fc2_w, w.fc2_s}, d / 16, F32, R, ctx->fbuf, fpl, EpResidual{h, w.fc2_b, d, R}));
+    if (fold && next) WM_HIP(launch_skinny_rows(st, WRef{w.fc2_w, w.fc2_s}, d / 16, F32, R, ctx->fbuf, fpl, res_fold(w.fc2_b, next->ln1_w)));
+    else WM_HIP(launch_skinny_rows(st, WRef{w.fc2_w, w.fc2_s}, d / 16, F32, R, ctx->fbuf, fpl, EpResidual{h, w.fc2_b, d, R}));
+    return WM_OK;
+}
+
+// c[n] = sum_k W[n][k] gamma[k], bf[n] = b[n] + sum_k W[n][k] beta[k] of one LayerNorm-fed matrix in the packed layout (bf16, or fp8 e4m3 with one
+// scale per row): one wave per output row, fp64 sums (once per context, wm_create).  (wm_common.h "LayerNorm folded into the GEMM it feeds")
+__global__ void k_fold_vectors(const bf16_t* __restrict__ W, const float* __restrict__ wscale, const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const float* __restrict__ bias, int N, int K, float* __restrict__ c, float* __restrict__ bf)
+{
+    const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    double sc = 0.0, sb = 0.0;
+    for (int k = lane; k < K; k += 64) {
+        const size_t i = packed_index(n, k, K >> 5);
+        float wv;
+        if (wscale) {
+            const unsigned char b8 = reinterpret_cast<const unsigned char*>(W)[i];
+            wv = __builtin_amdgcn_cvt_f32_fp8((int)b8, 0) * wscale[n];
+        } else wv = bf2f(W[i]);
+        sc += (double)wv * (double)gamma[k]; sb += (double)wv * (double)beta[k];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sc += __shfl_xor(sc, o, 64); sb += __shfl_xor(sb, o, 64); }
+    if (lane == 0) { c[n] = (float)sc; bf[n] = (float)((double)bias[n] + sb); }
+}
+
+int wm_dec_fold_init(wm_ctx* ctx)
+{
+    hipStream_t st = ctx->stream;
+    const int d = ctx->d, ffn = ctx->ffn;
+    float* p = ctx->foldv;
+    for (auto& w : ctx->dec) {
+        float* v[6];
+        const int len[6] = {3 * d, 3 * d, d, d, ffn, ffn};
+        for (int i = 0; i < 6; ++i) { v[i] = p; p += len[i]; }
+        hipLaunchKernelGGL(k_fold_vectors, dim3((3 * d + 3) / 4), dim3(256), 0, st, w.qkv_w, w.qkv_s, w.ln1_w, w.ln1_b, w.qkv_b, 3 * d, d, v[0], v[1]);
+        hipLaunchKernelGGL(k_fold_vectors, dim3((d + 3) / 4), dim3(256), 0, st, w.cq_w, w.cq_s, w.ln2_w, w.ln2_b, w.cq_b, d, d, v[2], v[3]);
+        hipLaunchKernelGGL(k_fold_vectors, dim3((ffn + 3) / 4), dim3(256), 0, st, w.fc1_w, w.fc1_s, w.ln3_w, w.ln3_b, w.fc1_b, ffn, d, v[4], v[5]);
+        WM_HIP(hipGetLastError());
+        w.qkv_c = v[0]; w.qkv_bf = v[1]; w.cq_c = v[2]; w.cq_bf = v[3]; w.fc1_c = v[4]; w.fc1_bf = v[5];
+    }
     return WM_OK;
 }
 
@@ -1172,16 +1270,21 @@ int wm_dec_stage_layers(wm_ctx* ctx, int b0, int nb, int Mper, int mode)
     // mode 2 = merged step: per stream either its verify rows (as mode 1) or its one base row (k_step_begin: rowinfo / sinfo)
     const int* base = (mode == 0 ? ctx->kvlen : ctx->L) + b0;          // mode 2: positions come from rowinfo / sinfo
     if (R > ctx->Rcap || Mper > ctx->Mmax) { ctx->err = "decode pass exceeds the row capacity of the context"; return WM_ERR_ARG; }
+    // LayerNorm fold: the embed launch also writes layer 0's QKV operand (gamma_ln1 o h) and the rows' statistics partials
+    const float* eg = ctx->ln_fold ? ctx->dec[0].ln1_w : nullptr;
+    const size_t expl = (size_t)ctx->Rcap * d;
     if (mode == 2)
         hipLaunchKernelGGL(k_embed, dim3(R), dim3(256), 0, st, ctx->h, ctx->tok_emb, ctx->dec_pos, base,
                            ctx->cand + (size_t)b0 * WM_CAND_STRIDE, WM_CAND_STRIDE, 0, Mper, d, ctx->V, ctx->Tmax, (const int*)nullptr,
-                           ctx->rowinfo, ctx->ids, ctx->gp.Tids);
+                           ctx->rowinfo, ctx->ids, ctx->gp.Tids, eg, ctx->xn, expl, ctx->lnstats, ctx->Rcap);
     else if (mode == 0)
         hipLaunchKernelGGL(k_embed, dim3(R), dim3(256), 0, st, ctx->h, ctx->tok_emb, ctx->dec_pos, base,
-                           ctx->ids + (size_t)b0 * ctx->gp.Tids, ctx->gp.Tids, 1, Mper, d, ctx->V, ctx->Tmax, nullptr);
+                           ctx->ids + (size_t)b0 * ctx->gp.Tids, ctx->gp.Tids, 1, Mper, d, ctx->V, ctx->Tmax, (const int*)nullptr,
+                           (const int4*)nullptr, (const int*)nullptr, 0, eg, ctx->xn, expl, ctx->lnstats, ctx->Rcap);
     else
         hipLaunchKernelGGL(k_embed, dim3(R), dim3(256), 0, st, ctx->h, ctx->tok_emb, ctx->dec_pos, base,
-                           ctx->cand + (size_t)b0 * WM_CAND_STRIDE, WM_CAND_STRIDE, 0, Mper, d, ctx->V, ctx->Tmax, ctx->tn ? ctx->tree->depth : nullptr);
+                           ctx->cand + (size_t)b0 * WM_CAND_STRIDE, WM_CAND_STRIDE, 0, Mper, d, ctx->V, ctx->Tmax, ctx->tn ? ctx->tree->depth : nullptr,
+                           (const int4*)nullptr, (const int*)nullptr, 0, eg, ctx->xn, expl, ctx->lnstats, ctx->Rcap);
     WM_HIP(hipGetLastError());
     ctx->cur_anc = (mode == 1 && ctx->tn) ? ctx->tree->anc : nullptr;
     // batched hidden-state carry: a stream whose previous verify pass accepted a > 0 candidates already has the state
@@ -1205,9 +1308,12 @@ int wm_dec_stage_final(wm_ctx* ctx, int b0, int nb, int Mper, int mode, int medu
     const int d = ctx->d, K32 = d / 32, R = nb * Mper;
     const int* base = (mode == 0 ? ctx->kvlen : ctx->L) + b0;          // mode 2: positions come from rowinfo / sinfo
     float* hf = ctx->hf + (size_t)b0 * Mper * d;          // rows of this chunk; persists until the stream's next pass
+    // (Medusa-Block + LayerNorm fold: the rows copied to hblk are the extra layer's LN1 input — its QKV operand and statistics partials go out here)
+    const bool bfold = ctx->block && ctx->ln_fold && !ctx->gp.vanilla;
     hipLaunchKernelGGL(k_rows_norm, dim3((R + 3) / 4), dim3(256), 0, st, ctx->h, 1, 0, ctx->dec_lnf_w, ctx->dec_lnf_b, 1,
                        hf, ctx->block ? ctx->hblk : nullptr, nullptr, (size_t)0, K32, 1, 0, d, R,
-                       (mode == 0 && Mper == 1 && ctx->dev_carry) ? ctx->carry + b0 : nullptr, ctx->hf_keep + (size_t)b0 * d);
+                       (mode == 0 && Mper == 1 && ctx->dev_carry) ? ctx->carry + b0 : nullptr, ctx->hf_keep + (size_t)b0 * d,
+                       bfold ? ctx->dec[ctx->nkv - 1].ln1_w : nullptr, ctx->xn, (size_t)ctx->Rcap * d, ctx->lnstats, ctx->Rcap);
     WM_HIP(hipGetLastError());
     ctx->hf_cur = hf;
     if (ctx->block && !ctx->gp.vanilla) {
@@ -1461,21 +1567,42 @@ int wm_dec_profile(wm_ctx* ctx, int kernel, int rows, int reps, float* ms, doubl
     // the QKV epilogue scatters K / V rows into the self-attention cache: the rows go in as the verify pass would put them, Rcap / maxB
     // rows per stream from position 0 (<= 64 <= Tal; all of them on one stream would run past a head's slab once rows > Tal)
     const int mper = ctx->Rcap / ctx->maxB;
+    const bool fold = ctx->ln_fold;       // the launches as dec_layer issues them (LayerNorm folded: wm_common.h)
+    const FoldIn fin_base{ctx->lnstats, nullptr, d / 16, ctx->Rcap, 1.0f / (float)d};
+    auto fold_in = [&](const float* c) { FoldIn f = fin_base; f.c = c; return f; };
+    auto res_fold = [&](const float* bias, const float* gnext) {
+        EpResidualFold e{ctx->h, bias, d, R}; e.gnext = gnext; e.xo = ctx->xn; e.xplane = xpl; e.stats = ctx->lnstats; e.K32 = K32; e.sld = ctx->Rcap;
+        return e;
+    };
     auto body = [&]() -> int {
-        if (all || kernel == 1)
+        if ((all || kernel == 1) && fold)
+            WM_HIP(launch_skinny_fold(st, WRef{w.qkv_w, w.qkv_s}, 3 * d / 16, K32, R, ctx->xn, xpl, fold_in(w.qkv_c),
+                                      EpQKVDec{ctx->qbuf, ctx->kc, ctx->vc, w.qkv_bf, ctx->kvlen, mper, d, H, ctx->Tal, R}));
+        else if (all || kernel == 1)
             WM_HIP(launch_skinny_norm(st, WRef{w.qkv_w, w.qkv_s}, 3 * d / 16, K32, ctx->h, w.ln1_w, w.ln1_b, d, R, 1, 0, 1,
                                       EpQKVDec{ctx->qbuf, ctx->kc, ctx->vc, w.qkv_b, ctx->kvlen, mper, d, H, ctx->Tal, R}, ctx->xbuf, xpl));
-        if (all || kernel == 2)
+        if ((all || kernel == 2) && fold)
+            WM_HIP(launch_skinny_rows(st, WRef{w.out_w, w.out_s}, d / 16, K32, R, ctx->xbuf, xpl, res_fold(w.out_b, w.ln2_w)));
+        else if (all || kernel == 2)
             WM_HIP(launch_skinny_rows(st, WRef{w.out_w, w.out_s}, d / 16, K32, R, ctx->xbuf, xpl, EpResidual{ctx->h, w.out_b, d, R}));
-        if (all || kernel == 3)
+        if ((all || kernel == 3) && fold)
+            WM_HIP(launch_skinny_fold(st, WRef{w.cq_w, w.cq_s}, d / 16, K32, R, ctx->xn, xpl, fold_in(w.cq_c), EpF32{ctx->qbuf, w.cq_bf, d, R, 0.125f}));
+        else if (all || kernel == 3)
             WM_HIP(launch_skinny_norm(st, WRef{w.cq_w, w.cq_s}, d / 16, K32, ctx->h, w.ln2_w, w.ln2_b, d, R, 1, 0, 1, EpF32{ctx->qbuf, w.cq_b, d, R, 0.125f},
                                       ctx->xbuf, xpl));
-        if (all || kernel == 4)
+        if ((all || kernel == 4) && fold)
+            WM_HIP(launch_skinny_rows(st, WRef{w.cout_w, w.cout_s}, d / 16, K32, R, ctx->xbuf, xpl, res_fold(w.cout_b, w.ln3_w)));
+        else if (all || kernel == 4)
             WM_HIP(launch_skinny_rows(st, WRef{w.cout_w, w.cout_s}, d / 16, K32, R, ctx->xbuf, xpl, EpResidual{ctx->h, w.cout_b, d, R}));
-        if (all || kernel == 5)
+        if ((all || kernel == 5) && fold)
+            WM_HIP(launch_skinny_fold(st, WRef{w.fc1_w, w.fc1_s}, ctx->ffn / 16, K32, R, ctx->xn, xpl, fold_in(w.fc1_c),
+                                      EpPackedAct<1>{ctx->fbuf, ctx->fbuf + fpl, w.fc1_bf, F32, R}));
+        else if (all || kernel == 5)
             WM_HIP(launch_skinny_norm(st, WRef{w.fc1_w, w.fc1_s}, ctx->ffn / 16, K32, ctx->h, w.ln3_w, w.ln3_b, d, R, 1, 0, 1,
                                       EpPackedAct<1>{ctx->fbuf, ctx->fbuf + fpl, w.fc1_b, F32, R}, ctx->xbuf, xpl));
-        if (all || kernel == 6)
+        if ((all || kernel == 6) && fold)
+            WM_HIP(launch_skinny_rows(st, WRef{w.fc2_w, w.fc2_s}, d / 16, F32, R, ctx->fbuf, fpl, res_fold(w.fc2_b, w.ln1_w)));
+        else if (all || kernel == 6)
             WM_HIP(launch_skinny_rows(st, WRef{w.fc2_w, w.fc2_s}, d / 16, F32, R, ctx->fbuf, fpl, EpResidual{ctx->h, w.fc2_b, d, R}));
         if (kernel == 7)
             WM_HIP(launch_skinny_rows(st, ctx->vocab_w, ctx->Vpad / 16, K32, R, ctx->ybuf, xpl, EpLogits{ctx->logits, nullptr, ctx->Vpad, R, 1.0f}));

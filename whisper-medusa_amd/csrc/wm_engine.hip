@@ -34,7 +34,8 @@ extern "C" void wm_destroy(wm_ctx* ctx)
                     ctx->enc_out, ctx->kx, ctx->vx, ctx->kc, ctx->vc, ctx->h, ctx->hblk, ctx->hf, ctx->qbuf, ctx->xbuf, ctx->fbuf,
                     ctx->ybuf, ctx->cml, ctx->co, ctx->ticket, ctx->logits, ctx->amax, ctx->pc, ctx->part1, ctx->part2, ctx->ids, ctx->L, ctx->kvlen,
                     ctx->finished, ctx->cand, ctx->niter, ctx->hist, ctx->supmask, ctx->exppen, ctx->tap_tok, ctx->done,
-                    ctx->hf_keep, ctx->hb_keep, ctx->carry, ctx->rowinfo, ctx->sinfo, ctx->steprows, ctx->rs_table, ctx->tree, ctx->sel_src, ctx->sel_n, ctx->sel_base, ctx->exn8, ctx->exs};
+                    ctx->hf_keep, ctx->hb_keep, ctx->carry, ctx->rowinfo, ctx->sinfo, ctx->steprows, ctx->rs_table, ctx->tree, ctx->sel_src, ctx->sel_n, ctx->sel_base, ctx->exn8, ctx->exs,
+                    ctx->xn, ctx->lnstats, ctx->foldv};
     for (void* b : bufs) if (b) hipFree(b);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
@@ -196,6 +197,12 @@ extern "C" int wm_create(const wm_config* cfg, const wm_weights* w, int device, 
     }
     CREATE_HIP(dev_alloc(&ctx->qbuf, RW * d, st));
     CREATE_HIP(dev_alloc(&ctx->xbuf, 2 * RW * d, st));          // hi + lo planes
+    { const char* v = std::getenv("WM_LN_FOLD"); ctx->ln_fold = !(v && std::atoi(v) == 0); }
+    if (ctx->ln_fold) {
+        CREATE_HIP(dev_alloc(&ctx->xn, 2 * RW * d, st));
+        CREATE_HIP(dev_alloc(&ctx->lnstats, RW * (d / 16), st));
+        CREATE_HIP(dev_alloc(&ctx->foldv, (size_t)ctx->nkv * 2 * (4 * d + ctx->ffn), st));
+    }
     CREATE_HIP(dev_alloc(&ctx->fbuf, 2 * RW * ctx->ffn, st));
     CREATE_HIP(dev_alloc(&ctx->ybuf, 2 * RW * d, st));
     CREATE_HIP(dev_alloc(&ctx->cml, RW * H * ctx->NS * 2, st));
@@ -221,6 +228,7 @@ extern "C" int wm_create(const wm_config* cfg, const wm_weights* w, int device, 
     CREATE_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->hostflags), 64, hipHostMallocMapped));
     CREATE_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->hostflags_dev), ctx->hostflags, 0));
     ctx->hostflags[0] = ctx->hostflags[1] = 0;
+    if (ctx->ln_fold && wm_dec_fold_init(ctx) != WM_OK) { g_create_err = "wm_create: " + ctx->err; wm_destroy(ctx); return WM_ERR_HIP; }
     CREATE_HIP(hipStreamSynchronize(st));
 #undef CREATE_HIP
     *out = ctx;

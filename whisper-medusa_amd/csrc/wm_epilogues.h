@@ -9,23 +9,44 @@
 // batch at kernel entry:  pre(m, n) only LOADS the operands the element needs (bias, residual, cache position) — no
 // arithmetic, so nothing waits on them while the weight stream is in flight —, fin(m, n, v, pre) does the arithmetic and the
 // store once the accumulator exists.  store4(m, n, v) = fin(m, n, v, pre(m, n)) for the kernels that do not prefetch.
-struct EpPre { float4 a, b; int i; };
+struct EpPre { float4 a, b; int i; float4 c; };      // (c: only the folding residual epilogue; a field nobody reads costs no register)
 
-struct EpResidual {            // h[m][n] = (h[m][n] + bias[n]) + v      (out_proj / fc2 + residual, HF:modeling_whisper.py:396-413)
+// h[m][n] = (h[m][n] + bias[n]) + v      (out_proj / fc2 + residual, HF:modeling_whisper.py:396-413)
+// FOLD (round 6, wm_common.h "LayerNorm folded into the GEMM it feeds"): the row this launch completes is the input of the NEXT LayerNorm-fed
+// GEMM, so the epilogue also writes that GEMM's operand gamma_next o h as packed hi / lo planes (`xo`) and the tile's partial (sum, sum of
+// squares) of h into the statistics table — the three LayerNorm launches per layer of a batched pass and the statistics prologue of the
+// single-stream launches disappear.  fin() must then be called by all 64 lanes of a wave together (the partial crosses the four 16-lane rows).
+template <bool FOLD>
+struct EpResidualT {
     float* h; const float* bias; int ld; int M;
+    const float* gnext = nullptr; bf16_t* xo = nullptr; size_t xplane = 0; float2* stats = nullptr; int K32 = 0, sld = 0;
     __device__ __forceinline__ EpPre pre(int m, int n) const {
         // rows >= M read row M - 1 (never stored): no exec-masked loads in the launch's request batch (wm_skinny_gemm.h LdPacked::issue)
         EpPre p; p.i = 0;
         p.a = *reinterpret_cast<const float4*>(h + (size_t)min(m, M - 1) * ld + n); p.b = *reinterpret_cast<const float4*>(bias + n);
+        if constexpr (FOLD) p.c = *reinterpret_cast<const float4*>(gnext + n);
         return p;
     }
     __device__ __forceinline__ void fin(int m, int n, f32x4_t v, const EpPre& p) const {
-        if (m >= M) return;
-        *reinterpret_cast<float4*>(h + (size_t)m * ld + n) =
-            make_float4((p.a.x + p.b.x) + v[0], (p.a.y + p.b.y) + v[1], (p.a.z + p.b.z) + v[2], (p.a.w + p.b.w) + v[3]);
+        const float4 y = make_float4((p.a.x + p.b.x) + v[0], (p.a.y + p.b.y) + v[1], (p.a.z + p.b.z) + v[2], (p.a.w + p.b.w) + v[3]);
+        if constexpr (!FOLD) {
+            if (m < M) *reinterpret_cast<float4*>(h + (size_t)m * ld + n) = y;
+        } else {
+            // lane (row = lane & 15, g = lane >> 4) holds features n .. n + 3 = 16 tile + 4 g ..: the tile's partial of a row is the sum over its 4 g-lanes
+            const float s = rows4_sum((y.x + y.y) + (y.z + y.w));
+            const float q = rows4_sum((y.x * y.x + y.y * y.y) + (y.z * y.z + y.w * y.w));
+            if (m < M) {
+                *reinterpret_cast<float4*>(h + (size_t)m * ld + n) = y;
+                const size_t o = packed_index(m, n, K32);
+                st_hilo4(xo + o, xo + xplane + o, make_float4(y.x * p.c.x, y.y * p.c.y, y.z * p.c.z, y.w * p.c.w));
+                if ((n & 15) == 0) stats[(size_t)(n >> 4) * sld + m] = make_float2(s, q);
+            }
+        }
     }
     __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const { fin(m, n, v, pre(m, n)); }
 };
+typedef EpResidualT<false> EpResidual;
+typedef EpResidualT<true> EpResidualFold;
 
 template <bool BIAS>            // out[m][n] = (v + bias[n]) * scale   (BIAS: cross-attn q;  !BIAS: vocabulary logits, scale 1)
 struct EpF32T {                 // two TYPES, not a run-time null test: a branch around the bias load in the launch's request batch breaks the

@@ -26,6 +26,8 @@ struct DecLayerW {
     const float *ln1_w, *ln1_b, *qkv_b, *out_b, *ln2_w, *ln2_b, *cq_b, *cout_b, *ln3_w, *ln3_b, *fc1_b, *fc2_b;
     const bf16_t *qkv_w, *out_w, *cq_w, *cout_w, *fc1_w, *fc2_w;     // packed bf16 — or packed fp8 e4m3 when the scales below are set
     const float *qkv_s = nullptr, *out_s = nullptr, *cq_s = nullptr, *cout_s = nullptr, *fc1_s = nullptr, *fc2_s = nullptr;
+    // LayerNorm folded into the three LayerNorm-fed GEMMs (wm_common.h; computed in wm_create by wm_dec_fold_init): c = W gamma, bf = b + W beta
+    const float *qkv_c = nullptr, *qkv_bf = nullptr, *cq_c = nullptr, *cq_bf = nullptr, *fc1_c = nullptr, *fc1_bf = nullptr;
 };
 
 // scalars every decode kernel may need (passed by value)
@@ -118,6 +120,10 @@ struct wm_ctx {
     int *hostflags = nullptr, *hostflags_dev = nullptr;                     // host-mapped {carry, finished}
     hipGraphExec_t graph_base = nullptr;
     bf16_t *xbuf = nullptr, *fbuf = nullptr, *ybuf = nullptr;
+    // LayerNorm fold (round 6): operand gamma o x of the next LayerNorm-fed GEMM (hi / lo planes, written by the launch that produced x), the
+    // rows' statistics partials [d / 16 tiles][Rcap rows] and the fold vectors of every decoder layer; WM_LN_FOLD=0 keeps the LayerNorm launches
+    bf16_t* xn = nullptr; float2* lnstats = nullptr; float* foldv = nullptr;
+    bool ln_fold = false;
     float *cml = nullptr, *co = nullptr;   // cross-attention partials
     int* ticket = nullptr;                 // [16 streams][H] arrival tickets of the cross-attention key splits
     float* logits = nullptr;               // [32][Vpad]
@@ -163,3 +169,4 @@ int wm_dec_iter_base(wm_ctx* ctx, int Mper_base);   // base pass layers + final 
 int wm_dec_iter_rest(wm_ctx* ctx, int Mper_base);
 int wm_dec_step(wm_ctx* ctx, int);   // heads, candidates, verify pass, accept
 int wm_dec_profile(wm_ctx* ctx, int kernel, int rows, int reps, float* ms, double* bytes);
+int wm_dec_fold_init(wm_ctx* ctx);   // c = W gamma, b' = b + W beta of every LayerNorm-fed decoder GEMM (needs ctx->foldv)

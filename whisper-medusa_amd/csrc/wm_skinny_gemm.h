@@ -127,6 +127,10 @@ static thread_local PfJob g_pf_job = {nullptr, nullptr, 0u, 0u, 0ull};     // ho
 // host: a second matrix OF THE SAME SIZE the next batched LayerNorm launch (R > 16 rows) should also pull in (LN3 + FC1: the FC2 weights, which
 // no launch in between can carry); cleared by that launch
 static thread_local const void* g_ln_pf_extra = nullptr;
+// host: the prefetch job of a BATCHED launch (k_rows_gemm / k_skinny2_gemm; round 6: with the LayerNorm folded there is no LayerNorm launch left to
+// carry the next GEMM's weights, so the launch that produces the residual row carries them); sliced = pf_block_sliced (token-tile consumer)
+static thread_local PfJob g_pf_batched = {nullptr, nullptr, 0u, 0u, 0ull};
+static thread_local int g_pf_batched_sliced = 0;
 
 __device__ __forceinline__ void pf_block(const PfJob& pf, int job)
 {
@@ -333,10 +337,12 @@ typedef LdNormT<false> LdIdent;
 // when the slice is long: the second half is issued as soon as the first has been consumed).  RT = weight row tiles per
 // wave (register blocking: the token fragment — and, for LdNorm, its normalisation — is shared by RT tiles; used where one
 // tile per block would put more blocks than CUs on the chip).  RT > 1 needs ksplit >= RT.
-template <int NK, int RT, bool W8, class Ld, class Ep>
+// FOLD (round 6): the operand is gamma o x written by the producing launch, the block sums the rows' statistics partials and the accumulator
+// becomes rstd (acc - mean c) before the epilogue (wm_common.h "LayerNorm folded into the GEMM it feeds"); Ld = LdPacked.
+template <int NK, int RT, bool W8, class Ld, class Ep, bool FOLD = false>
 __global__ void __launch_bounds__(640)
 k_skinny_gemm(const bf16_t* __restrict__ W, const void* __restrict__ la, const void* __restrict__ lb, const void* __restrict__ lc, int li0, int li1,
-              int N16, int K32, int plan, int nmain, const float* __restrict__ wscale, const int* __restrict__ done, Ep ep, PfJob pf TL_ARG)
+              int N16, int K32, int plan, int nmain, const float* __restrict__ wscale, const int* __restrict__ done, Ep ep, PfJob pf, FoldIn fold TL_ARG)
 {
     // W .. nmain are 14 dwords: exactly what the kernarg preload delivers in SGPRs with the wave (-amdgpu-kernarg-preload-count=16 = the kernarg
     // pointer + 14 dwords); wscale, done and the structs behind them are s_loaded at the top of the main path and consumed after the request batch.
@@ -369,7 +375,7 @@ k_skinny_gemm(const bf16_t* __restrict__ W, const void* __restrict__ la, const v
     }
     if constexpr (!Ld::kNorm) ld.template issue<XB>(xr, smem, kt0, lane);
     EpPre pre; pre.i = 0; pre.a = make_float4(0.f, 0.f, 0.f, 0.f); pre.b = pre.a;
-    float4 wsc = make_float4(1.f, 1.f, 1.f, 1.f);
+    float4 wsc = make_float4(1.f, 1.f, 1.f, 1.f), fc4 = make_float4(0.f, 0.f, 0.f, 0.f);
     // the element this thread will finish: with K-slices, wave f < rt_per_wg * RT finishes the block's f-th row tile; without,
     // every wave finishes its own tile (RT == 1 there)
     const int tf = (ksplit > 1) ? blockIdx.x * rt_per_wg * RT + wave : tile0;
@@ -383,6 +389,14 @@ k_skinny_gemm(const bf16_t* __restrict__ W, const void* __restrict__ la, const v
         const int enc = min(tf, N16 - 1) * 16 + 4 * (lane >> 4);
         pre = ep.pre(em, enc);
         if constexpr (W8) wsc = *reinterpret_cast<const float4*>(wscale + enc);
+        if constexpr (FOLD) fc4 = *reinterpret_cast<const float4*>(fold.c + enc);
+    }
+    // FOLD: the thread's share of the 16 rows' statistics partials (group f_grp of row f_row; threads beyond 16 G repeat the last share)
+    FoldPart fpl; int f_slot = 0;
+    if constexpr (FOLD) {
+        const int idx = min((int)threadIdx.x, 2 * fold.T16 - 1);            // 16 rows x G = T16 / 8 groups
+        f_slot = idx;
+        fold_part_load(fpl, fold, min(idx & 15, li0 - 1), idx >> 4);        // li0 = M (LdPacked): rows >= M take the last row's (never stored)
     }
     ld.template stage<XB>(xr, smem);
     // done: every stream finished (the rest of this replay is a no-op).  Checked after the batch went out: the flag's
@@ -422,6 +436,9 @@ k_skinny_gemm(const bf16_t* __restrict__ W, const void* __restrict__ la, const v
     }
     TL_MID
 
+    // FOLD: group partials of the rows' statistics -> LDS (behind the K-slice partials), visible after the block barrier below
+    const float2* fpart = reinterpret_cast<const float2*>(smem + ld.lds_bytes() + (ksplit > 1 ? (size_t)rt_per_wg * RT * ksplit * 1024 : 0));
+    if constexpr (FOLD) const_cast<float2*>(fpart)[f_slot] = fold_part_sum(fpl);
     if (ksplit > 1) {
         float4* red = reinterpret_cast<float4*>(smem + ld.lds_bytes());
 #pragma unroll
@@ -435,11 +452,16 @@ k_skinny_gemm(const bf16_t* __restrict__ W, const void* __restrict__ la, const v
                 s[0] += p.x; s[1] += p.y; s[2] += p.z; s[3] += p.w;
             }
             if constexpr (W8) s = f32x4_t{s[0] * wsc.x, s[1] * wsc.y, s[2] * wsc.z, s[3] * wsc.w};
+            if constexpr (FOLD) s = fold_apply(s, fold_row_stat(fpart, em, 16, fold.T16 >> 3, fold.inv_d), fc4);
             ep.fin(em, en, s, pre);
         }
-    } else if (edo) {
-        if constexpr (W8) acc[0] = f32x4_t{acc[0][0] * wsc.x, acc[0][1] * wsc.y, acc[0][2] * wsc.z, acc[0][3] * wsc.w};
-        ep.fin(em, en, acc[0], pre);
+    } else {
+        if constexpr (FOLD) __syncthreads();
+        if (edo) {
+            if constexpr (W8) acc[0] = f32x4_t{acc[0][0] * wsc.x, acc[0][1] * wsc.y, acc[0][2] * wsc.z, acc[0][3] * wsc.w};
+            if constexpr (FOLD) acc[0] = fold_apply(acc[0], fold_row_stat(fpart, em, 16, fold.T16 >> 3, fold.inv_d), fc4);
+            ep.fin(em, en, acc[0], pre);
+        }
     }
     TL_END
 }
@@ -514,13 +536,23 @@ k_ln_tiles(const void* __restrict__ la, const void* __restrict__ lb, const void*
 // groups per block sharing token fragments through the L1, a 96-register budget — are kept as tests/microbench/r04_rows_variants.patch;
 // round 5's LDS-shared token tiles with register-direct weights (k_rows_lds) and the LayerNorm in the producing GEMM's tail with a
 // write-through hand-off as tests/microbench/r05_rows_lds_ln_tail.patch: measured, profiles/r05_rows_lds.md.)
-template <int NKR, int RT, int TT, bool W8, class Ep>
+template <int NKR, int RT, int TT, bool W8, class Ep, bool FOLD = false>
 __global__ void __launch_bounds__(640)
 k_rows_gemm(const bf16_t* __restrict__ W, const bf16_t* __restrict__ X, size_t plane, const int* __restrict__ done, const int* __restrict__ ntiles,
-            int N16, int K32, int ksplit, int MT, const float* __restrict__ wscale, Ep ep TL_ARG)
+            int N16, int K32, int ksplit, int MT, const float* __restrict__ wscale, Ep ep, FoldIn fold, PfJob pf, int pf_sliced TL_ARG)
 {
     // W .. MT are 14 dwords: preloaded (ntiles used to follow the epilogue struct: its pointer, then *ntiles — two scalar round trips at entry)
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    {   // extra rows of blocks behind the token-tile groups: prefetch-only (the next GEMM's weights towards the Infinity Cache / this XCD's L2)
+        const int ny = (MT + TT - 1) / TT;
+        if ((int)blockIdx.y >= ny) {
+            if (!(done && *done)) {
+                const int job = ((int)blockIdx.y - ny) * (int)gridDim.x + (int)blockIdx.x;
+                if (pf_sliced) pf_block_sliced(pf, job); else pf_block(pf, job);
+            }
+            return;
+        }
+    }
     TL_BEGIN
     // (checked first: moving the flag behind the first group of loads — a mid-loop exit — cost the 352-row launches ~3 us each, the
     //  compiler no longer overlapped the load groups across it: tests/microbench/r03_call4.sh)
@@ -545,6 +577,17 @@ k_rows_gemm(const bf16_t* __restrict__ W, const bf16_t* __restrict__ X, size_t p
     for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int j = 0; j < TT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // FOLD: the thread's share of the TT x 16 rows' statistics partials (wm_common.h) is requested ahead of the operand stream and summed into LDS
+    // as soon as the first operand group is on the wire: the 16 registers are free again before the MFMAs (held across the K loop they pushed the
+    // QKV instance from 127 to 144 registers: three waves per SIMD instead of four, two resident blocks instead of three)
+    const float2* fpart = reinterpret_cast<const float2*>(smem + (ksplit > 1 ? (size_t)RT * TT * ksplit * 1024 : 0));
+    FoldPart fpl; int f_slot = 0;
+    if constexpr (FOLD) {
+        const int idx = min((int)threadIdx.x, TT * 2 * fold.T16 - 1);          // TT x 16 rows x G = T16 / 8 groups
+        f_slot = idx;
+        const int r = idx % (TT * 16);
+        fold_part_load(fpl, fold, min(mt0 + (r >> 4), MT - 1) * 16 + (r & 15), idx / (TT * 16));
+    }
     constexpr int G = 4;          // k-tiles per load group
 #pragma unroll
     for (int kg = 0; kg < NKR; kg += G) {
@@ -555,6 +598,9 @@ k_rows_gemm(const bf16_t* __restrict__ W, const bf16_t* __restrict__ X, size_t p
             for (int j = 0; j < TT; ++j) { xh[j][u] = ld_frag(xp[j] + (size_t)(kg + u) * 512); xl[j][u] = ld_frag(xp[j] + plane + (size_t)(kg + u) * 512); }
 #pragma unroll
             for (int i = 0; i < RT; ++i) a[i][u] = ld_wfrag<W8, false>(W, wp[i] + (size_t)(kg + u) * 512);
+        }
+        if constexpr (FOLD) {
+            if (kg == 0) const_cast<float2*>(fpart)[f_slot] = fold_part_sum(fpl);      // (the partial loads are the oldest requests: their wait leaves the operand group in flight)
         }
 
 #pragma unroll
@@ -584,9 +630,26 @@ k_rows_gemm(const bf16_t* __restrict__ W, const bf16_t* __restrict__ X, size_t p
             }
             if (rt0 + i < N16 && mt0 + j < MT) {
                 if constexpr (W8) sacc = scale4(sacc, wscale, (rt0 + i) * 16 + 4 * (l2 >> 4));
+                if constexpr (FOLD)
+                    sacc = fold_apply(sacc, fold_row_stat(fpart, j * 16 + (l2 & 15), TT * 16, fold.T16 >> 3, fold.inv_d),
+                                      *reinterpret_cast<const float4*>(fold.c + (rt0 + i) * 16 + 4 * (l2 >> 4)));
                 ep.store4((mt0 + j) * 16 + (l2 & 15), (rt0 + i) * 16 + 4 * (l2 >> 4), sacc);
             }
         }
+    } else if constexpr (FOLD) {
+        // (one K-slice per block: d_model <= 256 only — the folded GEMMs keep <= 8 fragments per slice.  Tile by tile: the batched operand form
+        //  below would set the register budget of the instances every real model runs through the K-slice path above)
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int j = 0; j < TT; ++j)
+                if (rt0 + i < N16 && mt0 + j < MT) {
+                    if constexpr (W8) acc[i][j] = scale4(acc[i][j], wscale, (rt0 + i) * 16 + 4 * (lane >> 4));
+                    acc[i][j] = fold_apply(acc[i][j], fold_row_stat(fpart, j * 16 + (lane & 15), TT * 16, fold.T16 >> 3, fold.inv_d),
+                                           *reinterpret_cast<const float4*>(fold.c + (rt0 + i) * 16 + 4 * (lane >> 4)));
+                    ep.store4((mt0 + j) * 16 + (lane & 15), (rt0 + i) * 16 + 4 * (lane >> 4), acc[i][j]);
+                }
     } else {
         // operands of every tile's epilogue in one batch, then the stores (tile-by-tile store4 calls are dependent memory round trips:
         // loads cannot be hoisted over the previous tile's stores)
@@ -617,15 +680,19 @@ k_rows_gemm(const bf16_t* __restrict__ W, const bf16_t* __restrict__ X, size_t p
 // tiles' hi/lo fragments and the epilogue operands are requested in one batch at entry — with every weight fragment feeding
 // four MFMAs.  (The register-blocked kernel walked its K-slice in dependent groups of 4 fragments: FC2 at 32 rows took 15 us
 // against 7 us for the single-tile launch.)  Same plan, same accumulation order: bit-identical to single-stream runs.
-template <int NK, bool W8, class Ep>
+template <int NK, bool W8, class Ep, bool FOLD = false>
 __global__ void __launch_bounds__(640)
 k_skinny2_gemm(const bf16_t* __restrict__ W, const bf16_t* __restrict__ X, size_t plane, const int* __restrict__ done, int N16, int K32, int plan, int M,
-               const float* __restrict__ wscale, Ep ep)
+               const float* __restrict__ wscale, Ep ep, FoldIn fold, PfJob pf)
 {
     // W .. M are 12 dwords: preloaded (plane and M used to lie behind the 14th dword: the token requests waited for a scalar load);
     // plan = ksplit | rt_per_wg << 8 | ks_magic << 16
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ksplit = plan & 255, rt_per_wg = (plan >> 8) & 255, ks_magic = plan >> 16;
+    {   // blocks behind the row-tile groups: prefetch-only (one job per block of the NEXT two-tile GEMM, same XCD by construction)
+        const int nmain = (N16 + rt_per_wg - 1) / rt_per_wg;
+        if ((int)blockIdx.x >= nmain) { if (!(done && *done)) pf_block(pf, (int)blockIdx.x - pf_round8(nmain)); return; }
+    }
     // token fragments held at a time: 4 k-tiles x 2 token tiles x hi/lo = 64 registers next to the wave's NK weight fragments (a block
     // of 10 waves leaves 168 registers per lane); the next round is requested as soon as the MFMAs of this one have issued
     constexpr int XB = 4;
@@ -660,11 +727,19 @@ k_skinny2_gemm(const bf16_t* __restrict__ W, const bf16_t* __restrict__ X, size_
     const int en = tf * 16 + 4 * (lane >> 4);
     const bool edo = ((ksplit > 1) ? (wave < nfin) : true) && tf < N16;
     EpPre pre0, pre1; pre0.i = 0; pre0.a = make_float4(0.f, 0.f, 0.f, 0.f); pre0.b = pre0.a; pre1 = pre0;
-    float4 wsc = make_float4(1.f, 1.f, 1.f, 1.f);
+    float4 wsc = make_float4(1.f, 1.f, 1.f, 1.f), fc4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (edo) {
         if (ksplit > 1) pre0 = ep.pre((wave & 1) * 16 + (lane & 15), en);
         else { pre0 = ep.pre(lane & 15, en); pre1 = ep.pre(16 + (lane & 15), en); }
         if constexpr (W8) wsc = *reinterpret_cast<const float4*>(wscale + en);
+        if constexpr (FOLD) fc4 = *reinterpret_cast<const float4*>(fold.c + en);
+    }
+    // FOLD: the thread's share of the 32 rows' statistics partials (wm_common.h)
+    FoldPart fpl; int f_slot = 0;
+    if constexpr (FOLD) {
+        const int idx = min((int)threadIdx.x, 4 * fold.T16 - 1);              // 32 rows x G = T16 / 8 groups
+        f_slot = idx;
+        fold_part_load(fpl, fold, min(idx & 31, M - 1), idx >> 5);
     }
     if (done && *done) return;
 
@@ -679,6 +754,8 @@ k_skinny2_gemm(const bf16_t* __restrict__ W, const bf16_t* __restrict__ X, size_
             acc1 = mfma16(av, h1[u], acc1); acc1 = mfma16(av, l1[u], acc1);
         }
     }
+    const float2* fpart = reinterpret_cast<const float2*>(smem + (ksplit > 1 ? (size_t)rt_per_wg * 2 * ksplit * 1024 : 0));
+    if constexpr (FOLD) const_cast<float2*>(fpart)[f_slot] = fold_part_sum(fpl);
     if (ksplit > 1) {
         float4* red = reinterpret_cast<float4*>(smem);
         red[((rtl * 2 + 0) * ksplit + ks) * 64 + lane] = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
@@ -691,15 +768,23 @@ k_skinny2_gemm(const bf16_t* __restrict__ W, const bf16_t* __restrict__ X, size_
                 s[0] += p.x; s[1] += p.y; s[2] += p.z; s[3] += p.w;
             }
             if constexpr (W8) s = f32x4_t{s[0] * wsc.x, s[1] * wsc.y, s[2] * wsc.z, s[3] * wsc.w};
+            if constexpr (FOLD) s = fold_apply(s, fold_row_stat(fpart, (wave & 1) * 16 + (lane & 15), 32, fold.T16 >> 3, fold.inv_d), fc4);
             ep.fin((wave & 1) * 16 + (lane & 15), en, s, pre0);
         }
-    } else if (edo) {
-        if constexpr (W8) {
-            acc0 = f32x4_t{acc0[0] * wsc.x, acc0[1] * wsc.y, acc0[2] * wsc.z, acc0[3] * wsc.w};
-            acc1 = f32x4_t{acc1[0] * wsc.x, acc1[1] * wsc.y, acc1[2] * wsc.z, acc1[3] * wsc.w};
+    } else {
+        if constexpr (FOLD) __syncthreads();
+        if (edo) {
+            if constexpr (W8) {
+                acc0 = f32x4_t{acc0[0] * wsc.x, acc0[1] * wsc.y, acc0[2] * wsc.z, acc0[3] * wsc.w};
+                acc1 = f32x4_t{acc1[0] * wsc.x, acc1[1] * wsc.y, acc1[2] * wsc.z, acc1[3] * wsc.w};
+            }
+            if constexpr (FOLD) {
+                acc0 = fold_apply(acc0, fold_row_stat(fpart, lane & 15, 32, fold.T16 >> 3, fold.inv_d), fc4);
+                acc1 = fold_apply(acc1, fold_row_stat(fpart, 16 + (lane & 15), 32, fold.T16 >> 3, fold.inv_d), fc4);
+            }
+            ep.fin(lane & 15, en, acc0, pre0);
+            ep.fin(16 + (lane & 15), en, acc1, pre1);
         }
-        ep.fin(lane & 15, en, acc0, pre0);
-        ep.fin(16 + (lane & 15), en, acc1, pre1);
     }
 }
 
@@ -1015,20 +1100,37 @@ static inline PfJob pf_for_gemm(const bf16_t* W, bool fp8, int N16, int K32, boo
     return PfJob{reinterpret_cast<const char*>(W), nullptr, (unsigned)(tile * per_block), (unsigned)grid, tile * N16};
 }
 
+// The job a BATCHED launch (R > 16 rows) carries for the LayerNorm-folded GEMM (W, N16, K32) that follows it, `extra` = a second matrix of the
+// same size: MT == 2 -> consumer k_skinny2_gemm, one job per consumer block; MT >= 3 -> token-tile consumer, 64 KB pieces of XCD eighths.
+static inline void pf_set_batched(const bf16_t* W, const void* extra, bool fp8, int N16, int K32, int MT) {
+    const SkinnyPlan p = skinny_plan(N16, K32, true);
+    const unsigned long long wbytes = (unsigned long long)N16 * K32 * (fp8 ? 512 : 1024);
+    if (MT == 2 && skinny_env("WM_SKINNY2", 1) && p.ksplit * p.rt <= 10) {
+        g_pf_batched = PfJob{reinterpret_cast<const char*>(W), reinterpret_cast<const char*>(extra), (unsigned)((unsigned long long)p.rt * K32 * (fp8 ? 512 : 1024)),
+                             (unsigned)((N16 + p.rt - 1) / p.rt), wbytes};
+        g_pf_batched_sliced = 0;
+    } else {
+        const unsigned long long slice = ((wbytes + 7) / 8 + 1023) & ~1023ull;
+        g_pf_batched = PfJob{reinterpret_cast<const char*>(W), reinterpret_cast<const char*>(extra), 65536u, (unsigned)(8 * ((slice + 65535) / 65536)), wbytes};
+        g_pf_batched_sliced = 1;
+    }
+}
+
 // a weight matrix in the packed layout: bf16 (scale == nullptr) or fp8 e4m3 with one fp32 scale per output row
 struct WRef {
     const bf16_t* w; const float* scale;
     WRef(const bf16_t* w_, const float* scale_ = nullptr) : w(w_), scale(scale_) {}
 };
 
-template <int NK, int RT, bool W8, class Ld, class Ep>
-static inline hipError_t launch_skinny_nk_rt(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p, const Ld& ld, const Ep& ep) {
+template <int NK, int RT, bool W8, class Ld, class Ep, bool FOLD = false>
+static inline hipError_t launch_skinny_nk_rt(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p, const Ld& ld, const Ep& ep, const FoldIn& fold = FoldIn{}) {
     const int per_block = p.rt * RT;
     const int grid = (N16 + per_block - 1) / per_block;
     const int threads = 64 * p.ksplit * p.rt;
-    const size_t lds = (size_t)ld.lds_bytes() + (p.ksplit > 1 ? (size_t)per_block * p.ksplit * 1024 : 0);
+    const size_t lds = (size_t)ld.lds_bytes() + (p.ksplit > 1 ? (size_t)per_block * p.ksplit * 1024 : 0) + (FOLD ? (size_t)2 * fold.T16 * sizeof(float2) : 0);
+    if (FOLD && 2 * fold.T16 > threads) return hipErrorInvalidConfiguration;      // 16 rows x T16 / 8 partial groups, one per thread
     const int magic = (256 + p.ksplit - 1) / p.ksplit;         // (wave * magic) >> 8 == wave / ksplit for wave < 16
-    auto kern = k_skinny_gemm<NK, RT, W8, Ld, Ep>;
+    auto kern = k_skinny_gemm<NK, RT, W8, Ld, Ep, FOLD>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -1039,70 +1141,74 @@ static inline hipError_t launch_skinny_nk_rt(hipStream_t st, WRef W, int N16, in
     const LdArgs la = ld.pack();
     if (p.ksplit > 255 || p.rt > 255 || magic > 32767 || !ld.packs()) return hipErrorInvalidConfiguration;
     hipLaunchKernelGGL(kern, dim3(grid_all), dim3(threads), lds, st, W.w, la.a, la.b, la.c, la.i0, la.i1, N16, K32, p.ksplit | (p.rt << 8) | (magic << 16), grid,
-                       W.scale, g_skinny_done, ep, pf TL_PASS);
+                       W.scale, g_skinny_done, ep, pf, fold TL_PASS);
     return hipGetLastError();
 }
 // the bytes block j of the skinny GEMM (W, N16, K32, loader kind) reads: one prefetch job per consumer block
 static inline PfJob pf_for_gemm(const bf16_t* W, bool fp8, int N16, int K32, bool norm_loader);
-template <int NK, bool W8, class Ld, class Ep>
-static inline hipError_t launch_skinny_nk(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p, const Ld& ld, const Ep& ep) {
+template <int NK, bool W8, class Ld, class Ep, bool FOLD = false>
+static inline hipError_t launch_skinny_nk(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p, const Ld& ld, const Ep& ep, const FoldIn& fold = FoldIn{}) {
     if constexpr (NK <= 8) {
-        if (p.RT == 2 && p.ksplit >= 2) return launch_skinny_nk_rt<NK, 2, W8>(st, W, N16, K32, p, ld, ep);
+        if (p.RT == 2 && p.ksplit >= 2) return launch_skinny_nk_rt<NK, 2, W8, Ld, Ep, FOLD>(st, W, N16, K32, p, ld, ep, fold);
     }
-    return launch_skinny_nk_rt<NK, 1, W8>(st, W, N16, K32, p, ld, ep);
+    return launch_skinny_nk_rt<NK, 1, W8, Ld, Ep, FOLD>(st, W, N16, K32, p, ld, ep, fold);
 }
 
-template <bool W8, class Ld, class Ep>
-static inline hipError_t launch_skinny_w(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p, const Ld& ld, const Ep& ep) {
+template <bool W8, class Ld, class Ep, bool FOLD = false>
+static inline hipError_t launch_skinny_w(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p, const Ld& ld, const Ep& ep, const FoldIn& fold = FoldIn{}) {
     if (p.ksplit * p.rt > 10 || p.ksplit * p.nk != K32 || (Ld::kNorm && p.nk > 8)) return hipErrorInvalidConfiguration;
     if (Ld::kNorm && K32 * 16 > ((p.nk + 3) / 4) * 64 * p.ksplit * p.rt) return hipErrorInvalidConfiguration;      // gamma | beta float4 per thread (LdNormT::issue)
     switch (p.nk) {
-        case 4: return launch_skinny_nk<4, W8>(st, W, N16, K32, p, ld, ep);
-        case 8: return launch_skinny_nk<8, W8>(st, W, N16, K32, p, ld, ep);
-        case 12: if constexpr (!Ld::kNorm) return launch_skinny_nk<12, W8>(st, W, N16, K32, p, ld, ep); break;
-        case 16: if constexpr (!Ld::kNorm) return launch_skinny_nk<16, W8>(st, W, N16, K32, p, ld, ep); break;
+        case 4: return launch_skinny_nk<4, W8, Ld, Ep, FOLD>(st, W, N16, K32, p, ld, ep, fold);
+        case 8: return launch_skinny_nk<8, W8, Ld, Ep, FOLD>(st, W, N16, K32, p, ld, ep, fold);
+        case 12: if constexpr (!Ld::kNorm && !FOLD) return launch_skinny_nk<12, W8>(st, W, N16, K32, p, ld, ep); break;      // (a folded GEMM keeps the LayerNorm plan: <= 8 fragments per K-slice)
+        case 16: if constexpr (!Ld::kNorm && !FOLD) return launch_skinny_nk<16, W8>(st, W, N16, K32, p, ld, ep); break;
         default: break;
     }
     return hipErrorInvalidConfiguration;
 }
 
-template <class Ld, class Ep>
-static inline hipError_t launch_skinny(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p, const Ld& ld, const Ep& ep) {
-    if (W.scale) return launch_skinny_w<true>(st, W, N16, K32, p, ld, ep);
-    return launch_skinny_w<false>(st, W, N16, K32, p, ld, ep);
+template <class Ld, class Ep, bool FOLD = false>
+static inline hipError_t launch_skinny(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p, const Ld& ld, const Ep& ep, const FoldIn& fold = FoldIn{}) {
+    if (W.scale) return launch_skinny_w<true, Ld, Ep, FOLD>(st, W, N16, K32, p, ld, ep, fold);
+    return launch_skinny_w<false, Ld, Ep, FOLD>(st, W, N16, K32, p, ld, ep, fold);
 }
 
-template <int NKR, int RT, bool W8, class Ep, int TT = 2>
+template <int NKR, int RT, bool W8, class Ep, bool FOLD = false, int TT = 2>
 static inline hipError_t launch_rows_gemm_w(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p,
-                                            const bf16_t* X, size_t plane, int MT, const Ep& ep) {
+                                            const bf16_t* X, size_t plane, int MT, const Ep& ep, const FoldIn& fold = FoldIn{}) {
     const dim3 grid((N16 + RT - 1) / RT, (MT + TT - 1) / TT);
-    const size_t lds = p.ksplit > 1 ? (size_t)RT * TT * p.ksplit * 1024 : 0;
-    auto kern = k_rows_gemm<NKR, RT, TT, W8, Ep>;
+    const size_t lds = (p.ksplit > 1 ? (size_t)RT * TT * p.ksplit * 1024 : 0) + (FOLD ? (size_t)TT * 2 * fold.T16 * sizeof(float2) : 0);
+    if (FOLD && TT * 2 * fold.T16 > 64 * p.ksplit) return hipErrorInvalidConfiguration;      // TT x 16 rows x T16 / 8 partial groups, one per thread
+    auto kern = k_rows_gemm<NKR, RT, TT, W8, Ep, FOLD>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(64 * p.ksplit), lds, st, W.w, X, plane, g_skinny_done, g_skinny_ntiles, N16, K32, p.ksplit, MT, W.scale, ep TL_PASS);
+    const PfJob pf = g_pf_batched; const int pfs = g_pf_batched_sliced;
+    g_pf_batched = PfJob{nullptr, nullptr, 0u, 0u, 0ull};
+    const dim3 grid_all(grid.x, grid.y + (pf.n_jobs ? (pf.n_jobs + grid.x - 1) / grid.x : 0));
+    hipLaunchKernelGGL(kern, grid_all, dim3(64 * p.ksplit), lds, st, W.w, X, plane, g_skinny_done, g_skinny_ntiles, N16, K32, p.ksplit, MT, W.scale, ep, fold, pf, pfs TL_PASS);
     return hipGetLastError();
 }
 
-template <int NKR, int RT, class Ep>
+template <int NKR, int RT, class Ep, bool FOLD = false>
 static inline hipError_t launch_rows_gemm(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p,
-                                          const bf16_t* X, size_t plane, int MT, const Ep& ep) {
-    if (W.scale) return launch_rows_gemm_w<NKR, RT, true>(st, W, N16, K32, p, X, plane, MT, ep);
-    return launch_rows_gemm_w<NKR, RT, false>(st, W, N16, K32, p, X, plane, MT, ep);
+                                          const bf16_t* X, size_t plane, int MT, const Ep& ep, const FoldIn& fold = FoldIn{}) {
+    if (W.scale) return launch_rows_gemm_w<NKR, RT, true, Ep, FOLD>(st, W, N16, K32, p, X, plane, MT, ep, fold);
+    return launch_rows_gemm_w<NKR, RT, false, Ep, FOLD>(st, W, N16, K32, p, X, plane, MT, ep, fold);
 }
 
-template <int NKR, class Ep>
+template <int NKR, class Ep, bool FOLD = false>
 static inline hipError_t launch_skinny_mt_nk(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p,
-                                             const bf16_t* X, size_t plane, int MT, const Ep& ep) {
+                                             const bf16_t* X, size_t plane, int MT, const Ep& ep, const FoldIn& fold = FoldIn{}) {
     static const int min_blocks = skinny_env("WM_ROWS_GEMM_MIN_BLOCKS", 400);
     // weight row tiles per wave: as many as still leave >= 400 blocks (~1.5 per CU; swept 100..800 at 8 and 32 streams) (register blocking divides the L2 re-reads
     // of the token operand; with few token tiles the chip has to be filled by features instead).  Same results.
     const int groups = (MT + 1) / 2;
-    if (((N16 + 3) / 4) * groups >= min_blocks) return launch_rows_gemm<NKR, 4>(st, W, N16, K32, p, X, plane, MT, ep);
-    if (((N16 + 1) / 2) * groups >= min_blocks) return launch_rows_gemm<NKR, 2>(st, W, N16, K32, p, X, plane, MT, ep);
-    return launch_rows_gemm<NKR, 1>(st, W, N16, K32, p, X, plane, MT, ep);
+    if (((N16 + 3) / 4) * groups >= min_blocks) return launch_rows_gemm<NKR, 4, Ep, FOLD>(st, W, N16, K32, p, X, plane, MT, ep, fold);
+    if (((N16 + 1) / 2) * groups >= min_blocks) return launch_rows_gemm<NKR, 2, Ep, FOLD>(st, W, N16, K32, p, X, plane, MT, ep, fold);
+    return launch_rows_gemm<NKR, 1, Ep, FOLD>(st, W, N16, K32, p, X, plane, MT, ep, fold);
 }
 
 // ---- LDS-ring token-tile GEMM: tile shape and launch ----
@@ -1161,45 +1267,69 @@ static inline bool use_tile_gemm(int N16, int K32, int MT, bool w8, int nk) {
     return min_mt > 0 && MT >= min_mt && N16 >= min_n16 && !w8 && (nk & 1) == 0 && (K32 & 1) == 0;
 }
 
-template <int NK, bool W8, class Ep>
-static inline hipError_t launch_skinny2_nk(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p, const bf16_t* X, size_t plane, int R, const Ep& ep) {
+template <int NK, bool W8, class Ep, bool FOLD = false>
+static inline hipError_t launch_skinny2_nk(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p, const bf16_t* X, size_t plane, int R, const Ep& ep,
+                                           const FoldIn& fold = FoldIn{}) {
     const int grid = (N16 + p.rt - 1) / p.rt, threads = 64 * p.ksplit * p.rt;
-    const size_t lds = p.ksplit > 1 ? (size_t)p.rt * 2 * p.ksplit * 1024 : 0;
+    const size_t lds = (p.ksplit > 1 ? (size_t)p.rt * 2 * p.ksplit * 1024 : 0) + (FOLD ? (size_t)4 * fold.T16 * sizeof(float2) : 0);
+    if (FOLD && 4 * fold.T16 > threads) return hipErrorInvalidConfiguration;      // 32 rows x T16 / 8 partial groups, one per thread
     const int magic = (256 + p.ksplit - 1) / p.ksplit;
-    hipLaunchKernelGGL((k_skinny2_gemm<NK, W8, Ep>), dim3(grid), dim3(threads), lds, st, W.w, X, plane, g_skinny_done, N16, K32, p.ksplit | (p.rt << 8) | (magic << 16), R,
-                       W.scale, ep);
+    PfJob pf = g_pf_batched;
+    g_pf_batched = PfJob{nullptr, nullptr, 0u, 0u, 0ull};
+    if (g_pf_batched_sliced) pf.n_jobs = 0;          // (a job cut for the token-tile consumer: not this kernel's kind)
+    const int grid_all = pf.n_jobs ? pf_round8(grid) + (int)pf.n_jobs : grid;
+    hipLaunchKernelGGL((k_skinny2_gemm<NK, W8, Ep, FOLD>), dim3(grid_all), dim3(threads), lds, st, W.w, X, plane, g_skinny_done, N16, K32, p.ksplit | (p.rt << 8) | (magic << 16), R,
+                       W.scale, ep, fold, pf);
     return hipGetLastError();
 }
-template <bool W8, class Ep>
-static inline hipError_t launch_skinny2_w(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p, const bf16_t* X, size_t plane, int R, const Ep& ep) {
+template <bool W8, class Ep, bool FOLD = false>
+static inline hipError_t launch_skinny2_w(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p, const bf16_t* X, size_t plane, int R, const Ep& ep,
+                                          const FoldIn& fold = FoldIn{}) {
     switch (p.nk) {
-        case 4: return launch_skinny2_nk<4, W8>(st, W, N16, K32, p, X, plane, R, ep);
-        case 8: return launch_skinny2_nk<8, W8>(st, W, N16, K32, p, X, plane, R, ep);
-        case 12: return launch_skinny2_nk<12, W8>(st, W, N16, K32, p, X, plane, R, ep);
-        case 16: return launch_skinny2_nk<16, W8>(st, W, N16, K32, p, X, plane, R, ep);
-        default: return hipErrorInvalidConfiguration;
+        case 4: return launch_skinny2_nk<4, W8, Ep, FOLD>(st, W, N16, K32, p, X, plane, R, ep, fold);
+        case 8: return launch_skinny2_nk<8, W8, Ep, FOLD>(st, W, N16, K32, p, X, plane, R, ep, fold);
+        case 12: if constexpr (!FOLD) return launch_skinny2_nk<12, W8>(st, W, N16, K32, p, X, plane, R, ep); break;
+        case 16: if constexpr (!FOLD) return launch_skinny2_nk<16, W8>(st, W, N16, K32, p, X, plane, R, ep); break;
+        default: break;
     }
+    return hipErrorInvalidConfiguration;
 }
-template <class Ep>
-static inline hipError_t launch_skinny2(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p, const bf16_t* X, size_t plane, int R, const Ep& ep) {
-    if (W.scale) return launch_skinny2_w<true>(st, W, N16, K32, p, X, plane, R, ep);
-    return launch_skinny2_w<false>(st, W, N16, K32, p, X, plane, R, ep);
+template <class Ep, bool FOLD = false>
+static inline hipError_t launch_skinny2(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p, const bf16_t* X, size_t plane, int R, const Ep& ep,
+                                        const FoldIn& fold = FoldIn{}) {
+    if (W.scale) return launch_skinny2_w<true, Ep, FOLD>(st, W, N16, K32, p, X, plane, R, ep, fold);
+    return launch_skinny2_w<false, Ep, FOLD>(st, W, N16, K32, p, X, plane, R, ep, fold);
 }
 
-template <class Ep>
+template <class Ep, bool FOLD = false>
 static inline hipError_t launch_skinny_mt(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p,
-                                          const bf16_t* X, size_t plane, int MT, int R, const Ep& ep) {
+                                          const bf16_t* X, size_t plane, int MT, int R, const Ep& ep, const FoldIn& fold = FoldIn{}) {
     // the LDS-ring tile kernel (same accumulation order, bit-identical results)
-    if (use_tile_gemm(N16, K32, MT, W.scale != nullptr, p.nk))
-        return launch_tile_gemm(st, W.w, N16, K32, p.nk, X, plane, MT, ep);
+    if constexpr (!FOLD) {
+        if (use_tile_gemm(N16, K32, MT, W.scale != nullptr, p.nk))
+            return launch_tile_gemm(st, W.w, N16, K32, p.nk, X, plane, MT, ep);
+    }
     // two token tiles: the weight-streaming kernel with a second token tile (WM_SKINNY2=0: the register-blocked kernel)
     if (MT == 2 && skinny_env("WM_SKINNY2", 1) && p.ksplit * p.rt <= 10 && p.ksplit * p.nk == K32)
-        return launch_skinny2(st, W, N16, K32, p, X, plane, R, ep);
-    if (p.nk == 16) return launch_skinny_mt_nk<16>(st, W, N16, K32, p, X, plane, MT, ep);
-    if (p.nk == 12) return launch_skinny_mt_nk<12>(st, W, N16, K32, p, X, plane, MT, ep);
-    if (p.nk == 8) return launch_skinny_mt_nk<8>(st, W, N16, K32, p, X, plane, MT, ep);
-    if (p.nk == 4) return launch_skinny_mt_nk<4>(st, W, N16, K32, p, X, plane, MT, ep);
+        return launch_skinny2<Ep, FOLD>(st, W, N16, K32, p, X, plane, R, ep, fold);
+    if constexpr (!FOLD) {
+        if (p.nk == 16) return launch_skinny_mt_nk<16>(st, W, N16, K32, p, X, plane, MT, ep);
+        if (p.nk == 12) return launch_skinny_mt_nk<12>(st, W, N16, K32, p, X, plane, MT, ep);
+    }
+    if (p.nk == 8) return launch_skinny_mt_nk<8, Ep, FOLD>(st, W, N16, K32, p, X, plane, MT, ep, fold);
+    if (p.nk == 4) return launch_skinny_mt_nk<4, Ep, FOLD>(st, W, N16, K32, p, X, plane, MT, ep, fold);
     return hipErrorInvalidConfiguration;
+}
+
+// LayerNorm-fed GEMM with the LayerNorm folded (wm_common.h): X = gamma o x as packed hi / lo planes (written by the launch that produced x),
+// fold = the rows' statistics partials + c = W gamma; the epilogue's bias is b' = b + W beta.  The plan is the LayerNorm plan (<= 8 fragments per
+// K-slice: 64 ksplit threads >= 32 d / 128 partial groups, whatever d_model), shared by the 16-row, two-tile and token-tile kernels.
+template <class Ep>
+static inline hipError_t launch_skinny_fold(hipStream_t st, WRef W, int N16, int K32, int R, const bf16_t* X, size_t plane, const FoldIn& fold, const Ep& ep) {
+    const SkinnyPlan p = skinny_plan(N16, K32, true);
+    if (p.nk > 8 || fold.T16 * 16 != K32 * 32) return hipErrorInvalidConfiguration;
+    if (R <= 16) return launch_skinny<LdPacked, Ep, true>(st, W, N16, K32, p, LdPacked{X, K32, plane, R}, ep, fold);
+    return launch_skinny_mt<Ep, true>(st, W, N16, K32, p, X, plane, (R + 15) / 16, R, ep, fold);
 }
 
 // out = X (R token rows, packed hi/lo planes in global memory) times W^T (N = 16*N16 features, K = 32*K32)
