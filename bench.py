@@ -117,7 +117,7 @@ def median(v):
     return v[len(v) // 2]
 
 
-def cpu_baseline_leg(cfg, sd, eng, gp, wav0, engine_ids, n_iters, fp8, full_budget):
+def cpu_baseline_leg(cfg, sd, eng, gp, wav0, engine_ids, n_iters, fp8, full_budget, act="hilo"):
     """The oracle (a CPU port of the reference algorithm, oracle/) on the host cores of this box, SURVEY.md §8d: split
     log-mel / encoder / decode timers, 1 warm-up + 3 timed runs each, median.  The decode sample is `n_iters` Medusa iterations
     (the whole 128-token budget with --cpu-full).  Parity: the oracle in the engine's numeric contract (sim="bf16"), fed with
@@ -158,7 +158,7 @@ def cpu_baseline_leg(cfg, sd, eng, gp, wav0, engine_ids, n_iters, fp8, full_budg
     t_dec, r = timed(lambda: orc.decode(enc, gp, max_iters=iters))
     ntok = len(r.ids) - len(gp.prompt)
     # parity on the same iterations, engine contract
-    orc16 = Oracle(cfg, sd_cpu, sim="bf16", dec_fp8=fp8, enc_fp8=fp8)
+    orc16 = Oracle(cfg, sd_cpu, sim="bf16", dec_fp8=fp8, enc_fp8=fp8, act=act)
     r16 = orc16.decode(enc, gp, max_iters=iters)
     ok = engine_ids[: len(r16.ids)] == r16.ids
     first = next((i for i, (a, b) in enumerate(zip(engine_ids, r16.ids)) if a != b), min(len(engine_ids), len(r16.ids)))
@@ -209,12 +209,12 @@ def acceptance_sensitivity(eng, cfg, gp_base, B, max_new, fp8=False, accepts=Non
     return out
 
 
-def leg_parity(cfg, sd, eng, gp, fp8, iters=8):
+def leg_parity(cfg, sd, eng, gp, fp8, iters=8, act="hilo"):
     """Stream 0 of the leg's LAST decoded batch against the oracle in the engine's numeric contract, fed with the engine's encoder
     output, for the first `iters` Medusa iterations (the checker, never the thing measured)."""
     from oracle.whisper_medusa_oracle import Oracle
     torch.set_num_threads(min(os.cpu_count() or 1, 16))
-    orc = Oracle(cfg, {k: v.float().cpu() for k, v in sd.items()}, sim="bf16", dec_fp8=fp8, enc_fp8=fp8)
+    orc = Oracle(cfg, {k: v.float().cpu() for k, v in sd.items()}, sim="bf16", dec_fp8=fp8, enc_fp8=fp8, act=act)
     enc = eng.encoder_output(1)[0]
     ref = orc.decode(enc, gp, max_iters=iters)
     got = eng.tokens(0)
@@ -222,16 +222,16 @@ def leg_parity(cfg, sd, eng, gp, fp8, iters=8):
     return {"parity_checked": bool(got[:n] == ref.ids), "parity_tokens_compared": n - len(gp.prompt), "parity_iterations": ref.n_iters}
 
 
-def extra_config(name, heads, B, fp8, dev, logit_std, max_new, steps=8):
+def extra_config(name, heads, B, fp8, dev, logit_std, max_new, steps=8, f16=False):
     """One more BASELINE.json config measured in the same process (B streams, one context): whole-step tokens/s, decode
     iteration time, vanilla anchor, roofline fractions, and a parity check of stream 0 against the oracle."""
     from whisper_medusa import MedusaConfig, WhisperMedusaModel, ACCEPT_TYPICAL, synth, weights
     cfg = MedusaConfig.large_v2(heads, K=10)
     sd = synth.synth_state_dict(cfg, seed=0, device=str(dev), logit_std=logit_std)
-    blob, offs = weights.build_blob(cfg, sd, device=dev, dec_fp8=fp8, enc_fp8=fp8)
+    blob, offs = weights.build_blob(cfg, sd, device=dev, dec_fp8=fp8, enc_fp8=fp8, act_fp16=f16)
     sd_cpu = {k: v.cpu() for k, v in sd.items()}
     del sd
-    model = WhisperMedusaModel.from_blob(cfg, blob, offs, max_batch=B, dec_weight_fp8=fp8, enc_fp8=fp8)
+    model = WhisperMedusaModel.from_blob(cfg, blob, offs, max_batch=B, dec_weight_fp8=fp8, enc_fp8=fp8, act_fp16=f16)
     eng = model.engine
     n_samp = cfg.n_mel_frames * 160
     wav = torch.from_numpy(np.stack([synth.synth_clip(500 + j, n_samp) for j in range(B)])).to(dev)
@@ -248,7 +248,7 @@ def extra_config(name, heads, B, fp8, dev, logit_std, max_new, steps=8):
         n, st = step(); tok += n; it += st["iterations"]; ms_dec += st["ms_decode"]; ms_enc += st["ms_encode"]; sched += st.get("schedule_steps", 0)
     torch.cuda.synchronize(); el = time.perf_counter() - t0
     try:
-        parity = leg_parity(cfg, sd_cpu, eng, gp, fp8)
+        parity = leg_parity(cfg, sd_cpu, eng, gp, fp8, act="f16" if f16 else "hilo")
     except Exception as e:  # noqa: BLE001
         parity = {"parity_checked": False, "parity_error": repr(e)}
     del sd_cpu
@@ -259,6 +259,7 @@ def extra_config(name, heads, B, fp8, dev, logit_std, max_new, steps=8):
     t_iter = ms_dec / max(it, 1)
     bytes_iter = decode_iter_bytes(cfg, B, len(gp.prompt) + max_new / 2, fp8)
     out = {"config": name, "streams": B, "heads": heads, "fp8_decoder_weights": fp8, "steps": steps,
+           "decode_operands": "fp16 single plane" if f16 else "bf16 hi/lo pair",
            "tokens_per_sec": round(tok / el, 1), "decode_tokens_per_sec": round(tok / (ms_dec * 1e-3), 1),
            "ms_per_iteration": round(t_iter, 4), "tokens_per_iteration": round(tok / max(it, 1) / B, 3),
            "vanilla_tokens_per_sec": round(van, 1), "medusa_over_vanilla": round(tok / (ms_dec * 1e-3) / van, 3),
@@ -301,6 +302,9 @@ def main():
     ap.add_argument("--fp8-weights", action="store_true",
                     help="BASELINE configs[4]: encoder QKV / FC1 / cross-K/V projection on the fp8 MFMA (e4m3 x e4m3, per-row scales) and the "
                          "decoder-layer matrices stored as fp8 e4m3 + per-row scale (widened to bf16 in registers: the decode step is HBM-bound)")
+    ap.add_argument("--act", choices=["hilo", "f16"], default=None,
+                    help="decode numerics contract (include/wm.h wm_config.act_fp16): bf16 hi/lo operand pairs (libwm.so) or one fp16 plane "
+                         "(libwm_f16.so); default: the engine's (WM_ACT)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vanilla", action="store_true",
                     help="skip the vanilla-greedy anchor (PMC passes: only Medusa iterations in the counter totals)")
@@ -314,6 +318,8 @@ def main():
     from whisper_medusa import MedusaConfig, WhisperMedusaModel, ACCEPT_TYPICAL
     from whisper_medusa import synth, weights, dist as wd
 
+    from whisper_medusa.engine import default_act_fp16
+    f16 = default_act_fp16() if args.act is None else args.act == "f16"
     rank, local, world = wd.init_from_env()
     assert world == args.gpus or (world == 1 and args.gpus == 1), f"WORLD_SIZE={world} but --gpus {args.gpus}"
     if not torch.cuda.is_available():
@@ -334,14 +340,14 @@ def main():
     blob = offs = sd = None
     if rank == 0:
         sd = synth.synth_state_dict(cfg, seed=0, device=str(dev), logit_std=args.logit_std)
-        blob, offs = weights.build_blob(cfg, sd, device=dev, dec_fp8=args.fp8_weights, enc_fp8=args.fp8_weights)
+        blob, offs = weights.build_blob(cfg, sd, device=dev, dec_fp8=args.fp8_weights, enc_fp8=args.fp8_weights, act_fp16=f16)
     t0 = time.time()
     blob, offs = wd.broadcast_blob(blob, offs, device=dev)
     torch.cuda.synchronize()
     if args.test_setup_delay_s > 0:      # tests/test_bench_dist.py stretches the one-time set-up phase to show that it lies outside the timed region
         time.sleep(args.test_setup_delay_s)
     t_bcast = time.time() - t0
-    model = WhisperMedusaModel.from_blob(cfg, blob, offs, max_batch=B, dec_weight_fp8=args.fp8_weights, enc_fp8=args.fp8_weights)
+    model = WhisperMedusaModel.from_blob(cfg, blob, offs, max_batch=B, dec_weight_fp8=args.fp8_weights, enc_fp8=args.fp8_weights, act_fp16=f16)
     eng = model.engine
 
     # ---- inputs resident in HBM ----
@@ -355,7 +361,7 @@ def main():
     pool = None
     if args.micro_batches > 1:
         from whisper_medusa.pool import ContextPool
-        pool = ContextPool(cfg, blob, offs, args.micro_batches, B, dec_weight_fp8=args.fp8_weights, enc_fp8=args.fp8_weights)
+        pool = ContextPool(cfg, blob, offs, args.micro_batches, B, dec_weight_fp8=args.fp8_weights, enc_fp8=args.fp8_weights, act_fp16=f16)
 
     def step():
         wav = wavs[step_no[0] % n_sets]
@@ -449,11 +455,13 @@ def main():
         "metric": "decoded_tokens_per_sec", "value": round(tokens_all / elapsed, 2), "unit": "tokens/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16" if not args.fp8_weights else "bf16 + fp8 e4m3 (fp8 MFMA in the encoder's LayerNorm-fed GEMMs and the cross-K/V projection, fp8-stored decoder-layer weights)", "data": "synthetic",
+        "vs_baseline": None, "dtype": ("bf16" if not args.fp8_weights else "bf16 + fp8 e4m3 (fp8 MFMA in the encoder's LayerNorm-fed GEMMs and the cross-K/V projection, fp8-stored decoder-layer weights)")
+                                      + (" + fp16 decoder GEMM operands (one plane; fp32 accumulate)" if f16 else ""), "data": "synthetic",
         "config": {"workload": f"whisper-{args.model} + medusa-{args.heads} K={cfg.medusa_num_heads}, "
                                f"{B} x 30 s clip(s) per GPU, log-mel+encoder+decode, max_new_tokens={args.max_new}, "
                                f"typical acceptance (T=1.0), hipGraph decode loop, random-init weights (logit_std={args.logit_std})",
                    "streams_per_gpu": B, "micro_batches": args.micro_batches, "fp8_decoder_weights": bool(args.fp8_weights), "parallelism": f"dp{world}",
+                   "decode_operands": "fp16 single plane (wm_config.act_fp16 = 1)" if f16 else "bf16 hi/lo pair (wm_config.act_fp16 = 0)",
                    "max_new_tokens": args.max_new},
         "tokens_per_sec_per_gpu": round(tokens_all / elapsed / world, 2),
         "ranks_seen": len(per_rank_tokens), "tokens_per_rank": [int(t) for t in per_rank_tokens],
@@ -494,7 +502,7 @@ def main():
                                             ("configs[1] shape at 32 streams (Medusa-Linear)", "base_head", 32, False),
                                             ("configs[4] fp8 (encoder fp8 MFMA + fp8 decoder weights) + Medusa-Linear, 32 streams", "base_head", 32, True)):
                 try:
-                    extra.append(extra_config(name, heads_x, Bx, fp8x, dev, args.logit_std, args.max_new))
+                    extra.append(extra_config(name, heads_x, Bx, fp8x, dev, args.logit_std, args.max_new, f16=f16))
                 except Exception as e:  # noqa: BLE001
                     extra.append({"config": name, "failed": repr(e)})
             out["configs"] = extra
@@ -504,7 +512,8 @@ def main():
         try:
             eng.encode(eng.logmel(wavs[0][:1].contiguous()))
             ids0 = eng.decode(gp, 1)[0]
-            out["cpu_baseline"] = cpu_baseline_leg(cfg, sd, eng, gp, wavs[0][0], ids0, args.cpu_iters, args.fp8_weights, args.cpu_full)
+            out["cpu_baseline"] = cpu_baseline_leg(cfg, sd, eng, gp, wavs[0][0], ids0, args.cpu_iters, args.fp8_weights, args.cpu_full,
+                                                   act="f16" if f16 else "hilo")
         except Exception as e:  # noqa: BLE001
             out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
                                    "sample": f"failed: {e!r}", "parity_checked": False}

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define WM_ABI_VERSION 7
+#define WM_ABI_VERSION 8
 
 #define WM_OK 0
 #define WM_ERR_ARG (-1)      /* bad argument / unsupported configuration (reference: ValueError, model.py:225-229) */
@@ -72,6 +72,13 @@ typedef struct wm_config {
                                  * entries per encoder layer (qkv, qkv scales, fc1, fc1 scales) + 2 (cross-K/V) appended after the
                                  * decoder scales, the bf16 entries of those matrices may then be 16-byte placeholders — and the
                                  * LayerNorm output quantised to e4m3 with one scale per token row; 0: bf16 */
+    int32_t act_fp16;           /* the decode numerics contract (ABI v8).  0: every decoder GEMM operand is a bf16 hi / lo pair
+                                 * (~17 mantissa bits, two planes, two MFMAs per weight fragment), decoder matrices bf16.  1: ONE fp16 plane
+                                 * (11 bits: the precision of the reference's own half-precision inference, model.py:1223-1347 under
+                                 * torch.float16), one v_mfma_f32_16x16x32_f16 per weight fragment; the blob then holds the decoder-layer
+                                 * matrices, the Medusa heads and the packed vocabulary projection as fp16 (exact from bf16 for |w| >= 2^-17;
+                                 * whisper_medusa/weights.py build_blob(act_fp16=True)).  A library is BUILT for one contract
+                                 * (wm_build_act_fp16(): libwm.so 0, libwm_f16.so 1); wm_create refuses the other. */
 } wm_config;
 
 /* Packed parameter blob (layout: whisper_medusa/weights.py).  The blob
@@ -130,6 +137,8 @@ int wm_create(const wm_config* cfg, const wm_weights* w, int device, void* hip_s
 void wm_destroy(wm_ctx* ctx);
 const char* wm_last_error(const wm_ctx* ctx);     /* ctx may be NULL: last create error */
 int wm_abi_version(void);
+/* the decode numerics contract this library was compiled for (wm_config.act_fp16 must equal it) */
+int wm_build_act_fp16(void);
 
 /* ---- audio front door (replaces what the reference's callers do with torchaudio before the
  * feature extractor: `input_speech.mean(dim=0)` and `torchaudio.transforms.Resample(sr, 16000)`, README.md:120-125,

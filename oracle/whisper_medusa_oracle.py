@@ -30,6 +30,7 @@ Only ``resample_sinc_hann`` (torchaudio, not installed) is unpinned — see its 
 NUMERICS.  ``sim="fp32"`` is the reference's default dtype.  ``sim="bf16"`` mirrors
 the engine's storage/rounding contract: parameters are
 bf16-representable; in the ENCODER every GEMM input is rounded to bf16 (MFMA prefill);
+(``act="f16"``: the decoder GEMM operands are ONE fp16 plane instead of the hi/lo pair below — wm_config.act_fp16)
 in the DECODER GEMM/attention operands are carried as a bf16 hi/lo pair (x = hi + lo,
 ~17 mantissa bits, ``_rd``) so they are effectively unrounded; the self/cross KV cache
 and the encoder output are stored in bf16; all accumulation / LayerNorm / softmax /
@@ -284,9 +285,15 @@ class DecodeResult:
 class Oracle:
     """Functional Whisper-Medusa over a plain state dict (reference key layout)."""
 
-    def __init__(self, cfg, sd: Dict[str, torch.Tensor], sim: str = "fp32", dec_fp8: bool = False, enc_fp8: bool = False):
-        assert sim in ("fp32", "bf16")
+    def __init__(self, cfg, sd: Dict[str, torch.Tensor], sim: str = "fp32", dec_fp8: bool = False, enc_fp8: bool = False, act: Optional[str] = None):
+        if act is None:         # the contract the engine defaults to in this process (whisper_medusa.engine.default_act_fp16: WM_ACT)
+            import os as _os
+            act = "f16" if _os.environ.get("WM_ACT", "hilo").lower() in ("f16", "fp16") else "hilo"
+        assert sim in ("fp32", "bf16") and act in ("hilo", "f16")
         self.cfg, self.sim = cfg, sim
+        # decoder GEMM operand of the engine contract: "hilo" = bf16 hi + bf16 lo (two planes, ~17 bits), "f16" = ONE fp16 plane (11 bits; the
+        # decoder matrices are then held in fp16 — exact from bf16 for |w| >= 2^-17 —, wm_config.act_fp16).  Attention operands (q, P) stay hi / lo.
+        self.act = act
         # BASELINE.json configs[4] "fp8 MFMA" (not a reference feature): the encoder GEMMs whose operand is a LayerNorm output
         # (q/k/v, fc1) and the cross-K/V projection multiply e4m3 by e4m3: the LayerNorm output row x is quantised as
         # q_x = rne_e4m3(x / s_x), s_x = max|x| / 448 (1 for a zero row), the weight row likewise, and the product is
@@ -320,13 +327,40 @@ class Oracle:
         hi = _bf16(x)
         return hi + _bf16(x - hi)
 
+    def _rg(self, x):          # decoder GEMM operands
+        if self.sim == "bf16" and self.act == "f16":
+            return x.to(torch.float16).to(torch.float32)
+        return self._rd(x)
+
     def _lin(self, x, prefix, bias=True, dec=False):
-        xr = self._rd(x) if dec else self._r(x)
+        xr = self._rg(x) if dec else self._r(x)
         if prefix in self.q8:
             q, scale = self.q8[prefix]
             y = (xr @ q.t()) * scale
         else:
             y = xr @ self.sd[prefix + ".weight"].t()
+        if bias and (prefix + ".bias") in self.sd:
+            y = y + self.sd[prefix + ".bias"]
+        return y
+
+    def _lin_ln(self, h, ln_prefix, prefix, bias=True):
+        """linear(LayerNorm(h)) of a decoder layer (HF:modeling_whisper.py:416-505, pre-LN).  fp32 / hi-lo contract: exactly that.  fp16
+        single-plane contract (act="f16"): the engine's rounding point — it multiplies the operand fp16(gamma o h) and applies the row statistics
+        to the product (csrc/wm_common.h "LayerNorm folded into the GEMM it feeds"):  rstd (W fp16(gamma o h) - mean W gamma) + (b + W beta),
+        the same algebra with the rounding where the engine has it (hi / lo carries ~17 bits either way: no visible rounding point there)."""
+        if not (self.sim == "bf16" and self.act == "f16"):
+            return self._lin(self._ln(h, ln_prefix), prefix, bias=bias, dec=True)
+        g, b = self.sd[ln_prefix + ".weight"], self.sd[ln_prefix + ".bias"]
+        if prefix in self.q8:
+            q, scale = self.q8[prefix]
+            W = q * scale[:, None]
+        else:
+            W = self.sd[prefix + ".weight"]
+        z = (h * g).to(torch.float16).to(torch.float32)
+        mean = h.mean(dim=-1, keepdim=True)
+        var = ((h * h).mean(dim=-1, keepdim=True) - mean * mean).clamp_min(0.0)
+        rstd = torch.rsqrt(var + 1e-5)
+        y = rstd * (z @ W.t() - mean * (W @ g)[None, :]) + (W @ b)[None, :]
         if bias and (prefix + ".bias") in self.sd:
             y = y + self.sd[prefix + ".bias"]
         return y
@@ -409,10 +443,10 @@ class Oracle:
     # ---- F3 decoder layer (HF:modeling_whisper.py:416-505) ------------------------------
     def _dec_layer(self, lp, h, slot, st, T):
         kv_len = st["kv_len"]
-        xn = self._ln(h, lp + ".self_attn_layer_norm")
-        q = self._rd(self._lin(xn, lp + ".self_attn.q_proj", dec=True) * HEAD_DIM ** -0.5)
-        k = self._r(self._lin(xn, lp + ".self_attn.k_proj", bias=False, dec=True))
-        v = self._r(self._lin(xn, lp + ".self_attn.v_proj", dec=True))
+        ln1 = lp + ".self_attn_layer_norm"
+        q = self._rd(self._lin_ln(h, ln1, lp + ".self_attn.q_proj") * HEAD_DIM ** -0.5)
+        k = self._r(self._lin_ln(h, ln1, lp + ".self_attn.k_proj", bias=False))
+        v = self._r(self._lin_ln(h, ln1, lp + ".self_attn.v_proj"))
         kc, vc = st["self_kv"][slot]
         kc = torch.cat([kc[:, :kv_len], self._heads(k)], dim=1)      # contiguous cache: rows kv_len.. overwritten
         vc = torch.cat([vc[:, :kv_len], self._heads(v)], dim=1)
@@ -427,13 +461,11 @@ class Oracle:
                         mask[m_, kv_len + n_] = -float("inf")
         a = self._attend(self._heads(q), kc, vc, mask, dec=True)
         h = h + self._lin(a, lp + ".self_attn.out_proj", dec=True)
-        xn = self._ln(h, lp + ".encoder_attn_layer_norm")
-        q = self._rd(self._lin(xn, lp + ".encoder_attn.q_proj", dec=True) * HEAD_DIM ** -0.5)
+        q = self._rd(self._lin_ln(h, lp + ".encoder_attn_layer_norm", lp + ".encoder_attn.q_proj") * HEAD_DIM ** -0.5)
         kx, vx = st["cross_kv"][slot]
         a = self._attend(self._heads(q), kx, vx, dec=True)
         h = h + self._lin(a, lp + ".encoder_attn.out_proj", dec=True)
-        xn = self._ln(h, lp + ".final_layer_norm")
-        h = h + self._lin(F.gelu(self._lin(xn, lp + ".fc1", dec=True)), lp + ".fc2", dec=True)
+        h = h + self._lin(F.gelu(self._lin_ln(h, lp + ".final_layer_norm", lp + ".fc1")), lp + ".fc2", dec=True)
         return h
 
     def new_state(self, enc: torch.Tensor) -> dict:
@@ -446,7 +478,7 @@ class Oracle:
         return x + F.silu(self._lin(x, f"medusa_heads.{k}.0.linear", dec=True))
 
     def _vocab(self, y):
-        return self._rd(y) @ self.sd["whisper_model.proj_out.weight"].t()      # tied, no bias (model.py:1277)
+        return self._rg(y) @ self.sd["whisper_model.proj_out.weight"].t()      # tied, no bias (model.py:1277)
 
     def decoder_pass(self, st: dict, tokens: List[int], pos0: int, disable_medusa: bool,
                      last_only: bool = False, depth: Optional[List[int]] = None, anc: Optional[List[int]] = None) -> torch.Tensor:

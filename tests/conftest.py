@@ -28,7 +28,7 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 #   * the cheap kernel-level parity files run first, tests/test_gpu_large.py last: an overrun would cut the least;
 #   * a `slow` marker exists for tests that cost minutes of host-CPU oracle time (skipped unless WM_SLOW=1); none carries it at present.
 # tests/test_host.py::test_recorded_gpu_suite_duration_fits_the_driver_limit reads the durations the last whole-suite run recorded.
-GPU_FILE_ORDER = ["test_gpu_parity.py", "test_gpu_tree.py", "test_gpu_features.py", "test_bench_dist.py", "test_gpu_large.py"]
+GPU_FILE_ORDER = ["test_gpu_parity.py", "test_gpu_act.py", "test_gpu_tree.py", "test_gpu_features.py", "test_bench_dist.py", "test_gpu_large.py"]
 _DURATIONS = {}
 
 

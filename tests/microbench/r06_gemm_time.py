@@ -13,10 +13,12 @@ NAMES = {0: "layer(6)", 1: "LN1+QKV", 2: "out-proj", 3: "LN2+cross-q", 4: "cross
 dev = torch.device("cuda", 0)
 cfg = MedusaConfig.large_v2("base_head", K=10)
 sd = synth.synth_state_dict(cfg, seed=0, device=str(dev), logit_std=4.5)
-blob, offs = weights.build_blob(cfg, sd, device=dev)
+from whisper_medusa.engine import default_act_fp16  # noqa: E402
+f16 = default_act_fp16()                # WM_ACT=f16: the fp16 single-plane decode contract (libwm_f16.so)
+blob, offs = weights.build_blob(cfg, sd, device=dev, act_fp16=f16)
 del sd
-eng = WhisperMedusaModel.from_blob(cfg, blob, offs, max_batch=32).engine
-tag = os.path.basename(os.environ.get("WM_LIB", "libwm.so"))
+eng = WhisperMedusaModel.from_blob(cfg, blob, offs, max_batch=32, act_fp16=f16).engine
+tag = os.path.basename(os.environ.get("WM_LIB", "libwm_f16.so" if f16 else "libwm.so"))
 for rows in (352, 176, 32):
     out = []
     for kern in (1, 2, 3, 4, 5, 6, 0):

@@ -14,15 +14,18 @@ from whisper_medusa.config import HEADS_BLOCK
 
 def test_library_exports_every_declared_symbol(built_lib):
     hdr = open(os.path.join(ROOT, "include", "wm.h")).read()
-    declared = sorted(set(re.findall(r"\b(wm_[a-z_]+)\s*\(", hdr)))
+    declared = sorted(set(re.findall(r"\b(wm_[a-z0-9_]+)\s*\(", hdr)))
     assert "wm_create" in declared and "wm_decode_run" in declared and len(declared) >= 14
-    lib = ctypes.CDLL(built_lib)
-    for name in declared:
-        assert hasattr(lib, name), f"libwm.so does not export {name}"
-    assert lib.wm_abi_version() == 7
     from whisper_medusa import engine
+    # both product libraries: the same C-ABI, built for the two decode numerics contracts (wm_config.act_fp16)
+    for path, f16 in ((built_lib, 0), (engine.LIB_PATH_F16, 1)):
+        lib = ctypes.CDLL(path)
+        for name in declared:
+            assert hasattr(lib, name), f"{os.path.basename(path)} does not export {name}"
+        assert lib.wm_abi_version() == 8 and lib.wm_build_act_fp16() == f16
     assert sorted(engine.EXPORTS) == declared
     engine.load_library()          # prototypes resolve
+    engine.load_library(act_fp16=True)
 
 
 def test_fp8_mfma_operand_layout_matches_the_kernel_index_function():
@@ -53,6 +56,12 @@ def test_create_rejects_bad_arguments(built_lib):
     assert b"ABI" in lib.wm_last_error(None)
     cfg = engine.WmConfig(1, 100, 2, 2, 2, 512, 1031, 80, 96, 64, 4, 0, 1)       # d_model not a multiple of 128
     assert lib.wm_create(ctypes.byref(cfg), ctypes.byref(w), 0, None, ctypes.byref(h)) == -1
+    # a library serves ONE decode numerics contract (wm_build_act_fp16); the other is refused, not silently computed in the wrong format
+    for lib_, f16 in ((lib, 0), (engine.load_library(act_fp16=True), 1)):
+        cfg = engine.WmConfig(engine.WM_ABI_VERSION, 128, 2, 2, 2, 512, 1031, 80, 96, 64, 4, 0, 1)
+        cfg.act_fp16 = 1 - f16
+        assert lib_.wm_create(ctypes.byref(cfg), ctypes.byref(w), 0, None, ctypes.byref(h)) == -1
+        assert b"contract" in lib_.wm_last_error(None)
 
 
 def test_engine_fails_loudly_without_gpu():

@@ -47,10 +47,17 @@ def _compile(src, extra=(), suffix=""):
     return obj
 
 
+LIB_F16 = os.path.join(OUT_DIR, "libwm_f16.so")      # the same sources for the fp16 single-plane decode contract (csrc/wm_common.h, wm_config.act_fp16)
+
+
 def build(force=False, verbose=True):
-    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest_src():
-        return LIB
-    return build_variant(LIB, verbose=verbose)
+    """Both product libraries: libwm.so (bf16 hi / lo decode operands) and libwm_f16.so (-DWM_ACT_F16)."""
+    newest = _newest_src()
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < newest:
+        build_variant(LIB, verbose=verbose)
+    if force or not os.path.exists(LIB_F16) or os.path.getmtime(LIB_F16) < newest:
+        build_variant(LIB_F16, ("-DWM_ACT_F16",), "_f16", verbose=verbose)
+    return LIB
 
 
 def build_variant(lib, extra=(), suffix="", verbose=True):

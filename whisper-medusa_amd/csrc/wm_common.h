@@ -169,21 +169,6 @@ __device__ __forceinline__ bf16x8_t ld_frag_nt(const bf16_t* p) {    // streamed
 // the MFMA and the hi/lo token operand are those of the bf16 path.
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
 // NT: streamed once per pass (single-stream GEMMs) -> nt policy; re-read by other token-tile groups (batched GEMM) -> default
-template <bool W8, bool NT>
-__device__ __forceinline__ bf16x8_t ld_wfrag(const bf16_t* W, size_t elem) {
-    if constexpr (W8) {
-        const u32x2_t* p8 = reinterpret_cast<const u32x2_t*>(reinterpret_cast<const unsigned char*>(W) + elem);
-        const u32x2_t v = NT ? __builtin_nontemporal_load(p8) : *p8;
-        const f32x2_t a = __builtin_amdgcn_cvt_pk_f32_fp8(v[0], false), b = __builtin_amdgcn_cvt_pk_f32_fp8(v[0], true);
-        const f32x2_t c = __builtin_amdgcn_cvt_pk_f32_fp8(v[1], false), d = __builtin_amdgcn_cvt_pk_f32_fp8(v[1], true);
-        uint4 r;
-        r.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf16x2_t)); r.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(b, bf16x2_t));
-        r.z = __builtin_bit_cast(uint32_t, __builtin_convertvector(c, bf16x2_t)); r.w = __builtin_bit_cast(uint32_t, __builtin_convertvector(d, bf16x2_t));
-        return __builtin_bit_cast(bf16x8_t, r);
-    } else {
-        return NT ? ld_frag_nt(W + elem) : ld_frag(W + elem);
-    }
-}
 __device__ __forceinline__ f32x4_t scale4(f32x4_t v, const float* wscale, int n) {       // n % 4 == 0
     const float4 s = *reinterpret_cast<const float4*>(wscale + n);
     return f32x4_t{v[0] * s.x, v[1] * s.y, v[2] * s.z, v[3] * s.w};
@@ -198,6 +183,89 @@ __device__ __forceinline__ void st_hilo4(bf16_t* hi, bf16_t* lo, float4 y)
     b.x = pack_bf2(y.x - __uint_as_float(a.x << 16), y.y - __uint_as_float(a.x & 0xffff0000u));
     b.y = pack_bf2(y.z - __uint_as_float(a.y << 16), y.w - __uint_as_float(a.y & 0xffff0000u));
     *reinterpret_cast<uint2*>(lo) = b;
+}
+
+// ---- the decoder GEMMs' activation operand (the decode numerics contract) ----------------------------------------------
+// Two contracts, one source: the library is built for one of them (build.py: libwm.so = hi / lo, libwm_f16.so = -DWM_ACT_F16; wm_create
+// refuses a wm_config.act_fp16 that is not the build's).
+//   hi / lo (rounds 1-5): an activation is a bf16 PAIR x = hi + lo (~17 mantissa bits) in two planes; two v_mfma_f32_16x16x32_bf16 per weight
+//     fragment; decoder matrices bf16.
+//   f16 (round 6): ONE fp16 plane (11 mantissa bits — the precision the reference's own fp16 / bf16 inference carries); one
+//     v_mfma_f32_16x16x32_f16 per weight fragment; decoder matrices held as fp16 (exact from bf16 for |w| >= 2^-17, e4m3 exactly).  Half the
+//     L2 -> CU bytes and half the MFMAs of every token operand: the 32-stream step is bound by exactly that (profiles/r06_upper_bounds.md).
+// Storage stays a raw 16-bit container (bf16_t) either way: same packed layout, same plane arithmetic (plane unused with one plane).
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+__device__ __forceinline__ uint32_t pack_h2(float lo, float hi) {        // round-to-nearest-even, like torch's .half()
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+}
+#ifdef WM_ACT_F16
+#define WM_ACT_PLANES 1
+typedef f16x8_t wfrag_t;                       // a weight fragment as the MFMA takes it
+struct ActFrag { f16x8_t h; };
+__device__ __forceinline__ f32x4_t mfma_act(wfrag_t a, const ActFrag& x, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, x.h, c, 0, 0, 0); }
+__device__ __forceinline__ ActFrag act_ld(const bf16_t* p, size_t) { ActFrag f; f.h = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(p)); return f; }
+__device__ __forceinline__ void act_st_frag(bf16_t* p, size_t, const ActFrag& f) { *reinterpret_cast<uint4*>(p) = __builtin_bit_cast(uint4, f.h); }
+__device__ __forceinline__ ActFrag act_split8(float4 y0, float4 y1) {
+    uint4 h; h.x = pack_h2(y0.x, y0.y); h.y = pack_h2(y0.z, y0.w); h.z = pack_h2(y1.x, y1.y); h.w = pack_h2(y1.z, y1.w);
+    ActFrag f; f.h = __builtin_bit_cast(f16x8_t, h); return f;
+}
+__device__ __forceinline__ void act_st4(bf16_t* p, bf16_t*, float4 y) {      // 4 consecutive k of one row
+    uint2 a; a.x = pack_h2(y.x, y.y); a.y = pack_h2(y.z, y.w);
+    *reinterpret_cast<uint2*>(p) = a;
+}
+__device__ __host__ __forceinline__ float w16_to_f32(bf16_t v) {            // a decoder-matrix element of the blob (fp16 in this build)
+    return (float)__builtin_bit_cast(_Float16, v);
+}
+#else
+#define WM_ACT_PLANES 2
+typedef bf16x8_t wfrag_t;
+struct ActFrag { bf16x8_t h, l; };
+__device__ __forceinline__ f32x4_t mfma_act(wfrag_t a, const ActFrag& x, f32x4_t c) { c = mfma16(a, x.h, c); return mfma16(a, x.l, c); }
+__device__ __forceinline__ ActFrag act_ld(const bf16_t* p, size_t plane) { ActFrag f; f.h = ld_frag(p); f.l = ld_frag(p + plane); return f; }
+__device__ __forceinline__ void act_st_frag(bf16_t* p, size_t plane, const ActFrag& f) {
+    *reinterpret_cast<uint4*>(p) = __builtin_bit_cast(uint4, f.h); *reinterpret_cast<uint4*>(p + plane) = __builtin_bit_cast(uint4, f.l);
+}
+__device__ __forceinline__ ActFrag act_split8(float4 y0, float4 y1) {
+    uint4 h, l;
+    h.x = pack_bf2(y0.x, y0.y); h.y = pack_bf2(y0.z, y0.w); h.z = pack_bf2(y1.x, y1.y); h.w = pack_bf2(y1.z, y1.w);
+    l.x = pack_bf2(y0.x - __uint_as_float(h.x << 16), y0.y - __uint_as_float(h.x & 0xffff0000u));
+    l.y = pack_bf2(y0.z - __uint_as_float(h.y << 16), y0.w - __uint_as_float(h.y & 0xffff0000u));
+    l.z = pack_bf2(y1.x - __uint_as_float(h.z << 16), y1.y - __uint_as_float(h.z & 0xffff0000u));
+    l.w = pack_bf2(y1.z - __uint_as_float(h.w << 16), y1.w - __uint_as_float(h.w & 0xffff0000u));
+    ActFrag f; f.h = __builtin_bit_cast(bf16x8_t, h); f.l = __builtin_bit_cast(bf16x8_t, l); return f;
+}
+__device__ __forceinline__ void act_st4(bf16_t* p, bf16_t* plo, float4 y) { st_hilo4(p, plo, y); }
+__device__ __host__ __forceinline__ float w16_to_f32(bf16_t v) {
+    const uint32_t u = ((uint32_t)v) << 16; return __builtin_bit_cast(float, u);
+}
+#endif
+
+// 8 e4m3 values (two dwords) -> the MFMA's weight fragment type of this build (bf16 or fp16: both hold every e4m3 value exactly)
+__device__ __forceinline__ uint4 fp8x8_to_w16(unsigned v0, unsigned v1) {
+    const f32x2_t a = __builtin_amdgcn_cvt_pk_f32_fp8(v0, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(v0, true);
+    const f32x2_t c = __builtin_amdgcn_cvt_pk_f32_fp8(v1, false), d = __builtin_amdgcn_cvt_pk_f32_fp8(v1, true);
+    uint4 r;
+#if WM_ACT_PLANES == 1
+    r.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, f16x2_t)); r.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(b, f16x2_t));
+    r.z = __builtin_bit_cast(uint32_t, __builtin_convertvector(c, f16x2_t)); r.w = __builtin_bit_cast(uint32_t, __builtin_convertvector(d, f16x2_t));
+#else
+    r.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf16x2_t)); r.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(b, bf16x2_t));
+    r.z = __builtin_bit_cast(uint32_t, __builtin_convertvector(c, bf16x2_t)); r.w = __builtin_bit_cast(uint32_t, __builtin_convertvector(d, bf16x2_t));
+#endif
+    return r;
+}
+template <bool W8, bool NT>
+__device__ __forceinline__ wfrag_t ld_wfrag(const bf16_t* W, size_t elem) {
+    if constexpr (W8) {
+        const u32x2_t* p8 = reinterpret_cast<const u32x2_t*>(reinterpret_cast<const unsigned char*>(W) + elem);
+        const u32x2_t v = NT ? __builtin_nontemporal_load(p8) : *p8;
+        return __builtin_bit_cast(wfrag_t, fp8x8_to_w16(v[0], v[1]));
+    } else {
+        const u32x4_t* p = reinterpret_cast<const u32x4_t*>(W + elem);
+        return __builtin_bit_cast(wfrag_t, NT ? __builtin_nontemporal_load(p) : *p);
+    }
 }
 
 // ---- LayerNorm folded into the GEMM it feeds (round 6) -------------------------------------------------------------------------

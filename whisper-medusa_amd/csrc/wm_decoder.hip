@@ -47,7 +47,7 @@ __global__ void k_embed(float* __restrict__ h, const bf16_t* __restrict__ tok_em
         if (gnext) {            // (kernel-uniform; a 16-feature tile = 4 adjacent lanes, all inside the loop together: d % 16 == 0)
             const float4 g = *reinterpret_cast<const float4*>(gnext + j);
             const size_t o = packed_index(row, j, d >> 5);
-            st_hilo4(xo + o, xo + xplane + o, make_float4(y.x * g.x, y.y * g.y, y.z * g.z, y.w * g.w));
+            act_st4(xo + o, xo + xplane + o, make_float4(y.x * g.x, y.y * g.y, y.z * g.z, y.w * g.w));
             float sm = (y.x + y.y) + (y.z + y.w), q = (y.x * y.x + y.y * y.y) + (y.z * y.z + y.w * y.w);
             sm += __shfl_xor(sm, 1, 64); q += __shfl_xor(q, 1, 64);
             sm += __shfl_xor(sm, 2, 64); q += __shfl_xor(q, 2, 64);
@@ -113,7 +113,7 @@ __global__ void k_rows_norm(const float* __restrict__ src, int src_mul, int src_
             if (gnext) {        // (kernel-uniform; features 4 j .. 4 j + 3: a 16-feature tile = 4 adjacent lanes, all of them below nv: d % 16 == 0)
                 const float4 g = reinterpret_cast<const float4*>(gnext)[j];
                 const size_t o = packed_index(m, j * 4, K32);
-                st_hilo4(xo + o, xo + xplane + o, make_float4(y.x * g.x, y.y * g.y, y.z * g.z, y.w * g.w));
+                act_st4(xo + o, xo + xplane + o, make_float4(y.x * g.x, y.y * g.y, y.z * g.z, y.w * g.w));
                 float sm = (y.x + y.y) + (y.z + y.w), q2 = (y.x * y.x + y.y * y.y) + (y.z * y.z + y.w * y.w);
                 sm += __shfl_xor(sm, 1, 64); q2 += __shfl_xor(q2, 1, 64);
                 sm += __shfl_xor(sm, 2, 64); q2 += __shfl_xor(q2, 2, 64);
@@ -121,7 +121,7 @@ __global__ void k_rows_norm(const float* __restrict__ src, int src_mul, int src_
             }
             if (out_p) {
                 const size_t o = packed_index(m * p_mul + p_off, j * 4, K32);
-                st_hilo4(out_p + o, out_p + p_plane + o, y);
+                act_st4(out_p + o, out_p + p_plane + o, y);
             }
         }
     }
@@ -371,7 +371,7 @@ k_attn_mfma(const bf16_t* __restrict__ kmat, const bf16_t* __restrict__ vtmat, c
 #pragma unroll
             for (int u = 0; u < NK; ++u) {
                 bf16x8_t bh, bl;
-                fq.ln.template frag<NK>(xr, lnb, u, w * NK + u, lane, bh, bl);
+                fq.ln.template frag_hilo<NK>(xr, lnb, u, w * NK + u, lane, bh, bl);
                 const size_t o = ((size_t)(w * NK + u) * 64 + lane) * 16;
                 *reinterpret_cast<uint4*>(smem_attn + o) = __builtin_bit_cast(uint4, bh);
                 *reinterpret_cast<uint4*>(smem_attn + (size_t)KT * 1024 + o) = __builtin_bit_cast(uint4, bl);
@@ -495,7 +495,7 @@ k_attn_mfma(const bf16_t* __restrict__ kmat, const bf16_t* __restrict__ vtmat, c
         if (qr < rows) {
             const float inv = 1.0f / L;
             const size_t oi = packed_index(row, hd * 64 + ch, K32);
-            st_hilo4(xout + oi, xout + xplane + oi, make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv));
+            act_st4(xout + oi, xout + xplane + oi, make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv));
         }
         TL_END
         return;
@@ -560,7 +560,7 @@ k_attn_mfma(const bf16_t* __restrict__ kmat, const bf16_t* __restrict__ vtmat, c
         }
         const float inv = 1.0f / Lt;
         const size_t oi = packed_index(row, hd * 64 + ch, K32);
-        st_hilo4(xout + oi, xout + xplane + oi, make_float4(o4.x * inv, o4.y * inv, o4.z * inv, o4.w * inv));
+        act_st4(xout + oi, xout + xplane + oi, make_float4(o4.x * inv, o4.y * inv, o4.z * inv, o4.w * inv));
     }
     TL_END
 }
@@ -1109,7 +1109,8 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
     const SkinnyPlan cqp = skinny_plan(d / 16, K32, true);
     const bool fuse_shape = (cqp.nk == 8 && cqp.ksplit >= 1 && cqp.ksplit <= 5) || (cqp.nk == 4 && (cqp.ksplit == 1 || cqp.ksplit == 3));
     // (not under the merged-step schedule's dense rows: the fused instance reads q at stream * Mper + row)
-    const bool fuse_cq = fuse_env && !fold && R <= 16 && !f8 && fuse_shape && H * 4 == d / 16 && rowinfo == nullptr;       // single tile: nqt == 1
+    // (hi / lo builds only: the fused kernel multiplies bf16 weights by the hi / lo pair itself)
+    const bool fuse_cq = WM_ACT_PLANES == 2 && fuse_env && !fold && R <= 16 && !f8 && fuse_shape && H * 4 == d / 16 && rowinfo == nullptr;       // single tile: nqt == 1
     const PfJob kvjob = (pf && nqt == 1 && ctx->NS % xgrid == 0 && ctx->Spad == ctx->NS * 256)
         ? PfJob{reinterpret_cast<const char*>(kx), reinterpret_cast<const char*>(vx), (unsigned)(ctx->NS / xgrid) * 256 * 128,
                 (unsigned)(xgrid * H * nb), (unsigned long long)H * nb * ctx->Spad * 128}
@@ -1163,6 +1164,7 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
         }
         TL_SET(slot * 16 + 5 + 8192 * Mper);
         static const bool xattn_nt = [] { const char* v = std::getenv("WM_XATTN_NT"); return v ? std::atoi(v) != 0 : true; }();
+#if WM_ACT_PLANES == 2
         if (fuse_cq) {
             const LdNorm ln{h, w.ln2_w, w.ln2_b, d, K32, R, 1, 0};
 #define WM_XFUSE(NKv, KSv)                                                                                                    \
@@ -1185,7 +1187,9 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
             else if (cqp.nk == 4 && cqp.ksplit == 3) WM_XFUSE(4, 3);
             else WM_XFUSE(4, 1);
 #undef WM_XFUSE
-        } else if (xattn_nt)
+        } else
+#endif
+        if (xattn_nt)
             hipLaunchKernelGGL((k_attn_mfma<true, true, NoFuseQ>), dim3(xgrid, H, zs), dim3(256), sizeof(AttnLds<WM_XATTN_SPB_MAX>), st, kx, vx, ctx->qbuf, sinfo, sskip,
                                Mper | (nz << 8), H | (ctx->NS << 8) | (nqt << 16) | (xgrid << 24), ctx->Spad, ctx->S, g_skinny_done, K32, ctx->xbuf, xpl, ctx->cml, ctx->co, ctx->ticket, xpf, NoFuseQ{}, nullptr, base TL_PASS);
         else
@@ -1233,7 +1237,7 @@ __global__ void k_fold_vectors(const bf16_t* __restrict__ W, const float* __rest
         if (wscale) {
             const unsigned char b8 = reinterpret_cast<const unsigned char*>(W)[i];
             wv = __builtin_amdgcn_cvt_f32_fp8((int)b8, 0) * wscale[n];
-        } else wv = bf2f(W[i]);
+        } else wv = w16_to_f32(W[i]);        // bf16, or fp16 in an f16 build
         sc += (double)wv * (double)gamma[k]; sb += (double)wv * (double)beta[k];
     }
 #pragma unroll

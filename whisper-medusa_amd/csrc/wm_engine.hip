@@ -19,6 +19,7 @@ static hipError_t dev_alloc(T** p, size_t n, hipStream_t st)
 }
 
 extern "C" int wm_abi_version(void) { return WM_ABI_VERSION; }
+extern "C" int wm_build_act_fp16(void) { return WM_ACT_PLANES == 1 ? 1 : 0; }
 
 extern "C" const char* wm_last_error(const wm_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
@@ -48,6 +49,9 @@ extern "C" int wm_create(const wm_config* cfg, const wm_weights* w, int device, 
     g_create_err.clear();
     if (!cfg || !w || !out) { g_create_err = "wm_create: null argument"; return WM_ERR_ARG; }
     if (cfg->abi_version != WM_ABI_VERSION) { g_create_err = "wm_create: ABI version mismatch"; return WM_ERR_ARG; }
+    if ((cfg->act_fp16 != 0) != (WM_ACT_PLANES == 1)) {
+        g_create_err = std::string("wm_create: this library is built for the ") + (WM_ACT_PLANES == 1 ? "fp16 single-plane" : "bf16 hi / lo") +
+                       " decode contract (wm_build_act_fp16), wm_config.act_fp16 asks for the other"; return WM_ERR_ARG; }
     if (cfg->d_model <= 0 || cfg->d_model % 128 || cfg->n_heads * WM_HEAD_DIM != cfg->d_model || cfg->d_model > 2048) {
         g_create_err = "wm_create: d_model must be a multiple of 128 (<= 2048) with 64-wide heads"; return WM_ERR_ARG; }
     if (cfg->ffn_dim % 128 || cfg->medusa_heads < 1 || cfg->medusa_heads > 15 || cfg->max_batch < 1 || cfg->n_mels * 3 > 256 ||

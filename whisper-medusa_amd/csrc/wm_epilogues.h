@@ -38,7 +38,7 @@ struct EpResidualT {
             if (m < M) {
                 *reinterpret_cast<float4*>(h + (size_t)m * ld + n) = y;
                 const size_t o = packed_index(m, n, K32);
-                st_hilo4(xo + o, xo + xplane + o, make_float4(y.x * p.c.x, y.y * p.c.y, y.z * p.c.z, y.w * p.c.w));
+                act_st4(xo + o, xo + xplane + o, make_float4(y.x * p.c.x, y.y * p.c.y, y.z * p.c.z, y.w * p.c.w));
                 if ((n & 15) == 0) stats[(size_t)(n >> 4) * sld + m] = make_float2(s, q);
             }
         }
@@ -80,7 +80,7 @@ struct EpPackedAct {           // out_lo != nullptr: decoder path, value kept as
         if (ACT == 1) { x0 = gelu_erf(x0); x1 = gelu_erf(x1); x2 = gelu_erf(x2); x3 = gelu_erf(x3); }
         if (ACT == 2) { x0 = gelu_phi(x0); x1 = gelu_phi(x1); x2 = gelu_phi(x2); x3 = gelu_phi(x3); }
         const size_t o = packed_index(m, n, K32out);
-        if (out_lo) { st_hilo4(out + o, out_lo + o, make_float4(x0, x1, x2, x3)); return; }
+        if (out_lo) { act_st4(out + o, out_lo + o, make_float4(x0, x1, x2, x3)); return; }      // decoder: the next GEMM's operand (wm_common.h ActFrag)
         uint2 u; u.x = pack_bf2(x0, x1); u.y = pack_bf2(x2, x3);
         *reinterpret_cast<uint2*>(out + o) = u;
     }
@@ -162,8 +162,8 @@ struct EpHead {
         if (m >= M) return;
         const int k = n / d, c = n - k * d;
         const size_t o = packed_index(m * row_mul + row_off + k, c, K32);
-        st_hilo4(y + o, y_lo + o, make_float4(p.b.x + silu(v[0] + p.a.x), p.b.y + silu(v[1] + p.a.y),
-                                               p.b.z + silu(v[2] + p.a.z), p.b.w + silu(v[3] + p.a.w)));
+        act_st4(y + o, y_lo + o, make_float4(p.b.x + silu(v[0] + p.a.x), p.b.y + silu(v[1] + p.a.y),
+                                              p.b.z + silu(v[2] + p.a.z), p.b.w + silu(v[3] + p.a.w)));
     }
     __device__ __forceinline__ void store4(int m, int n, f32x4_t v) const { fin(m, n, v, pre(m, n)); }
 };

@@ -83,17 +83,9 @@ __device__ __forceinline__ typename WRaw<W8>::type ld_wraw(const bf16_t* W, size
     }
 }
 template <bool W8>
-__device__ __forceinline__ bf16x8_t w_expand(typename WRaw<W8>::type v) {
-    if constexpr (W8) {      // e4m3 -> bf16 is exact
-        const f32x2_t a = __builtin_amdgcn_cvt_pk_f32_fp8(v[0], false), b = __builtin_amdgcn_cvt_pk_f32_fp8(v[0], true);
-        const f32x2_t c = __builtin_amdgcn_cvt_pk_f32_fp8(v[1], false), d = __builtin_amdgcn_cvt_pk_f32_fp8(v[1], true);
-        uint4 r;
-        r.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf16x2_t)); r.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(b, bf16x2_t));
-        r.z = __builtin_bit_cast(uint32_t, __builtin_convertvector(c, bf16x2_t)); r.w = __builtin_bit_cast(uint32_t, __builtin_convertvector(d, bf16x2_t));
-        return __builtin_bit_cast(bf16x8_t, r);
-    } else {
-        return __builtin_bit_cast(bf16x8_t, v);
-    }
+__device__ __forceinline__ wfrag_t w_expand(typename WRaw<W8>::type v) {
+    if constexpr (W8) return __builtin_bit_cast(wfrag_t, fp8x8_to_w16(v[0], v[1]));      // e4m3 -> bf16 / fp16 is exact
+    else return __builtin_bit_cast(wfrag_t, v);
 }
 
 // 8 fp32 values -> bf16 hi / lo MFMA fragments
@@ -180,7 +172,7 @@ struct LdPacked {
     __device__ __forceinline__ static LdPacked make(const void* a, const void* b, const void*, int i0, int, int K32_) {
         return LdPacked{reinterpret_cast<const bf16_t*>(a), K32_, reinterpret_cast<size_t>(b), i0};
     }
-    template <int NB> struct Regs { bf16x8_t h[NB], l[NB]; };
+    template <int NB> struct Regs { ActFrag x[NB]; };
     __host__ __device__ int lds_bytes() const { return 0; }
     // Lanes of rows >= M read row M - 1 again (the same 16 bytes as that row's lane: no extra traffic) instead of being switched off: an
     // exec-masked load into a zero-initialised register made the compiler copy the loaded value inside the masked region — an
@@ -192,13 +184,13 @@ struct LdPacked {
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
             const bf16_t* p = X + ((size_t)(kt0 + u) * 64 + ln) * 8;
-            r.h[u] = ld_frag(p); r.l[u] = ld_frag(p + plane);
+            r.x[u] = act_ld(p, plane);
         }
     }
     template <int NB> __device__ __forceinline__ void stats(Regs<NB>&, char*, int, int, bool, int, int = 0) const {}
     template <int NB> __device__ __forceinline__ void stage(const Regs<NB>&, char*) const {}
     template <int NB>
-    __device__ __forceinline__ void frag(const Regs<NB>& r, const char*, int u, int, int, bf16x8_t& bh, bf16x8_t& bl) const { bh = r.h[u]; bl = r.l[u]; }
+    __device__ __forceinline__ ActFrag frag(const Regs<NB>& r, const char*, int u, int, int) const { return r.x[u]; }
 };
 
 // ---- token operand: fp32 residual rows -> LayerNorm (or identity) -> hi/lo fragments, in registers -------------------
@@ -315,7 +307,23 @@ struct LdNormT {
         r.rstd = rsqrtf(fmaxf(tq / (float)d - r.mean * r.mean, 0.f) + 1e-5f);
     }
     template <int NB>
-    __device__ __forceinline__ void frag(const Regs<NB>& r, const char* smem, int u, int kt, int lane, bf16x8_t& bh, bf16x8_t& bl) const {
+    __device__ __forceinline__ ActFrag frag(const Regs<NB>& r, const char* smem, int u, int kt, int lane) const {
+        float4 y0 = r.v0[u], y1 = r.v1[u];
+        if constexpr (NORM) {
+            const float* gb = reinterpret_cast<const float*>(smem) + kt * 32 + (lane >> 4) * 8;
+            const float4 g0 = *reinterpret_cast<const float4*>(gb), g1 = *reinterpret_cast<const float4*>(gb + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(gb + d), b1 = *reinterpret_cast<const float4*>(gb + d + 4);
+            const float m = r.mean, rs = r.rstd;
+            y0.x = __builtin_fmaf((y0.x - m) * rs, g0.x, b0.x); y0.y = __builtin_fmaf((y0.y - m) * rs, g0.y, b0.y);
+            y0.z = __builtin_fmaf((y0.z - m) * rs, g0.z, b0.z); y0.w = __builtin_fmaf((y0.w - m) * rs, g0.w, b0.w);
+            y1.x = __builtin_fmaf((y1.x - m) * rs, g1.x, b1.x); y1.y = __builtin_fmaf((y1.y - m) * rs, g1.y, b1.y);
+            y1.z = __builtin_fmaf((y1.z - m) * rs, g1.z, b1.z); y1.w = __builtin_fmaf((y1.w - m) * rs, g1.w, b1.w);
+        }
+        return act_split8(y0, y1);
+    }
+    // (the fused cross-attention query of wm_decoder.hip — hi / lo builds only — stages the two planes through LDS itself)
+    template <int NB>
+    __device__ __forceinline__ void frag_hilo(const Regs<NB>& r, const char* smem, int u, int kt, int lane, bf16x8_t& bh, bf16x8_t& bl) const {
         float4 y0 = r.v0[u], y1 = r.v1[u];
         if constexpr (NORM) {
             const float* gb = reinterpret_cast<const float*>(smem) + kt * 32 + (lane >> 4) * 8;
@@ -411,27 +419,17 @@ k_skinny_gemm(const bf16_t* __restrict__ W, const void* __restrict__ la, const v
     for (int i = 0; i < RT; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < XB; ++u) {
-        bf16x8_t bh, bl;
-        ld.template frag<XB>(xr, smem, u, kt0 + u, lane, bh, bl);
+        const ActFrag xf = ld.template frag<XB>(xr, smem, u, kt0 + u, lane);
 #pragma unroll
-        for (int i = 0; i < RT; ++i) {
-            const bf16x8_t av = w_expand<W8>(a[i][u]);
-            acc[i] = mfma16(av, bh, acc[i]);
-            acc[i] = mfma16(av, bl, acc[i]);
-        }
+        for (int i = 0; i < RT; ++i) acc[i] = mfma_act(w_expand<W8>(a[i][u]), xf, acc[i]);
     }
     if constexpr (XB < NK) {
         ld.template issue<XB>(xr, smem, kt0 + XB, lane);
 #pragma unroll
         for (int u = 0; u < XB; ++u) {
-            bf16x8_t bh, bl;
-            ld.template frag<XB>(xr, smem, u, kt0 + XB + u, lane, bh, bl);
+            const ActFrag xf = ld.template frag<XB>(xr, smem, u, kt0 + XB + u, lane);
 #pragma unroll
-            for (int i = 0; i < RT; ++i) {
-                const bf16x8_t av = w_expand<W8>(a[i][XB + u]);
-                acc[i] = mfma16(av, bh, acc[i]);
-                acc[i] = mfma16(av, bl, acc[i]);
-            }
+            for (int i = 0; i < RT; ++i) acc[i] = mfma_act(w_expand<W8>(a[i][XB + u]), xf, acc[i]);
         }
     }
     TL_MID
@@ -517,13 +515,9 @@ k_ln_tiles(const void* __restrict__ la, const void* __restrict__ lb, const void*
     const bool mine = live && (lane & 15) >= rlo && (lane & 15) <= rhi;
 #pragma unroll
     for (int u = 0; u < NK; ++u) {
-        bf16x8_t bh, bl;
-        ld.template frag<NK>(xr, smem, u, kt0 + u, lane, bh, bl);
+        const ActFrag f = ld.template frag<NK>(xr, smem, u, kt0 + u, lane);
         const size_t o = ((size_t)(kt0 + u) * 64 + lane) * 8;
-        if (mine) {
-            *reinterpret_cast<uint4*>(dst + o) = __builtin_bit_cast(uint4, bh);
-            *reinterpret_cast<uint4*>(dst + plane + o) = __builtin_bit_cast(uint4, bl);
-        }
+        if (mine) act_st_frag(dst + o, plane, f);
     }
 }
 
@@ -591,11 +585,11 @@ k_rows_gemm(const bf16_t* __restrict__ W, const bf16_t* __restrict__ X, size_t p
     constexpr int G = 4;          // k-tiles per load group
 #pragma unroll
     for (int kg = 0; kg < NKR; kg += G) {
-        bf16x8_t a[RT][G], xh[TT][G], xl[TT][G];
+        wfrag_t a[RT][G]; ActFrag x[TT][G];
 #pragma unroll
         for (int u = 0; u < G; ++u) {
 #pragma unroll
-            for (int j = 0; j < TT; ++j) { xh[j][u] = ld_frag(xp[j] + (size_t)(kg + u) * 512); xl[j][u] = ld_frag(xp[j] + plane + (size_t)(kg + u) * 512); }
+            for (int j = 0; j < TT; ++j) x[j][u] = act_ld(xp[j] + (size_t)(kg + u) * 512, plane);
 #pragma unroll
             for (int i = 0; i < RT; ++i) a[i][u] = ld_wfrag<W8, false>(W, wp[i] + (size_t)(kg + u) * 512);
         }
@@ -608,7 +602,7 @@ k_rows_gemm(const bf16_t* __restrict__ W, const bf16_t* __restrict__ X, size_t p
 #pragma unroll
             for (int i = 0; i < RT; ++i)
 #pragma unroll
-                for (int j = 0; j < TT; ++j) { acc[i][j] = mfma16(a[i][u], xh[j][u], acc[i][j]); acc[i][j] = mfma16(a[i][u], xl[j][u], acc[i][j]); }
+                for (int j = 0; j < TT; ++j) acc[i][j] = mfma_act(a[i][u], x[j][u], acc[i][j]);
     }
     TL_PREP          // timeline build: the wave's MFMAs have issued
     if (ksplit > 1) {
@@ -710,14 +704,14 @@ k_skinny2_gemm(const bf16_t* __restrict__ W, const bf16_t* __restrict__ X, size_
     }
     // rows >= M of the second tile read its last valid row again (16 < M <= 32; LdPacked::issue: no exec-masked loads)
     const int ln1 = min(lane & 15, M - 17) + (lane & 48);
-    bf16x8_t h0[XB], l0[XB], h1[XB], l1[XB];
+    ActFrag x0[XB], x1[XB];
     auto issue = [&](int kt) {
 #pragma unroll
         for (int u = 0; u < XB; ++u) {
             const bf16_t* p0 = X + ((size_t)(kt + u) * 64 + lane) * 8;
             const bf16_t* p1 = X + ((size_t)K32 * 64 + (size_t)(kt + u) * 64 + ln1) * 8;
-            h0[u] = ld_frag(p0); l0[u] = ld_frag(p0 + plane);
-            h1[u] = ld_frag(p1); l1[u] = ld_frag(p1 + plane);
+            x0[u] = act_ld(p0, plane);
+            x1[u] = act_ld(p1, plane);
         }
     };
     issue(kt0);
@@ -749,9 +743,9 @@ k_skinny2_gemm(const bf16_t* __restrict__ W, const bf16_t* __restrict__ X, size_
         if (r > 0) issue(kt0 + r * XB);
 #pragma unroll
         for (int u = 0; u < XB; ++u) {
-            const bf16x8_t av = w_expand<W8>(a[r * XB + u]);
-            acc0 = mfma16(av, h0[u], acc0); acc0 = mfma16(av, l0[u], acc0);
-            acc1 = mfma16(av, h1[u], acc1); acc1 = mfma16(av, l1[u], acc1);
+            const wfrag_t av = w_expand<W8>(a[r * XB + u]);
+            acc0 = mfma_act(av, x0[u], acc0);
+            acc1 = mfma_act(av, x1[u], acc1);
         }
     }
     const float2* fpart = reinterpret_cast<const float2*>(smem + (ksplit > 1 ? (size_t)rt_per_wg * 2 * ksplit * 1024 : 0));
@@ -829,20 +823,10 @@ k_skinny2_norm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, i
     f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     ld.template stats<NK>(x0, smem, ks, ksplit, rtl == 0, lane, 0);
 #pragma unroll
-    for (int u = 0; u < NK; ++u) {
-        bf16x8_t bh, bl;
-        ld.template frag<NK>(x0, smem, u, kt0 + u, lane, bh, bl);
-        const bf16x8_t av = w_expand<W8>(a[u]);
-        acc0 = mfma16(av, bh, acc0); acc0 = mfma16(av, bl, acc0);
-    }
+    for (int u = 0; u < NK; ++u) acc0 = mfma_act(w_expand<W8>(a[u]), ld.template frag<NK>(x0, smem, u, kt0 + u, lane), acc0);
     ld.template stats<NK>(x1, smem, ks, ksplit, rtl == 0, lane, 1);
 #pragma unroll
-    for (int u = 0; u < NK; ++u) {
-        bf16x8_t bh, bl;
-        ld.template frag<NK>(x1, smem, u, kt0 + u, lane, bh, bl);
-        const bf16x8_t av = w_expand<W8>(a[u]);
-        acc1 = mfma16(av, bh, acc1); acc1 = mfma16(av, bl, acc1);
-    }
+    for (int u = 0; u < NK; ++u) acc1 = mfma_act(w_expand<W8>(a[u]), ld.template frag<NK>(x1, smem, u, kt0 + u, lane), acc1);
     if (ksplit > 1) {
         float4* red = reinterpret_cast<float4*>(smem + ld.lds_bytes());
         red[((rtl * 2 + 0) * ksplit + ks) * 64 + lane] = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
@@ -904,7 +888,7 @@ __device__ __forceinline__ void wm_wait_younger(int younger)          // block-u
 template <int F, int TT>
 struct TileGemmCfg {
     static constexpr int TH = TT / 2;
-    static constexpr int NPW = 8 * F, NPX = 4 * TT, NP = NPW + NPX;   // 1 KiB pieces of a stage (2 k-tiles)
+    static constexpr int NPW = 8 * F, NPX = 2 * TT * WM_ACT_PLANES, NP = NPW + NPX;   // 1 KiB pieces of a stage (2 k-tiles; token tiles: one plane or hi + lo)
     static constexpr int LPW = NP / 8;                                // pieces per wave per stage
     static constexpr int STAGE = NP * 1024;
     static constexpr int R_FIT = (160 * 1024) / STAGE;
@@ -956,18 +940,16 @@ k_tile_gemm(const bf16_t* __restrict__ W, int N16, int K32, int nk, const bf16_t
                                              (__attribute__((address_space(3))) void*)(sb + i * 8192), 16, 0, 0);
     };
     // fragments of one stage (both k-tiles): a[kk][i], token hi / lo [kk][j]
-    struct Frags { bf16x8_t a[2][F], xh[2][TH], xl[2][TH]; };
+    struct Frags { wfrag_t a[2][F]; ActFrag x[2][TH]; };
     auto frag_load = [&](int s, Frags& f) {
         const char* sb = smem + (s % R) * STAGE + lane * 16;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-            for (int i = 0; i < F; ++i) f.a[kk][i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb + ((w * F + i) * 2 + kk) * 1024));
+            for (int i = 0; i < F; ++i) f.a[kk][i] = __builtin_bit_cast(wfrag_t, *reinterpret_cast<const uint4*>(sb + ((w * F + i) * 2 + kk) * 1024));
 #pragma unroll
-            for (int j = 0; j < TH; ++j) {
-                f.xh[kk][j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb + C::NPW * 1024 + ((hh * TH + j) * 2 + kk) * 1024));
-                f.xl[kk][j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb + (C::NPW + 2 * TT) * 1024 + ((hh * TH + j) * 2 + kk) * 1024));
-            }
+            for (int j = 0; j < TH; ++j)        // (LDS image: the hi plane's 2 TT pieces, then — two-plane builds — the lo plane's, 2 TT KiB further)
+                f.x[kk][j] = act_ld(reinterpret_cast<const bf16_t*>(sb + C::NPW * 1024 + ((hh * TH + j) * 2 + kk) * 1024), (size_t)TT * 1024);
         }
     };
 #pragma unroll
@@ -1010,11 +992,7 @@ k_tile_gemm(const bf16_t* __restrict__ W, int N16, int K32, int nk, const bf16_t
 #pragma unroll
             for (int i = 0; i < F; ++i)
 #pragma unroll
-                for (int j = 0; j < TH; ++j) acc[i][j] = mfma16(cur.a[kk][i], cur.xh[kk][j], acc[i][j]);
-#pragma unroll
-            for (int i = 0; i < F; ++i)
-#pragma unroll
-                for (int j = 0; j < TH; ++j) acc[i][j] = mfma16(cur.a[kk][i], cur.xl[kk][j], acc[i][j]);
+                for (int j = 0; j < TH; ++j) acc[i][j] = mfma_act(cur.a[kk][i], cur.x[kk][j], acc[i][j]);      // (per output: hi then lo, k ascending)
         }
         left -= 2;
         if (left == 0) {                       // slice complete: add its partial to the running total, start a fresh accumulator
@@ -1223,6 +1201,7 @@ static inline TilePlan tile_plan(int N16, int MT) {
     for (int F = 2; F >= 1; --F)
         for (int TT = 2; TT <= 8; TT += 2) {
             if ((envF && F != envF) || (envTT && TT != envTT)) continue;
+            if ((8 * F + 2 * TT * WM_ACT_PLANES) % 8) continue;          // a stage's pieces are dealt evenly to the 8 waves
             const int blocks = ((N16 + 4 * F - 1) / (4 * F)) * ((MT + TT - 1) / TT);
             const double rounds = blocks <= 256 ? 1.0 : blocks / 256.0;
             const double cost = rounds * (128.0 * F + 64.0 * TT);
@@ -1250,7 +1229,7 @@ static inline hipError_t launch_tile_gemm_ft(hipStream_t st, const bf16_t* W, in
 template <class Ep>
 static inline hipError_t launch_tile_gemm(hipStream_t st, const bf16_t* W, int N16, int K32, int nk, const bf16_t* X, size_t plane, int MT, const Ep& ep) {
     const TilePlan t = tile_plan(N16, MT);
-#define WM_TG(Fv, TTv) if (t.F == Fv && t.TT == TTv) return launch_tile_gemm_ft<Fv, TTv>(st, W, N16, K32, nk, X, plane, MT, ep)
+#define WM_TG(Fv, TTv) if constexpr ((8 * Fv + 2 * TTv * WM_ACT_PLANES) % 8 == 0) if (t.F == Fv && t.TT == TTv) return launch_tile_gemm_ft<Fv, TTv>(st, W, N16, K32, nk, X, plane, MT, ep)
     WM_TG(1, 2); WM_TG(1, 4); WM_TG(1, 6); WM_TG(1, 8);
     WM_TG(2, 2); WM_TG(2, 4); WM_TG(2, 6); WM_TG(2, 8);
 #undef WM_TG

@@ -196,13 +196,17 @@ def _resolve_checkpoint(name_or_path, revision=None, cache_dir=None, local_files
 
 class WhisperMedusaModel:
     def __init__(self, config: MedusaConfig, state_dict: Dict[str, torch.Tensor], device: Union[str, torch.device, None] = None,
-                 max_batch: int = 1, dec_weight_fp8: bool = False, enc_fp8: bool = False):
+                 max_batch: int = 1, dec_weight_fp8: bool = False, enc_fp8: bool = False, act_fp16: Optional[bool] = None):
         self.config = config
         self.generation_config = config          # posterior_threshold / alpha / token ids live on the config here
         self._sd = state_dict
         self._max_batch = max_batch
         self._fp8 = bool(dec_weight_fp8)         # decoder-layer matrices stored as fp8 e4m3 + per-row scale (BASELINE configs[4])
         self._enc_fp8 = bool(enc_fp8)            # encoder QKV / FC1 / cross-K/V projection on the fp8 MFMA (BASELINE configs[4])
+        # decode numerics contract (include/wm.h wm_config.act_fp16): False = bf16 hi / lo operand pairs (libwm.so), True = one fp16
+        # plane (libwm_f16.so, decoder matrices held as fp16); None = the default (engine.default_act_fp16: WM_ACT)
+        from .engine import default_act_fp16
+        self._act_fp16 = default_act_fp16() if act_fp16 is None else bool(act_fp16)
         self._micro_batches = 1                  # contexts a batch is decoded with; None = automatic (set_micro_batches(None))
         self._pool = None
         self._engine: Optional[Engine] = None
@@ -214,7 +218,7 @@ class WhisperMedusaModel:
     # ---- construction ---------------------------------------------------------------------
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path, *args, device=None, max_batch: int = 1, dec_weight_fp8: bool = False,
-                        enc_fp8: bool = False, **kwargs):
+                        enc_fp8: bool = False, act_fp16: Optional[bool] = None, **kwargs):
         """Load ``config.json`` + ``model.safetensors`` from a checkpoint directory, or from a Hugging Face hub name
         (``aiola/whisper-medusa-linear-libri``, README.md:101-104 of the reference) resolved through ``huggingface_hub`` — its
         local cache first, a download when the machine has network access (reference model.py:265-291)."""
@@ -222,7 +226,7 @@ class WhisperMedusaModel:
                                                             kwargs.get("cache_dir"), kwargs.get("local_files_only", False))
         config = MedusaConfig.from_pretrained(pretrained_model_name_or_path)
         sd = _weights.load_state_dict_from_dir(pretrained_model_name_or_path)
-        return cls(config, sd, device=device, max_batch=max_batch, dec_weight_fp8=dec_weight_fp8, enc_fp8=enc_fp8)
+        return cls(config, sd, device=device, max_batch=max_batch, dec_weight_fp8=dec_weight_fp8, enc_fp8=enc_fp8, act_fp16=act_fp16)
 
     def save_pretrained(self, save_directory: str, safe_serialization: bool = True) -> None:
         """``config.json`` + ``model.safetensors`` with the reference's parameter names (what its Trainer writes,
@@ -253,13 +257,13 @@ class WhisperMedusaModel:
         if self._blob is None:
             if not self._sd:
                 raise RuntimeError("nothing to export: the model holds neither a state dict nor a packed blob")
-            self._blob, self._offsets = _weights.build_blob(self.config, self._sd, device="cpu", dec_fp8=self._fp8, enc_fp8=self._enc_fp8)
+            self._blob, self._offsets = _weights.build_blob(self.config, self._sd, device="cpu", dec_fp8=self._fp8, enc_fp8=self._enc_fp8, act_fp16=self._act_fp16)
         os.makedirs(save_directory, exist_ok=True)
         self.config.save_pretrained(save_directory)
         raw = self._blob.detach().cpu().contiguous().numpy().tobytes()
         with open(os.path.join(save_directory, "wm_packed.bin"), "wb") as f:
             f.write(raw)
-        meta = dict(packed_format=self.PACKED_FORMAT, abi_layout=WM_ABI_VERSION, dec_weight_fp8=self._fp8, enc_fp8=self._enc_fp8,
+        meta = dict(packed_format=self.PACKED_FORMAT, abi_layout=WM_ABI_VERSION, dec_weight_fp8=self._fp8, enc_fp8=self._enc_fp8, act_fp16=self._act_fp16,
                     n_bytes=len(raw), sha256=hashlib.sha256(raw).hexdigest(), offsets=[int(o) for o in self._offsets])
         with open(os.path.join(save_directory, "wm_packed.json"), "w") as f:
             json.dump(meta, f)
@@ -280,19 +284,20 @@ class WhisperMedusaModel:
         config = MedusaConfig.from_pretrained(directory)
         if len(meta["offsets"]) != _weights.n_table_entries(config, meta["dec_weight_fp8"], meta["enc_fp8"]):
             raise ValueError("packed export's offset table does not match its config")
-        self = cls(config, {}, device=None, max_batch=max_batch, dec_weight_fp8=meta["dec_weight_fp8"], enc_fp8=meta["enc_fp8"])
+        self = cls(config, {}, device=None, max_batch=max_batch, dec_weight_fp8=meta["dec_weight_fp8"], enc_fp8=meta["enc_fp8"],
+                   act_fp16=bool(meta.get("act_fp16", False)))
         self._blob, self._offsets = torch.from_numpy(raw), np.asarray(meta["offsets"], dtype=np.uint64)
         return self.to(device) if device is not None else self
 
     @classmethod
     def from_blob(cls, config: MedusaConfig, blob: torch.Tensor, offsets: np.ndarray, max_batch: int = 1, dec_weight_fp8: bool = False,
-                  enc_fp8: bool = False):
+                  enc_fp8: bool = False, act_fp16: bool = False):
         """Build directly from a packed parameter blob already resident on a GPU (the path the
         8-GPU data-parallel launcher uses after the RCCL broadcast, ``dist.py``)."""
-        self = cls(config, {}, device=None, max_batch=max_batch, dec_weight_fp8=dec_weight_fp8, enc_fp8=enc_fp8)
+        self = cls(config, {}, device=None, max_batch=max_batch, dec_weight_fp8=dec_weight_fp8, enc_fp8=enc_fp8, act_fp16=act_fp16)
         self._blob, self._offsets = blob, offsets
         self.device = blob.device
-        self._engine = Engine(config, blob, offsets, max_batch=max_batch, device=blob.device, dec_weight_fp8=dec_weight_fp8, enc_fp8=enc_fp8)
+        self._engine = Engine(config, blob, offsets, max_batch=max_batch, device=blob.device, dec_weight_fp8=dec_weight_fp8, enc_fp8=enc_fp8, act_fp16=act_fp16)
         return self
 
     def to(self, device):
@@ -312,12 +317,12 @@ class WhisperMedusaModel:
             self._engine = None
         with torch.cuda.device(device):
             if self._sd:
-                self._blob, self._offsets = _weights.build_blob(self.config, self._sd, device=device, dec_fp8=self._fp8, enc_fp8=self._enc_fp8)
+                self._blob, self._offsets = _weights.build_blob(self.config, self._sd, device=device, dec_fp8=self._fp8, enc_fp8=self._enc_fp8, act_fp16=self._act_fp16)
             elif self._blob is not None:
                 self._blob = self._blob.to(device)                 # built with from_blob: move the packed blob itself
             else:
                 raise RuntimeError("model has neither a state dict nor a packed blob to place on the device")
-            self._engine = Engine(self.config, self._blob, self._offsets, max_batch=self._max_batch, device=device, dec_weight_fp8=self._fp8, enc_fp8=self._enc_fp8)
+            self._engine = Engine(self.config, self._blob, self._offsets, max_batch=self._max_batch, device=device, dec_weight_fp8=self._fp8, enc_fp8=self._enc_fp8, act_fp16=self._act_fp16)
         self._drop_pool()
         self.device = device
         return self
@@ -333,7 +338,7 @@ class WhisperMedusaModel:
             self._max_batch = max_batch
             if self._engine is not None:
                 self._engine.close()
-                self._engine = Engine(self.config, self._blob, self._offsets, max_batch=max_batch, device=self.device, dec_weight_fp8=self._fp8, enc_fp8=self._enc_fp8)
+                self._engine = Engine(self.config, self._blob, self._offsets, max_batch=max_batch, device=self.device, dec_weight_fp8=self._fp8, enc_fp8=self._enc_fp8, act_fp16=self._act_fp16)
             self._drop_pool()
         return self
 
@@ -374,7 +379,7 @@ class WhisperMedusaModel:
             from .pool import ContextPool
             _ = self.engine                                         # raises when not on a HIP device
             # automatic policy: contexts of ONE stream each (per_ctx = ceil(max_batch / contexts) must not depend on the first batch's size)
-            self._pool = ContextPool(self.config, self._blob, self._offsets, n, n if auto else max(self._max_batch, n), self._fp8, self._enc_fp8)
+            self._pool = ContextPool(self.config, self._blob, self._offsets, n, n if auto else max(self._max_batch, n), self._fp8, self._enc_fp8, self._act_fp16)
             self._pool_n = n
         elif auto and have < n:
             self._pool.grow(n)

@@ -16,13 +16,15 @@ from .config import MedusaConfig, GenParams, HEADS_BLOCK
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwm.so")      # the product library; tests/microbench scripts may point WM_LIB at a debug build
-WM_ABI_VERSION = 7
+LIB_PATH_F16 = os.path.join(_HERE, "libwm_f16.so")  # the same sources built for the fp16 single-plane decode contract (wm_config.act_fp16)
+WM_ABI_VERSION = 8
 
 
 class WmConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "abi_version", "d_model", "enc_layers", "dec_layers", "n_heads", "ffn_dim", "vocab", "n_mels",
-        "n_ctx", "n_tgt", "medusa_heads", "heads_type", "max_batch", "dec_weight_fp8")] + [("medusa_choices", C.c_int32 * 16), ("enc_fp8", C.c_int32)]
+        "n_ctx", "n_tgt", "medusa_heads", "heads_type", "max_batch", "dec_weight_fp8")] + [("medusa_choices", C.c_int32 * 16), ("enc_fp8", C.c_int32),
+                                                                                          ("act_fp16", C.c_int32)]
 
 
 class WmWeights(C.Structure):
@@ -49,19 +51,25 @@ class WmStats(C.Structure):
                 ("graph_replays", C.c_int32), ("schedule_steps", C.c_int32)]
 
 
-EXPORTS = ["wm_create", "wm_destroy", "wm_last_error", "wm_abi_version", "wm_resample_len", "wm_resample", "wm_logmel", "wm_encode", "wm_set_encoder_output",
+EXPORTS = ["wm_create", "wm_destroy", "wm_last_error", "wm_abi_version", "wm_build_act_fp16", "wm_resample_len", "wm_resample", "wm_logmel", "wm_encode", "wm_set_encoder_output",
            "wm_decode_begin", "wm_decode_run", "wm_get_tokens", "wm_get_stats", "wm_sync",
            "wm_get_encoder_output", "wm_forward_logits", "wm_get_cross_kv", "wm_profile_kernel"]
 
-_lib = None
+_lib = {}
 
 
-def load_library(path: Optional[str] = None) -> C.CDLL:
-    """dlopen libwm.so and declare the prototypes.  Raises if the library has not been built."""
+def default_act_fp16() -> bool:
+    """The decode numerics contract a model gets when the caller does not choose (``act_fp16=None``): WM_ACT=hilo|f16, default hilo."""
+    return os.environ.get("WM_ACT", "hilo").lower() in ("f16", "fp16")
+
+
+def load_library(path: Optional[str] = None, act_fp16: bool = False) -> C.CDLL:
+    """dlopen libwm.so (bf16 hi / lo decode contract) or libwm_f16.so (fp16 single-plane contract) and declare the prototypes.
+    Raises if the library has not been built."""
     global _lib
-    if _lib is not None and path is None:
-        return _lib
-    p = path or os.environ.get("WM_LIB") or LIB_PATH
+    if path is None and act_fp16 in _lib:
+        return _lib[act_fp16]
+    p = path or os.environ.get("WM_LIB_F16" if act_fp16 else "WM_LIB") or (LIB_PATH_F16 if act_fp16 else LIB_PATH)
     if not os.path.exists(p):
         raise RuntimeError(f"{p} not found: build the HIP engine first (python whisper-medusa_amd/build.py). "
                            "There is no CPU fallback.")
@@ -71,6 +79,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.wm_destroy.argtypes = [vp]; lib.wm_destroy.restype = None
     lib.wm_last_error.argtypes = [vp]; lib.wm_last_error.restype = C.c_char_p
     lib.wm_abi_version.argtypes = []
+    lib.wm_build_act_fp16.argtypes = []
     lib.wm_resample_len.argtypes = [C.c_int64, i32, i32]; lib.wm_resample_len.restype = C.c_int64
     lib.wm_resample.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
     lib.wm_logmel.argtypes = [vp, vp, i32, i32, vp]
@@ -90,8 +99,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
             getattr(lib, name).restype = i32
     if lib.wm_abi_version() != WM_ABI_VERSION and not (os.environ.get("WM_LIB") and os.environ.get("WM_ABI_ANY")):
         raise RuntimeError("libwm.so ABI version mismatch")        # WM_ABI_ANY: A/B runs against an older debug build (tests/microbench)
+    if bool(lib.wm_build_act_fp16()) != bool(act_fp16) and path is None:
+        raise RuntimeError(f"{p} is built for the other decode contract (wm_build_act_fp16)")
     if path is None:
-        _lib = lib
+        _lib[act_fp16] = lib
     return lib
 
 
@@ -104,10 +115,11 @@ class Engine:
     """One context = one GPU.  ``blob`` is the packed parameter tensor (uint8, on that GPU)."""
 
     def __init__(self, cfg: MedusaConfig, blob: torch.Tensor, offsets: np.ndarray, max_batch: int = 1,
-                 device: Optional[torch.device] = None, dec_weight_fp8: bool = False, enc_fp8: bool = False):
+                 device: Optional[torch.device] = None, dec_weight_fp8: bool = False, enc_fp8: bool = False, act_fp16: bool = False):
         if not torch.cuda.is_available():
             raise RuntimeError("no HIP device visible: the Whisper-Medusa engine has no CPU path")
-        self.lib = load_library()
+        self.act_fp16 = bool(act_fp16)
+        self.lib = load_library(act_fp16=self.act_fp16)
         self.cfg = cfg
         self.device = torch.device(device if device is not None else blob.device)
         if self.device.type != "cuda" or blob.device != self.device:
@@ -119,7 +131,7 @@ class Engine:
                      cfg.decoder_ffn_dim, cfg.vocab_size, cfg.num_mel_bins, cfg.max_source_positions,
                      cfg.max_target_positions, cfg.medusa_num_heads,
                      1 if cfg.medusa_heads_type == HEADS_BLOCK else 0, self.max_batch, 1 if dec_weight_fp8 else 0,
-                     (C.c_int32 * 16)(*[int(x) for x in cfg.medusa_choices]), 1 if enc_fp8 else 0)
+                     (C.c_int32 * 16)(*[int(x) for x in cfg.medusa_choices]), 1 if enc_fp8 else 0, 1 if self.act_fp16 else 0)
         w = WmWeights(C.c_void_p(blob.data_ptr()), blob.numel(),
                       self._offsets.ctypes.data_as(C.POINTER(C.c_uint64)), len(self._offsets))
         # every context owns a private non-blocking HIP stream (NULL -> wm_create makes one): several contexts built under

@@ -24,11 +24,17 @@ def _rup(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
 
-def pack_matrix(w: torch.Tensor) -> torch.Tensor:
-    """Row-major [N, K] -> bf16 packed [N/16][K/32][64][8] (flat).  N % 16 == 0, K % 32 == 0."""
+def pack_matrix(w: torch.Tensor, fp16: bool = False) -> torch.Tensor:
+    """Row-major [N, K] -> bf16 packed [N/16][K/32][64][8] (flat).  N % 16 == 0, K % 32 == 0.
+    ``fp16`` (wm_config.act_fp16, the fp16 single-plane decode contract): the bf16-rounded parameter re-expressed as fp16 — the same value
+    for every |w| >= 2^-17 (bf16 carries 8 significant bits, fp16's subnormal step is 2^-24), absolute error <= 3e-8 below — returned as the
+    16-bit container the blob stores (bfloat16-typed view of the fp16 bits)."""
     n, k = w.shape
     assert n % 16 == 0 and k % 32 == 0, (n, k)
-    t = w.to(torch.bfloat16).view(n // 16, 16, k // 32, 4, 8)      # (nt, r, kt, g, e)
+    t = w.to(torch.bfloat16)
+    if fp16:
+        t = t.to(torch.float32).to(torch.float16).view(torch.bfloat16)
+    t = t.view(n // 16, 16, k // 32, 4, 8)                          # (nt, r, kt, g, e)
     return t.permute(0, 2, 3, 1, 4).contiguous().view(-1)          # (nt, kt, g, r, e): lane = g*16 + r
 
 
@@ -82,15 +88,19 @@ def _pad2(w: torch.Tensor, n: int, k: int) -> torch.Tensor:
     return out
 
 
-def canonical_tensors(cfg: MedusaConfig, sd: Dict[str, torch.Tensor], device, dec_fp8: bool = False, enc_fp8: bool = False) -> List[torch.Tensor]:
+def canonical_tensors(cfg: MedusaConfig, sd: Dict[str, torch.Tensor], device, dec_fp8: bool = False, enc_fp8: bool = False,
+                      act_fp16: bool = False) -> List[torch.Tensor]:
     """The parameter list in the engine's canonical order; each entry is a flat fp32 / bf16 (/ uint8 fp8) tensor.
     ``dec_fp8``: the six matrices of every decoder layer are stored as fp8 e4m3 and their per-row scales are appended.
     ``enc_fp8``: the encoder matrices that multiply a LayerNorm output (q/k/v, fc1) and the fused cross-K/V projection are
     ALSO given as e4m3 in the fp8-MFMA layout with per-row scales (appended last: 4 entries per encoder layer + 2); their
-    bf16 entries shrink to 16-byte placeholders (the engine does not read them in that mode)."""
+    bf16 entries shrink to 16-byte placeholders (the engine does not read them in that mode).
+    ``act_fp16``: the matrices the DECODE GEMMs stream — decoder-layer matrices (unless fp8), Medusa heads, packed vocabulary projection —
+    are stored as fp16 (`pack_matrix(fp16=True)`); everything the encoder reads stays bf16."""
     d, dev = cfg.d_model, device
     f32 = lambda t: t.detach().to(dev, torch.float32).contiguous().view(-1)
     mat = lambda t: pack_matrix(t.detach().to(dev, torch.float32))
+    dmat = lambda t: pack_matrix(t.detach().to(dev, torch.float32), fp16=act_fp16)          # a matrix of the decode GEMMs
     zeros = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
     np32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev).view(-1)
     enc, dec = "whisper_model.model.encoder", "whisper_model.model.decoder"
@@ -106,10 +116,10 @@ def canonical_tensors(cfg: MedusaConfig, sd: Dict[str, torch.Tensor], device, de
     emb = sd[dec + ".embed_tokens.weight"].to(dev, torch.float32)
     proj = sd.get("whisper_model.proj_out.weight", sd[dec + ".embed_tokens.weight"]).to(dev, torch.float32)
     vpad = _rup(cfg.vocab_size, 128)
-    out += [emb.to(torch.bfloat16).contiguous().view(-1), mat(_pad2(proj, vpad, d))]
+    out += [emb.to(torch.bfloat16).contiguous().view(-1), dmat(_pad2(proj, vpad, d))]
     out += [f32(sd[dec + ".embed_positions.weight"]), f32(sd[dec + ".layer_norm.weight"]), f32(sd[dec + ".layer_norm.bias"])]
     n_res = cfg.medusa_num_heads + (0 if cfg.is_block else 1)
-    out += [mat(torch.cat([sd[f"medusa_heads.{k}.0.linear.weight"].to(dev, torch.float32) for k in range(n_res)], 0)),
+    out += [dmat(torch.cat([sd[f"medusa_heads.{k}.0.linear.weight"].to(dev, torch.float32) for k in range(n_res)], 0)),
             f32(torch.cat([sd[f"medusa_heads.{k}.0.linear.bias"].to(dev, torch.float32) for k in range(n_res)], 0))]
     kv_prefixes = [f"{dec}.layers.{i}" for i in range(cfg.decoder_layers)] + (["medusa_block"] if cfg.is_block else [])
     enc8: List[torch.Tensor] = []
@@ -135,7 +145,7 @@ def canonical_tensors(cfg: MedusaConfig, sd: Dict[str, torch.Tensor], device, de
 
     def wmat(w, fp8):
         if not fp8:
-            return mat(w)
+            return dmat(w)
         q, sc = quantize_rows_e4m3(w)
         scales.append(sc.to(dev).contiguous())
         return pack_matrix_fp8(q).to(dev)
@@ -155,8 +165,9 @@ def canonical_tensors(cfg: MedusaConfig, sd: Dict[str, torch.Tensor], device, de
         p = f"{enc}.layers.{i}"
         wq = torch.cat([sd[p + ".self_attn.q_proj.weight"], sd[p + ".self_attn.k_proj.weight"], sd[p + ".self_attn.v_proj.weight"]], 0)
         bq = torch.cat([f32(sd[p + ".self_attn.q_proj.bias"]), zeros(d), f32(sd[p + ".self_attn.v_proj.bias"])])
-        out += ln(p + ".self_attn_layer_norm") + [emat(wq), bq] + lin(p + ".self_attn.out_proj")
-        out += ln(p + ".final_layer_norm") + [emat(sd[p + ".fc1.weight"]), f32(sd[p + ".fc1.bias"])] + lin(p + ".fc2")
+        elin = lambda q_: [mat(sd[q_ + ".weight"]), f32(sd[q_ + ".bias"])]          # encoder matrices stay bf16 whatever the decode contract
+        out += ln(p + ".self_attn_layer_norm") + [emat(wq), bq] + elin(p + ".self_attn.out_proj")
+        out += ln(p + ".final_layer_norm") + [emat(sd[p + ".fc1.weight"]), f32(sd[p + ".fc1.bias"])] + elin(p + ".fc2")
     for p in kv_prefixes:
         out += ln(p + ".self_attn_layer_norm") + qkv(p + ".self_attn", dec_fp8) + lin(p + ".self_attn.out_proj", dec_fp8)
         out += ln(p + ".encoder_attn_layer_norm") + lin(p + ".encoder_attn.q_proj", dec_fp8) + lin(p + ".encoder_attn.out_proj", dec_fp8)
@@ -170,9 +181,10 @@ def n_table_entries(cfg: MedusaConfig, dec_fp8: bool = False, enc_fp8: bool = Fa
             + (4 * cfg.encoder_layers + 2 if enc_fp8 else 0))
 
 
-def build_blob(cfg: MedusaConfig, sd: Dict[str, torch.Tensor], device="cpu", dec_fp8: bool = False, enc_fp8: bool = False) -> Tuple[torch.Tensor, np.ndarray]:
+def build_blob(cfg: MedusaConfig, sd: Dict[str, torch.Tensor], device="cpu", dec_fp8: bool = False, enc_fp8: bool = False,
+               act_fp16: bool = False) -> Tuple[torch.Tensor, np.ndarray]:
     """-> (uint8 blob on ``device``, uint64 offsets[n_table_entries])."""
-    tensors = canonical_tensors(cfg, sd, device, dec_fp8, enc_fp8)
+    tensors = canonical_tensors(cfg, sd, device, dec_fp8, enc_fp8, act_fp16)
     assert len(tensors) == n_table_entries(cfg, dec_fp8, enc_fp8), (len(tensors), n_table_entries(cfg, dec_fp8, enc_fp8))
     offsets, total = [], 0
     for t in tensors:
