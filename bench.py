@@ -117,14 +117,15 @@ def median(v):
     return v[len(v) // 2]
 
 
-def cpu_baseline_leg(cfg, sd, eng, gp, wav0, engine_ids, n_iters, fp8, full_budget, act="hilo"):
+def cpu_baseline_leg(cfg, sd, eng, gp, wav0, engine_ids, n_iters, fp8, full_budget, act="hilo", xkv8=None):
     """The oracle (a CPU port of the reference algorithm, oracle/) on the host cores of this box, SURVEY.md §8d: split
     log-mel / encoder / decode timers, 1 warm-up + 3 timed runs each, median.  The decode sample is `n_iters` Medusa iterations
     (the whole 128-token budget with --cpu-full).  Parity: the oracle in the engine's numeric contract (sim="bf16"), fed with
     the engine's encoder output, must emit exactly the engine's token ids for those iterations."""
     from oracle.whisper_medusa_oracle import Oracle, log_mel
     sd_cpu = {k: v.float().cpu() for k, v in sd.items()}
-    orc = Oracle(cfg, sd_cpu, sim="fp32", dec_fp8=fp8, enc_fp8=fp8)             # the reference's default dtype
+    xkv8 = fp8 if xkv8 is None else xkv8
+    orc = Oracle(cfg, sd_cpu, sim="fp32", dec_fp8=fp8, enc_fp8=fp8, xkv_fp8=xkv8)             # the reference's default dtype
     n = cfg.n_mel_frames * 160
     wav = wav0.cpu().numpy()
     # The host thread count is calibrated, not assumed: the decode loop is a chain of small ops and skinny GEMVs, and on the GPU box's 256
@@ -158,7 +159,7 @@ def cpu_baseline_leg(cfg, sd, eng, gp, wav0, engine_ids, n_iters, fp8, full_budg
     t_dec, r = timed(lambda: orc.decode(enc, gp, max_iters=iters))
     ntok = len(r.ids) - len(gp.prompt)
     # parity on the same iterations, engine contract
-    orc16 = Oracle(cfg, sd_cpu, sim="bf16", dec_fp8=fp8, enc_fp8=fp8, act=act)
+    orc16 = Oracle(cfg, sd_cpu, sim="bf16", dec_fp8=fp8, enc_fp8=fp8, act=act, xkv_fp8=xkv8)
     r16 = orc16.decode(enc, gp, max_iters=iters)
     ok = engine_ids[: len(r16.ids)] == r16.ids
     first = next((i for i, (a, b) in enumerate(zip(engine_ids, r16.ids)) if a != b), min(len(engine_ids), len(r16.ids)))
@@ -214,7 +215,7 @@ def leg_parity(cfg, sd, eng, gp, fp8, iters=8, act="hilo"):
     output, for the first `iters` Medusa iterations (the checker, never the thing measured)."""
     from oracle.whisper_medusa_oracle import Oracle
     torch.set_num_threads(min(os.cpu_count() or 1, 16))
-    orc = Oracle(cfg, {k: v.float().cpu() for k, v in sd.items()}, sim="bf16", dec_fp8=fp8, enc_fp8=fp8, act=act)
+    orc = Oracle(cfg, {k: v.float().cpu() for k, v in sd.items()}, sim="bf16", dec_fp8=fp8, enc_fp8=fp8, act=act, xkv_fp8=fp8)
     enc = eng.encoder_output(1)[0]
     ref = orc.decode(enc, gp, max_iters=iters)
     got = eng.tokens(0)
@@ -231,7 +232,7 @@ def extra_config(name, heads, B, fp8, dev, logit_std, max_new, steps=8, f16=Fals
     blob, offs = weights.build_blob(cfg, sd, device=dev, dec_fp8=fp8, enc_fp8=fp8, act_fp16=f16)
     sd_cpu = {k: v.cpu() for k, v in sd.items()}
     del sd
-    model = WhisperMedusaModel.from_blob(cfg, blob, offs, max_batch=B, dec_weight_fp8=fp8, enc_fp8=fp8, act_fp16=f16)
+    model = WhisperMedusaModel.from_blob(cfg, blob, offs, max_batch=B, dec_weight_fp8=fp8, enc_fp8=fp8, act_fp16=f16, cross_kv_fp8=fp8)
     eng = model.engine
     n_samp = cfg.n_mel_frames * 160
     wav = torch.from_numpy(np.stack([synth.synth_clip(500 + j, n_samp) for j in range(B)])).to(dev)
@@ -258,7 +259,7 @@ def extra_config(name, heads, B, fp8, dev, logit_std, max_new, steps=8, f16=Fals
     van = B * max_new / (stv["ms_decode"] * 1e-3)
     t_iter = ms_dec / max(it, 1)
     bytes_iter = decode_iter_bytes(cfg, B, len(gp.prompt) + max_new / 2, fp8)
-    out = {"config": name, "streams": B, "heads": heads, "fp8_decoder_weights": fp8, "steps": steps,
+    out = {"config": name, "streams": B, "heads": heads, "fp8_decoder_weights": fp8, "fp8_cross_kv": fp8, "steps": steps,
            "decode_operands": "fp16 single plane" if f16 else "bf16 hi/lo pair",
            "tokens_per_sec": round(tok / el, 1), "decode_tokens_per_sec": round(tok / (ms_dec * 1e-3), 1),
            "ms_per_iteration": round(t_iter, 4), "tokens_per_iteration": round(tok / max(it, 1) / B, 3),
@@ -305,6 +306,7 @@ def main():
     ap.add_argument("--act", choices=["hilo", "f16"], default=None,
                     help="decode numerics contract (include/wm.h wm_config.act_fp16): bf16 hi/lo operand pairs (libwm.so) or one fp16 plane "
                          "(libwm_f16.so); default: the engine's (WM_ACT)")
+    ap.add_argument("--bf16-cross-kv", action="store_true", help="with --fp8-weights: keep the decode loop on the bf16 cross-K/V cache (round 5's configs[4] leg; A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vanilla", action="store_true",
                     help="skip the vanilla-greedy anchor (PMC passes: only Medusa iterations in the counter totals)")
@@ -347,7 +349,9 @@ def main():
     if args.test_setup_delay_s > 0:      # tests/test_bench_dist.py stretches the one-time set-up phase to show that it lies outside the timed region
         time.sleep(args.test_setup_delay_s)
     t_bcast = time.time() - t0
-    model = WhisperMedusaModel.from_blob(cfg, blob, offs, max_batch=B, dec_weight_fp8=args.fp8_weights, enc_fp8=args.fp8_weights, act_fp16=f16)
+    xkv8 = bool(args.fp8_weights) and not args.bf16_cross_kv
+    model = WhisperMedusaModel.from_blob(cfg, blob, offs, max_batch=B, dec_weight_fp8=args.fp8_weights, enc_fp8=args.fp8_weights, act_fp16=f16,
+                                         cross_kv_fp8=xkv8)
     eng = model.engine
 
     # ---- inputs resident in HBM ----
@@ -361,7 +365,7 @@ def main():
     pool = None
     if args.micro_batches > 1:
         from whisper_medusa.pool import ContextPool
-        pool = ContextPool(cfg, blob, offs, args.micro_batches, B, dec_weight_fp8=args.fp8_weights, enc_fp8=args.fp8_weights, act_fp16=f16)
+        pool = ContextPool(cfg, blob, offs, args.micro_batches, B, dec_weight_fp8=args.fp8_weights, enc_fp8=args.fp8_weights, act_fp16=f16, cross_kv_fp8=bool(args.fp8_weights) and not args.bf16_cross_kv)
 
     def step():
         wav = wavs[step_no[0] % n_sets]
@@ -460,7 +464,7 @@ def main():
         "config": {"workload": f"whisper-{args.model} + medusa-{args.heads} K={cfg.medusa_num_heads}, "
                                f"{B} x 30 s clip(s) per GPU, log-mel+encoder+decode, max_new_tokens={args.max_new}, "
                                f"typical acceptance (T=1.0), hipGraph decode loop, random-init weights (logit_std={args.logit_std})",
-                   "streams_per_gpu": B, "micro_batches": args.micro_batches, "fp8_decoder_weights": bool(args.fp8_weights), "parallelism": f"dp{world}",
+                   "streams_per_gpu": B, "micro_batches": args.micro_batches, "fp8_decoder_weights": bool(args.fp8_weights), "fp8_cross_kv": xkv8, "parallelism": f"dp{world}",
                    "decode_operands": "fp16 single plane (wm_config.act_fp16 = 1)" if f16 else "bf16 hi/lo pair (wm_config.act_fp16 = 0)",
                    "max_new_tokens": args.max_new},
         "tokens_per_sec_per_gpu": round(tokens_all / elapsed / world, 2),
@@ -513,7 +517,7 @@ def main():
             eng.encode(eng.logmel(wavs[0][:1].contiguous()))
             ids0 = eng.decode(gp, 1)[0]
             out["cpu_baseline"] = cpu_baseline_leg(cfg, sd, eng, gp, wavs[0][0], ids0, args.cpu_iters, args.fp8_weights, args.cpu_full,
-                                                   act="f16" if f16 else "hilo")
+                                                   act="f16" if f16 else "hilo", xkv8=xkv8)
         except Exception as e:  # noqa: BLE001
             out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
                                    "sample": f"failed: {e!r}", "parity_checked": False}

@@ -79,6 +79,12 @@ typedef struct wm_config {
                                  * matrices, the Medusa heads and the packed vocabulary projection as fp16 (exact from bf16 for |w| >= 2^-17;
                                  * whisper_medusa/weights.py build_blob(act_fp16=True)).  A library is BUILT for one contract
                                  * (wm_build_act_fp16(): libwm.so 0, libwm_f16.so 1); wm_create refuses the other. */
+    int32_t cross_kv_fp8;       /* 1 (BASELINE.json configs[4]; ABI v8): the decode loop reads the encoder cross-K/V — the dominant HBM stream of a
+                                 * batched step, 245.8 MB per stream and pass in bf16 — from an fp8 e4m3 copy with ONE fp32 scale per (kv layer,
+                                 * stream, head) for K and one for V (scale = max|x| / 448 over the head's 1500 x 64 values), written by a
+                                 * quantisation pass behind wm_encode's cross-K/V projection (HF WhisperAttention cross branch,
+                                 * modeling_whisper.py:322-335); K's scale rides on the query, V's on the normalised output.  The bf16 projection
+                                 * stays in HBM (wm_get_cross_kv returns it).  0: the bf16 cache. */
 } wm_config;
 
 /* Packed parameter blob (layout: whisper_medusa/weights.py).  The blob

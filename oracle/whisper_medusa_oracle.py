@@ -285,10 +285,11 @@ class DecodeResult:
 class Oracle:
     """Functional Whisper-Medusa over a plain state dict (reference key layout)."""
 
-    def __init__(self, cfg, sd: Dict[str, torch.Tensor], sim: str = "fp32", dec_fp8: bool = False, enc_fp8: bool = False, act: Optional[str] = None):
+    def __init__(self, cfg, sd: Dict[str, torch.Tensor], sim: str = "fp32", dec_fp8: bool = False, enc_fp8: bool = False, act: Optional[str] = None,
+                 xkv_fp8: bool = False):
         if act is None:         # the contract the engine defaults to in this process (whisper_medusa.engine.default_act_fp16: WM_ACT)
             import os as _os
-            act = "f16" if _os.environ.get("WM_ACT", "hilo").lower() in ("f16", "fp16") else "hilo"
+            act = "f16" if _os.environ.get("WM_ACT", "f16").lower() in ("f16", "fp16") else "hilo"
         assert sim in ("fp32", "bf16") and act in ("hilo", "f16")
         self.cfg, self.sim = cfg, sim
         # decoder GEMM operand of the engine contract: "hilo" = bf16 hi + bf16 lo (two planes, ~17 bits), "f16" = ONE fp16 plane (11 bits; the
@@ -299,6 +300,9 @@ class Oracle:
         # q_x = rne_e4m3(x / s_x), s_x = max|x| / 448 (1 for a zero row), the weight row likewise, and the product is
         # ((q_x . q_w) * s_x) * s_w in fp32.  The cross-K/V projection quantises the STORED (bf16) encoder output.
         self.enc_fp8 = enc_fp8
+        # wm_config.cross_kv_fp8 (BASELINE configs[4]; not a reference feature): the decoder reads the cross-K/V from an fp8 e4m3 copy with one
+        # scale per (kv layer, head) for K and one for V: scale = max|x| / 448 over the head's S x 64 stored (bf16) values, q = rne_e4m3(x / scale)
+        self.xkv_fp8 = xkv_fp8
         self.w8: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
         self.sd = {k: v.detach().to(torch.float32).cpu() for k, v in sd.items()}
         self.H = cfg.d_model // HEAD_DIM
@@ -372,6 +376,13 @@ class Oracle:
         q = (x / scale[:, None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32)
         return q, scale
 
+    @staticmethod
+    def _q8_heads(x: torch.Tensor) -> torch.Tensor:
+        """[H, S, 64] -> its e4m3 image with one scale per head (csrc/wm_encoder.hip k_xkv_quant), dequantised."""
+        amax = x.abs().amax(dim=(1, 2))
+        scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))[:, None, None]
+        return (x / scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32) * scale
+
     def _lin8(self, x, prefix, bias=True):
         """fp8-MFMA linear: e4m3 activations (row scale) x e4m3 weights (row scale), fp32 accumulation."""
         if prefix not in self.w8:
@@ -437,7 +448,10 @@ class Oracle:
         for lp in self._kv_layer_prefixes():
             k = self._r(lin(enc, lp + ".encoder_attn.k_proj", bias=False))
             v = self._r(lin(enc, lp + ".encoder_attn.v_proj"))
-            out.append((self._heads(k), self._heads(v)))
+            kh, vh = self._heads(k), self._heads(v)
+            if self.xkv_fp8:
+                kh, vh = self._q8_heads(kh), self._q8_heads(vh)
+            out.append((kh, vh))
         return out
 
     # ---- F3 decoder layer (HF:modeling_whisper.py:416-505) ------------------------------

@@ -15,6 +15,11 @@ from whisper_medusa import synth  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 
+
+def default_act_f16():
+    """The decode numerics contract this process defaults to (engine AND oracle): WM_ACT, default f16 (whisper_medusa/engine.py)."""
+    return os.environ.get("WM_ACT", "f16").lower() in ("f16", "fp16")
+
 # (tag, config factory, checkpoint seed, max_new) — must match oracle/make_golden.py:main()
 GOLDEN_MODELS = {
     "micro": (lambda: MedusaConfig.micro(K=4), 11, 40),

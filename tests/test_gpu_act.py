@@ -121,3 +121,38 @@ def test_large_f16_contract_against_oracle_and_the_fp32_table(gpu):
                      clips_equal_to_hilo_contract=same, clips=N)
         print(f"large f16 {m}: {agree} / {total} ids agree with the fp32-pinned table; {same} / {N} clips identical to the hi / lo contract")
         assert agree >= 0.97 * total
+
+
+@pytest.mark.parametrize("f16", ACTS)
+@pytest.mark.parametrize("heads", ["base_head", "medusa_block"])
+def test_fp8_cross_kv_matches_the_oracle(gpu, heads, f16):
+    """wm_config.cross_kv_fp8 on the tiny.en shape, both contracts: the decode loop reads the encoder cross-K/V from its e4m3 copy (per-head
+    scales on the query / the output); the oracle quantises its cross-K/V the same way (Oracle(xkv_fp8=True)).  Also: the bf16 tap still returns
+    the unquantised projection, and the quantised run differs from the bf16-cache run (the switch does something)."""
+    cfg = MedusaConfig.tiny_en(heads, K=4)
+    sd = synth.synth_state_dict(cfg, seed=23, device=str(gpu))
+    n = cfg.n_mel_frames * 160
+    wav = np.stack([synth.synth_clip(120 + i, n) for i in range(3)])
+    from oracle.whisper_medusa_oracle import Oracle
+    outs = {}
+    for x8 in (True, False):
+        model = WhisperMedusaModel(cfg, sd, device=gpu, max_batch=3, act_fp16=f16, cross_kv_fp8=x8)
+        eng = model.engine
+        feats = model.extract_features(wav)
+        orc = Oracle(cfg, _cpu(sd), sim="bf16", act="f16" if f16 else "hilo", xkv_fp8=x8)
+        gp = golden_gen_params(cfg, ACCEPT_TYPICAL, 32)
+        eng.encode(feats)
+        enc = eng.encoder_output(3)
+        both = eng.decode(gp, 3)
+        for b in range(3):
+            check_tokens(orc, enc[b], gp, both[b], label=f"tiny {heads} xkv8={x8} act={'f16' if f16 else 'hilo'} b={b}")
+        prompt = synth.default_prompt(cfg)
+        eng.encode(feats[:1].contiguous())
+        z = eng.forward_logits([prompt], 0, False)[:, 0]
+        ref = orc.decoder_pass(orc.new_state(eng.encoder_output(1)[0]), prompt, 0, disable_medusa=False)
+        rel = float((z - ref).abs().max()) / float(ref.abs().max())
+        print("tiny", heads, "xkv8", x8, "f16", f16, "prompt pass max rel to scale", rel)
+        assert rel <= 3e-3
+        outs[x8] = z
+        model.engine.close()
+    assert float((outs[True] - outs[False]).abs().max()) > 1e-4

@@ -28,6 +28,26 @@ def test_library_exports_every_declared_symbol(built_lib):
     engine.load_library(act_fp16=True)
 
 
+def test_fp16_decoder_matrices_hold_the_bf16_parameters():
+    """wm_config.act_fp16: the decode GEMMs' matrices are stored as fp16.  weights.pack_matrix(fp16=True) re-expresses the bf16-rounded
+    parameter: the SAME value for every |w| >= 2^-17 (bf16 has 8 significant bits, fp16's subnormal step is 2^-24), |error| <= 3e-8 below;
+    layout = the bf16 packing's; the encoder's matrices stay bf16 whatever the contract (canonical_tensors)."""
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(32, 64, generator=g) * torch.logspace(-9, 1, 64)[None, :]
+    pb = weights.unpack_matrix(weights.pack_matrix(w), 32, 64).float()
+    ph = weights.unpack_matrix(weights.pack_matrix(w, fp16=True), 32, 64).view(torch.float16).float()
+    big = pb.abs() >= 2.0 ** -17
+    assert big.any() and (~big).any() and torch.equal(ph[big], pb[big]) and float((ph - pb).abs().max()) <= 3e-8
+    cfg = MedusaConfig.micro(K=2)
+    sd = synth.synth_state_dict(cfg, seed=2)
+    a = weights.canonical_tensors(cfg, sd, "cpu")
+    b = weights.canonical_tensors(cfg, sd, "cpu", act_fp16=True)
+    n_enc = 19 + 12 * cfg.encoder_layers
+    same = [torch.equal(x.view(torch.uint8), y.view(torch.uint8)) for x, y in zip(a, b)]
+    assert all(same[i] for i in (3, 5, 10)) and all(same[19 + 12 * l + j] for l in range(cfg.encoder_layers) for j in (2, 4, 8, 10))     # conv / token table / encoder matrices
+    assert not same[11] and not same[15] and not same[n_enc + 2]          # packed vocabulary projection, Medusa heads, first decoder QKV: fp16
+
+
 def test_fp8_mfma_operand_layout_matches_the_kernel_index_function():
     """weights.pack_matrix_fp8_k128 against csrc/wm_encoder.hip f8k_index restated: lane (row & 15, g) of a 128-k unit holds the 32
     consecutive k = 32 g .. + 31, half h of the unit = bytes 16 h .. + 15 of every lane, K zero-padded to 128."""
@@ -296,26 +316,26 @@ def test_packed_export_roundtrip_and_checks(tmp_path):
     from whisper_medusa import WhisperMedusaModel, weights
     cfg = MedusaConfig.micro(K=3)
     sd = synth.synth_state_dict(cfg, seed=4)
-    for dec8, enc8 in ((False, False), (True, True)):
-        d = tmp_path / f"p{int(dec8)}{int(enc8)}"
-        m = WhisperMedusaModel(cfg, sd, dec_weight_fp8=dec8, enc_fp8=enc8)
+    for dec8, enc8, f16 in ((False, False, False), (True, True, False), (False, False, True), (True, True, True)):
+        d = tmp_path / f"p{int(dec8)}{int(enc8)}{int(f16)}"
+        m = WhisperMedusaModel(cfg, sd, dec_weight_fp8=dec8, enc_fp8=enc8, act_fp16=f16, cross_kv_fp8=dec8)
         m.save_packed(str(d))
-        blob, offs = weights.build_blob(cfg, sd, dec_fp8=dec8, enc_fp8=enc8)
+        blob, offs = weights.build_blob(cfg, sd, dec_fp8=dec8, enc_fp8=enc8, act_fp16=f16)
         m2 = WhisperMedusaModel.from_packed(str(d))
         assert torch.equal(m2._blob, blob) and m2._offsets.tolist() == offs.tolist()
         assert (m2._fp8, m2._enc_fp8) == (dec8, enc8) and m2.config.to_dict() == cfg.to_dict()
-    small, big = (tmp_path / "p00" / "wm_packed.bin").stat().st_size, (tmp_path / "p11" / "wm_packed.bin").stat().st_size
+    small, big = (tmp_path / "p000" / "wm_packed.bin").stat().st_size, (tmp_path / "p110" / "wm_packed.bin").stat().st_size
     assert big < small                                     # e4m3 matrices: fewer bytes despite the scale vectors
-    meta_path = tmp_path / "p11" / "wm_packed.json"
+    meta_path = tmp_path / "p110" / "wm_packed.json"
     meta = json.loads(meta_path.read_text())
     meta["abi_layout"] -= 1
     meta_path.write_text(json.dumps(meta))
     with pytest.raises(ValueError, match="re-export"):
-        WhisperMedusaModel.from_packed(str(tmp_path / "p11"))
-    with open(tmp_path / "p00" / "wm_packed.bin", "r+b") as f:
+        WhisperMedusaModel.from_packed(str(tmp_path / "p110"))
+    with open(tmp_path / "p000" / "wm_packed.bin", "r+b") as f:
         f.seek(1000); f.write(b"\x55\xaa")
     with pytest.raises(ValueError, match="corrupt"):
-        WhisperMedusaModel.from_packed(str(tmp_path / "p00"))
+        WhisperMedusaModel.from_packed(str(tmp_path / "p000"))
 
 
 def test_automatic_micro_batch_policy():

@@ -169,6 +169,15 @@ __device__ __forceinline__ bf16x8_t ld_frag_nt(const bf16_t* p) {    // streamed
 // the MFMA and the hi/lo token operand are those of the bf16 path.
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
 // NT: streamed once per pass (single-stream GEMMs) -> nt policy; re-read by other token-tile groups (batched GEMM) -> default
+// 8 e4m3 values -> a bf16 MFMA fragment, whatever the build's decoder-weight type (attention operands are bf16 in both contracts)
+__device__ __forceinline__ bf16x8_t fp8x8_to_bf16(unsigned v0, unsigned v1) {
+    const f32x2_t a = __builtin_amdgcn_cvt_pk_f32_fp8(v0, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(v0, true);
+    const f32x2_t c = __builtin_amdgcn_cvt_pk_f32_fp8(v1, false), d = __builtin_amdgcn_cvt_pk_f32_fp8(v1, true);
+    uint4 r;
+    r.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf16x2_t)); r.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(b, bf16x2_t));
+    r.z = __builtin_bit_cast(uint32_t, __builtin_convertvector(c, bf16x2_t)); r.w = __builtin_bit_cast(uint32_t, __builtin_convertvector(d, bf16x2_t));
+    return __builtin_bit_cast(bf16x8_t, r);
+}
 __device__ __forceinline__ f32x4_t scale4(f32x4_t v, const float* wscale, int n) {       // n % 4 == 0
     const float4 s = *reinterpret_cast<const float4*>(wscale + n);
     return f32x4_t{v[0] * s.x, v[1] * s.y, v[2] * s.z, v[3] * s.w};

@@ -6,6 +6,7 @@
 #include "wm_internal.h"
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include "wm_skinny_gemm.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -157,6 +158,29 @@ __device__ __forceinline__ void split_hilo8(const float* x, bf16x8_t& hi, bf16x8
 
 struct KVStep { bf16x8_t k00, k01, k10, k11, v[4]; };        // one 32-key step: K rows as A fragments, V^T fragments
 struct AttnAcc { float m_run, l_run; f32x4_t o[4]; };
+// the same step from the fp8 e4m3 copy of the cross-K/V (wm_config.cross_kv_fp8; layouts: wm_encoder.hip k_xkv_quant): four 16-byte loads
+// instead of eight — lane (key c, g) holds dims 16 g .. + 15 of keys kb + c and kb + 16 + c (k0, k1: two MFMA fragments each, the query is loaded
+// in the same dim order) and its 8 keys of the dim-tile pairs (0, 1) and (2, 3) of V^T (v01, v23) —, widened to bf16 right before the MFMAs
+struct KVStep8 { u32x4_t k0, k1, v01, v23; };
+__device__ __forceinline__ void kv_load8(KVStep8& t, const unsigned char* kp, const unsigned char* vp, int kb, int c, int g, int lane)
+{
+    const unsigned char* kr = kp + (size_t)(kb + c) * 64 + g * 16;
+    const unsigned char* vr = vp + ((size_t)(kb >> 5) * 128 + lane) * 16;
+    t.k0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(kr));
+    t.k1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(kr + 16 * 64));
+    t.v01 = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(vr));
+    t.v23 = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(vr + 1024));
+}
+__device__ __forceinline__ KVStep kv_widen(const KVStep8& r)
+{
+    KVStep t;
+    t.k00 = fp8x8_to_bf16(r.k0[0], r.k0[1]); t.k01 = fp8x8_to_bf16(r.k0[2], r.k0[3]);
+    t.k10 = fp8x8_to_bf16(r.k1[0], r.k1[1]); t.k11 = fp8x8_to_bf16(r.k1[2], r.k1[3]);
+    t.v[0] = fp8x8_to_bf16(r.v01[0], r.v01[1]); t.v[1] = fp8x8_to_bf16(r.v01[2], r.v01[3]);
+    t.v[2] = fp8x8_to_bf16(r.v23[0], r.v23[1]); t.v[3] = fp8x8_to_bf16(r.v23[2], r.v23[3]);
+    return t;
+}
+__device__ __forceinline__ const KVStep& kv_widen(const KVStep& r) { return r; }
 
 // 8 fully coalesced 16-B-per-lane loads: K rows are 128-B lines, the V^T fragments of a step are 4 contiguous KiB
 // NT: the cross K/V of a (stream, head) is read by one block once per pass — stream it past the caches (nt policy)
@@ -285,7 +309,7 @@ struct FuseQ {
 };
 struct NoFuseQ { static constexpr bool kOn = false; static constexpr int NK = 1, KS = 1; };
 
-template <bool CROSS, bool NT, class FQ>
+template <bool CROSS, bool NT, class FQ, bool KV8 = false>
 __global__ void __launch_bounds__(FQ::kOn ? (FQ::KS > 4 ? 64 * FQ::KS : 256) : 256)
 k_attn_mfma(const bf16_t* __restrict__ kmat, const bf16_t* __restrict__ vtmat, const float* __restrict__ q,
             const int4* __restrict__ sinfo, const int* __restrict__ sskip, int mper_nbz, int h_ns, int rows_alloc, int S,
@@ -298,8 +322,11 @@ k_attn_mfma(const bf16_t* __restrict__ kmat, const bf16_t* __restrict__ vtmat, c
             // second dependent one in front of every K/V request of a merged step —, and gx, a HIDDEN kernel argument (one more
             // scalar round trip before the first request of every cross-attention launch), rides in bits 24-31 of h_ns.
             const int* __restrict__ done, int K32, bf16_t* __restrict__ xout, size_t xplane, float* __restrict__ ml, float* __restrict__ po,
-            int* __restrict__ ticket, PfJob pf, FQ fq, const unsigned long long* __restrict__ anc_tab, const int* __restrict__ base TL_ARG)
+            int* __restrict__ ticket, PfJob pf, FQ fq, const unsigned long long* __restrict__ anc_tab, const int* __restrict__ base,
+            // KV8 (cross_kv_fp8): kmat / vtmat are the e4m3 copies, one byte per element; the scales of the launch's streams [stream][head]
+            const float* __restrict__ kscale, const float* __restrict__ vscale TL_ARG)
 {
+    static_assert(!KV8 || (CROSS && !FQ::kOn), "the fp8 K/V copy exists for the cross-attention only");
     // Mper query rows per stream as nqt tiles of <= 16 (a candidate tree of more than 16 nodes; the chain and every base pass: one tile);
     // blockIdx.z = stream * nqt + query tile
     const int Mper = mper_nbz & 0xff, nbz = mper_nbz >> 8, H = h_ns & 0xff, NS = (h_ns >> 8) & 0xff, nqt = max((h_ns >> 16) & 0xff, 1);
@@ -334,16 +361,25 @@ k_attn_mfma(const bf16_t* __restrict__ kmat, const bf16_t* __restrict__ vtmat, c
 
     const bf16_t* kp = kmat + ((size_t)s * H + hd) * rows_alloc * 64;
     const bf16_t* vp = vtmat + ((size_t)s * H + hd) * 64 * rows_alloc;
+    const unsigned char* kp8 = reinterpret_cast<const unsigned char*>(kmat) + ((size_t)s * H + hd) * rows_alloc * 64;       // KV8: the same element index, one byte each
+    const unsigned char* vp8 = reinterpret_cast<const unsigned char*>(vtmat) + ((size_t)s * H + hd) * rows_alloc * 64;
 
     // The launch's memory batch goes out before anything is waited for: K/V do not depend on q nor on the cache length.
     // Self: wave w walks the 32-key steps w, w+4, ... with the next step in flight; its first step is fetched whatever
     // the length turns out to be (the rows exist: rows_alloc is a multiple of 32).  Cross: a wave owns 64 keys (two steps)
     // of every split and keeps the same two steps of the NEXT split in flight while it works on this one (16 KiB per wave,
     // 3 blocks per CU): bytes in flight are what the cross-K/V stream needs.  Then q (written by the previous launch).
-    KVStep c0 = {}, c1 = {};
+    typename std::conditional<KV8, KVStep8, KVStep>::type c0 = {}, c1 = {};
     int kb = CROSS ? sp0 * 256 + w * 64 : 32 * w;
-    if (aw && (CROSS ? (kb < S) : (kb < rows_alloc))) kv_load<NT>(c0, kp, vp, kb, c, g, lane);
-    if (aw && CROSS && kb + 32 < S) kv_load<NT>(c1, kp, vp, kb + 32, c, g, lane);
+    if constexpr (KV8) {
+        if (aw && kb < S) kv_load8(c0, kp8, vp8, kb, c, g, lane);
+        if (aw && kb + 32 < S) kv_load8(c1, kp8, vp8, kb + 32, c, g, lane);
+    } else {
+        if (aw && (CROSS ? (kb < S) : (kb < rows_alloc))) kv_load<NT>(c0, kp, vp, kb, c, g, lane);
+        if (aw && CROSS && kb + 32 < S) kv_load<NT>(c1, kp, vp, kb + 32, c, g, lane);
+    }
+    float ksc = 1.f, vsc = 1.f;
+    if constexpr (KV8) { ksc = kscale[s * H + hd]; vsc = vscale[s * H + hd]; }
     float4 qraw[2][2];
 #pragma unroll
     for (int ds = 0; ds < 2; ++ds) { qraw[ds][0] = make_float4(0.f, 0.f, 0.f, 0.f); qraw[ds][1] = qraw[ds][0]; }
@@ -413,7 +449,8 @@ k_attn_mfma(const bf16_t* __restrict__ kmat, const bf16_t* __restrict__ vtmat, c
 #pragma unroll
         for (int ds = 0; ds < 2; ++ds) {
             if (c < rows) {
-                const float4* qp = reinterpret_cast<const float4*>(q + (size_t)(row_s + r0 + c) * d + hd * 64 + ds * 32 + g * 8);
+                // (KV8: the fp8 K rows are loaded 16 consecutive dims per lane; fragment ds of lane g then holds dims 16 g + 8 ds .. + 7)
+                const float4* qp = reinterpret_cast<const float4*>(q + (size_t)(row_s + r0 + c) * d + hd * 64 + (KV8 ? g * 16 + ds * 8 : ds * 32 + g * 8));
                 qraw[ds][0] = qp[0]; qraw[ds][1] = qp[1];
             }
         }
@@ -425,6 +462,12 @@ k_attn_mfma(const bf16_t* __restrict__ kmat, const bf16_t* __restrict__ vtmat, c
     const int limit = CROSS ? S : ((!CROSS && anc_tab) ? min(b0, rows_alloc) : min(b0 + r0 + c + 1, rows_alloc));
     int kend = CROSS ? min(S, kb + 64) : min(b0 + cnt_s, rows_alloc);
     bf16x8_t qhi[2], qlo[2];
+    if constexpr (KV8) {            // K's scale rides on the query: (q s_k) . k8 = q . (s_k k8)
+#pragma unroll
+        for (int ds = 0; ds < 2; ++ds)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) { qraw[ds][e].x *= ksc; qraw[ds][e].y *= ksc; qraw[ds][e].z *= ksc; qraw[ds][e].w *= ksc; }
+    }
 #pragma unroll
     for (int ds = 0; ds < 2; ++ds) split_hilo8(qraw[ds][0], qraw[ds][1], qhi[ds], qlo[ds]);
     TL_PREP
@@ -441,15 +484,22 @@ k_attn_mfma(const bf16_t* __restrict__ kmat, const bf16_t* __restrict__ vtmat, c
         if (CROSS) {
             // each step's registers are refilled with the same step of the NEXT split as soon as its math has issued
             const int nkb = (sp + 1) * 256 + w * 64, nkend = (sp + 1 < sp1) ? min(S, nkb + 64) : 0;
-            if (aw && kb < kend) attn_block64(st, c0, c1, qhi, qlo, kb, g, limit, kb + 32 < kend);
-            if (aw && nkb < nkend) kv_load<NT>(c0, kp, vp, nkb, c, g, lane);
-            if (aw && nkb + 32 < nkend) kv_load<NT>(c1, kp, vp, nkb + 32, c, g, lane);
+            if (aw && kb < kend) attn_block64(st, kv_widen(c0), kv_widen(c1), qhi, qlo, kb, g, limit, kb + 32 < kend);
+            if constexpr (KV8) {
+                if (aw && nkb < nkend) kv_load8(c0, kp8, vp8, nkb, c, g, lane);
+                if (aw && nkb + 32 < nkend) kv_load8(c1, kp8, vp8, nkb + 32, c, g, lane);
+            } else {
+                if (aw && nkb < nkend) kv_load<NT>(c0, kp, vp, nkb, c, g, lane);
+                if (aw && nkb + 32 < nkend) kv_load<NT>(c1, kp, vp, nkb + 32, c, g, lane);
+            }
             kb = nkb; kend = nkend;
         } else {
             for (; kb < kend; kb += 128) {
                 const bool second = CROSS ? false : ((kb >> 7) & 1);        // two register sets alternate: the next step is in flight
-                if (kb + 128 < kend) { if (second) kv_load<NT>(c0, kp, vp, kb + 128, c, g, lane); else kv_load<NT>(c1, kp, vp, kb + 128, c, g, lane); }
-                if (second) attn_step(st, c1, qhi, qlo, kb, g, limit, b0, anc); else attn_step(st, c0, qhi, qlo, kb, g, limit, b0, anc);
+                if constexpr (!KV8) {
+                    if (kb + 128 < kend) { if (second) kv_load<NT>(c0, kp, vp, kb + 128, c, g, lane); else kv_load<NT>(c1, kp, vp, kb + 128, c, g, lane); }
+                    if (second) attn_step(st, c1, qhi, qlo, kb, g, limit, b0, anc); else attn_step(st, c0, qhi, qlo, kb, g, limit, b0, anc);
+                }
             }
         }
         const float m_run = st.m_run, l_run = st.l_run;
@@ -558,7 +608,7 @@ k_attn_mfma(const bf16_t* __restrict__ kmat, const bf16_t* __restrict__ vtmat, c
                 o4.x += ov[sp].x * e; o4.y += ov[sp].y * e; o4.z += ov[sp].z * e; o4.w += ov[sp].w * e;
             }
         }
-        const float inv = 1.0f / Lt;
+        const float inv = vsc / Lt;             // (KV8: V's scale rides on the normalised output)
         const size_t oi = packed_index(row, hd * 64 + ch, K32);
         act_st4(xout + oi, xout + xplane + oi, make_float4(o4.x * inv, o4.y * inv, o4.z * inv, o4.w * inv));
     }
@@ -1063,8 +1113,14 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
     const size_t xpl = (size_t)ctx->Rcap * d, fpl = (size_t)ctx->Rcap * ctx->ffn;
     bf16_t* kc = ctx->kc + ((size_t)slot * ctx->maxB + b0) * H * ctx->Tal * 64;
     bf16_t* vc = ctx->vc + ((size_t)slot * ctx->maxB + b0) * H * ctx->Tal * 64;
-    const bf16_t* kx = ctx->kx + ((size_t)slot * ctx->Benc + b0) * H * ctx->Spad * 64;
-    const bf16_t* vx = ctx->vx + ((size_t)slot * ctx->Benc + b0) * H * ctx->Spad * 64;
+    const size_t xoff = ((size_t)slot * ctx->Benc + b0) * H * ctx->Spad * 64;
+    // cross_kv_fp8: the decode loop streams the e4m3 copy (one byte per element: half the bytes) + one scale per (stream, head) for K and V
+    const bool x8 = ctx->xkv8;
+    const bf16_t* kx = x8 ? reinterpret_cast<const bf16_t*>(ctx->kx8 + xoff) : ctx->kx + xoff;
+    const bf16_t* vx = x8 ? reinterpret_cast<const bf16_t*>(ctx->vx8 + xoff) : ctx->vx + xoff;
+    const float* kxs = x8 ? ctx->kxs + ((size_t)slot * ctx->Benc + b0) * H : nullptr;
+    const float* vxs = x8 ? ctx->vxs + ((size_t)slot * ctx->Benc + b0) * H : nullptr;
+    const unsigned xkb = x8 ? 64u : 128u;        // bytes of one key row of a head
     // In-launch prefetch (single-tile passes, WM_PREFETCH != 0): launch k carries extra blocks that pull the operand of launch
     // k+1 into L2 (wm_skinny_gemm.h PfJob).  The self-attention launch is tiny, so LN1+QKV fetches for the launch after it.
     const bool pf = ctx->prefetch && R <= 16 && !kv_only;
@@ -1110,10 +1166,10 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
     const bool fuse_shape = (cqp.nk == 8 && cqp.ksplit >= 1 && cqp.ksplit <= 5) || (cqp.nk == 4 && (cqp.ksplit == 1 || cqp.ksplit == 3));
     // (not under the merged-step schedule's dense rows: the fused instance reads q at stream * Mper + row)
     // (hi / lo builds only: the fused kernel multiplies bf16 weights by the hi / lo pair itself)
-    const bool fuse_cq = WM_ACT_PLANES == 2 && fuse_env && !fold && R <= 16 && !f8 && fuse_shape && H * 4 == d / 16 && rowinfo == nullptr;       // single tile: nqt == 1
+    const bool fuse_cq = WM_ACT_PLANES == 2 && fuse_env && !x8 && !fold && R <= 16 && !f8 && fuse_shape && H * 4 == d / 16 && rowinfo == nullptr;       // single tile: nqt == 1
     const PfJob kvjob = (pf && nqt == 1 && ctx->NS % xgrid == 0 && ctx->Spad == ctx->NS * 256)
-        ? PfJob{reinterpret_cast<const char*>(kx), reinterpret_cast<const char*>(vx), (unsigned)(ctx->NS / xgrid) * 256 * 128,
-                (unsigned)(xgrid * H * nb), (unsigned long long)H * nb * ctx->Spad * 128}
+        ? PfJob{reinterpret_cast<const char*>(kx), reinterpret_cast<const char*>(vx), (unsigned)(ctx->NS / xgrid) * 256 * xkb,
+                (unsigned)(xgrid * H * nb), (unsigned long long)H * nb * ctx->Spad * xkb}
         : PfJob{nullptr, nullptr, 0u, 0u, 0ull};
     // 2. causal self-attention over the contiguous cache (20 blocks: its spare CUs fetch this layer's cross K/V when the
     //    fused cross-attention follows two launches later; otherwise LN2 + cross-q carries that job)
@@ -1128,7 +1184,7 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
         const int zs = spf.n_jobs ? nz + (pf_round8(main_total) - main_total + (int)spf.n_jobs + H - 1) / H : nz;
         TL_SET(slot * 16 + 2 + 8192 * Mper);
         hipLaunchKernelGGL((k_attn_mfma<false, false, NoFuseQ>), dim3(1, H, zs), dim3(256), sizeof(AttnLds<1>), st, kc, vc, ctx->qbuf, sinfo, sskip,
-                           Mper | (nz << 8), H | (1 << 8) | (nqt << 16) | (1 << 24), ctx->Tal, 0, g_skinny_done, K32, ctx->xbuf, xpl, nullptr, nullptr, nullptr, spf, NoFuseQ{}, ctx->cur_anc, base TL_PASS);
+                           Mper | (nz << 8), H | (1 << 8) | (nqt << 16) | (1 << 24), ctx->Tal, 0, g_skinny_done, K32, ctx->xbuf, xpl, nullptr, nullptr, nullptr, spf, NoFuseQ{}, ctx->cur_anc, base, (const float*)nullptr, (const float*)nullptr TL_PASS);
         WM_HIP(hipGetLastError());
     }
     // 3. out_proj + residual
@@ -1177,7 +1233,7 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
                 WM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
                 hipLaunchKernelGGL(kern, dim3(xgrid, H, zs), dim3(64 * (KSv > 4 ? KSv : 4)), lds, st, kx, vx, ctx->qbuf, (const int4*)nullptr, sskip, \
                                    Mper | (nz << 8), H | (ctx->NS << 8) | (nqt << 16) | (xgrid << 24), ctx->Spad, ctx->S, g_skinny_done, K32, ctx->xbuf, xpl, ctx->cml, ctx->co, ctx->ticket, xpf, \
-                                   FQ{ln, w.cq_w, w.cq_b}, nullptr, base TL_PASS);                                                    \
+                                   FQ{ln, w.cq_w, w.cq_b}, nullptr, base, (const float*)nullptr, (const float*)nullptr TL_PASS);                                                    \
             } while (0)
             if (cqp.nk == 8 && cqp.ksplit == 5) WM_XFUSE(8, 5);
             else if (cqp.nk == 8 && cqp.ksplit == 4) WM_XFUSE(8, 4);
@@ -1189,12 +1245,16 @@ static int dec_layer(wm_ctx* ctx, const DecLayerW& w, int slot, float* h, int b0
 #undef WM_XFUSE
         } else
 #endif
-        if (xattn_nt)
+        if (x8)
+            hipLaunchKernelGGL((k_attn_mfma<true, true, NoFuseQ, true>), dim3(xgrid, H, zs), dim3(256), sizeof(AttnLds<WM_XATTN_SPB_MAX>), st, kx, vx, ctx->qbuf, sinfo, sskip,
+                               Mper | (nz << 8), H | (ctx->NS << 8) | (nqt << 16) | (xgrid << 24), ctx->Spad, ctx->S, g_skinny_done, K32, ctx->xbuf, xpl, ctx->cml, ctx->co, ctx->ticket, xpf, NoFuseQ{}, nullptr, base,
+                               kxs, vxs TL_PASS);
+        else if (xattn_nt)
             hipLaunchKernelGGL((k_attn_mfma<true, true, NoFuseQ>), dim3(xgrid, H, zs), dim3(256), sizeof(AttnLds<WM_XATTN_SPB_MAX>), st, kx, vx, ctx->qbuf, sinfo, sskip,
-                               Mper | (nz << 8), H | (ctx->NS << 8) | (nqt << 16) | (xgrid << 24), ctx->Spad, ctx->S, g_skinny_done, K32, ctx->xbuf, xpl, ctx->cml, ctx->co, ctx->ticket, xpf, NoFuseQ{}, nullptr, base TL_PASS);
+                               Mper | (nz << 8), H | (ctx->NS << 8) | (nqt << 16) | (xgrid << 24), ctx->Spad, ctx->S, g_skinny_done, K32, ctx->xbuf, xpl, ctx->cml, ctx->co, ctx->ticket, xpf, NoFuseQ{}, nullptr, base, (const float*)nullptr, (const float*)nullptr TL_PASS);
         else
             hipLaunchKernelGGL((k_attn_mfma<true, false, NoFuseQ>), dim3(xgrid, H, zs), dim3(256), sizeof(AttnLds<WM_XATTN_SPB_MAX>), st, kx, vx, ctx->qbuf, sinfo, sskip,
-                               Mper | (nz << 8), H | (ctx->NS << 8) | (nqt << 16) | (xgrid << 24), ctx->Spad, ctx->S, g_skinny_done, K32, ctx->xbuf, xpl, ctx->cml, ctx->co, ctx->ticket, xpf, NoFuseQ{}, nullptr, base TL_PASS);
+                               Mper | (nz << 8), H | (ctx->NS << 8) | (nqt << 16) | (xgrid << 24), ctx->Spad, ctx->S, g_skinny_done, K32, ctx->xbuf, xpl, ctx->cml, ctx->co, ctx->ticket, xpf, NoFuseQ{}, nullptr, base, (const float*)nullptr, (const float*)nullptr TL_PASS);
         WM_HIP(hipGetLastError());
     }
     // 6. out_proj + residual

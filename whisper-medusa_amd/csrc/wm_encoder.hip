@@ -1515,6 +1515,73 @@ k_pack_hidden(const float* __restrict__ hid, bf16_t* __restrict__ out_p, int S, 
     *reinterpret_cast<uint4*>(out_p + packed_index((int)row, k, d / 32)) = o;
 }
 
+// ---------------------------------------------------------------------------------------------
+// wm_config.cross_kv_fp8: e4m3 copy of the projected cross-K/V (the decode loop's dominant HBM stream at several streams).
+// One block per (head, stream, kv layer): max|x| over the head's S x 64 keys (padding rows excluded) for K and for V -> scale = max / 448
+// (1 for an all-zero slab), then q = rne_e4m3(x / scale).  K keeps its row-major [Spad][64] order (one byte per element: a decode lane
+// (key c, g) then loads the 16 consecutive dims 16 g .. + 15 of its key with ONE 16-byte load = two MFMA fragments; the query is
+// permuted to match, wm_decoder.hip k_attn_mfma).  V: the V^T fragment layout [Spad/32][4 dim tiles][64 lanes][8] becomes
+// [Spad/32][2][64 lanes][16]: a lane's 8 keys of dim tiles 2 j and 2 j + 1 adjacent (one 16-byte load per pair).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned bf2_absmax(unsigned w, unsigned m) {      // max of the two bf16 magnitudes of a dword and m
+    return max(m, max(w & 0x7fffu, (w >> 16) & 0x7fffu));
+}
+__device__ __forceinline__ uint2 bf8_to_fp8(uint4 v, float inv_unused, float scale) {
+    const float x0 = __uint_as_float(v.x << 16), x1 = __uint_as_float(v.x & 0xffff0000u), x2 = __uint_as_float(v.y << 16), x3 = __uint_as_float(v.y & 0xffff0000u);
+    const float x4 = __uint_as_float(v.z << 16), x5 = __uint_as_float(v.z & 0xffff0000u), x6 = __uint_as_float(v.w << 16), x7 = __uint_as_float(v.w & 0xffff0000u);
+    auto q = [&](float x) { return fminf(fmaxf(x / scale, -448.f), 448.f); };
+    int a = __builtin_amdgcn_cvt_pk_fp8_f32(q(x0), q(x1), 0, false); a = __builtin_amdgcn_cvt_pk_fp8_f32(q(x2), q(x3), a, true);
+    int b = __builtin_amdgcn_cvt_pk_fp8_f32(q(x4), q(x5), 0, false); b = __builtin_amdgcn_cvt_pk_fp8_f32(q(x6), q(x7), b, true);
+    return make_uint2((unsigned)a, (unsigned)b);
+}
+__global__ void __launch_bounds__(256)
+k_xkv_quant(const bf16_t* __restrict__ kx, const bf16_t* __restrict__ vx, unsigned char* __restrict__ kx8, unsigned char* __restrict__ vx8,
+            float* __restrict__ kxs, float* __restrict__ vxs, int S, int Spad)
+{
+    __shared__ unsigned s_k[4], s_v[4];
+    const size_t head = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;          // [kv layer][stream][head]
+    const size_t slab = (size_t)Spad * 64;
+    const uint4* kp = reinterpret_cast<const uint4*>(kx + head * slab);
+    const uint4* vp = reinterpret_cast<const uint4*>(vx + head * slab);
+    const int n16 = Spad * 8;                   // 16-byte units (8 bf16) of a slab
+    unsigned mk = 0u, mv = 0u;
+    for (int i = threadIdx.x; i < n16; i += 256) {
+        if ((i >> 3) < S) { const uint4 a = kp[i]; mk = bf2_absmax(a.x, bf2_absmax(a.y, bf2_absmax(a.z, bf2_absmax(a.w, mk)))); }      // K row = i / 8
+        // V^T fragment unit i = (t * 4 + dt) * 64 + lane: element e of lane (c, g) is key 32 t + 16 (e >> 2) + 4 g + (e & 3)
+        const int t = i >> 8, g = (i & 63) >> 4, k0 = 32 * t + 4 * g;
+        const uint4 b = vp[i];
+        const unsigned h0 = (b.x & 0x7fffu), h1 = (b.x >> 16) & 0x7fffu, h2 = (b.y & 0x7fffu), h3 = (b.y >> 16) & 0x7fffu;
+        const unsigned h4 = (b.z & 0x7fffu), h5 = (b.z >> 16) & 0x7fffu, h6 = (b.w & 0x7fffu), h7 = (b.w >> 16) & 0x7fffu;
+        if (k0 + 0 < S) mv = max(mv, h0); if (k0 + 1 < S) mv = max(mv, h1); if (k0 + 2 < S) mv = max(mv, h2); if (k0 + 3 < S) mv = max(mv, h3);
+        if (k0 + 16 < S) mv = max(mv, h4); if (k0 + 17 < S) mv = max(mv, h5); if (k0 + 18 < S) mv = max(mv, h6); if (k0 + 19 < S) mv = max(mv, h7);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mk = max(mk, (unsigned)__shfl_xor((int)mk, o, 64)); mv = max(mv, (unsigned)__shfl_xor((int)mv, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { s_k[threadIdx.x >> 6] = mk; s_v[threadIdx.x >> 6] = mv; }
+    __syncthreads();
+    mk = max(max(s_k[0], s_k[1]), max(s_k[2], s_k[3])); mv = max(max(s_v[0], s_v[1]), max(s_v[2], s_v[3]));
+    const float ak = __uint_as_float(mk << 16), av = __uint_as_float(mv << 16);
+    const float sk = ak > 0.f ? ak / 448.0f : 1.0f, sv = av > 0.f ? av / 448.0f : 1.0f;
+    if (threadIdx.x == 0) { kxs[head] = sk; vxs[head] = sv; }
+    unsigned char* k8 = kx8 + head * slab;
+    unsigned char* v8 = vx8 + head * slab;
+    for (int i = threadIdx.x; i < n16; i += 256) {
+        *reinterpret_cast<uint2*>(k8 + (size_t)i * 8) = bf8_to_fp8(kp[i], 0.f, sk);
+        const int t = i >> 8, dt = (i >> 6) & 3, lane = i & 63;
+        *reinterpret_cast<uint2*>(v8 + (((size_t)(t * 2 + (dt >> 1)) * 64 + lane) * 16 + (dt & 1) * 8)) = bf8_to_fp8(vp[i], 0.f, sv);
+    }
+}
+
+int wm_enc_quant_cross_kv(wm_ctx* ctx, int B)
+{
+    if (!ctx->xkv8) return WM_OK;
+    // (slabs are indexed [kv layer][B][H]: the B of THIS encode, like kx / vx)
+    hipLaunchKernelGGL(k_xkv_quant, dim3(ctx->H, B, ctx->nkv), dim3(256), 0, ctx->stream, ctx->kx, ctx->vx, ctx->kx8, ctx->vx8, ctx->kxs, ctx->vxs,
+                       ctx->S, ctx->Spad);
+    WM_HIP(hipGetLastError());
+    return WM_OK;
+}
+
 int wm_enc_set_output(wm_ctx* ctx, const float* hidden, int B)
 {
     hipStream_t st = ctx->stream;
@@ -1526,6 +1593,7 @@ int wm_enc_set_output(wm_ctx* ctx, const float* hidden, int B)
     hipLaunchKernelGGL(k_pack_hidden, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, hidden, ctx->enc_out, S, Spad, d, n8);
     WM_HIP(hipGetLastError());
     WM_HIP(launch_gemm_tiled(st, ctx->enc_out, ctx->ckv_w, M, ctx->nkv * 2 * d, K32, EpCrossKV{ctx->kx, ctx->vx, ctx->ckv_b, Spad, H, d, B}));
+    { const int rq = wm_enc_quant_cross_kv(ctx, B); if (rq) return rq; }
     ctx->Benc = B;
     WM_HIP(hipEventRecord(ctx->ev1, st));
     WM_HIP(hipEventSynchronize(ctx->ev1));
@@ -1612,6 +1680,7 @@ int wm_enc_encode(wm_ctx* ctx, const float* feats, int B)
         WM_HIP(launch_gemm_tiled(st, ctx->enc_out, ctx->ckv_w, M, ctx->nkv * 2 * d, K32,
                                  EpCrossKV{ctx->kx, ctx->vx, ctx->ckv_b, Spad, H, d, B}));
     }
+    { const int rq = wm_enc_quant_cross_kv(ctx, B); if (rq) return rq; }
     ctx->Benc = B;
     WM_HIP(hipEventRecord(ctx->ev1, st));
     WM_HIP(hipEventSynchronize(ctx->ev1));

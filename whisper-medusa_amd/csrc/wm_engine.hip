@@ -36,7 +36,7 @@ extern "C" void wm_destroy(wm_ctx* ctx)
                     ctx->ybuf, ctx->cml, ctx->co, ctx->ticket, ctx->logits, ctx->amax, ctx->pc, ctx->part1, ctx->part2, ctx->ids, ctx->L, ctx->kvlen,
                     ctx->finished, ctx->cand, ctx->niter, ctx->hist, ctx->supmask, ctx->exppen, ctx->tap_tok, ctx->done,
                     ctx->hf_keep, ctx->hb_keep, ctx->carry, ctx->rowinfo, ctx->sinfo, ctx->steprows, ctx->rs_table, ctx->tree, ctx->sel_src, ctx->sel_n, ctx->sel_base, ctx->exn8, ctx->exs,
-                    ctx->xn, ctx->lnstats, ctx->foldv};
+                    ctx->xn, ctx->lnstats, ctx->foldv, ctx->kx8, ctx->vx8, ctx->kxs, ctx->vxs};
     for (void* b : bufs) if (b) hipFree(b);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
@@ -181,6 +181,13 @@ extern "C" int wm_create(const wm_config* cfg, const wm_weights* w, int device, 
     CREATE_HIP(dev_alloc(&ctx->enc_out, Menc * d, st));
     CREATE_HIP(dev_alloc(&ctx->kx, (size_t)ctx->nkv * Menc * d, st));
     CREATE_HIP(dev_alloc(&ctx->vx, (size_t)ctx->nkv * Menc * d, st));
+    ctx->xkv8 = cfg->cross_kv_fp8 != 0;
+    if (ctx->xkv8) {
+        CREATE_HIP(dev_alloc(&ctx->kx8, (size_t)ctx->nkv * Menc * d, st));
+        CREATE_HIP(dev_alloc(&ctx->vx8, (size_t)ctx->nkv * Menc * d, st));
+        CREATE_HIP(dev_alloc(&ctx->kxs, (size_t)ctx->nkv * B * H, st));
+        CREATE_HIP(dev_alloc(&ctx->vxs, (size_t)ctx->nkv * B * H, st));
+    }
     CREATE_HIP(dev_alloc(&ctx->kc, (size_t)ctx->nkv * B * H * Tal * 64, st));
     CREATE_HIP(dev_alloc(&ctx->vc, (size_t)ctx->nkv * B * H * Tal * 64, st));
     ctx->Rcap = ctx->Mmax * ctx->maxB;

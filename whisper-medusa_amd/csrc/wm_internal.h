@@ -94,6 +94,10 @@ struct wm_ctx {
 
     // ---- caches ----
     bf16_t *kx = nullptr, *vx = nullptr;   // cross K/V [nkv][Benc][H][Spad][64]
+    // wm_config.cross_kv_fp8: e4m3 copies (K row-major [Spad][64] bytes; V^T fragments with the dim-tile pairs of a lane adjacent:
+    // [Spad/32][2][64 lanes][16 B]) + one fp32 scale per (kv layer, stream, head) each; written by wm_enc_quant_cross_kv
+    unsigned char *kx8 = nullptr, *vx8 = nullptr; float *kxs = nullptr, *vxs = nullptr;
+    bool xkv8 = false;
     bf16_t *kc = nullptr, *vc = nullptr;   // self K/V  [nkv][maxB][H][Tal][64]
     int Benc = 0;                          // batch of the last wm_encode
 
@@ -158,6 +162,7 @@ int wm_enc_resample(wm_ctx* ctx, const float* in, int B, int channels, int n_in,
 int wm_enc_logmel(wm_ctx* ctx, const float* wav, int B, int n_samples, float* feats);
 int wm_enc_encode(wm_ctx* ctx, const float* feats, int B);
 int wm_enc_set_output(wm_ctx* ctx, const float* hidden, int B);
+int wm_enc_quant_cross_kv(wm_ctx* ctx, int B);      // cross_kv_fp8: the e4m3 copy of the projected cross-K/V of B streams
 // implemented in wm_decoder.hip
 int wm_dec_stage_layers(wm_ctx* ctx, int b0, int nb, int Mper, int mode /*0 base, 1 verify*/);
 int wm_dec_stage_final(wm_ctx* ctx, int b0, int nb, int Mper, int mode, int medusa);

@@ -26,6 +26,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include "wm_common.h"
 #include "wm_epilogues.h"
 
@@ -1289,7 +1290,8 @@ static inline hipError_t launch_skinny_mt(hipStream_t st, WRef W, int N16, int K
             return launch_tile_gemm(st, W.w, N16, K32, p.nk, X, plane, MT, ep);
     }
     // two token tiles: the weight-streaming kernel with a second token tile (WM_SKINNY2=0: the register-blocked kernel)
-    if (MT == 2 && skinny_env("WM_SKINNY2", 1) && p.ksplit * p.rt <= 10 && p.ksplit * p.nk == K32)
+    const bool s2_dbg = (FOLD ? skinny_env("WM_SKINNY2_FOLD", 1) : 1) && (std::is_same<Ep, EpResidualFold>::value ? skinny_env("WM_SKINNY2_RESFOLD", 1) : 1);
+    if (MT == 2 && skinny_env("WM_SKINNY2", 1) && s2_dbg && p.ksplit * p.rt <= 10 && p.ksplit * p.nk == K32)
         return launch_skinny2<Ep, FOLD>(st, W, N16, K32, p, X, plane, R, ep, fold);
     if constexpr (!FOLD) {
         if (p.nk == 16) return launch_skinny_mt_nk<16>(st, W, N16, K32, p, X, plane, MT, ep);

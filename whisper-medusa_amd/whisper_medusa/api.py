@@ -196,7 +196,8 @@ def _resolve_checkpoint(name_or_path, revision=None, cache_dir=None, local_files
 
 class WhisperMedusaModel:
     def __init__(self, config: MedusaConfig, state_dict: Dict[str, torch.Tensor], device: Union[str, torch.device, None] = None,
-                 max_batch: int = 1, dec_weight_fp8: bool = False, enc_fp8: bool = False, act_fp16: Optional[bool] = None):
+                 max_batch: int = 1, dec_weight_fp8: bool = False, enc_fp8: bool = False, act_fp16: Optional[bool] = None,
+                 cross_kv_fp8: bool = False):
         self.config = config
         self.generation_config = config          # posterior_threshold / alpha / token ids live on the config here
         self._sd = state_dict
@@ -207,6 +208,7 @@ class WhisperMedusaModel:
         # plane (libwm_f16.so, decoder matrices held as fp16); None = the default (engine.default_act_fp16: WM_ACT)
         from .engine import default_act_fp16
         self._act_fp16 = default_act_fp16() if act_fp16 is None else bool(act_fp16)
+        self._xkv_fp8 = bool(cross_kv_fp8)       # the decode loop streams an e4m3 copy of the encoder cross-K/V (BASELINE configs[4]; wm_config.cross_kv_fp8)
         self._micro_batches = 1                  # contexts a batch is decoded with; None = automatic (set_micro_batches(None))
         self._pool = None
         self._engine: Optional[Engine] = None
@@ -218,7 +220,7 @@ class WhisperMedusaModel:
     # ---- construction ---------------------------------------------------------------------
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path, *args, device=None, max_batch: int = 1, dec_weight_fp8: bool = False,
-                        enc_fp8: bool = False, act_fp16: Optional[bool] = None, **kwargs):
+                        enc_fp8: bool = False, act_fp16: Optional[bool] = None, cross_kv_fp8: bool = False, **kwargs):
         """Load ``config.json`` + ``model.safetensors`` from a checkpoint directory, or from a Hugging Face hub name
         (``aiola/whisper-medusa-linear-libri``, README.md:101-104 of the reference) resolved through ``huggingface_hub`` — its
         local cache first, a download when the machine has network access (reference model.py:265-291)."""
@@ -226,7 +228,7 @@ class WhisperMedusaModel:
                                                             kwargs.get("cache_dir"), kwargs.get("local_files_only", False))
         config = MedusaConfig.from_pretrained(pretrained_model_name_or_path)
         sd = _weights.load_state_dict_from_dir(pretrained_model_name_or_path)
-        return cls(config, sd, device=device, max_batch=max_batch, dec_weight_fp8=dec_weight_fp8, enc_fp8=enc_fp8, act_fp16=act_fp16)
+        return cls(config, sd, device=device, max_batch=max_batch, dec_weight_fp8=dec_weight_fp8, enc_fp8=enc_fp8, act_fp16=act_fp16, cross_kv_fp8=cross_kv_fp8)
 
     def save_pretrained(self, save_directory: str, safe_serialization: bool = True) -> None:
         """``config.json`` + ``model.safetensors`` with the reference's parameter names (what its Trainer writes,
@@ -263,7 +265,7 @@ class WhisperMedusaModel:
         raw = self._blob.detach().cpu().contiguous().numpy().tobytes()
         with open(os.path.join(save_directory, "wm_packed.bin"), "wb") as f:
             f.write(raw)
-        meta = dict(packed_format=self.PACKED_FORMAT, abi_layout=WM_ABI_VERSION, dec_weight_fp8=self._fp8, enc_fp8=self._enc_fp8, act_fp16=self._act_fp16,
+        meta = dict(packed_format=self.PACKED_FORMAT, abi_layout=WM_ABI_VERSION, dec_weight_fp8=self._fp8, enc_fp8=self._enc_fp8, act_fp16=self._act_fp16, cross_kv_fp8=self._xkv_fp8,
                     n_bytes=len(raw), sha256=hashlib.sha256(raw).hexdigest(), offsets=[int(o) for o in self._offsets])
         with open(os.path.join(save_directory, "wm_packed.json"), "w") as f:
             json.dump(meta, f)
@@ -285,19 +287,19 @@ class WhisperMedusaModel:
         if len(meta["offsets"]) != _weights.n_table_entries(config, meta["dec_weight_fp8"], meta["enc_fp8"]):
             raise ValueError("packed export's offset table does not match its config")
         self = cls(config, {}, device=None, max_batch=max_batch, dec_weight_fp8=meta["dec_weight_fp8"], enc_fp8=meta["enc_fp8"],
-                   act_fp16=bool(meta.get("act_fp16", False)))
+                   act_fp16=bool(meta.get("act_fp16", False)), cross_kv_fp8=bool(meta.get("cross_kv_fp8", False)))
         self._blob, self._offsets = torch.from_numpy(raw), np.asarray(meta["offsets"], dtype=np.uint64)
         return self.to(device) if device is not None else self
 
     @classmethod
     def from_blob(cls, config: MedusaConfig, blob: torch.Tensor, offsets: np.ndarray, max_batch: int = 1, dec_weight_fp8: bool = False,
-                  enc_fp8: bool = False, act_fp16: bool = False):
+                  enc_fp8: bool = False, act_fp16: bool = False, cross_kv_fp8: bool = False):
         """Build directly from a packed parameter blob already resident on a GPU (the path the
         8-GPU data-parallel launcher uses after the RCCL broadcast, ``dist.py``)."""
-        self = cls(config, {}, device=None, max_batch=max_batch, dec_weight_fp8=dec_weight_fp8, enc_fp8=enc_fp8, act_fp16=act_fp16)
+        self = cls(config, {}, device=None, max_batch=max_batch, dec_weight_fp8=dec_weight_fp8, enc_fp8=enc_fp8, act_fp16=act_fp16, cross_kv_fp8=cross_kv_fp8)
         self._blob, self._offsets = blob, offsets
         self.device = blob.device
-        self._engine = Engine(config, blob, offsets, max_batch=max_batch, device=blob.device, dec_weight_fp8=dec_weight_fp8, enc_fp8=enc_fp8, act_fp16=act_fp16)
+        self._engine = Engine(config, blob, offsets, max_batch=max_batch, device=blob.device, dec_weight_fp8=dec_weight_fp8, enc_fp8=enc_fp8, act_fp16=act_fp16, cross_kv_fp8=cross_kv_fp8)
         return self
 
     def to(self, device):
@@ -322,7 +324,7 @@ class WhisperMedusaModel:
                 self._blob = self._blob.to(device)                 # built with from_blob: move the packed blob itself
             else:
                 raise RuntimeError("model has neither a state dict nor a packed blob to place on the device")
-            self._engine = Engine(self.config, self._blob, self._offsets, max_batch=self._max_batch, device=device, dec_weight_fp8=self._fp8, enc_fp8=self._enc_fp8, act_fp16=self._act_fp16)
+            self._engine = Engine(self.config, self._blob, self._offsets, max_batch=self._max_batch, device=device, dec_weight_fp8=self._fp8, enc_fp8=self._enc_fp8, act_fp16=self._act_fp16, cross_kv_fp8=self._xkv_fp8)
         self._drop_pool()
         self.device = device
         return self
@@ -338,7 +340,7 @@ class WhisperMedusaModel:
             self._max_batch = max_batch
             if self._engine is not None:
                 self._engine.close()
-                self._engine = Engine(self.config, self._blob, self._offsets, max_batch=max_batch, device=self.device, dec_weight_fp8=self._fp8, enc_fp8=self._enc_fp8, act_fp16=self._act_fp16)
+                self._engine = Engine(self.config, self._blob, self._offsets, max_batch=max_batch, device=self.device, dec_weight_fp8=self._fp8, enc_fp8=self._enc_fp8, act_fp16=self._act_fp16, cross_kv_fp8=self._xkv_fp8)
             self._drop_pool()
         return self
 
@@ -379,7 +381,7 @@ class WhisperMedusaModel:
             from .pool import ContextPool
             _ = self.engine                                         # raises when not on a HIP device
             # automatic policy: contexts of ONE stream each (per_ctx = ceil(max_batch / contexts) must not depend on the first batch's size)
-            self._pool = ContextPool(self.config, self._blob, self._offsets, n, n if auto else max(self._max_batch, n), self._fp8, self._enc_fp8, self._act_fp16)
+            self._pool = ContextPool(self.config, self._blob, self._offsets, n, n if auto else max(self._max_batch, n), self._fp8, self._enc_fp8, self._act_fp16, self._xkv_fp8)
             self._pool_n = n
         elif auto and have < n:
             self._pool.grow(n)

@@ -24,7 +24,7 @@ class WmConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "abi_version", "d_model", "enc_layers", "dec_layers", "n_heads", "ffn_dim", "vocab", "n_mels",
         "n_ctx", "n_tgt", "medusa_heads", "heads_type", "max_batch", "dec_weight_fp8")] + [("medusa_choices", C.c_int32 * 16), ("enc_fp8", C.c_int32),
-                                                                                          ("act_fp16", C.c_int32)]
+                                                                                          ("act_fp16", C.c_int32), ("cross_kv_fp8", C.c_int32)]
 
 
 class WmWeights(C.Structure):
@@ -59,8 +59,10 @@ _lib = {}
 
 
 def default_act_fp16() -> bool:
-    """The decode numerics contract a model gets when the caller does not choose (``act_fp16=None``): WM_ACT=hilo|f16, default hilo."""
-    return os.environ.get("WM_ACT", "hilo").lower() in ("f16", "fp16")
+    """The decode numerics contract a model gets when the caller does not choose (``act_fp16=None``): WM_ACT=f16|hilo.  Default f16 (round 6:
+    token ids identical to the hi / lo contract and to the fp32-pinned tables in every compared run, one stream +7 %, 32 streams +16 %;
+    DESIGN.md §2) — WM_ACT=hilo keeps rounds 1-5's bf16 hi / lo operand pairs."""
+    return os.environ.get("WM_ACT", "f16").lower() in ("f16", "fp16")
 
 
 def load_library(path: Optional[str] = None, act_fp16: bool = False) -> C.CDLL:
@@ -115,7 +117,8 @@ class Engine:
     """One context = one GPU.  ``blob`` is the packed parameter tensor (uint8, on that GPU)."""
 
     def __init__(self, cfg: MedusaConfig, blob: torch.Tensor, offsets: np.ndarray, max_batch: int = 1,
-                 device: Optional[torch.device] = None, dec_weight_fp8: bool = False, enc_fp8: bool = False, act_fp16: bool = False):
+                 device: Optional[torch.device] = None, dec_weight_fp8: bool = False, enc_fp8: bool = False, act_fp16: bool = False,
+                 cross_kv_fp8: bool = False):
         if not torch.cuda.is_available():
             raise RuntimeError("no HIP device visible: the Whisper-Medusa engine has no CPU path")
         self.act_fp16 = bool(act_fp16)
@@ -131,7 +134,7 @@ class Engine:
                      cfg.decoder_ffn_dim, cfg.vocab_size, cfg.num_mel_bins, cfg.max_source_positions,
                      cfg.max_target_positions, cfg.medusa_num_heads,
                      1 if cfg.medusa_heads_type == HEADS_BLOCK else 0, self.max_batch, 1 if dec_weight_fp8 else 0,
-                     (C.c_int32 * 16)(*[int(x) for x in cfg.medusa_choices]), 1 if enc_fp8 else 0, 1 if self.act_fp16 else 0)
+                     (C.c_int32 * 16)(*[int(x) for x in cfg.medusa_choices]), 1 if enc_fp8 else 0, 1 if self.act_fp16 else 0, 1 if cross_kv_fp8 else 0)
         w = WmWeights(C.c_void_p(blob.data_ptr()), blob.numel(),
                       self._offsets.ctypes.data_as(C.POINTER(C.c_uint64)), len(self._offsets))
         # every context owns a private non-blocking HIP stream (NULL -> wm_create makes one): several contexts built under

@@ -52,12 +52,12 @@ def merge_stats(stats: Sequence[dict]) -> dict:
 
 class ContextPool:
     def __init__(self, cfg: MedusaConfig, blob: torch.Tensor, offsets: np.ndarray, contexts: int, max_batch: int,
-                 dec_weight_fp8: bool = False, enc_fp8: bool = False, act_fp16: bool = False):
+                 dec_weight_fp8: bool = False, enc_fp8: bool = False, act_fp16: bool = False, cross_kv_fp8: bool = False):
         if contexts < 1:
             raise ValueError("contexts must be >= 1")
         self.cfg = cfg
         self.per_ctx = (max_batch + contexts - 1) // contexts
-        self._mk = lambda: Engine(cfg, blob, offsets, max_batch=self.per_ctx, device=blob.device, dec_weight_fp8=dec_weight_fp8, enc_fp8=enc_fp8, act_fp16=act_fp16)
+        self._mk = lambda: Engine(cfg, blob, offsets, max_batch=self.per_ctx, device=blob.device, dec_weight_fp8=dec_weight_fp8, enc_fp8=enc_fp8, act_fp16=act_fp16, cross_kv_fp8=cross_kv_fp8)
         self.engines = [self._mk() for _ in range(contexts)]
         self._ex = ThreadPoolExecutor(max_workers=contexts, thread_name_prefix="wm-ctx") if contexts > 1 else None
         self.last_stats: dict = {}
