@@ -48,6 +48,38 @@ def test_decode_loop_matches_the_oracle_in_its_contract(gpu, shape, f16):
 
 
 @pytest.mark.parametrize("f16", ACTS)
+@pytest.mark.parametrize("heads", ["base_head", "medusa_block"])
+def test_two_tile_passes_leave_the_single_stream_cache_bit_for_bit(gpu, heads, f16):
+    """Batch invariance below the token level.  A pass of 17..32 rows (two streams with a long prompt: the 2 x 16-row prefix chunks, the 2 x 9-row first
+    base pass) runs the two-tile kernels where a single stream runs the 16-row kernel; the self-K/V cache they leave must be the single-stream
+    run's bit for bit.  Probed through wm_forward_logits at position P (that entry point walks streams one at a time: the probe itself has no
+    batch): logits from the cache of the two-stream run == logits from the cache of each stream alone, exactly.
+    (Round 6: with the LayerNorm folded, hipcc contracted rstd * (acc - mean c) + bias into an fma in one GEMM kernel and not in another — the
+    cross-q rows of a two-tile pass differed in the last bit of 28 % of their elements, and a token flipped now and then; csrc/wm_common.h nofuse.)"""
+    cfg = MedusaConfig.micro(K=4, heads_type=heads, n_tgt=96)
+    sd = synth.synth_state_dict(cfg, seed=41)
+    model = WhisperMedusaModel(cfg, sd, device=gpu, max_batch=2, act_fp16=f16)
+    eng = model.engine
+    n = cfg.n_mel_frames * 160
+    feats = model.extract_features([synth.synth_clip(3, n), synth.synth_clip(4, n)[: n // 2]])
+    eng.encode(feats)
+    enc = eng.encoder_output(2)
+    for plen in (23, 15, 7, 3):                    # 2 x (16 + 9), 2 x (16 + 1), 2 x 9, 2 x 5 rows
+        pid = torch.tensor([cfg.vocab_size - 5] + [10 + (7 * i) % 900 for i in range(plen - 1)])
+        gp = model._gen_params(None, None, (6, 1.3), 20, None, None, False, None, None, None, None, pid)
+        P = len(gp.prompt)
+        eng.set_encoder_output(enc)
+        eng.decode(gp, 2, max_iters=1)
+        two = eng.forward_logits([[5], [5]], P, False)
+        for b in range(2):
+            eng.set_encoder_output(enc[b: b + 1])
+            eng.decode(gp, 1, max_iters=1)
+            one = eng.forward_logits([[5]], P, False)[:, 0]
+            assert torch.equal(two[:, b], one), (heads, f16, P, b, float((two[:, b] - one).abs().max()))
+    eng.close()
+
+
+@pytest.mark.parametrize("f16", ACTS)
 def test_prompt_pass_logits_in_its_contract(gpu, f16):
     """all heads' logits of one prompt pass (tiny.en) against the oracle in the same contract"""
     cfg = MedusaConfig.tiny_en(K=4)

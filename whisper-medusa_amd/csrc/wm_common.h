@@ -178,9 +178,17 @@ __device__ __forceinline__ bf16x8_t fp8x8_to_bf16(unsigned v0, unsigned v1) {
     r.z = __builtin_bit_cast(uint32_t, __builtin_convertvector(c, bf16x2_t)); r.w = __builtin_bit_cast(uint32_t, __builtin_convertvector(d, bf16x2_t));
     return __builtin_bit_cast(bf16x8_t, r);
 }
+// A product that must stay a product.  hipcc contracts a * b + c into one fma wherever a multiply meets an add after inlining, and WHETHER it does
+// depends on the code around it: the same epilogue arithmetic came out as fma(x, rstd, bias) in one GEMM kernel and as mul + add in another
+// (round 6: the cross-q projection of a two-tile pass differed from the 16-row launch's in the last bit of 28 % of its outputs; behind the fp16
+// operand rounding of the next GEMM that is a token now and then).  Batch invariance needs every kernel that can finish a given output to round it
+// the same way: products that feed an epilogue's add go through this (no instruction: the value just becomes opaque to the combiner).
+__device__ __forceinline__ float nofuse(float x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ f32x4_t scale4v(f32x4_t v, float4 s) {
+    return f32x4_t{nofuse(v[0] * s.x), nofuse(v[1] * s.y), nofuse(v[2] * s.z), nofuse(v[3] * s.w)};
+}
 __device__ __forceinline__ f32x4_t scale4(f32x4_t v, const float* wscale, int n) {       // n % 4 == 0
-    const float4 s = *reinterpret_cast<const float4*>(wscale + n);
-    return f32x4_t{v[0] * s.x, v[1] * s.y, v[2] * s.z, v[3] * s.w};
+    return scale4v(v, *reinterpret_cast<const float4*>(wscale + n));
 }
 
 // store 4 consecutive values as a bf16 hi/lo pair (x = hi + lo keeps ~17 mantissa bits)
@@ -308,9 +316,14 @@ __device__ __forceinline__ float2 fold_part_sum(const FoldPart& fp) {
 __device__ __forceinline__ float2 fold_row_stat(const float2* part, int r, int nrows, int G, float inv_d) {
     float s = 0.f, q = 0.f;
     for (int g2 = 0; g2 < G; ++g2) { const float2 p = part[g2 * nrows + r]; s += p.x; q += p.y; }
+    // (explicit fma / nofuse: every kernel rounds these the same way whatever the compiler would contract around them — see nofuse above)
     const float mean = s * inv_d;
-    return make_float2(mean, rsqrtf(fmaxf(q * inv_d - mean * mean, 0.f) + 1e-5f));
+    return make_float2(mean, rsqrtf(fmaxf(__builtin_fmaf(-mean, mean, q * inv_d), 0.f) + 1e-5f));
 }
 __device__ __forceinline__ f32x4_t fold_apply(f32x4_t v, float2 mr, float4 c) {
-    return f32x4_t{mr.y * (v[0] - mr.x * c.x), mr.y * (v[1] - mr.x * c.y), mr.y * (v[2] - mr.x * c.z), mr.y * (v[3] - mr.x * c.w)};
+    return f32x4_t{nofuse(mr.y * __builtin_fmaf(-mr.x, c.x, v[0])), nofuse(mr.y * __builtin_fmaf(-mr.x, c.y, v[1])),
+                   nofuse(mr.y * __builtin_fmaf(-mr.x, c.z, v[2])), nofuse(mr.y * __builtin_fmaf(-mr.x, c.w, v[3]))};
 }
+// a 4-feature share of a row's statistics partial (sum, sum of squares): fixed rounding points
+__device__ __forceinline__ float sum4(float4 y) { return (y.x + y.y) + (y.z + y.w); }
+__device__ __forceinline__ float sumsq4(float4 y) { return __builtin_fmaf(y.x, y.x, y.y * y.y) + __builtin_fmaf(y.z, y.z, y.w * y.w); }

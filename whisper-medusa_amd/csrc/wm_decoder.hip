@@ -49,7 +49,7 @@ __global__ void k_embed(float* __restrict__ h, const bf16_t* __restrict__ tok_em
             const float4 g = *reinterpret_cast<const float4*>(gnext + j);
             const size_t o = packed_index(row, j, d >> 5);
             act_st4(xo + o, xo + xplane + o, make_float4(y.x * g.x, y.y * g.y, y.z * g.z, y.w * g.w));
-            float sm = (y.x + y.y) + (y.z + y.w), q = (y.x * y.x + y.y * y.y) + (y.z * y.z + y.w * y.w);
+            float sm = sum4(y), q = sumsq4(y);
             sm += __shfl_xor(sm, 1, 64); q += __shfl_xor(q, 1, 64);
             sm += __shfl_xor(sm, 2, 64); q += __shfl_xor(q, 2, 64);
             if ((j & 15) == 0) stats[(size_t)(j >> 4) * sld + row] = make_float2(sm, q);

@@ -33,8 +33,8 @@ struct EpResidualT {
             if (m < M) *reinterpret_cast<float4*>(h + (size_t)m * ld + n) = y;
         } else {
             // lane (row = lane & 15, g = lane >> 4) holds features n .. n + 3 = 16 tile + 4 g ..: the tile's partial of a row is the sum over its 4 g-lanes
-            const float s = rows4_sum((y.x + y.y) + (y.z + y.w));
-            const float q = rows4_sum((y.x * y.x + y.y * y.y) + (y.z * y.z + y.w * y.w));
+            const float s = rows4_sum(sum4(y));
+            const float q = rows4_sum(sumsq4(y));
             if (m < M) {
                 *reinterpret_cast<float4*>(h + (size_t)m * ld + n) = y;
                 const size_t o = packed_index(m, n, K32);

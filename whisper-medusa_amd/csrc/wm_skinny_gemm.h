@@ -450,14 +450,14 @@ k_skinny_gemm(const bf16_t* __restrict__ W, const void* __restrict__ la, const v
                 const float4 p = red[(wave * ksplit + k2) * 64 + lane];
                 s[0] += p.x; s[1] += p.y; s[2] += p.z; s[3] += p.w;
             }
-            if constexpr (W8) s = f32x4_t{s[0] * wsc.x, s[1] * wsc.y, s[2] * wsc.z, s[3] * wsc.w};
+            if constexpr (W8) s = scale4v(s, wsc);
             if constexpr (FOLD) s = fold_apply(s, fold_row_stat(fpart, em, 16, fold.T16 >> 3, fold.inv_d), fc4);
             ep.fin(em, en, s, pre);
         }
     } else {
         if constexpr (FOLD) __syncthreads();
         if (edo) {
-            if constexpr (W8) acc[0] = f32x4_t{acc[0][0] * wsc.x, acc[0][1] * wsc.y, acc[0][2] * wsc.z, acc[0][3] * wsc.w};
+            if constexpr (W8) acc[0] = scale4v(acc[0], wsc);
             if constexpr (FOLD) acc[0] = fold_apply(acc[0], fold_row_stat(fpart, em, 16, fold.T16 >> 3, fold.inv_d), fc4);
             ep.fin(em, en, acc[0], pre);
         }
@@ -762,7 +762,7 @@ k_skinny2_gemm(const bf16_t* __restrict__ W, const bf16_t* __restrict__ X, size_
                 const float4 p = red[(wave * ksplit + k2) * 64 + lane];
                 s[0] += p.x; s[1] += p.y; s[2] += p.z; s[3] += p.w;
             }
-            if constexpr (W8) s = f32x4_t{s[0] * wsc.x, s[1] * wsc.y, s[2] * wsc.z, s[3] * wsc.w};
+            if constexpr (W8) s = scale4v(s, wsc);
             if constexpr (FOLD) s = fold_apply(s, fold_row_stat(fpart, (wave & 1) * 16 + (lane & 15), 32, fold.T16 >> 3, fold.inv_d), fc4);
             ep.fin((wave & 1) * 16 + (lane & 15), en, s, pre0);
         }
@@ -770,8 +770,8 @@ k_skinny2_gemm(const bf16_t* __restrict__ W, const bf16_t* __restrict__ X, size_
         if constexpr (FOLD) __syncthreads();
         if (edo) {
             if constexpr (W8) {
-                acc0 = f32x4_t{acc0[0] * wsc.x, acc0[1] * wsc.y, acc0[2] * wsc.z, acc0[3] * wsc.w};
-                acc1 = f32x4_t{acc1[0] * wsc.x, acc1[1] * wsc.y, acc1[2] * wsc.z, acc1[3] * wsc.w};
+                acc0 = scale4v(acc0, wsc);
+                acc1 = scale4v(acc1, wsc);
             }
             if constexpr (FOLD) {
                 acc0 = fold_apply(acc0, fold_row_stat(fpart, lane & 15, 32, fold.T16 >> 3, fold.inv_d), fc4);
@@ -839,13 +839,13 @@ k_skinny2_norm(const bf16_t* __restrict__ W, const float* __restrict__ wscale, i
                 const float4 p = red[(wave * ksplit + k2) * 64 + lane];
                 s[0] += p.x; s[1] += p.y; s[2] += p.z; s[3] += p.w;
             }
-            if constexpr (W8) s = f32x4_t{s[0] * wsc.x, s[1] * wsc.y, s[2] * wsc.z, s[3] * wsc.w};
+            if constexpr (W8) s = scale4v(s, wsc);
             ep.fin((wave & 1) * 16 + (lane & 15), en, s, pre0);
         }
     } else if (edo) {
         if constexpr (W8) {
-            acc0 = f32x4_t{acc0[0] * wsc.x, acc0[1] * wsc.y, acc0[2] * wsc.z, acc0[3] * wsc.w};
-            acc1 = f32x4_t{acc1[0] * wsc.x, acc1[1] * wsc.y, acc1[2] * wsc.z, acc1[3] * wsc.w};
+            acc0 = scale4v(acc0, wsc);
+            acc1 = scale4v(acc1, wsc);
         }
         ep.fin(lane & 15, en, acc0, pre0);
         ep.fin(16 + (lane & 15), en, acc1, pre1);
