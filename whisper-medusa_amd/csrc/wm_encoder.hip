@@ -22,6 +22,24 @@ __device__ __forceinline__ void glds16(const bf16_t* gsrc, char* lds_wave_base)
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+#ifndef WM_FLASH_VALU
+#define WM_FLASH_VALU 2      // k_flash_enc softmax arithmetic (see the kernel); A/B builds: -DWM_FLASH_VALU=1
+#endif
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// max of values known not to be NaN, as the instruction itself (fmaxf canonicalises every operand first under IEEE mode)
+__device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float vmax2(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float rows4_vmax(float v) {       // rows4_max (wm_common.h) on vmax2
+    const unsigned u = __float_as_uint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float y = vmax2(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const unsigned w = __float_as_uint(y);
+    const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return vmax2(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+#ifndef WM_GEMM_SCHED
+#define WM_GEMM_SCHED 3      // k_gemm_256p K-loop schedule (see the kernel); A/B builds: build.py --variant NAME -DWM_GEMM_SCHED=1|2
+#endif
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // Block barrier of the LDS-DMA ring kernels.  NOT __syncthreads(): an LDS-DMA in flight is a pending LDS write on the vector
@@ -391,26 +409,80 @@ k_gemm_256p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, int K32,
             // production form: the steady state (NST - 2 stages in flight behind the one needed, one refill per step) is a loop without a test
             // inside, the last four steps (nothing left to refill, the ring drains) are peeled with their waits as constants.  The generic
             // step() chooses its wait and its refill at run time: three scalar branches per step in front of the barrier.
+            // WM_GEMM_SCHED (build-time; round 6).  The ISA of the form below without its trailing sched_barrier (rounds 3-5): the compiler sank 31 of a
+            // step's 32 MFMAs below the NEXT step's wait + s_barrier (MFMAs touch no memory: nothing ordered them against the barrier), so every other
+            // barrier interval held ONE MFMA and an exposed lgkmcnt(0) on the 12 fragment reads just issued, the following one 63 MFMAs.
+            //  1: a sched_barrier closes each step — its MFMAs stay between its own barrier and the next;
+            //  2: as 1, and the step's requests are dealt out in front of four groups of 8 MFMAs (one LDS-DMA piece + three fragment reads each)
+            //     instead of 16 requests ahead of the first MFMA: the issue of the requests (vector-memory and LDS queues shared by 8 waves) runs
+            //     in the shadow of the previous group's MFMAs.  Same operands, same accumulators, same order per accumulator: bit-identical.
+            //  3: as 2 with the requests in front of the first three groups only (2 + 1 + 1 LDS-DMA pieces, 4 fragment reads each): the last group's
+            //     8 MFMAs stand between the step's last fragment read and the lgkmcnt(0) of the next barrier;
+            //  4: 2 with the wave priority raised over the MFMA groups (the other wave of the SIMD issues its requests around them).
+            auto quarter = [&](int t, int q, bool refill, bf16x8_t (&ac)[4], bf16x8_t (&bc)[8], bf16x8_t (&an)[4], bf16x8_t (&bn)[8]) {
+                const bf16_t* xs = reinterpret_cast<const bf16_t*>(smem + ((t + 1) % NST) * STAGE);
+                const bf16_t* ws = xs + 16 * 512;
+                auto piece = [&](int i) {
+                    const int blk = wa * LPW + i;
+                    const bool isx = blk < 16;
+                    glds16((isx ? xg : wg) + ((size_t)(isx ? blk : blk - 16) * K32 + t + NST) * 512, smem + ((t + NST) % NST) * STAGE + blk * 1024);
+                };
+                if constexpr (WM_GEMM_SCHED == 3) {
+                    if (refill) { if (q == 0) { piece(0); piece(1); } else if (q < 3) piece(q + 1); }
+                    if (q == 0) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) an[i] = ld_frag(ws + ((wn * 4 + i) * 64 + lane) * 8);
+                    } else if (q < 3) {
+#pragma unroll
+                        for (int j = 4 * (q - 1); j < 4 * q; ++j) bn[j] = ld_frag(xs + ((wm * 8 + j) * 64 + lane) * 8);
+                    }
+                } else {
+                    if (refill) piece(q);
+                    an[q] = ld_frag(ws + ((wn * 4 + q) * 64 + lane) * 8);
+                    bn[2 * q] = ld_frag(xs + ((wm * 8 + 2 * q) * 64 + lane) * 8);
+                    bn[2 * q + 1] = ld_frag(xs + ((wm * 8 + 2 * q + 1) * 64 + lane) * 8);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (WM_GEMM_SCHED == 4) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int j = 2 * q; j < 2 * q + 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i][j] = SW ? mfma16(bc[j], ac[i], acc[i][j]) : mfma16(ac[i], bc[j], acc[i][j]);
+                if constexpr (WM_GEMM_SCHED == 4) __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+            };
             auto steady = [&](int t, bf16x8_t (&ac)[4], bf16x8_t (&bc)[8], bf16x8_t (&an)[4], bf16x8_t (&bn)[8]) {
                 wait_vmcnt<2 * LPW>();
                 ring_barrier();
-                stage_load(xg, wg, t + NST);
-                frag_load(t + 1, an, bn);
-                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (WM_GEMM_SCHED >= 2 && LPW == 4) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
+                    for (int q = 0; q < 4; ++q) quarter(t, q, true, ac, bc, an, bn);
+                } else {
+                    stage_load(xg, wg, t + NST);
+                    frag_load(t + 1, an, bn);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[i][j] = SW ? mfma16(bc[j], ac[i], acc[i][j]) : mfma16(ac[i], bc[j], acc[i][j]);
+                    for (int j = 0; j < 8; ++j)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[i][j] = SW ? mfma16(bc[j], ac[i], acc[i][j]) : mfma16(ac[i], bc[j], acc[i][j]);
+                    if constexpr (WM_GEMM_SCHED >= 1) __builtin_amdgcn_sched_barrier(0);
+                }
             };
             auto drain = [&](int t, auto younger, bf16x8_t (&ac)[4], bf16x8_t (&bc)[8], bf16x8_t (&an)[4], bf16x8_t (&bn)[8]) {
                 wait_vmcnt<decltype(younger)::value * LPW>();
                 ring_barrier();
-                frag_load(t + 1, an, bn);              // (after the last step: a stale buffer, unused)
-                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (WM_GEMM_SCHED >= 2 && LPW == 4) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
+                    for (int q = 0; q < 4; ++q) quarter(t, q, false, ac, bc, an, bn);      // (after the last step: a stale buffer, unused)
+                } else {
+                    frag_load(t + 1, an, bn);              // (after the last step: a stale buffer, unused)
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[i][j] = SW ? mfma16(bc[j], ac[i], acc[i][j]) : mfma16(ac[i], bc[j], acc[i][j]);
+                    for (int j = 0; j < 8; ++j)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[i][j] = SW ? mfma16(bc[j], ac[i], acc[i][j]) : mfma16(ac[i], bc[j], acc[i][j]);
+                    if constexpr (WM_GEMM_SCHED >= 1) __builtin_amdgcn_sched_barrier(0);
+                }
             };
             int t = 0;
             for (; t < NT - NST; t += 2) {             // NT is even and >= NST (the launcher checks)
@@ -955,87 +1027,202 @@ k_flash_enc(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kt, const b
         for (int dt = 0; dt < 4; ++dt) o[t][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
 
+    // one 32-key half step of the wave's QT query tiles: 4 K fragments (two key tiles x two 32-dim halves) and 4 V^T fragments
+    struct KF { bf16x8_t a00, a01, a10, a11; };
+    struct VF { bf16x8_t va[4]; };
+    auto read_k = [&](KF& f, int i, int hh) {
+        const bf16_t* sb = reinterpret_cast<const bf16_t*>(smem + (i % NST) * STAGE);
+        f.a00 = ld_frag(sb + ((4 * hh + 0) * 64 + lane) * 8); f.a01 = ld_frag(sb + ((4 * hh + 1) * 64 + lane) * 8);
+        f.a10 = ld_frag(sb + ((4 * hh + 2) * 64 + lane) * 8); f.a11 = ld_frag(sb + ((4 * hh + 3) * 64 + lane) * 8);
+    };
+    auto read_v = [&](VF& f, int i, int hh) {
+        const bf16_t* sb = reinterpret_cast<const bf16_t*>(smem + (i % NST) * STAGE);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) f.va[dt] = ld_frag(sb + 4096 + ((4 * hh + dt) * 64 + lane) * 8);
+    };
+    struct SC { f32x4_t s0[G], s1[G]; };            // the scores of one group of G query tiles against one half step's 32 keys
+    auto scores = [&](const KF& f, int t0, SC& sc) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            sc.s0[u] = f32x4_t{0.f, 0.f, 0.f, 0.f}; sc.s1[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            sc.s0[u] = mfma16(f.a00, qb[t0 + u][0], sc.s0[u]); sc.s0[u] = mfma16(f.a01, qb[t0 + u][1], sc.s0[u]);
+            sc.s1[u] = mfma16(f.a10, qb[t0 + u][0], sc.s1[u]); sc.s1[u] = mfma16(f.a11, qb[t0 + u][1], sc.s1[u]);
+        }
+    };
+    // mask (last keys), softmax arithmetic, ONE rescale decision, PV MFMAs of the group
+    auto soft_pv = [&](const VF& f, int t0, int kb, SC& sc) {
+        const bool tail = kb + 32 > S;
+        if (tail) {
+#pragma unroll
+            for (int u = 0; u < G; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (kb + 4 * g + r >= S) sc.s0[u][r] = -INFINITY;
+                    if (kb + 16 + 4 * g + r >= S) sc.s1[u][r] = -INFINITY;
+                }
+        }
+        float alpha[G];
+        bf16x8_t pb[G];
+        bool any_rescale = false;
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            const int t = t0 + u;
+#if WM_FLASH_VALU
+            // Round 6 (ISA of the form in the #else branch: 120 max instructions per 64-key step and wave, 15 per tile and half — fmaxf under
+            // IEEE mode canonicalises each operand with a v_max x, x first, and MFMA results / permlane outputs are never "known canonical").
+            // The scores are finite or -inf, never NaN: v_max3_f32 / v_max_f32 directly (4 + 3 per tile and half, tree of depth 2), same values.
+            float mx = vmax3(vmax3(sc.s0[u][0], sc.s0[u][1], sc.s0[u][2]), vmax3(sc.s0[u][3], sc.s1[u][0], sc.s1[u][1]), vmax2(sc.s1[u][2], sc.s1[u][3]));
+            mx = rows4_vmax(mx);
+            const float m_new = vmax2(m_run[t], mx);
+            // exp(s - m) = 2^(s log2e - m log2e): one fma + v_exp_f32 per score; the fmas as v_pk_fma_f32 (two scores per instruction: an
+            // accumulator's 4 values sit in an aligned register quad) — the same fma per score, half the issue slots
+            const float nml = -m_new * kLog2e;
+            alpha[u] = __builtin_amdgcn_exp2f(fmaf(m_run[t], kLog2e, nml));
+            float p0[4], p1[4], rs = 0.f;
+            const f32x2_t l2 = {kLog2e, kLog2e}, n2 = {nml, nml};
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {
+                const f32x2_t e0 = __builtin_elementwise_fma(f32x2_t{sc.s0[u][r], sc.s0[u][r + 1]}, l2, n2);
+                const f32x2_t e1 = __builtin_elementwise_fma(f32x2_t{sc.s1[u][r], sc.s1[u][r + 1]}, l2, n2);
+                p0[r] = __builtin_amdgcn_exp2f(e0[0]); p0[r + 1] = __builtin_amdgcn_exp2f(e0[1]);
+                p1[r] = __builtin_amdgcn_exp2f(e1[0]); p1[r + 1] = __builtin_amdgcn_exp2f(e1[1]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rs += p0[r] + p1[r];
+#else
+            float mx = fmaxf(fmaxf(fmaxf(sc.s0[u][0], sc.s0[u][1]), fmaxf(sc.s0[u][2], sc.s0[u][3])), fmaxf(fmaxf(sc.s1[u][0], sc.s1[u][1]), fmaxf(sc.s1[u][2], sc.s1[u][3])));
+            mx = rows4_max(mx);
+            const float m_new = fmaxf(m_run[t], mx);
+            // exp(s - m) = 2^(s log2e - m log2e): one fma + v_exp_f32 per score (the sub / mul / exp form was a fifth more VALU issue
+            // in a kernel bound by it: ~500 VALU + 72 exp against 64 MFMAs per 64-key step and wave)
+            const float nml = -m_new * kLog2e;
+            alpha[u] = __builtin_amdgcn_exp2f(fmaf(m_run[t], kLog2e, nml));
+            float p0[4], p1[4], rs = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                p0[r] = __builtin_amdgcn_exp2f(fmaf(sc.s0[u][r], kLog2e, nml)); p1[r] = __builtin_amdgcn_exp2f(fmaf(sc.s1[u][r], kLog2e, nml));
+                rs += p0[r] + p1[r];
+            }
+#endif
+            l_run[t] = fmaf(l_run[t], alpha[u], rs);          // this lane's 8 keys per step only: the four g-lanes of a row meet once, at the end
+            m_run[t] = m_new;
+            uint4 pw;
+            pw.x = pack_bf2(p0[0], p0[1]); pw.y = pack_bf2(p0[2], p0[3]);
+            pw.z = pack_bf2(p1[0], p1[1]); pw.w = pack_bf2(p1[2], p1[3]);
+            pb[u] = __builtin_bit_cast(bf16x8_t, pw);
+            any_rescale = any_rescale || (alpha[u] != 1.0f);
+        }
+        // lazy rescale: once the running maxima have settled alpha is exactly 1 for every query of the wave and the 16 multiplies
+        // per tile are skipped (one wave-uniform branch per group; x * 1.0f == x, results unchanged)
+        if (__builtin_amdgcn_ballot_w64(any_rescale) != 0ull) {
+#pragma unroll
+            for (int u = 0; u < G; ++u)
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) { o[t0 + u][dt][0] *= alpha[u]; o[t0 + u][dt][1] *= alpha[u]; o[t0 + u][dt][2] *= alpha[u]; o[t0 + u][dt][3] *= alpha[u]; }
+        }
+#pragma unroll
+        for (int u = 0; u < G; ++u)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[t0 + u][dt] = mfma16(f.va[dt], pb[u], o[t0 + u][dt]);
+    };
+    auto half = [&](const KF& kf, const VF& vf, int kb) {
+        // The query tiles of the wave go through each phase in GROUPS — the score MFMAs of the group, then its softmax arithmetic,
+        // ONE rescale decision, then its PV MFMAs — so the tiles' dependent chains (MFMA -> row max across lanes -> exp -> row sum
+        // -> convert -> MFMA) interleave.  Tile by tile with a rescale branch inside (round 2), every tile was its own scheduling
+        // region and its chain latency was exposed: the kernel sat at ~37 % of its VALU bound.
+#pragma unroll
+        for (int t0 = 0; t0 < QT; t0 += G) {
+            SC sc;
+            scores(kf, t0, sc);
+            soft_pv(vf, t0, kb, sc);
+        }
+    };
+#if WM_FLASH_VALU >= 2
+    // Round 6.  K fragments one half step ahead in a second register set (the GEMM's trick), V^T fragments requested at the start of their half step
+    // (first use behind the group's score MFMAs and softmax), ONE barrier per step at its middle:
+    //   read K (i, 1), V (i, 0) | arithmetic (i, 0) | wait stage i+1, barrier | refill stage i+2, read K (i+1, 0), V (i, 1) | arithmetic (i, 1)
+    // The barrier of step i says: stage i+1 landed for everyone, and every wave is done with stage i-1 (its last reads, V (i-1, 1), retired by the
+    // lgkmcnt(0) of ring_barrier at the latest) — the buffer refilled next, stage (i+2) % 3.  Before: every half step began with 8 fragment reads
+    // and an lgkmcnt(0) in front of its first MFMA (an exposed LDS round trip, twice per step and wave).  613 -> 521 us per launch at 32 clips.
+    // WM_FLASH_VALU >= 3 on top: the score MFMAs of the NEXT group (of this half step, or of the next one) are issued BEFORE the softmax arithmetic
+    // of the current group, into a second score buffer — the matrix pipe works through them while the wave's VALU does max / exp / pack (before: a
+    // wave's MFMAs and its softmax alternated; only the SIMD's other wave filled the gaps).  Same arithmetic per output in every form.
+    {
+        constexpr int NG = QT / G;                       // groups per half step; units u = half * NG + group, score buffer u & 1
+        static_assert(QT % G == 0, "groups tile the wave's query tiles");
+        constexpr bool PIPE = WM_FLASH_VALU >= 3;
+        if (nsteps > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ring_barrier();
+        KF k0, k1;
+        VF v;
+        SC sc[2];
+        read_k(k0, 0, 0);
+        if constexpr (PIPE) scores(k0, 0, sc[0]);
+        // every step but the last has both halves (its second half starts below S): no test between the requests and the arithmetic
+        for (int i = 0; i + 1 < nsteps; ++i) {
+            read_k(k1, i, 1); read_v(v, i, 0);
+            __builtin_amdgcn_sched_barrier(0);                        // (left alone the reads sink towards their first use)
+            if constexpr (PIPE) {
+#pragma unroll
+                for (int u = 0; u < NG; ++u) {
+                    if (u + 1 < NG) scores(k0, (u + 1) * G, sc[(u + 1) & 1]); else scores(k1, 0, sc[(u + 1) & 1]);
+                    soft_pv(v, u * G, i * 64, sc[u & 1]);
+                }
+            } else half(k0, v, i * 64);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // stage i+1, requested a step ago (stage i+2 goes out below)
+            ring_barrier();
+            if (i + 2 < nsteps) stage_load((i + 2) % NST, i + 2);
+            read_k(k0, i + 1, 0); read_v(v, i, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PIPE) {
+#pragma unroll
+                for (int u = NG; u < 2 * NG; ++u) {
+                    if (u + 1 < 2 * NG) scores(k1, (u + 1 - NG) * G, sc[(u + 1) & 1]); else scores(k0, 0, sc[(u + 1) & 1]);
+                    soft_pv(v, (u - NG) * G, i * 64 + 32, sc[u & 1]);
+                }
+            } else half(k1, v, i * 64 + 32);
+        }
+        const int il = nsteps - 1;
+        const bool second = il * 64 + 32 < S;                         // block-uniform
+        if (second) read_k(k1, il, 1);
+        read_v(v, il, 0);
+        if constexpr (PIPE) {
+#pragma unroll
+            for (int u = 0; u < NG; ++u) {
+                if (u + 1 < NG) scores(k0, (u + 1) * G, sc[(u + 1) & 1]);
+                else if (second) scores(k1, 0, sc[(u + 1) & 1]);
+                soft_pv(v, u * G, il * 64, sc[u & 1]);
+            }
+        } else half(k0, v, il * 64);
+        if (second) {
+            read_v(v, il, 1);
+            if constexpr (PIPE) {
+#pragma unroll
+                for (int u = NG; u < 2 * NG; ++u) {
+                    if (u + 1 < 2 * NG) scores(k1, (u + 1 - NG) * G, sc[(u + 1) & 1]);
+                    soft_pv(v, (u - NG) * G, il * 64 + 32, sc[u & 1]);
+                }
+            } else half(k1, v, il * 64 + 32);
+        }
+    }
+#else
     for (int i = 0; i < nsteps; ++i) {
         // stage i has landed when at most the 4 loads of stage i+1 are still outstanding (vmcnt counts in order)
         if (i + 1 < nsteps) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ring_barrier();                                                // everyone's part landed; everyone is done with stage i-1
         if (i + 2 < nsteps) stage_load((i + 2) % NST, i + 2);
-        const bf16_t* sb = reinterpret_cast<const bf16_t*>(smem + (i % NST) * STAGE);
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             const int kb = i * 64 + hh * 32;
             if (kb >= S) break;                                        // block-uniform
-            const bf16x8_t a00 = ld_frag(sb + ((4 * hh + 0) * 64 + lane) * 8), a01 = ld_frag(sb + ((4 * hh + 1) * 64 + lane) * 8);
-            const bf16x8_t a10 = ld_frag(sb + ((4 * hh + 2) * 64 + lane) * 8), a11 = ld_frag(sb + ((4 * hh + 3) * 64 + lane) * 8);
-            bf16x8_t va[4];
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) va[dt] = ld_frag(sb + 4096 + ((4 * hh + dt) * 64 + lane) * 8);
-            const bool tail = kb + 32 > S;
-            // The query tiles of the wave go through each phase in GROUPS — the score MFMAs of the group, then its softmax arithmetic,
-            // ONE rescale decision, then its PV MFMAs — so the tiles' dependent chains (MFMA -> row max across lanes -> exp -> row sum
-            // -> convert -> MFMA) interleave.  Tile by tile with a rescale branch inside (round 2), every tile was its own scheduling
-            // region and its chain latency was exposed: the kernel sat at ~37 % of its VALU bound.
-#pragma unroll
-            for (int t0 = 0; t0 < QT; t0 += G) {
-                f32x4_t s0[G], s1[G];
-#pragma unroll
-                for (int u = 0; u < G; ++u) {
-                    s0[u] = f32x4_t{0.f, 0.f, 0.f, 0.f}; s1[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                    s0[u] = mfma16(a00, qb[t0 + u][0], s0[u]); s0[u] = mfma16(a01, qb[t0 + u][1], s0[u]);
-                    s1[u] = mfma16(a10, qb[t0 + u][0], s1[u]); s1[u] = mfma16(a11, qb[t0 + u][1], s1[u]);
-                }
-                if (tail) {
-#pragma unroll
-                    for (int u = 0; u < G; ++u)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            if (kb + 4 * g + r >= S) s0[u][r] = -INFINITY;
-                            if (kb + 16 + 4 * g + r >= S) s1[u][r] = -INFINITY;
-                        }
-                }
-                float alpha[G];
-                bf16x8_t pb[G];
-                bool any_rescale = false;
-#pragma unroll
-                for (int u = 0; u < G; ++u) {
-                    const int t = t0 + u;
-                    float mx = fmaxf(fmaxf(fmaxf(s0[u][0], s0[u][1]), fmaxf(s0[u][2], s0[u][3])), fmaxf(fmaxf(s1[u][0], s1[u][1]), fmaxf(s1[u][2], s1[u][3])));
-                    mx = rows4_max(mx);
-                    const float m_new = fmaxf(m_run[t], mx);
-                    // exp(s - m) = 2^(s log2e - m log2e): one fma + v_exp_f32 per score (the sub / mul / exp form was a fifth more VALU issue
-                    // in a kernel bound by it: ~500 VALU + 72 exp against 64 MFMAs per 64-key step and wave)
-                    const float nml = -m_new * kLog2e;
-                    alpha[u] = __builtin_amdgcn_exp2f(fmaf(m_run[t], kLog2e, nml));
-                    float p0[4], p1[4], rs = 0.f;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        p0[r] = __builtin_amdgcn_exp2f(fmaf(s0[u][r], kLog2e, nml)); p1[r] = __builtin_amdgcn_exp2f(fmaf(s1[u][r], kLog2e, nml));
-                        rs += p0[r] + p1[r];
-                    }
-                    l_run[t] = fmaf(l_run[t], alpha[u], rs);          // this lane's 8 keys per step only: the four g-lanes of a row meet once, at the end
-                    m_run[t] = m_new;
-                    uint4 pw;
-                    pw.x = pack_bf2(p0[0], p0[1]); pw.y = pack_bf2(p0[2], p0[3]);
-                    pw.z = pack_bf2(p1[0], p1[1]); pw.w = pack_bf2(p1[2], p1[3]);
-                    pb[u] = __builtin_bit_cast(bf16x8_t, pw);
-                    any_rescale = any_rescale || (alpha[u] != 1.0f);
-                }
-                // lazy rescale: once the running maxima have settled alpha is exactly 1 for every query of the wave and the 16 multiplies
-                // per tile are skipped (one wave-uniform branch per group; x * 1.0f == x, results unchanged)
-                if (__builtin_amdgcn_ballot_w64(any_rescale) != 0ull) {
-#pragma unroll
-                    for (int u = 0; u < G; ++u)
-#pragma unroll
-                        for (int dt = 0; dt < 4; ++dt) { o[t0 + u][dt][0] *= alpha[u]; o[t0 + u][dt][1] *= alpha[u]; o[t0 + u][dt][2] *= alpha[u]; o[t0 + u][dt][3] *= alpha[u]; }
-                }
-#pragma unroll
-                for (int u = 0; u < G; ++u)
-#pragma unroll
-                    for (int dt = 0; dt < 4; ++dt) o[t0 + u][dt] = mfma16(va[dt], pb[u], o[t0 + u][dt]);
-            }
+            KF kf; VF vf;
+            read_k(kf, i, hh); read_v(vf, i, hh);
+            half(kf, vf, kb);
         }
     }
+#endif
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         const float inv = 1.0f / rows4_sum(l_run[t]);
