@@ -1143,67 +1143,35 @@ k_flash_enc(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kt, const b
     //   read K (i, 1), V (i, 0) | arithmetic (i, 0) | wait stage i+1, barrier | refill stage i+2, read K (i+1, 0), V (i, 1) | arithmetic (i, 1)
     // The barrier of step i says: stage i+1 landed for everyone, and every wave is done with stage i-1 (its last reads, V (i-1, 1), retired by the
     // lgkmcnt(0) of ring_barrier at the latest) — the buffer refilled next, stage (i+2) % 3.  Before: every half step began with 8 fragment reads
-    // and an lgkmcnt(0) in front of its first MFMA (an exposed LDS round trip, twice per step and wave).  613 -> 521 us per launch at 32 clips.
-    // WM_FLASH_VALU >= 3 on top: the score MFMAs of the NEXT group (of this half step, or of the next one) are issued BEFORE the softmax arithmetic
-    // of the current group, into a second score buffer — the matrix pipe works through them while the wave's VALU does max / exp / pack (before: a
-    // wave's MFMAs and its softmax alternated; only the SIMD's other wave filled the gaps).  Same arithmetic per output in every form.
+    // and an lgkmcnt(0) in front of its first MFMA (an exposed LDS round trip, twice per step and wave): 613 -> 521 us per launch at 32 clips
+    // (profiles/r06_encoder_prefill.md; measured on top and not kept: the next group's score MFMAs issued ahead of the current group's softmax, +0.5 %).
     {
-        constexpr int NG = QT / G;                       // groups per half step; units u = half * NG + group, score buffer u & 1
-        static_assert(QT % G == 0, "groups tile the wave's query tiles");
-        constexpr bool PIPE = WM_FLASH_VALU >= 3;
         if (nsteps > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ring_barrier();
         KF k0, k1;
         VF v;
-        SC sc[2];
         read_k(k0, 0, 0);
-        if constexpr (PIPE) scores(k0, 0, sc[0]);
         // every step but the last has both halves (its second half starts below S): no test between the requests and the arithmetic
         for (int i = 0; i + 1 < nsteps; ++i) {
             read_k(k1, i, 1); read_v(v, i, 0);
             __builtin_amdgcn_sched_barrier(0);                        // (left alone the reads sink towards their first use)
-            if constexpr (PIPE) {
-#pragma unroll
-                for (int u = 0; u < NG; ++u) {
-                    if (u + 1 < NG) scores(k0, (u + 1) * G, sc[(u + 1) & 1]); else scores(k1, 0, sc[(u + 1) & 1]);
-                    soft_pv(v, u * G, i * 64, sc[u & 1]);
-                }
-            } else half(k0, v, i * 64);
+            half(k0, v, i * 64);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // stage i+1, requested a step ago (stage i+2 goes out below)
             ring_barrier();
             if (i + 2 < nsteps) stage_load((i + 2) % NST, i + 2);
             read_k(k0, i + 1, 0); read_v(v, i, 1);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (PIPE) {
-#pragma unroll
-                for (int u = NG; u < 2 * NG; ++u) {
-                    if (u + 1 < 2 * NG) scores(k1, (u + 1 - NG) * G, sc[(u + 1) & 1]); else scores(k0, 0, sc[(u + 1) & 1]);
-                    soft_pv(v, (u - NG) * G, i * 64 + 32, sc[u & 1]);
-                }
-            } else half(k1, v, i * 64 + 32);
+            half(k1, v, i * 64 + 32);
         }
         const int il = nsteps - 1;
         const bool second = il * 64 + 32 < S;                         // block-uniform
         if (second) read_k(k1, il, 1);
         read_v(v, il, 0);
-        if constexpr (PIPE) {
-#pragma unroll
-            for (int u = 0; u < NG; ++u) {
-                if (u + 1 < NG) scores(k0, (u + 1) * G, sc[(u + 1) & 1]);
-                else if (second) scores(k1, 0, sc[(u + 1) & 1]);
-                soft_pv(v, u * G, il * 64, sc[u & 1]);
-            }
-        } else half(k0, v, il * 64);
+        half(k0, v, il * 64);
         if (second) {
             read_v(v, il, 1);
-            if constexpr (PIPE) {
-#pragma unroll
-                for (int u = NG; u < 2 * NG; ++u) {
-                    if (u + 1 < 2 * NG) scores(k1, (u + 1 - NG) * G, sc[(u + 1) & 1]);
-                    soft_pv(v, (u - NG) * G, il * 64 + 32, sc[u & 1]);
-                }
-            } else half(k1, v, il * 64 + 32);
+            half(k1, v, il * 64 + 32);
         }
     }
 #else

@@ -33,9 +33,6 @@
 // ---- optional in-kernel timeline (build with -DWM_TIMELINE -> libwm_tl.so; tests/microbench/timeline.py) ----------
 // Thread 0 of every block appends one record {tag, block, realtime at entry / exit (100 MHz, chip-wide), shader cycles from
 // entry to "operands ready", "products done" and exit}.  Not compiled into the product library.
-#ifndef WM_ROWS_TT4
-#define WM_ROWS_TT4 0      // round 6 experiment: four-token-tile instances of k_rows_gemm (see launch_skinny_mt_nk)
-#endif
 #ifdef WM_TIMELINE
 struct TlRec { unsigned tag, block; unsigned long long rt0, rt1; unsigned c_prep, c_mid, c_end, pad; };
 static __device__ TlRec* g_tl_buf = nullptr;
@@ -579,18 +576,14 @@ k_rows_gemm(const bf16_t* __restrict__ W, const bf16_t* __restrict__ X, size_t p
     // as soon as the first operand group is on the wire: the 16 registers are free again before the MFMAs (held across the K loop they pushed the
     // QKV instance from 127 to 144 registers: three waves per SIMD instead of four, two resident blocks instead of three)
     const float2* fpart = reinterpret_cast<const float2*>(smem + (ksplit > 1 ? (size_t)RT * TT * ksplit * 1024 : 0));
-    constexpr int FP = (TT + 1) / 2;          // partial slots per thread (two token tiles' worth each: the launcher checks TT * 2 * T16 <= FP * threads)
-    FoldPart fpl[FP]; int f_slot[FP];
+    FoldPart fpl; int f_slot = 0;
     if constexpr (FOLD) {
-#pragma unroll
-        for (int s2 = 0; s2 < FP; ++s2) {
-            const int idx = min((int)threadIdx.x + s2 * (int)blockDim.x, TT * 2 * fold.T16 - 1);          // TT x 16 rows x G = T16 / 8 groups
-            f_slot[s2] = idx;
-            const int r = idx % (TT * 16);
-            fold_part_load(fpl[s2], fold, min(mt0 + (r >> 4), MT - 1) * 16 + (r & 15), idx / (TT * 16));
-        }
+        const int idx = min((int)threadIdx.x, TT * 2 * fold.T16 - 1);          // TT x 16 rows x G = T16 / 8 groups
+        f_slot = idx;
+        const int r = idx % (TT * 16);
+        fold_part_load(fpl, fold, min(mt0 + (r >> 4), MT - 1) * 16 + (r & 15), idx / (TT * 16));
     }
-    constexpr int G = TT >= 4 ? 2 : 4;          // k-tiles per load group (four token tiles: 8 fragments per k-tile, 16 per group either way)
+    constexpr int G = 4;          // k-tiles per load group
 #pragma unroll
     for (int kg = 0; kg < NKR; kg += G) {
         wfrag_t a[RT][G]; ActFrag x[TT][G];
@@ -602,10 +595,7 @@ k_rows_gemm(const bf16_t* __restrict__ W, const bf16_t* __restrict__ X, size_t p
             for (int i = 0; i < RT; ++i) a[i][u] = ld_wfrag<W8, false>(W, wp[i] + (size_t)(kg + u) * 512);
         }
         if constexpr (FOLD) {
-            if (kg == 0) {      // (the partial loads are the oldest requests: their wait leaves the operand group in flight)
-#pragma unroll
-                for (int s2 = 0; s2 < FP; ++s2) const_cast<float2*>(fpart)[f_slot[s2]] = fold_part_sum(fpl[s2]);
-            }
+            if (kg == 0) const_cast<float2*>(fpart)[f_slot] = fold_part_sum(fpl);      // (the partial loads are the oldest requests: their wait leaves the operand group in flight)
         }
 
 #pragma unroll
@@ -1168,7 +1158,7 @@ static inline hipError_t launch_rows_gemm_w(hipStream_t st, WRef W, int N16, int
                                             const bf16_t* X, size_t plane, int MT, const Ep& ep, const FoldIn& fold = FoldIn{}) {
     const dim3 grid((N16 + RT - 1) / RT, (MT + TT - 1) / TT);
     const size_t lds = (p.ksplit > 1 ? (size_t)RT * TT * p.ksplit * 1024 : 0) + (FOLD ? (size_t)TT * 2 * fold.T16 * sizeof(float2) : 0);
-    if (FOLD && TT * 2 * fold.T16 > ((TT + 1) / 2) * 64 * p.ksplit) return hipErrorInvalidConfiguration;      // TT x 16 rows x T16 / 8 partial groups, (TT + 1) / 2 per thread
+    if (FOLD && TT * 2 * fold.T16 > 64 * p.ksplit) return hipErrorInvalidConfiguration;      // TT x 16 rows x T16 / 8 partial groups, one per thread
     auto kern = k_rows_gemm<NKR, RT, TT, W8, Ep, FOLD>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1181,11 +1171,11 @@ static inline hipError_t launch_rows_gemm_w(hipStream_t st, WRef W, int N16, int
     return hipGetLastError();
 }
 
-template <int NKR, int RT, class Ep, bool FOLD = false, int TT = 2>
+template <int NKR, int RT, class Ep, bool FOLD = false>
 static inline hipError_t launch_rows_gemm(hipStream_t st, WRef W, int N16, int K32, const SkinnyPlan& p,
                                           const bf16_t* X, size_t plane, int MT, const Ep& ep, const FoldIn& fold = FoldIn{}) {
-    if (W.scale) return launch_rows_gemm_w<NKR, RT, true, Ep, FOLD, TT>(st, W, N16, K32, p, X, plane, MT, ep, fold);
-    return launch_rows_gemm_w<NKR, RT, false, Ep, FOLD, TT>(st, W, N16, K32, p, X, plane, MT, ep, fold);
+    if (W.scale) return launch_rows_gemm_w<NKR, RT, true, Ep, FOLD>(st, W, N16, K32, p, X, plane, MT, ep, fold);
+    return launch_rows_gemm_w<NKR, RT, false, Ep, FOLD>(st, W, N16, K32, p, X, plane, MT, ep, fold);
 }
 
 template <int NKR, class Ep, bool FOLD = false>
@@ -1194,16 +1184,6 @@ static inline hipError_t launch_skinny_mt_nk(hipStream_t st, WRef W, int N16, in
     static const int min_blocks = skinny_env("WM_ROWS_GEMM_MIN_BLOCKS", 400);
     // weight row tiles per wave: as many as still leave >= 400 blocks (~1.5 per CU; swept 100..800 at 8 and 32 streams) (register blocking divides the L2 re-reads
     // of the token operand; with few token tiles the chip has to be filled by features instead).  Same results.
-#if WM_ROWS_TT4
-    // Round 6 experiment (build -DWM_ROWS_TT4=1, run WM_ROWS_TT=4): FOUR token tiles per wave once a pass has >= WM_ROWS_TT4_MIN_MT token tiles.  With one fp16
-    // operand plane a token fragment is 4 registers (8 as a hi / lo pair: round 4's four-tile variant needed 128 registers for the token operand alone);
-    // 4 x 4 tiles per wave ask the L2 for 8 fragments per 16 MFMAs instead of 6 per 8.  Same accumulation order per output: bit-identical.
-    if (skinny_env("WM_ROWS_TT", 2) == 4 && MT >= skinny_env("WM_ROWS_TT4_MIN_MT", 5)) {
-        const int g4 = (MT + 3) / 4, mb4 = skinny_env("WM_ROWS_TT4_MIN_BLOCKS", 200);
-        if (((N16 + 3) / 4) * g4 >= mb4) return launch_rows_gemm<NKR, 4, Ep, FOLD, 4>(st, W, N16, K32, p, X, plane, MT, ep, fold);
-        return launch_rows_gemm<NKR, 2, Ep, FOLD, 4>(st, W, N16, K32, p, X, plane, MT, ep, fold);
-    }
-#endif
     const int groups = (MT + 1) / 2;
     if (((N16 + 3) / 4) * groups >= min_blocks) return launch_rows_gemm<NKR, 4, Ep, FOLD>(st, W, N16, K32, p, X, plane, MT, ep, fold);
     if (((N16 + 1) / 2) * groups >= min_blocks) return launch_rows_gemm<NKR, 2, Ep, FOLD>(st, W, N16, K32, p, X, plane, MT, ep, fold);
