@@ -38,9 +38,15 @@ def _newest_src():
     return max(os.path.getmtime(f) for f in files)
 
 
+# Per-source flags.  wm_encoder.hip: -fno-honor-nans — its softmax / LayerNorm / GELU arithmetic never produces or tests a NaN (masked scores are -inf), and with
+# `nnan` on the fmaxf calls the backend drops the operand canonicalisation (a v_max x, x per operand under IEEE mode) in front of every maximum over MFMA results:
+# 120 -> 62 max instructions per 64-key step and wave of the encoder flash attention, same values (csrc/wm_encoder.hip: vmax2; profiles/r06_encoder_prefill.md).
+SRC_FLAGS = {"wm_encoder.hip": ["-fno-honor-nans"]}
+
+
 def _compile(src, extra=(), suffix=""):
     obj = os.path.join(CSRC, src.replace(".hip", suffix + ".o"))
-    cmd = [HIPCC] + FLAGS + list(extra) + ["-c", os.path.join(CSRC, src), "-o", obj]
+    cmd = [HIPCC] + FLAGS + SRC_FLAGS.get(src, []) + list(extra) + ["-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

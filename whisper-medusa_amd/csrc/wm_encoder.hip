@@ -26,17 +26,15 @@ __device__ __forceinline__ void glds16(const bf16_t* gsrc, char* lds_wave_base)
 #define WM_FLASH_VALU 2      // k_flash_enc softmax arithmetic (see the kernel); A/B builds: -DWM_FLASH_VALU=1
 #endif
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
-// max of values known not to be NaN, as the instruction itself (fmaxf canonicalises every operand first under IEEE mode)
-__device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-__device__ __forceinline__ float vmax2(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ float rows4_vmax(float v) {       // rows4_max (wm_common.h) on vmax2
-    const unsigned u = __float_as_uint(v);
-    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    const float y = vmax2(__uint_as_float(a[0]), __uint_as_float(a[1]));
-    const unsigned w = __float_as_uint(y);
-    const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
-    return vmax2(__uint_as_float(b[0]), __uint_as_float(b[1]));
-}
+// max of values known not to be NaN.  fmaxf under IEEE mode canonicalises every operand that is not "known canonical" with a v_max x, x first — MFMA
+// results and permlane outputs never are: 15 instructions per 8-score tile where 7 do.  This file is compiled with -fno-honor-nans (build.py: its
+// softmax / LayerNorm / GELU arithmetic never produces or tests a NaN; -inf masks are infinities, not NaNs), which puts `nnan` on the calls and lets
+// the backend emit v_max_f32 / v_max3_f32 as written.
+// (NOT inline asm: an asm statement reading MFMA results gets none of the wait states the compiler inserts between a matrix instruction and the VALU
+// instruction that reads its result — round 6, call 17: a first form, `asm("v_max3_f32 ...")`, made the encoder output of the 96-frame test shapes,
+// whose groups are one query tile, differ from run to run.)
+__device__ __forceinline__ float vmax2(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ float rows4_vmax(float v) { return rows4_max(v); }
 #ifndef WM_GEMM_SCHED
 #define WM_GEMM_SCHED 3      // k_gemm_256p K-loop schedule (see the kernel); A/B builds: build.py --variant NAME -DWM_GEMM_SCHED=1|2
 #endif
@@ -1070,8 +1068,8 @@ k_flash_enc(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kt, const b
 #if WM_FLASH_VALU
             // Round 6 (ISA of the form in the #else branch: 120 max instructions per 64-key step and wave, 15 per tile and half — fmaxf under
             // IEEE mode canonicalises each operand with a v_max x, x first, and MFMA results / permlane outputs are never "known canonical").
-            // The scores are finite or -inf, never NaN: v_max3_f32 / v_max_f32 directly (4 + 3 per tile and half, tree of depth 2), same values.
-            float mx = vmax3(vmax3(sc.s0[u][0], sc.s0[u][1], sc.s0[u][2]), vmax3(sc.s0[u][3], sc.s1[u][0], sc.s1[u][1]), vmax2(sc.s1[u][2], sc.s1[u][3]));
+            // The scores are finite or -inf, never NaN: with -fno-honor-nans the maxima are 3 v_max3_f32 + v_max_f32 (+ 3 across lanes and against the running maximum), same values.
+            float mx = vmax2(vmax2(vmax2(sc.s0[u][0], sc.s0[u][1]), vmax2(sc.s0[u][2], sc.s0[u][3])), vmax2(vmax2(sc.s1[u][0], sc.s1[u][1]), vmax2(sc.s1[u][2], sc.s1[u][3])));
             mx = rows4_vmax(mx);
             const float m_new = vmax2(m_run[t], mx);
             // exp(s - m) = 2^(s log2e - m log2e): one fma + v_exp_f32 per score; the fmas as v_pk_fma_f32 (two scores per instruction: an
