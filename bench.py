@@ -400,6 +400,7 @@ def main():
     hist = np.zeros(cfg.medusa_num_heads + 1, dtype=np.int64)
     replays = 0
     sched_steps = 0
+    sib_hits = 0
     for _ in range(args.steps):
         n, st = step()
         tokens += n
@@ -408,6 +409,7 @@ def main():
         hist += np.asarray(st["accept_hist"], dtype=np.int64)
         replays += st["graph_replays"]
         sched_steps += st.get("schedule_steps", 0)
+        sib_hits += st.get("sibling_hits", 0)
     torch.cuda.synchronize()
     wd.barrier()
     elapsed = wd.max_over_ranks(time.perf_counter() - t0, dev)
@@ -448,7 +450,8 @@ def main():
     # what actually ran (the carry skips work SURVEY §8d's figure counts): a stream's base pass follows an accept length of 0 (and opens
     # every decode call); one stream: the host then skips the whole pass, several streams: only that stream's attention
     n_it_streams = max(int(hist.sum()), 1)
-    p0 = min(1.0, (float(hist[0]) + args.steps * B) / n_it_streams)
+    # (wm_config.sibling_rows, one stream: an accept length of 0 whose next root rode along as a sibling row needs no base pass either)
+    p0 = min(1.0, (float(hist[0]) - sib_hits + args.steps * B) / n_it_streams)
     p_base_pass = p0 if (B == 1 and args.micro_batches == 1) else 1.0
     bytes_exec = executed_bytes(cfg, B, mean_len, args.fp8_weights, p_base_pass, p0)
     passes_per_iter = 1.0 + p_base_pass
@@ -483,6 +486,7 @@ def main():
         "decode_tokens_per_sec_per_gpu": round(tokens / (ms_dec * 1e-3), 2),
         "iters_per_sec": round(iters / (ms_dec * 1e-3), 2), "tokens_per_iter": round(tok_per_iter, 3),
         "accept_hist": hist.tolist(), "graph_replays": int(replays),
+        "sibling_rows": int(getattr(eng, "sibling_rows", 0)) if B == 1 else 0, "sibling_hits": int(sib_hits),
         "ms_logmel_per_step": round(ms_mel / args.steps, 3), "ms_encode_per_step": round(ms_enc / args.steps, 3),
         "ms_decode_per_step": round(ms_dec / args.steps, 3), "weight_broadcast_s": round(t_bcast, 3),
         "vanilla_anchor": None if vanilla_tps is None else

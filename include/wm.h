@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define WM_ABI_VERSION 8
+#define WM_ABI_VERSION 9
 
 #define WM_OK 0
 #define WM_ERR_ARG (-1)      /* bad argument / unsupported configuration (reference: ValueError, model.py:225-229) */
@@ -85,6 +85,13 @@ typedef struct wm_config {
                                  * quantisation pass behind wm_encode's cross-K/V projection (HF WhisperAttention cross branch,
                                  * modeling_whisper.py:322-335); K's scale rides on the query, V's on the normalised output.  The bf16 projection
                                  * stays in HBM (wm_get_cross_kv returns it).  0: the bf16 cache. */
+    int32_t sibling_rows;       /* ABI v9.  S > 0 (one stream, candidate chain): the verify pass carries, in the spare rows of its 16-row tile, head 1's
+                                 * top-2 .. top-(S+1) tokens as LEAVES under the root (position L + 1, attending the history, the root and
+                                 * themselves; S <= 15 - medusa_heads, <= 5).  Acceptance is evaluated on the chain exactly as without them
+                                 * (medusa_utils.py:526-641: the emitted ids are the reference's); when the chain accepts nothing (a = 0) and
+                                 * argmax v_0 — the next root, model.py:710-713 — is one of the siblings, that row's post-LN state IS the
+                                 * state the next base pass would compute for it: its K/V rows move to position L + 1 and the base pass is
+                                 * skipped (the hidden-state carry of an accept length > 0, extended to a = 0).  0: off. */
 } wm_config;
 
 /* Packed parameter blob (layout: whisper_medusa/weights.py).  The blob
@@ -135,6 +142,7 @@ typedef struct wm_stats {
     int32_t schedule_steps;         /* merged-step schedule (several streams, candidate chain): passes that carried rows since
                                      * wm_decode_begin (a stream's iteration takes one pass, two after an accept length of 0);
                                      * 0 = lock-step schedule (base pass + verify pass per iteration) */
+    int32_t sibling_hits;           /* wm_config.sibling_rows: iterations with accept length 0 whose next root was a sibling row (base pass skipped) */
 } wm_stats;
 
 /* ---- lifecycle (replaces WhisperMedusaModel.from_pretrained / .to(device), model.py:265-291) ---- */

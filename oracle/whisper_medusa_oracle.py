@@ -280,6 +280,7 @@ class DecodeResult:
     verified: int = 0                   # decode_tree(engine_ids=...): ids confirmed identical to the engine's
     tie: Optional[dict] = None          # ... and the first differing iteration's decision margins
     ties: List[dict] = field(default_factory=list)   # decode_tree(engine_groups=...): every iteration whose outcome differed from the engine's
+    sibling_hits: int = 0               # decode(siblings=S): accept length 0 AND the next root among head 1's top-2 .. top-(S+1) (wm_config.sibling_rows)
 
 
 class Oracle:
@@ -538,7 +539,10 @@ class Oracle:
 
     # ---- the decode loop (model.py:634-810) --------------------------
     @torch.no_grad()
-    def decode(self, enc: torch.Tensor, gp, trace: bool = False, max_iters: Optional[int] = None) -> DecodeResult:
+    def decode(self, enc: torch.Tensor, gp, trace: bool = False, max_iters: Optional[int] = None, siblings: int = 0) -> DecodeResult:
+        """The reference loop (model.py:634-793) over a candidate chain.  `siblings` = S > 0 additionally COUNTS (it changes no token) the iterations
+        in which the engine's sibling rows (include/wm.h: wm_config.sibling_rows) save the next base pass: the chain accepts nothing and the next
+        root — argmax v_0, model.py:710-713 — is one of head 1's top-2 .. top-(S+1) processed tokens."""
         if gp.vanilla:
             return self._decode_vanilla(enc, gp, max_iters)
         cfg = self.cfg
@@ -562,6 +566,8 @@ class Oracle:
             a, dbg = evaluate_posterior_chain(v, cand, gp)                        # model.py:697-703
             if a == 0:                                                            # model.py:710-713, medusa_utils.py:636-641
                 emit = [int(cand[0]), int(torch.argmax(v[0]))]
+                if siblings > 0 and int(torch.argmax(v[0])) in torch.topk(z[1], siblings + 1).indices[1:].tolist():
+                    res.sibling_hits += 1
                 st["kv_len"] = L + 1                                              # model.py:388-392 keep [:a+1]
             else:
                 emit = [int(t) for t in cand[: a + 1]]

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import MedusaConfig, synth, check_tokens, default_act_f16, ACCEPT_GREEDY, ACCEPT_TYPICAL
+from helpers import MedusaConfig, synth, check_tokens, default_act_f16, record_table, ACCEPT_GREEDY, ACCEPT_TYPICAL
 from whisper_medusa import WhisperMedusaModel
 
 pytestmark = pytest.mark.gpu
@@ -220,7 +220,15 @@ def test_large_linear_decode_loop_matches_the_oracle(large, large_oracle, mode):
         hist[a] += 1
     assert st["accept_hist"] == hist.tolist() and st["iterations"] == len(accepts)
     assert st["graph_replays"] > 0
-    print("large linear", "typical" if mode == ACCEPT_TYPICAL else "exact-match", "accept lengths", accepts)
+    # sibling rows (wm_config.sibling_rows, on by default at one stream): the engine's count of saved base passes is the oracle's count of
+    # "nothing accepted AND the next root among head 1's top-2 .. top-6" whenever the ids are strictly the oracle's
+    if eng.sibling_rows > 0:
+        ref = large_oracle.decode(enc, gp, siblings=min(eng.sibling_rows, 15 - cfg.medusa_num_heads))
+        if got == ref.ids:
+            assert st["sibling_hits"] == ref.sibling_hits, (st["sibling_hits"], ref.sibling_hits)
+        record_table(f"large-v2 sibling rows ({'typical' if mode == ACCEPT_TYPICAL else 'exact-match'})", iterations=int(st["iterations"]),
+                     accept_length_0=int(st["accept_hist"][0]), sibling_hits=int(st["sibling_hits"]), oracle_sibling_hits=int(ref.sibling_hits))
+    print("large linear", "typical" if mode == ACCEPT_TYPICAL else "exact-match", "accept lengths", accepts, "sibling hits", st.get("sibling_hits"))
 
 
 def test_large_one_stream_of_a_four_stream_batch_matches_the_oracle(large, large_oracle):

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol(built_lib):
         lib = ctypes.CDLL(path)
         for name in declared:
             assert hasattr(lib, name), f"{os.path.basename(path)} does not export {name}"
-        assert lib.wm_abi_version() == 8 and lib.wm_build_act_fp16() == f16
+        assert lib.wm_abi_version() == 9 and lib.wm_build_act_fp16() == f16
     assert sorted(engine.EXPORTS) == declared
     engine.load_library()          # prototypes resolve
     engine.load_library(act_fp16=True)

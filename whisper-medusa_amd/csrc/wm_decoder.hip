@@ -783,6 +783,85 @@ __global__ void k_set_cand(const int* __restrict__ amax, int* __restrict__ cand,
     if (e < n) cand[(e / rps) * WM_CAND_STRIDE + (e % rps)] = amax[e];
 }
 
+// Sibling rows (wm_config.sibling_rows; one stream): the tokens of nodes K+1 .. K+S of the verify pass = head 1's top-2 .. top-(S+1) processed
+// logits (descending, lower index first on equal values), leaves under the root at position L + 1.  They never enter the acceptance rule
+// (medusa_utils.py:526-641 runs on the chain); k_accept only asks whether the next root — argmax v_0 after an accept length of 0 — is one of them.
+// SIB_SPLIT blocks per stream, each over a contiguous slice of row 1: every thread keeps a sorted top-6 of its strided share, six rounds of
+// block-wide argmax pop the slice's winners into `part`; the last block to arrive (ticket) merges the SIB_SPLIT x 6 partials the same way.
+// (A first form — one block per stream over the whole row — took 131 us per iteration, more than the base passes it saved: call 21.)
+constexpr int SIB_SPLIT = 32;
+__device__ __forceinline__ void sib_block_pop(float (&tv)[6], int (&ti)[6], float* sv, int* si, int tid, float& mx, int& mi)
+{
+    const int lane = tid & 63, w = tid >> 6;
+    mx = tv[0]; mi = ti[0];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(mx, o, 64); const int oi = __shfl_xor(mi, o, 64);
+        if (ov > mx || (ov == mx && oi < mi)) { mx = ov; mi = oi; }
+    }
+    if (lane == 0) { sv[w] = mx; si[w] = mi; }
+    __syncthreads();
+    mx = sv[0]; mi = si[0];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) if (sv[q] > mx || (sv[q] == mx && si[q] < mi)) { mx = sv[q]; mi = si[q]; }
+    if (ti[0] == mi && mi != 0x7fffffff) {              // token indices are distinct: exactly one thread owns the winner
+#pragma unroll
+        for (int q = 0; q < 5; ++q) { tv[q] = tv[q + 1]; ti[q] = ti[q + 1]; }
+        tv[5] = -INFINITY; ti[5] = 0x7fffffff;
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void sib_insert(float (&tv)[6], int (&ti)[6], float v, int vi)
+{
+    if (v > tv[5] || (v == tv[5] && vi < ti[5])) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            if (v > tv[j] || (v == tv[j] && vi < ti[j])) { const float fv = tv[j]; const int fi = ti[j]; tv[j] = v; ti[j] = vi; v = fv; vi = fi; }
+    }
+}
+__global__ void __launch_bounds__(256)
+k_sib_cand(const float* __restrict__ logits, GenDev gp, const unsigned char* __restrict__ mask, const float* __restrict__ exppen,
+           const int* __restrict__ L, int* __restrict__ cand, const int* __restrict__ done, float2* __restrict__ part, int* __restrict__ ticket)
+{
+    __shared__ float sv[4]; __shared__ int si[4]; __shared__ int s_last;
+    if (done && *done) return;
+    const int rps = gp.K + 1, s = blockIdx.y, blk = blockIdx.x, S = gp.sib;
+    const int tid = threadIdx.x;
+    const int cur_len = L[s];
+    const float* x = logits + (size_t)(s * rps + 1) * gp.Vpad;
+    float tv[6]; int ti[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { tv[j] = -INFINITY; ti[j] = 0x7fffffff; }
+    const int per = (gp.V + SIB_SPLIT - 1) / SIB_SPLIT, n0 = blk * per, n1 = min(gp.V, n0 + per);
+    for (int n = n0 + tid; n < n1; n += 256) sib_insert(tv, ti, proc_logit(x[n], n, cur_len, gp, mask, exppen), n);
+    float2* mine = part + ((size_t)s * SIB_SPLIT + blk) * 6;
+    for (int j = 0; j < 6; ++j) {
+        float mx; int mi;
+        sib_block_pop(tv, ti, sv, si, tid, mx, mi);
+        if (tid == 0) mine[j] = make_float2(mx, __int_as_float(mi));
+    }
+    // the last block of the stream merges the partials (release: partials, fence, ticket; acquire: ticket, fence, partials)
+    if (tid == 0) {
+        __threadfence();
+        const int t = atomicAdd(ticket + s, 1);
+        s_last = (t == SIB_SPLIT - 1) ? 1 : 0;
+        if (s_last) { ticket[s] = 0; __threadfence(); }
+    }
+    __syncthreads();
+    if (!s_last) return;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { tv[j] = -INFINITY; ti[j] = 0x7fffffff; }
+    if (tid < SIB_SPLIT * 6) {
+        const float* pp = reinterpret_cast<const float*>(part + (size_t)s * SIB_SPLIT * 6 + tid);
+        tv[0] = __builtin_nontemporal_load(pp); ti[0] = __float_as_int(__builtin_nontemporal_load(pp + 1));
+    }
+    for (int j = 0; j <= S; ++j) {
+        float mx; int mi;
+        sib_block_pop(tv, ti, sv, si, tid, mx, mi);
+        if (tid == 0 && j > 0) cand[s * WM_CAND_STRIDE + gp.K + j] = (mi == 0x7fffffff) ? -1 : mi;      // (-1: fewer than j + 1 unsuppressed tokens — never a hit)
+    }
+}
+
 // merged-step schedule: what every stream contributes to this step's pass, as DENSE rows.  carry[s] (k_accept of the previous step /
 // iteration): 1 = the post-LN state of the stream's next base token is in hf_keep -> its K + 1 candidates are verified now (rows at L ..);
 // 0 = the stream accepted nothing: its next token ids[kvlen] needs the base pass first -> ONE row at position kvlen.
@@ -823,10 +902,11 @@ __global__ void k_accept(GenDev gp, const int* __restrict__ cand, const int* __r
                          int* __restrict__ finished, int* __restrict__ niter, long long* __restrict__ hist, int* __restrict__ done, int B,
                          int* __restrict__ carry, const float* __restrict__ hf, float* __restrict__ hf_keep, int d,
                          int* __restrict__ hostflags, const float* __restrict__ hb, float* __restrict__ hb_keep,
-                         const int4* __restrict__ sinfo = nullptr)
+                         const int4* __restrict__ sinfo = nullptr, int* __restrict__ sel_src = nullptr, int* __restrict__ sel_n = nullptr,
+                         int* __restrict__ sel_base = nullptr)
 {
     const int s = blockIdx.x, lane = threadIdx.x;
-    if (finished[s]) return;
+    if (finished[s]) { if (sel_n && lane == 0) sel_n[s] = 0; return; }
     const int K = gp.K, rps = K + 1;
     const int row0 = sinfo ? sinfo[s].x : s * rps;            // merged-step schedule: the stream's first dense row of this pass
     if (sinfo != nullptr && sinfo[s].w == 0) {
@@ -871,22 +951,35 @@ __global__ void k_accept(GenDev gp, const int* __restrict__ cand, const int* __r
     // hidden-state carry (a > 0): row a of the verify pass saw exactly the accepted prefix, so its post-LN state IS
     // what the next base pass would recompute for token c_a, and its K/V row is already in the cache: keep a+1 rows,
     // save the row, and let the next (redundant) base pass skip its layers.  Bit-identical tokens, half the passes.
-    const bool do_carry = carry != nullptr && a > 0;
+    // sibling rows (gp.sib > 0: one stream): nothing accepted, but the next root — argmax v_0, emitted above — was in the pass as leaf K + 1 + j under
+    // the root: that row saw the history, the root and itself at position L + 1, i.e. exactly what the next base pass would compute.  Its state is
+    // carried like row a's, its K/V rows move from provisional row K + 1 + j to row 1 (k_kv_compact), the base pass is skipped.
+    int sib_row = -1;
+    if (gp.sib > 0 && carry != nullptr && a == 0 && sel_n != nullptr && gp.force_accept < 0) {     // (a forced accept length prices the iteration AT that length: no hit)
+        const int nxt = amax[row0];
+        const unsigned long long hit = __ballot(lane < gp.sib && cand[s * WM_CAND_STRIDE + rps + lane] == nxt);
+        if (hit) sib_row = rps + (__ffsll((long long)hit) - 1);
+    }
+    const bool do_carry = carry != nullptr && (a > 0 || sib_row >= 0);
+    const int crow = (a > 0) ? a : sib_row;          // the pass row whose post-LN state is the next iteration's base state
     if (do_carry) {
-        const float4* srcp = reinterpret_cast<const float4*>(hf + (size_t)(row0 + a) * d);
+        const float4* srcp = reinterpret_cast<const float4*>(hf + (size_t)(row0 + crow) * d);
         float4* dstp = reinterpret_cast<float4*>(hf_keep + (size_t)s * d);
         for (int j = lane; j < (d >> 2); j += 64) dstp[j] = srcp[j];
         if (hb) {                  // Medusa-Block: the heads read the extra layer's output of that row (model.py:1414-1417)
-            const float4* bs = reinterpret_cast<const float4*>(hb + (size_t)(row0 + a) * d);
+            const float4* bs = reinterpret_cast<const float4*>(hb + (size_t)(row0 + crow) * d);
             float4* bd = reinterpret_cast<float4*>(hb_keep + (size_t)s * d);
             for (int j = lane; j < (d >> 2); j += 64) bd[j] = bs[j];
         }
     }
+    if (sel_n != nullptr && lane < 16) sel_src[s * 16 + lane] = (lane == 1 && sib_row >= 0) ? sib_row : lane;
     if (lane == 0) {
         const int Ln = Lcur + n_emit;
         L[s] = Ln;
-        kvlen[s] = (a == 0) ? Lcur + 1 : (do_carry ? Ln : Lcur + a);
+        kvlen[s] = (a == 0 && sib_row < 0) ? Lcur + 1 : (do_carry ? Ln : Lcur + a);
         if (carry) carry[s] = do_carry ? 1 : 0;
+        if (sel_n != nullptr) { sel_n[s] = sib_row >= 0 ? 2 : 0; sel_base[s] = Lcur; }
+        if (sib_row >= 0) atomicAdd(reinterpret_cast<unsigned long long*>(hist + 17), 1ull);
         niter[s] += 1;
         atomicAdd(reinterpret_cast<unsigned long long*>(hist + a), 1ull);
         atomicAdd(reinterpret_cast<unsigned long long*>(hist + 16), (unsigned long long)n_emit);
@@ -1337,6 +1430,8 @@ int wm_dec_stage_layers(wm_ctx* ctx, int b0, int nb, int Mper, int mode)
     // LayerNorm fold: the embed launch also writes layer 0's QKV operand (gamma_ln1 o h) and the rows' statistics partials
     const float* eg = ctx->ln_fold ? ctx->dec[0].ln1_w : nullptr;
     const size_t expl = (size_t)ctx->Rcap * d;
+    // node tables of a verify pass: the candidate tree, or the chain + sibling leaves of a single-stream pass that carries them (Mper > K + 1)
+    const TreeDev* ptree = ctx->tn ? ctx->tree : ((mode == 1 && ctx->gp.sib > 0 && Mper == ctx->K + 1 + ctx->gp.sib) ? ctx->sibtree : nullptr);
     if (mode == 2)
         hipLaunchKernelGGL(k_embed, dim3(R), dim3(256), 0, st, ctx->h, ctx->tok_emb, ctx->dec_pos, base,
                            ctx->cand + (size_t)b0 * WM_CAND_STRIDE, WM_CAND_STRIDE, 0, Mper, d, ctx->V, ctx->Tmax, (const int*)nullptr,
@@ -1347,10 +1442,10 @@ int wm_dec_stage_layers(wm_ctx* ctx, int b0, int nb, int Mper, int mode)
                            (const int4*)nullptr, (const int*)nullptr, 0, eg, ctx->xn, expl, ctx->lnstats, ctx->Rcap);
     else
         hipLaunchKernelGGL(k_embed, dim3(R), dim3(256), 0, st, ctx->h, ctx->tok_emb, ctx->dec_pos, base,
-                           ctx->cand + (size_t)b0 * WM_CAND_STRIDE, WM_CAND_STRIDE, 0, Mper, d, ctx->V, ctx->Tmax, ctx->tn ? ctx->tree->depth : nullptr,
+                           ctx->cand + (size_t)b0 * WM_CAND_STRIDE, WM_CAND_STRIDE, 0, Mper, d, ctx->V, ctx->Tmax, ptree ? ptree->depth : nullptr,
                            (const int4*)nullptr, (const int*)nullptr, 0, eg, ctx->xn, expl, ctx->lnstats, ctx->Rcap);
     WM_HIP(hipGetLastError());
-    ctx->cur_anc = (mode == 1 && ctx->tn) ? ctx->tree->anc : nullptr;
+    ctx->cur_anc = (mode == 1 && ptree) ? ptree->anc : nullptr;
     // batched hidden-state carry: a stream whose previous verify pass accepted a > 0 candidates already has the state
     // of its base token (k_accept saved it, k_rows_norm below picks it up); its rows still ride through the GEMMs
     // (the weights are streamed once for everybody) but its attention blocks exit, saving their K/V reads
@@ -1525,10 +1620,24 @@ int wm_dec_iter_rest(wm_ctx* ctx, int Mper_base)
         WM_HIP(hipGetLastError());
         hipLaunchKernelGGL(k_set_cand, dim3((nb * rps + 63) / 64), dim3(64), 0, st, ctx->amax, ctx->cand, rps, nb * rps);
         WM_HIP(hipGetLastError());
+        if (gp.sib > 0) {       // one stream: head 1's next-best tokens ride in the spare rows of the verify tile
+            hipLaunchKernelGGL(k_sib_cand, dim3(SIB_SPLIT, nb), dim3(256), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen, ctx->L, ctx->cand, g_skinny_done,
+                               ctx->sibpart, ctx->sibticket);
+            WM_HIP(hipGetLastError());
+        }
     }
     // (d) verify pass over the candidates (chain: positions L..L+K; tree: node n at L + depth(n), ancestor-masked), then
     //     posterior statistics of every row
-    rc = wm_dec_pass(ctx, 0, nb, vr, 1, 0, 1);
+    if (gp.sib > 0 && !ctx->tn) {
+        // the layers and the final LayerNorm (Medusa-Block: the extra layer) run over K + 1 + S rows; logits only for the chain's K + 1 (rows 0 .. K of the
+        // one stream): the sibling rows are wanted for their hidden state and their K/V rows
+        rc = wm_dec_stage_layers(ctx, 0, nb, rps + gp.sib, 1);
+        if (rc) return rc;
+        rc = wm_dec_stage_final(ctx, 0, nb, rps + gp.sib, 1, 0);
+        if (rc) return rc;
+        rc = wm_dec_stage_heads(ctx, rps, 1, 0, 0);
+    } else
+        rc = wm_dec_pass(ctx, 0, nb, vr, 1, 0, 1);
     if (rc) return rc;
     hipLaunchKernelGGL(k_select1, dim3(SEL_SP, nb * vr), dim3(256), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen, ctx->L, vr, ctx->part1);
     WM_HIP(hipGetLastError());
@@ -1555,8 +1664,14 @@ int wm_dec_iter_rest(wm_ctx* ctx, int Mper_base)
     hipLaunchKernelGGL(k_accept, dim3(B), dim3(64), 0, st, gp, ctx->cand, ctx->amax, ctx->pc, ctx->part2, ctx->ids, ctx->L,
                        ctx->kvlen, ctx->finished, ctx->niter, ctx->hist, ctx->done, B, (carry || ctx->dev_carry) ? ctx->carry : nullptr, ctx->hf,
                        carry ? ctx->hf : ctx->hf_keep, ctx->d, carry ? ctx->hostflags_dev : nullptr,
-                       ctx->block ? ctx->hblk : nullptr, carry ? ctx->hblk : ctx->hb_keep);
+                       ctx->block ? ctx->hblk : nullptr, carry ? ctx->hblk : ctx->hb_keep, (const int4*)nullptr,
+                       gp.sib > 0 ? ctx->sel_src : nullptr, gp.sib > 0 ? ctx->sel_n : nullptr, gp.sib > 0 ? ctx->sel_base : nullptr);
     WM_HIP(hipGetLastError());
+    if (gp.sib > 0) {           // a sibling hit: its K / V rows go from provisional row K + 1 + j to row 1 of every self-KV slot (no-op otherwise: sel_n = 0)
+        hipLaunchKernelGGL(k_kv_compact, dim3(ctx->H, B, ctx->nkv), dim3(256), 0, st, ctx->kc, ctx->vc, ctx->sel_src, ctx->sel_n, ctx->sel_base,
+                           ctx->H, ctx->Tal, ctx->maxB);
+        WM_HIP(hipGetLastError());
+    }
     return WM_OK;
 }
 

@@ -35,7 +35,7 @@ extern "C" void wm_destroy(wm_ctx* ctx)
                     ctx->enc_out, ctx->kx, ctx->vx, ctx->kc, ctx->vc, ctx->h, ctx->hblk, ctx->hf, ctx->qbuf, ctx->xbuf, ctx->fbuf,
                     ctx->ybuf, ctx->cml, ctx->co, ctx->ticket, ctx->logits, ctx->amax, ctx->pc, ctx->part1, ctx->part2, ctx->ids, ctx->L, ctx->kvlen,
                     ctx->finished, ctx->cand, ctx->niter, ctx->hist, ctx->supmask, ctx->exppen, ctx->tap_tok, ctx->done,
-                    ctx->hf_keep, ctx->hb_keep, ctx->carry, ctx->rowinfo, ctx->sinfo, ctx->steprows, ctx->rs_table, ctx->tree, ctx->sel_src, ctx->sel_n, ctx->sel_base, ctx->exn8, ctx->exs,
+                    ctx->hf_keep, ctx->hb_keep, ctx->carry, ctx->rowinfo, ctx->sinfo, ctx->steprows, ctx->rs_table, ctx->tree, ctx->sibtree, ctx->sibpart, ctx->sibticket, ctx->sel_src, ctx->sel_n, ctx->sel_base, ctx->exn8, ctx->exs,
                     ctx->xn, ctx->lnstats, ctx->foldv, ctx->kx8, ctx->vx8, ctx->kxs, ctx->vxs};
     for (void* b : bufs) if (b) hipFree(b);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
@@ -206,6 +206,24 @@ extern "C" int wm_create(const wm_config* cfg, const wm_weights* w, int device, 
         CREATE_HIP(dev_alloc(&ctx->tree, 1, st));
         CREATE_HIP(hipMemcpyAsync(ctx->tree, &ctx->tree_host, sizeof(TreeDev), hipMemcpyHostToDevice, st));
     }
+    // sibling rows (wm_config.sibling_rows): the chain's K + 1 nodes, then S leaves under the root — node K + 1 + j sits at depth 1 and sees the
+    // history, the root and itself.  Only the depth / ancestor tables are used (k_embed, k_attn_mfma); candidates and acceptance stay the chain's.
+    ctx->sib_cfg = 0;
+    if (ctx->tn == 0 && cfg->sibling_rows > 0) {
+        const int K = cfg->medusa_heads, S = std::min({(int)cfg->sibling_rows, 15 - K, 5});
+        if (S > 0) {
+            TreeDev sib{};               // (host staging: the copy below is awaited before the block ends)
+            sib.K = K; sib.n_nodes = K + 1 + S; sib.n_paths = 1;
+            for (int n = 0; n <= K; ++n) { sib.depth[n] = n; sib.parent[n] = n - 1; sib.anc[n] = (2ull << n) - 1ull; }
+            for (int j = 0; j < S; ++j) { const int n = K + 1 + j; sib.depth[n] = 1; sib.parent[n] = 0; sib.anc[n] = 1ull | (1ull << n); }
+            CREATE_HIP(dev_alloc(&ctx->sibtree, 1, st));
+            CREATE_HIP(dev_alloc(&ctx->sibpart, (size_t)cfg->max_batch * 32 * 6, st));
+            CREATE_HIP(dev_alloc(&ctx->sibticket, cfg->max_batch, st));
+            CREATE_HIP(hipMemcpyAsync(ctx->sibtree, &sib, sizeof(TreeDev), hipMemcpyHostToDevice, st));
+            CREATE_HIP(hipStreamSynchronize(st));
+            ctx->sib_cfg = S;
+        }
+    }
     CREATE_HIP(dev_alloc(&ctx->qbuf, RW * d, st));
     CREATE_HIP(dev_alloc(&ctx->xbuf, 2 * RW * d, st));          // hi + lo planes
     { const char* v = std::getenv("WM_LN_FOLD"); ctx->ln_fold = !(v && std::atoi(v) == 0); }
@@ -310,6 +328,7 @@ extern "C" int wm_decode_begin(wm_ctx* ctx, const wm_gen_params* gp, int B)
     // row inside the other streams' verify pass: wm_dec_step).  WM_NO_STEP=1: the lock-step iteration (base pass + verify pass for everybody).
     ctx->step_flow = ctx->dev_carry && ctx->tn == 0 && std::getenv("WM_NO_STEP") == nullptr;
     g.fuse = ctx->host_carry ? 1 : (ctx->dev_carry ? (ctx->step_flow ? 3 : 2) : 0);
+    g.sib = (ctx->host_carry && ctx->tn == 0 && ctx->sib_cfg > 0 && std::getenv("WM_NO_SIBLINGS") == nullptr) ? ctx->sib_cfg : 0;
     const bool same = ctx->graph && ctx->graph_B == B && std::memcmp(&g, &ctx->gp, sizeof(GenDev)) == 0;
     if (!same && ctx->graph) { hipGraphExecDestroy(ctx->graph); ctx->graph = nullptr; }
     if (!same && ctx->graph_base) { hipGraphExecDestroy(ctx->graph_base); ctx->graph_base = nullptr; }
@@ -479,6 +498,7 @@ extern "C" int wm_get_stats(wm_ctx* ctx, wm_stats* out)
     out->tokens_emitted = h[16];
     out->ms_logmel = ctx->ms_logmel; out->ms_encode = ctx->ms_encode; out->ms_decode = ctx->ms_decode;
     out->graph_replays = ctx->graph_replays;
+    out->sibling_hits = (int32_t)h[17];
     if (ctx->step_flow && ctx->steprows) {
         int sr[4] = {0, 0, 0, 0};
         WM_HIP(hipMemcpyAsync(sr, ctx->steprows, sizeof(sr), hipMemcpyDeviceToHost, ctx->stream));       // on the context's stream like every other read

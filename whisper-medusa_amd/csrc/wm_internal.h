@@ -36,6 +36,7 @@ struct GenDev {
     float thr, alpha, inv_temp;
     int accept_mode, vanilla, K, V, Vpad, Tids, fuse, force_accept;
     int begin;      // sequence length at which the begin-suppress list applies (wm_gen_params.begin_index; P when that is < 0)
+    int sib;        // sibling rows of this decode's verify pass (wm_config.sibling_rows; 0 unless one stream, chain candidates, hidden-state carry)
 };
 
 // Static tables of the candidate tree (device memory; medusa_utils.py:305-421).  Nodes are numbered depth by depth.
@@ -115,6 +116,10 @@ struct wm_ctx {
     int tn = 0, tp = 0;
     TreeDev tree_host{};
     TreeDev* tree = nullptr;
+    TreeDev* sibtree = nullptr;     // wm_config.sibling_rows: depth / ancestor tables of the chain + S leaves under the root (nodes K+1 .. K+S)
+    int sib_cfg = 0;                // S the context was created for (0: off)
+    float2* sibpart = nullptr;      // k_sib_cand: [maxB][32 slices][6] (value, token) partial winners of head 1's row
+    int* sibticket = nullptr;       // k_sib_cand: [maxB] arrival counters of the slices
     const unsigned long long* cur_anc = nullptr;                            // ancestor masks of the pass being enqueued (verify pass of a tree)
     int *sel_src = nullptr, *sel_n = nullptr, *sel_base = nullptr;          // K/V rows of the chosen path to move: [maxB*16], [maxB], [maxB]
     bool fuse = true;

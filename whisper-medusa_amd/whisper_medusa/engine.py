@@ -17,14 +17,14 @@ from .config import MedusaConfig, GenParams, HEADS_BLOCK
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwm.so")      # the product library; tests/microbench scripts may point WM_LIB at a debug build
 LIB_PATH_F16 = os.path.join(_HERE, "libwm_f16.so")  # the same sources built for the fp16 single-plane decode contract (wm_config.act_fp16)
-WM_ABI_VERSION = 8
+WM_ABI_VERSION = 9
 
 
 class WmConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "abi_version", "d_model", "enc_layers", "dec_layers", "n_heads", "ffn_dim", "vocab", "n_mels",
         "n_ctx", "n_tgt", "medusa_heads", "heads_type", "max_batch", "dec_weight_fp8")] + [("medusa_choices", C.c_int32 * 16), ("enc_fp8", C.c_int32),
-                                                                                          ("act_fp16", C.c_int32), ("cross_kv_fp8", C.c_int32)]
+                                                                                          ("act_fp16", C.c_int32), ("cross_kv_fp8", C.c_int32), ("sibling_rows", C.c_int32)]
 
 
 class WmWeights(C.Structure):
@@ -48,7 +48,7 @@ class WmStats(C.Structure):
     _fields_ = [("iterations", C.c_int64), ("iterations_launched", C.c_int64), ("tokens_emitted", C.c_int64),
                 ("accept_hist", C.c_int64 * 16),
                 ("ms_logmel", C.c_float), ("ms_encode", C.c_float), ("ms_decode", C.c_float),
-                ("graph_replays", C.c_int32), ("schedule_steps", C.c_int32)]
+                ("graph_replays", C.c_int32), ("schedule_steps", C.c_int32), ("sibling_hits", C.c_int32)]
 
 
 EXPORTS = ["wm_create", "wm_destroy", "wm_last_error", "wm_abi_version", "wm_build_act_fp16", "wm_resample_len", "wm_resample", "wm_logmel", "wm_encode", "wm_set_encoder_output",
@@ -56,6 +56,12 @@ EXPORTS = ["wm_create", "wm_destroy", "wm_last_error", "wm_abi_version", "wm_bui
            "wm_get_encoder_output", "wm_forward_logits", "wm_get_cross_kv", "wm_profile_kernel"]
 
 _lib = {}
+
+
+def default_sibling_rows() -> int:
+    """Sibling rows a context is created with when the caller does not choose: WM_SIBLINGS (default 5; the engine caps it at 15 - K).  They only
+    act in single-stream decodes over a candidate chain (include/wm.h: wm_config.sibling_rows); emitted ids are the reference's with or without."""
+    return int(os.environ.get("WM_SIBLINGS", "5"))
 
 
 def default_act_fp16() -> bool:
@@ -118,11 +124,13 @@ class Engine:
 
     def __init__(self, cfg: MedusaConfig, blob: torch.Tensor, offsets: np.ndarray, max_batch: int = 1,
                  device: Optional[torch.device] = None, dec_weight_fp8: bool = False, enc_fp8: bool = False, act_fp16: bool = False,
-                 cross_kv_fp8: bool = False):
+                 cross_kv_fp8: bool = False, sibling_rows: Optional[int] = None):
         if not torch.cuda.is_available():
             raise RuntimeError("no HIP device visible: the Whisper-Medusa engine has no CPU path")
         self.act_fp16 = bool(act_fp16)
         self.lib = load_library(act_fp16=self.act_fp16)
+        # wm_config.sibling_rows (include/wm.h): head 1's next-best tokens in the spare rows of a single-stream verify pass; WM_SIBLINGS=0 turns them off
+        self.sibling_rows = default_sibling_rows() if sibling_rows is None else int(sibling_rows)
         self.cfg = cfg
         self.device = torch.device(device if device is not None else blob.device)
         if self.device.type != "cuda" or blob.device != self.device:
@@ -134,7 +142,7 @@ class Engine:
                      cfg.decoder_ffn_dim, cfg.vocab_size, cfg.num_mel_bins, cfg.max_source_positions,
                      cfg.max_target_positions, cfg.medusa_num_heads,
                      1 if cfg.medusa_heads_type == HEADS_BLOCK else 0, self.max_batch, 1 if dec_weight_fp8 else 0,
-                     (C.c_int32 * 16)(*[int(x) for x in cfg.medusa_choices]), 1 if enc_fp8 else 0, 1 if self.act_fp16 else 0, 1 if cross_kv_fp8 else 0)
+                     (C.c_int32 * 16)(*[int(x) for x in cfg.medusa_choices]), 1 if enc_fp8 else 0, 1 if self.act_fp16 else 0, 1 if cross_kv_fp8 else 0, self.sibling_rows)
         w = WmWeights(C.c_void_p(blob.data_ptr()), blob.numel(),
                       self._offsets.ctypes.data_as(C.POINTER(C.c_uint64)), len(self._offsets))
         # every context owns a private non-blocking HIP stream (NULL -> wm_create makes one): several contexts built under
@@ -263,7 +271,7 @@ class Engine:
         return dict(iterations=s.iterations, iterations_launched=s.iterations_launched, tokens_emitted=s.tokens_emitted,
                     accept_hist=list(s.accept_hist)[: self.cfg.medusa_num_heads + 1],
                     ms_logmel=s.ms_logmel, ms_encode=s.ms_encode, ms_decode=s.ms_decode,
-                    graph_replays=s.graph_replays, schedule_steps=s.schedule_steps)
+                    graph_replays=s.graph_replays, schedule_steps=s.schedule_steps, sibling_hits=s.sibling_hits)
 
     def sync(self):
         self._check(self.lib.wm_sync(self.h), "wm_sync")
