@@ -78,10 +78,22 @@ def test_large_twelve_streams_equal_single_stream_runs(large):
         assert eng.decode(gp, 1)[0] == both[b], b
     model.set_micro_batches(2)                                # 2 contexts x 6 streams, concurrently
     out = model.generate(feats, language="en", max_new_tokens=40, exponential_decay_length_penalty=(140, 1.01), suppress_tokens=gp.suppress_tokens)
-    model.set_micro_batches(1)
-    for b in range(12):
-        got = out[b].tolist()
-        assert got[: len(both[b])] == both[b] and all(t == gp.pad_token_id for t in got[len(both[b]):]), b
+    pool = model._pool
+    try:
+        for b in range(12):
+            got = out[b].tolist()
+            if got[: len(both[b])] == both[b] and all(t == gp.pad_token_id for t in got[len(both[b]):]):
+                continue
+            # The pool's contexts ran 6-clip ENCODER passes, `both` a 12-clip one: other GEMM tiles, the same fp32 terms in another order (DESIGN.md §4
+            # "Batch invariance"; the decode path is bitwise batch-invariant GIVEN the encoder output).  Rounds 2-6 saw identical ids here in all but one
+            # of ~70 runs (round 6, call 23: stream 0 from its second token on); when a decision sits inside that difference the pool's run must still be
+            # the oracle's run on ITS encoder output — strictly, or along a followed numerical tie that check_tokens records.
+            from oracle.whisper_medusa_oracle import Oracle
+            orc = Oracle(cfg, {k: v.float().cpu() for k, v in sd.items()}, sim="bf16")
+            e = pool.engines[b // 6]
+            check_tokens(orc, e.encoder_output(6)[b % 6], gp, e.tokens(b % 6), label=f"twelve streams, pool stream {b}", tol_logit=2e-3)
+    finally:
+        model.set_micro_batches(1)
 
 
 def test_large_prompt_pass_against_oracle(large):
