@@ -28,6 +28,32 @@ def test_library_exports_every_declared_symbol(built_lib):
     engine.load_library(act_fp16=True)
 
 
+def test_ctypes_mirrors_follow_the_header_field_for_field(monkeypatch):
+    """include/wm.h is the boundary: whisper_medusa/engine.py's ctypes structures must list wm_config / wm_gen_params / wm_stats in the header's
+    order (a field added on one side only shifts everything behind it — ABI v9 added wm_config.sibling_rows and wm_stats.sibling_hits)."""
+    from whisper_medusa import engine
+    hdr = open(os.path.join(ROOT, "include", "wm.h")).read()
+
+    def fields(name):
+        body = re.search(r"typedef struct " + name + r" \{(.*?)\} " + name + ";", hdr, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        out = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            names = decl.split(None, 1)[1] if not decl.startswith("const") else decl.split(None, 2)[2]
+            out += [re.sub(r"\[[0-9]*\]|[\*\s]", "", n) for n in names.split(",")]
+        return out
+    assert fields("wm_config") == [f[0] for f in engine.WmConfig._fields_]
+    assert fields("wm_stats") == [f[0] for f in engine.WmStats._fields_]
+    assert fields("wm_gen_params") == [f[0] for f in engine.WmGenParams._fields_]
+    monkeypatch.setenv("WM_SIBLINGS", "0")
+    assert engine.default_sibling_rows() == 0
+    monkeypatch.delenv("WM_SIBLINGS")
+    assert engine.default_sibling_rows() == 5
+
+
 def test_fp16_decoder_matrices_hold_the_bf16_parameters():
     """wm_config.act_fp16: the decode GEMMs' matrices are stored as fp16.  weights.pack_matrix(fp16=True) re-expresses the bf16-rounded
     parameter: the SAME value for every |w| >= 2^-17 (bf16 has 8 significant bits, fp16's subnormal step is 2^-24), |error| <= 3e-8 below;
