@@ -4,7 +4,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r06c23; mkdir -p $O
+O=$R/gpurun_out/${WM_CALL_DIR:-r06c23}; mkdir -p $O
 ( time timeout 1500 python -m pytest tests -m gpu -x -q -p no:cacheprovider --durations=8 > $O/pytest_gpu.log 2>&1 ) 2>&1 | grep real; echo pytest rc $?
 grep -h "^FAILED\|^ERROR\|passed\|failed" $O/pytest_gpu.log | cut -c1-300 | tail -8
 grep -h "parity ties" $O/pytest_gpu.log | cut -c1-200

@@ -635,13 +635,54 @@ __device__ __forceinline__ float proc_logit(float x, int n, int cur_len, const G
     return x;
 }
 
+// Sibling rows (wm_config.sibling_rows; one stream): the tokens of nodes K+1 .. K+S of the verify pass = head 1's top-2 .. top-(S+1) processed
+// logits (descending, lower index first on equal values), leaves under the root at position L + 1.  They never enter the acceptance rule
+// (medusa_utils.py:526-641 runs on the chain); k_accept only asks whether the next root — argmax v_0 after an accept length of 0 — is one of them.
+// Selection rides on the candidate stage's own launches: the SEL_SP slice blocks of k_select1 that score head 1's row also keep a per-thread sorted
+// top-6 and pop their slice's six winners (block-wide arg-max rounds) into `sibpart`; k_cand_fin — the one-block kernel that turns the slice
+// partials into the chain's candidates — merges the SEL_SP x 6 partials the same way.  (Rounds of this: one block over the whole row, 131 us per
+// iteration — more than the base passes it saved; 32 slice blocks + last-arriver merge behind two fences, 18.7 us; this form adds no launch.)
+__device__ __forceinline__ void sib_block_pop(float (&tv)[6], int (&ti)[6], float* sv, int* si, int tid, float& mx, int& mi)
+{
+    const int lane = tid & 63, w = tid >> 6;
+    mx = tv[0]; mi = ti[0];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(mx, o, 64); const int oi = __shfl_xor(mi, o, 64);
+        if (ov > mx || (ov == mx && oi < mi)) { mx = ov; mi = oi; }
+    }
+    __syncthreads();                                    // (sv / si may still be read by the caller's previous round)
+    if (lane == 0) { sv[w] = mx; si[w] = mi; }
+    __syncthreads();
+    mx = sv[0]; mi = si[0];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) if (sv[q] > mx || (sv[q] == mx && si[q] < mi)) { mx = sv[q]; mi = si[q]; }
+    if (ti[0] == mi && mi != 0x7fffffff) {              // token indices are distinct: exactly one thread owns the winner
+#pragma unroll
+        for (int q = 0; q < 5; ++q) { tv[q] = tv[q + 1]; ti[q] = ti[q + 1]; }
+        tv[5] = -INFINITY; ti[5] = 0x7fffffff;
+    }
+}
+__device__ __forceinline__ void sib_insert(float (&tv)[6], int (&ti)[6], float v, int vi)
+{
+    if (v > tv[5] || (v == tv[5] && vi < ti[5])) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            if (v > tv[j] || (v == tv[j] && vi < ti[j])) { const float fv = tv[j]; const int fi = ti[j]; tv[j] = v; ti[j] = vi; v = fv; vi = fi; }
+    }
+}
+
+// NEED_Z = false (candidate stage: only the arg-max is consumed) skips the second sweep, the slice's softmax denominator
+template <bool NEED_Z = true>
 __global__ void __launch_bounds__(256)
 k_select1(const float* __restrict__ logits, GenDev gp, const unsigned char* __restrict__ mask, const float* __restrict__ exppen,
-          const int* __restrict__ L, int rps, float* __restrict__ part1, const int4* __restrict__ rowinfo = nullptr)
+          const int* __restrict__ L, int rps, float* __restrict__ part1, const int4* __restrict__ rowinfo = nullptr,
+          float2* __restrict__ sibpart = nullptr)
 {
     __shared__ float sv[4]; __shared__ int si[4]; __shared__ float sz[4];
     const int row = blockIdx.y, sp = blockIdx.x;
     int s = row / rps;
+    const bool sibrow = sibpart != nullptr && row - s * rps == 1;       // head 1's row of a stream whose verify pass carries sibling rows
     if (rowinfo) {                          // merged-step schedule: dense rows; only a stream's verify rows are scored
         const int4 ri = rowinfo[row];
         if (ri.w != 2) return;
@@ -652,22 +693,40 @@ k_select1(const float* __restrict__ logits, GenDev gp, const unsigned char* __re
     const float* x = logits + (size_t)row * gp.Vpad;
     const int per = (gp.V + SEL_SP - 1) / SEL_SP, n0 = sp * per, n1 = min(gp.V, n0 + per);
     float mx = -INFINITY; int mi = 0x7fffffff;
-    for (int n = n0 + tid; n < n1; n += 256) {
-        const float v = proc_logit(x[n], n, cur_len, gp, mask, exppen);
-        if (v > mx || (v == mx && n < mi)) { mx = v; mi = n; }
-    }
+    if (sibrow) {
+        // the slice's six best (the first of them is the slice arg-max the chain needs)
+        float tv[6]; int ti[6];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(mx, o, 64); const int oi = __shfl_xor(mi, o, 64);
-        if (ov > mx || (ov == mx && oi < mi)) { mx = ov; mi = oi; }
-    }
-    if (lane == 0) { sv[w] = mx; si[w] = mi; }
-    __syncthreads();
-    mx = sv[0]; mi = si[0];
+        for (int j = 0; j < 6; ++j) { tv[j] = -INFINITY; ti[j] = 0x7fffffff; }
+        for (int n = n0 + tid; n < n1; n += 256) sib_insert(tv, ti, proc_logit(x[n], n, cur_len, gp, mask, exppen), n);
+        float2* mine = sibpart + ((size_t)s * SEL_SP + sp) * 6;
+        float m0 = -INFINITY; int i0 = 0x7fffffff;
+        for (int j = 0; j < 6; ++j) {
+            float pm; int pi;
+            sib_block_pop(tv, ti, sv, si, tid, pm, pi);
+            if (j == 0) { m0 = pm; i0 = pi; }
+            if (tid == 0) mine[j] = make_float2(pm, __int_as_float(pi));
+        }
+        __syncthreads();
+        mx = m0; mi = i0;
+    } else {
+        for (int n = n0 + tid; n < n1; n += 256) {
+            const float v = proc_logit(x[n], n, cur_len, gp, mask, exppen);
+            if (v > mx || (v == mx && n < mi)) { mx = v; mi = n; }
+        }
 #pragma unroll
-    for (int k = 1; k < 4; ++k) if (sv[k] > mx || (sv[k] == mx && si[k] < mi)) { mx = sv[k]; mi = si[k]; }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(mx, o, 64); const int oi = __shfl_xor(mi, o, 64);
+            if (ov > mx || (ov == mx && oi < mi)) { mx = ov; mi = oi; }
+        }
+        if (lane == 0) { sv[w] = mx; si[w] = mi; }
+        __syncthreads();
+        mx = sv[0]; mi = si[0];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) if (sv[k] > mx || (sv[k] == mx && si[k] < mi)) { mx = sv[k]; mi = si[k]; }
+    }
     float z = 0.f;
-    if (mx != -INFINITY)
+    if (NEED_Z && mx != -INFINITY)
         for (int n = n0 + tid; n < n1; n += 256) {
             const float v = proc_logit(x[n], n, cur_len, gp, mask, exppen);
             z += (v == -INFINITY) ? 0.f : expf((v - mx) * gp.inv_temp);
@@ -776,86 +835,32 @@ __global__ void k_rows_take_carried(float* __restrict__ dst, const float* __rest
     for (int j = threadIdx.x; j < (d >> 2); j += blockDim.x) dp[j] = sp[j];
 }
 
-// candidates of the base pass: cand[s][i] = argmax of head i   (medusa_utils.py:446-458, top-1 chain)
-__global__ void k_set_cand(const int* __restrict__ amax, int* __restrict__ cand, int rps, int n)
-{
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < n) cand[(e / rps) * WM_CAND_STRIDE + (e % rps)] = amax[e];
-}
-
-// Sibling rows (wm_config.sibling_rows; one stream): the tokens of nodes K+1 .. K+S of the verify pass = head 1's top-2 .. top-(S+1) processed
-// logits (descending, lower index first on equal values), leaves under the root at position L + 1.  They never enter the acceptance rule
-// (medusa_utils.py:526-641 runs on the chain); k_accept only asks whether the next root — argmax v_0 after an accept length of 0 — is one of them.
-// SIB_SPLIT blocks per stream, each over a contiguous slice of row 1: every thread keeps a sorted top-6 of its strided share, six rounds of
-// block-wide argmax pop the slice's winners into `part`; the last block to arrive (ticket) merges the SIB_SPLIT x 6 partials the same way.
-// (A first form — one block per stream over the whole row — took 131 us per iteration, more than the base passes it saved: call 21.)
-constexpr int SIB_SPLIT = 32;
-__device__ __forceinline__ void sib_block_pop(float (&tv)[6], int (&ti)[6], float* sv, int* si, int tid, float& mx, int& mi)
-{
-    const int lane = tid & 63, w = tid >> 6;
-    mx = tv[0]; mi = ti[0];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(mx, o, 64); const int oi = __shfl_xor(mi, o, 64);
-        if (ov > mx || (ov == mx && oi < mi)) { mx = ov; mi = oi; }
-    }
-    if (lane == 0) { sv[w] = mx; si[w] = mi; }
-    __syncthreads();
-    mx = sv[0]; mi = si[0];
-#pragma unroll
-    for (int q = 1; q < 4; ++q) if (sv[q] > mx || (sv[q] == mx && si[q] < mi)) { mx = sv[q]; mi = si[q]; }
-    if (ti[0] == mi && mi != 0x7fffffff) {              // token indices are distinct: exactly one thread owns the winner
-#pragma unroll
-        for (int q = 0; q < 5; ++q) { tv[q] = tv[q + 1]; ti[q] = ti[q + 1]; }
-        tv[5] = -INFINITY; ti[5] = 0x7fffffff;
-    }
-    __syncthreads();
-}
-__device__ __forceinline__ void sib_insert(float (&tv)[6], int (&ti)[6], float v, int vi)
-{
-    if (v > tv[5] || (v == tv[5] && vi < ti[5])) {
-#pragma unroll
-        for (int j = 0; j < 6; ++j)
-            if (v > tv[j] || (v == tv[j] && vi < ti[j])) { const float fv = tv[j]; const int fi = ti[j]; tv[j] = v; ti[j] = vi; v = fv; vi = fi; }
-    }
-}
+// Candidates of the base pass: cand[s][i] = argmax of head i (medusa_utils.py:446-458, top-1 chain), from the slice partials in ONE launch (one
+// block per stream): row i's arg-max over its SEL_SP slices -> amax, cand[s][i] (rounds 1-5: k_select_argmax + a k_set_cand launch); with sibling rows, the S + 1 best of head 1's SEL_SP x 6 slice winners -> cand[s][K+1 ..].
 __global__ void __launch_bounds__(256)
-k_sib_cand(const float* __restrict__ logits, GenDev gp, const unsigned char* __restrict__ mask, const float* __restrict__ exppen,
-           const int* __restrict__ L, int* __restrict__ cand, const int* __restrict__ done, float2* __restrict__ part, int* __restrict__ ticket)
+k_cand_fin(const float* __restrict__ part1, GenDev gp, int* __restrict__ amax, int* __restrict__ cand, const float2* __restrict__ sibpart)
 {
-    __shared__ float sv[4]; __shared__ int si[4]; __shared__ int s_last;
-    if (done && *done) return;
-    const int rps = gp.K + 1, s = blockIdx.y, blk = blockIdx.x, S = gp.sib;
-    const int tid = threadIdx.x;
-    const int cur_len = L[s];
-    const float* x = logits + (size_t)(s * rps + 1) * gp.Vpad;
+    __shared__ float sv[4]; __shared__ int si[4];
+    const int s = blockIdx.x, tid = threadIdx.x, rps = gp.K + 1;
+    if (tid < rps) {
+        const float* p1 = part1 + (size_t)(s * rps + tid) * SEL_SP * 4;
+        float mx = -INFINITY; int mi = 0x7fffffff;
+        for (int k = 0; k < SEL_SP; ++k) {
+            const float v = p1[4 * k]; const int idx = __float_as_int(p1[4 * k + 1]);
+            if (v > mx || (v == mx && idx < mi)) { mx = v; mi = idx; }
+        }
+        amax[s * rps + tid] = mi;
+        cand[s * WM_CAND_STRIDE + tid] = mi;
+    }
+    if (gp.sib <= 0 || sibpart == nullptr) return;
     float tv[6]; int ti[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) { tv[j] = -INFINITY; ti[j] = 0x7fffffff; }
-    const int per = (gp.V + SIB_SPLIT - 1) / SIB_SPLIT, n0 = blk * per, n1 = min(gp.V, n0 + per);
-    for (int n = n0 + tid; n < n1; n += 256) sib_insert(tv, ti, proc_logit(x[n], n, cur_len, gp, mask, exppen), n);
-    float2* mine = part + ((size_t)s * SIB_SPLIT + blk) * 6;
-    for (int j = 0; j < 6; ++j) {
-        float mx; int mi;
-        sib_block_pop(tv, ti, sv, si, tid, mx, mi);
-        if (tid == 0) mine[j] = make_float2(mx, __int_as_float(mi));
+    if (tid < SEL_SP * 6) {
+        const float2 p = sibpart[(size_t)s * SEL_SP * 6 + tid];
+        tv[0] = p.x; ti[0] = __float_as_int(p.y);
     }
-    // the last block of the stream merges the partials (release: partials, fence, ticket; acquire: ticket, fence, partials)
-    if (tid == 0) {
-        __threadfence();
-        const int t = atomicAdd(ticket + s, 1);
-        s_last = (t == SIB_SPLIT - 1) ? 1 : 0;
-        if (s_last) { ticket[s] = 0; __threadfence(); }
-    }
-    __syncthreads();
-    if (!s_last) return;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) { tv[j] = -INFINITY; ti[j] = 0x7fffffff; }
-    if (tid < SIB_SPLIT * 6) {
-        const float* pp = reinterpret_cast<const float*>(part + (size_t)s * SIB_SPLIT * 6 + tid);
-        tv[0] = __builtin_nontemporal_load(pp); ti[0] = __float_as_int(__builtin_nontemporal_load(pp + 1));
-    }
-    for (int j = 0; j <= S; ++j) {
+    for (int j = 0; j <= gp.sib; ++j) {
         float mx; int mi;
         sib_block_pop(tv, ti, sv, si, tid, mx, mi);
         if (tid == 0 && j > 0) cand[s * WM_CAND_STRIDE + gp.K + j] = (mi == 0x7fffffff) ? -1 : mi;      // (-1: fewer than j + 1 unsuppressed tokens — never a hit)
@@ -1573,7 +1578,7 @@ int wm_dec_iteration(wm_ctx* ctx, int Mper_base)
             const int nb = min(chunk, B - b0);
             int rc = wm_dec_pass(ctx, b0, nb, Mper_base, 0, 0, 0);
             if (rc) return rc;
-            hipLaunchKernelGGL(k_select1, dim3(SEL_SP, nb), dim3(256), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen,
+            hipLaunchKernelGGL(k_select1<false>, dim3(SEL_SP, nb), dim3(256), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen,
                                ctx->L + b0, 1, ctx->part1);
             WM_HIP(hipGetLastError());
             hipLaunchKernelGGL(k_select_argmax, dim3((nb + 63) / 64), dim3(64), 0, st, ctx->part1, nb, b0, ctx->amax);
@@ -1614,17 +1619,13 @@ int wm_dec_iter_rest(wm_ctx* ctx, int Mper_base)
                            ctx->cand, g_skinny_done);
         WM_HIP(hipGetLastError());
     } else {
-        hipLaunchKernelGGL(k_select1, dim3(SEL_SP, nb * rps), dim3(256), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen, ctx->L, rps, ctx->part1);
+        // slice partials of every head's row (head 1's slices also keep their six best when the verify pass carries sibling rows), then ONE
+        // block per stream turns them into the chain's candidates (+ the sibling tokens)
+        hipLaunchKernelGGL(k_select1<false>, dim3(SEL_SP, nb * rps), dim3(256), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen, ctx->L, rps, ctx->part1,
+                           (const int4*)nullptr, gp.sib > 0 ? ctx->sibpart : nullptr);
         WM_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_select_argmax, dim3((nb * rps + 63) / 64), dim3(64), 0, st, ctx->part1, nb * rps, 0, ctx->amax);
+        hipLaunchKernelGGL(k_cand_fin, dim3(nb), dim3(256), 0, st, ctx->part1, gp, ctx->amax, ctx->cand, gp.sib > 0 ? ctx->sibpart : nullptr);
         WM_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_set_cand, dim3((nb * rps + 63) / 64), dim3(64), 0, st, ctx->amax, ctx->cand, rps, nb * rps);
-        WM_HIP(hipGetLastError());
-        if (gp.sib > 0) {       // one stream: head 1's next-best tokens ride in the spare rows of the verify tile
-            hipLaunchKernelGGL(k_sib_cand, dim3(SIB_SPLIT, nb), dim3(256), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen, ctx->L, ctx->cand, g_skinny_done,
-                               ctx->sibpart, ctx->sibticket);
-            WM_HIP(hipGetLastError());
-        }
     }
     // (d) verify pass over the candidates (chain: positions L..L+K; tree: node n at L + depth(n), ancestor-masked), then
     //     posterior statistics of every row
@@ -1639,7 +1640,7 @@ int wm_dec_iter_rest(wm_ctx* ctx, int Mper_base)
     } else
         rc = wm_dec_pass(ctx, 0, nb, vr, 1, 0, 1);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_select1, dim3(SEL_SP, nb * vr), dim3(256), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen, ctx->L, vr, ctx->part1);
+    hipLaunchKernelGGL(k_select1<true>, dim3(SEL_SP, nb * vr), dim3(256), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen, ctx->L, vr, ctx->part1);
     WM_HIP(hipGetLastError());
     if (gp.accept_mode == WM_ACCEPT_TYPICAL)
         hipLaunchKernelGGL(k_select2, dim3(SEL_SP, nb * vr), dim3(256), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen, ctx->L,
@@ -1699,11 +1700,9 @@ int wm_dec_step(wm_ctx* ctx, int)
     int rc = wm_dec_stage_heads(ctx, B, 1, 0, 1);
     ctx->hblk = hblk_rows;
     if (rc) return rc;
-    hipLaunchKernelGGL(k_select1, dim3(SEL_SP, B * rps), dim3(256), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen, ctx->L, rps, ctx->part1, (const int4*)nullptr);
+    hipLaunchKernelGGL(k_select1<false>, dim3(SEL_SP, B * rps), dim3(256), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen, ctx->L, rps, ctx->part1, (const int4*)nullptr, (float2*)nullptr);
     WM_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_select_argmax, dim3((B * rps + 63) / 64), dim3(64), 0, st, ctx->part1, B * rps, 0, ctx->amax);
-    WM_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_set_cand, dim3((B * rps + 63) / 64), dim3(64), 0, st, ctx->amax, ctx->cand, rps, B * rps);
+    hipLaunchKernelGGL(k_cand_fin, dim3(B), dim3(256), 0, st, ctx->part1, gp, ctx->amax, ctx->cand, (const float2*)nullptr);       // arg-max of every row -> cand, one launch
     WM_HIP(hipGetLastError());
     // (d) ONE pass over the dense rows: verify rows and base rows; the launches are sized for B * rps rows, token tiles beyond the step's
     //     rows exit at once (g_skinny_ntiles)
@@ -1713,7 +1712,7 @@ int wm_dec_step(wm_ctx* ctx, int)
     if (rc == WM_OK) rc = wm_dec_stage_heads(ctx, B * rps, 1, 0, 0);
     g_skinny_ntiles = nullptr;
     if (rc) return rc;
-    hipLaunchKernelGGL(k_select1, dim3(SEL_SP, B * rps), dim3(256), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen, ctx->L, rps, ctx->part1, (const int4*)ctx->rowinfo);
+    hipLaunchKernelGGL(k_select1<true>, dim3(SEL_SP, B * rps), dim3(256), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen, ctx->L, rps, ctx->part1, (const int4*)ctx->rowinfo, (float2*)nullptr);
     WM_HIP(hipGetLastError());
     if (gp.accept_mode == WM_ACCEPT_TYPICAL)
         hipLaunchKernelGGL(k_select2, dim3(SEL_SP, B * rps), dim3(256), 0, st, ctx->logits, gp, ctx->supmask, ctx->exppen, ctx->L,

@@ -35,7 +35,7 @@ extern "C" void wm_destroy(wm_ctx* ctx)
                     ctx->enc_out, ctx->kx, ctx->vx, ctx->kc, ctx->vc, ctx->h, ctx->hblk, ctx->hf, ctx->qbuf, ctx->xbuf, ctx->fbuf,
                     ctx->ybuf, ctx->cml, ctx->co, ctx->ticket, ctx->logits, ctx->amax, ctx->pc, ctx->part1, ctx->part2, ctx->ids, ctx->L, ctx->kvlen,
                     ctx->finished, ctx->cand, ctx->niter, ctx->hist, ctx->supmask, ctx->exppen, ctx->tap_tok, ctx->done,
-                    ctx->hf_keep, ctx->hb_keep, ctx->carry, ctx->rowinfo, ctx->sinfo, ctx->steprows, ctx->rs_table, ctx->tree, ctx->sibtree, ctx->sibpart, ctx->sibticket, ctx->sel_src, ctx->sel_n, ctx->sel_base, ctx->exn8, ctx->exs,
+                    ctx->hf_keep, ctx->hb_keep, ctx->carry, ctx->rowinfo, ctx->sinfo, ctx->steprows, ctx->rs_table, ctx->tree, ctx->sibtree, ctx->sibpart, ctx->sel_src, ctx->sel_n, ctx->sel_base, ctx->exn8, ctx->exs,
                     ctx->xn, ctx->lnstats, ctx->foldv, ctx->kx8, ctx->vx8, ctx->kxs, ctx->vxs};
     for (void* b : bufs) if (b) hipFree(b);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
@@ -217,8 +217,7 @@ extern "C" int wm_create(const wm_config* cfg, const wm_weights* w, int device, 
             for (int n = 0; n <= K; ++n) { sib.depth[n] = n; sib.parent[n] = n - 1; sib.anc[n] = (2ull << n) - 1ull; }
             for (int j = 0; j < S; ++j) { const int n = K + 1 + j; sib.depth[n] = 1; sib.parent[n] = 0; sib.anc[n] = 1ull | (1ull << n); }
             CREATE_HIP(dev_alloc(&ctx->sibtree, 1, st));
-            CREATE_HIP(dev_alloc(&ctx->sibpart, (size_t)cfg->max_batch * 32 * 6, st));
-            CREATE_HIP(dev_alloc(&ctx->sibticket, cfg->max_batch, st));
+            CREATE_HIP(dev_alloc(&ctx->sibpart, (size_t)cfg->max_batch * 16 * 6, st));      // SEL_SP = 16 slices
             CREATE_HIP(hipMemcpyAsync(ctx->sibtree, &sib, sizeof(TreeDev), hipMemcpyHostToDevice, st));
             CREATE_HIP(hipStreamSynchronize(st));
             ctx->sib_cfg = S;

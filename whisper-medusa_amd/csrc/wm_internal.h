@@ -118,8 +118,7 @@ struct wm_ctx {
     TreeDev* tree = nullptr;
     TreeDev* sibtree = nullptr;     // wm_config.sibling_rows: depth / ancestor tables of the chain + S leaves under the root (nodes K+1 .. K+S)
     int sib_cfg = 0;                // S the context was created for (0: off)
-    float2* sibpart = nullptr;      // k_sib_cand: [maxB][32 slices][6] (value, token) partial winners of head 1's row
-    int* sibticket = nullptr;       // k_sib_cand: [maxB] arrival counters of the slices
+    float2* sibpart = nullptr;      // [maxB][SEL_SP slices][6] (value, token): the slice winners of head 1's row (k_select1 -> k_cand_fin)
     const unsigned long long* cur_anc = nullptr;                            // ancestor masks of the pass being enqueued (verify pass of a tree)
     int *sel_src = nullptr, *sel_n = nullptr, *sel_base = nullptr;          // K/V rows of the chosen path to move: [maxB*16], [maxB], [maxB]
     bool fuse = true;
