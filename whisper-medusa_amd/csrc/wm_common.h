@@ -170,12 +170,13 @@ __device__ __forceinline__ bf16x8_t ld_frag_nt(const bf16_t* p) {    // streamed
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
 // NT: streamed once per pass (single-stream GEMMs) -> nt policy; re-read by other token-tile groups (batched GEMM) -> default
 // 8 e4m3 values -> a bf16 MFMA fragment, whatever the build's decoder-weight type (attention operands are bf16 in both contracts)
+// (round 6: v_cvt_scalef32_pk_bf16_fp8 / _pk_f16_fp8 with scale 1.0 — two e4m3 bytes to two 16-bit values in ONE instruction; rounds 4-5 went through
+//  fp32, v_cvt_pk_f32_fp8 + a pack: twice the VALU issue in front of the cross-attention MFMAs of the fp8 K/V cache and of every fp8 weight fragment.
+//  Same values for all 256 bytes: tests/microbench/fp8_cvt_direct.hip.)
 __device__ __forceinline__ bf16x8_t fp8x8_to_bf16(unsigned v0, unsigned v1) {
-    const f32x2_t a = __builtin_amdgcn_cvt_pk_f32_fp8(v0, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(v0, true);
-    const f32x2_t c = __builtin_amdgcn_cvt_pk_f32_fp8(v1, false), d = __builtin_amdgcn_cvt_pk_f32_fp8(v1, true);
     uint4 r;
-    r.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf16x2_t)); r.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(b, bf16x2_t));
-    r.z = __builtin_bit_cast(uint32_t, __builtin_convertvector(c, bf16x2_t)); r.w = __builtin_bit_cast(uint32_t, __builtin_convertvector(d, bf16x2_t));
+    r.x = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(v0, 1.0f, false)); r.y = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(v0, 1.0f, true));
+    r.z = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(v1, 1.0f, false)); r.w = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(v1, 1.0f, true));
     return __builtin_bit_cast(bf16x8_t, r);
 }
 // A product that must stay a product.  hipcc contracts a * b + c into one fma wherever a multiply meets an add after inlining, and WHETHER it does
@@ -261,15 +262,13 @@ __device__ __host__ __forceinline__ float w16_to_f32(bf16_t v) {
 
 // 8 e4m3 values (two dwords) -> the MFMA's weight fragment type of this build (bf16 or fp16: both hold every e4m3 value exactly)
 __device__ __forceinline__ uint4 fp8x8_to_w16(unsigned v0, unsigned v1) {
-    const f32x2_t a = __builtin_amdgcn_cvt_pk_f32_fp8(v0, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(v0, true);
-    const f32x2_t c = __builtin_amdgcn_cvt_pk_f32_fp8(v1, false), d = __builtin_amdgcn_cvt_pk_f32_fp8(v1, true);
     uint4 r;
 #if WM_ACT_PLANES == 1
-    r.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, f16x2_t)); r.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(b, f16x2_t));
-    r.z = __builtin_bit_cast(uint32_t, __builtin_convertvector(c, f16x2_t)); r.w = __builtin_bit_cast(uint32_t, __builtin_convertvector(d, f16x2_t));
+    r.x = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(v0, 1.0f, false)); r.y = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(v0, 1.0f, true));
+    r.z = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(v1, 1.0f, false)); r.w = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(v1, 1.0f, true));
 #else
-    r.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf16x2_t)); r.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(b, bf16x2_t));
-    r.z = __builtin_bit_cast(uint32_t, __builtin_convertvector(c, bf16x2_t)); r.w = __builtin_bit_cast(uint32_t, __builtin_convertvector(d, bf16x2_t));
+    r.x = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(v0, 1.0f, false)); r.y = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(v0, 1.0f, true));
+    r.z = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(v1, 1.0f, false)); r.w = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(v1, 1.0f, true));
 #endif
     return r;
 }
